@@ -1,0 +1,59 @@
+"""Seeded test cases shared by the golden generator, the oracle tests and the GPU parity tests
+(TEST INFRASTRUCTURE).  Inputs are closed-form (oracle/weights.py) so fixtures store outputs only."""
+from __future__ import annotations
+
+import json
+import os
+
+import numpy as np
+import torch
+
+from . import weights as WT
+from . import visper_oracle as O
+
+GOLDEN = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+
+
+def make_batch(B, T, img_col, vocab_hi=1000, gen_dim=1024, depth_dim=1024, seg_dim=1536, with_targets=("gen", "depth", "seg")):
+    """Same recipe as gen_golden.make_batch (ids uniform in [0,vocab_hi), one IMAGE token at img_col)."""
+    ids = (WT.unit_uniform("input_ids", B * T).reshape(B, T) * 0.28867 + 0.5) * vocab_hi
+    ids = torch.from_numpy(np.clip(ids, 0, vocab_hi - 1).astype(np.int64))
+    ids[:, img_col] = O.IMAGE_TOKEN_INDEX
+    labels = ids.clone()
+    labels[:, :img_col + 7] = O.IGNORE_INDEX
+    batch = dict(input_ids=ids, labels=labels, attention_mask=torch.ones_like(ids, dtype=torch.bool),
+                 images=WT.tensor("images", (B, 3, 336, 336)))
+    if "gen" in with_targets:
+        batch["gen_target"] = WT.tensor("gen_target", (B, 1, gen_dim)); batch["gen_mask"] = torch.ones(B)
+    if "depth" in with_targets:
+        batch["depth_target"] = WT.tensor("depth_target", (B, 576, depth_dim)); batch["depth_mask"] = torch.ones(B)
+    if "seg" in with_targets:
+        batch["seg_target"] = WT.tensor("seg_target", (B, seg_dim, 24, 24)); batch["seg_mask"] = torch.ones(B)
+    return batch
+
+
+def load_golden(name):
+    return np.load(os.path.join(GOLDEN, name), allow_pickle=False)
+
+
+def tiny_llama_case():
+    """(cfg, W, batch, golden) for tests/golden/tiny_llama_e2e.npz."""
+    g = load_golden("tiny_llama_e2e.npz")
+    t = json.loads(str(g["cfg"]))
+    cfg = O.make_config(arch="llama", vocab_size=t["vocab_size"], hidden_size=t["hidden_size"],
+                        intermediate_size=t["intermediate_size"], num_hidden_layers=t["num_hidden_layers"],
+                        num_attention_heads=t["num_attention_heads"], num_key_value_heads=t["num_key_value_heads"],
+                        vit_hidden=t["vit_hidden"], vit_inter=t["vit_inter"], vit_layers=t["vit_layers"],
+                        vit_heads=t["vit_heads"], aux_mode=t["aux_mode"], image_gen=t["image_gen"],
+                        image_seg=t["image_seg"], image_depth=t["image_depth"])
+    manifest = json.loads(str(g["manifest"]))
+    W = {k: WT.param(k, s) for k, s in manifest.items() if not k.startswith("da_v2_head.")}
+    batch = make_batch(2, 59, 38)
+    assert np.array_equal(batch["input_ids"].numpy(), g["input_ids"])
+    return cfg, W, batch, g
+
+
+def sub(t, n=4096):
+    f = t.detach().float().flatten()
+    step = max(1, f.numel() // n)
+    return f[::step][:n].numpy().copy()

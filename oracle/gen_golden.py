@@ -1,0 +1,288 @@
+"""Golden-vector generator: imports the REFERENCE ITSELF (read-only /root/reference) in the build
+container and writes small input/output fixtures to tests/golden/.  TEST INFRASTRUCTURE; runs only
+where /root/reference exists (never on the GPU box).  Nothing from the reference is copied: the
+fixtures hold tensors (subsampled outputs, losses, gradients, a parameter-name manifest) only.
+
+Recipe = SURVEY.md §8(c): third-party stubs, package shells that skip the reference __init__.py
+files, a stand-in BaseCausalLM, world_size-1 gloo group, synthetic frozen-teacher targets.
+
+Usage:  python oracle/gen_golden.py            (writes tests/golden/*.npz)
+"""
+import os
+import sys
+import types
+import json
+
+sys.dont_write_bytecode = True
+import numpy as np
+import torch
+import transformers  # noqa: F401  (must precede the stubs)
+from transformers import PreTrainedModel, CLIPVisionModel, CLIPVisionConfig
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+from oracle import weights as WT  # noqa: E402
+
+REF = "/root/reference"
+OUT = os.path.join(ROOT, "tests", "golden")
+
+
+class _Stub(types.ModuleType):
+    def __getattr__(self, n):
+        if n.startswith("__"):
+            raise AttributeError(n)
+        return sys.modules.get(f"{self.__name__}.{n}") or type(n, (), {})
+
+
+def _stub(name):
+    parts = name.split(".")
+    for i in range(1, len(parts) + 1):
+        k = ".".join(parts[:i])
+        if k not in sys.modules:
+            m = _Stub(k)
+            m.__path__ = []
+            sys.modules[k] = m
+
+
+def setup_reference():
+    sys.path.insert(0, REF)
+    for n in ["open_clip.model", "open_clip.coca_model", "open_clip.openai", "open_clip.pretrained",
+              "open_clip.transform", "open_clip.factory", "open_clip.transformer", "timm.models.convnext",
+              "diffusers", "cv2", "diffdist.functional", "torchvision.ops", "torchvision.transforms", "wandb",
+              "matplotlib", "matplotlib.pyplot", "matplotlib.cm", "icecream"]:
+        try:
+            __import__(n)
+        except Exception:
+            _stub(n)
+    sys.modules["diffdist.functional"].all_gather = lambda out, x: (out.__setitem__(0, x) or out)
+
+    def shell(name, path):
+        m = types.ModuleType(name)
+        m.__path__ = [path]
+        sys.modules[name] = m
+    shell("ola_vlm", f"{REF}/ola_vlm")
+    shell("ola_vlm.model", f"{REF}/ola_vlm/model")
+    shell("ola_vlm.model.language_model", f"{REF}/ola_vlm/model/language_model")
+    bl = types.ModuleType("ola_vlm.model.language_model.base_lm")
+
+    class BaseCausalLM(PreTrainedModel):
+        def __init__(self, config):
+            super().__init__(config)
+    bl.BaseCausalLM = BaseCausalLM
+    sys.modules[bl.__name__] = bl
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    if not dist.is_initialized():
+        dist.init_process_group("gloo", rank=0, world_size=1)
+
+
+class KeepMask(torch.Tensor):
+    """Mask whose in-place zero_() is a no-op -> the INTENDED (non-zeroed) loss."""
+    def zero_(self):
+        return self
+
+
+def sub(t, n=4096):
+    """Deterministic subsample of a tensor (flattened stride) to keep fixtures small."""
+    f = t.detach().float().flatten()
+    step = max(1, f.numel() // n)
+    return f[::step][:n].numpy().copy()
+
+
+def build_llama(tiny):
+    from ola_vlm.model.language_model.ola_llama import OlaLlavaLlamaForCausalLM, OlaLlavaLlamaConfig
+    from ola_vlm.model.multimodal_encoder.clip_encoder import CLIPVisionTower
+    from ola_vlm.model.multimodal_projector.builder import build_vision_projector
+    cfg = OlaLlavaLlamaConfig(vocab_size=tiny["vocab_size"], hidden_size=tiny["hidden_size"],
+                              intermediate_size=tiny["intermediate_size"], num_hidden_layers=tiny["num_hidden_layers"],
+                              num_attention_heads=tiny["num_attention_heads"],
+                              num_key_value_heads=tiny["num_key_value_heads"], rms_norm_eps=1e-5,
+                              max_position_embeddings=4096)
+    try:
+        cfg.rope_parameters = {"rope_type": "default", "rope_theta": 500000.0}
+    except Exception:
+        pass
+    cfg.rope_theta = 500000.0
+    cfg._attn_implementation = "eager"
+    cfg.aux_mode = tiny["aux_mode"]
+    cfg.num_task_tokens = 8
+    cfg.contrastive_loss_weight = 0.3
+    cfg.image_gen = dict(tiny["image_gen"])
+    cfg.image_seg = dict(tiny["image_seg"])
+    cfg.image_depth = dict(tiny["image_depth"])
+    cfg.image_generator = cfg.image_segmentor = "unused"
+    p = "/tmp/_empty_sd.pth"
+    torch.save({}, p)
+    cfg.depth_estimator = p
+    cfg.tokenizer_model_max_length = 4096
+    cfg.tokenizer_padding_side = "right"
+    model = OlaLlavaLlamaForCausalLM(cfg)
+    tower = CLIPVisionTower.__new__(CLIPVisionTower)
+    torch.nn.Module.__init__(tower)
+    tower.is_loaded, tower.select_layer, tower.select_feature = True, -2, "patch"
+    vcfg = CLIPVisionConfig(hidden_size=tiny["vit_hidden"], intermediate_size=tiny["vit_inter"],
+                            num_hidden_layers=tiny["vit_layers"], num_attention_heads=tiny["vit_heads"],
+                            image_size=336, patch_size=14)
+    vcfg._attn_implementation = "eager"
+    tower.vision_tower = CLIPVisionModel(vcfg).requires_grad_(False)
+    model.model.vision_tower = tower
+    cfg.mm_projector_type, cfg.mm_hidden_size = "mlp2x_gelu", tiny["vit_hidden"]
+    model.model.mm_projector = build_vision_projector(cfg)
+    model.model.initialize_special_tokens(cfg)
+    return model, cfg
+
+
+TINY_LLAMA = dict(
+    vocab_size=128256, hidden_size=64, intermediate_size=128, num_hidden_layers=4, num_attention_heads=4,
+    num_key_value_heads=2, vit_hidden=64, vit_inter=128, vit_layers=3, vit_heads=4, aux_mode="gen-depth-seg",
+    image_gen=dict(depth=1, dim_head=32, num_heads=4, num_tokens=1, output_dim=1024, ff_mult=1,
+                   img_layer_indices="4", img_loss_weight=0.5),
+    image_seg=dict(depth=1, dim_head=32, num_heads=4, num_tokens=576, output_dim=1536, ff_mult=1,
+                   seg_layer_indices="2-3", seg_loss_weight=0.5),
+    image_depth=dict(depth=1, dim_head=32, num_heads=4, num_tokens=576, output_dim=1024, ff_mult=1,
+                     depth_layer_indices="3", depth_loss_weight=0.5),
+)
+
+
+def make_batch(B, T, img_col, vocab_hi=1000):
+    ids = (WT.unit_uniform("input_ids", B * T).reshape(B, T) * 0.28867 + 0.5) * vocab_hi
+    ids = torch.from_numpy(np.clip(ids, 0, vocab_hi - 1).astype(np.int64))
+    ids[:, img_col] = -200
+    labels = ids.clone()
+    labels[:, :img_col + 7] = -100
+    images = WT.tensor("images", (B, 3, 336, 336))
+    tg = WT.tensor("gen_target", (B, 1, 1024))
+    td = WT.tensor("depth_target", (B, 576, 1024))
+    ts = WT.tensor("seg_target", (B, 1536, 24, 24))
+    return ids, labels, images, tg, td, ts
+
+
+def _fresh_tiny_llama(B):
+    """A NEW reference model per forward: under transformers 5.x (installed here; the reference pins
+    4.41.1) the outer model's first `output_hidden_states=True` call leaves duplicate recorder hooks on
+    the nested CLIP tower, so from the SECOND call on `hidden_states` has 2L+1 entries and
+    `hidden_states[-2]` silently selects a different layer.  Only a first call has the pinned semantics."""
+    model, cfg = build_llama(TINY_LLAMA)
+    # PT-stage trainability (ola_vlm_train.py:1127-1131,1147): LLM + tower frozen.
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    sd = {k: WT.param(k, s) for k, s in shapes.items() if not k.startswith("da_v2_head.")}
+    missing = model.load_state_dict(sd, strict=False)
+    assert all(k.startswith("da_v2_head.") for k in missing.missing_keys), missing
+    model.requires_grad_(False)
+    for n, p in model.named_parameters():
+        if ("mm_projector" in n or "_heads." in n or "special_" in n or "logit_scale" in n):
+            p.requires_grad_(True)
+    return model, shapes
+
+
+def run_tiny_llama():
+    B, T = 2, 59
+    ids, labels, images, tg, td, ts = make_batch(B, T, 38)
+    captured = []
+    res = {}
+    for mode in ("keep", "released"):
+        model, shapes = _fresh_tiny_llama(B)
+        model._get_gen_feats = lambda pil, dev: tg
+        model._get_seg_targets = lambda pil, h: ts
+        model._get_dav2_feats = lambda pil, dev: ([(td, None)], torch.zeros(B, 336, 336))
+        orig = model._emb_loss
+
+        def spy(preds, mask, tgt, scale, orig=orig):
+            r = orig(preds, mask, tgt, scale)
+            captured.append((tuple(preds.shape), [float(x) for x in r], sub(preds, 512)))
+            return r
+        model._emb_loss = spy
+        captured.clear()
+        # released mode: a non-fp32 mask so `.float()` copies (an fp32 mask zeroed twice in place breaks the
+        # reference's own backward when a task has two layers)
+        mk = (lambda: torch.ones(B).as_subclass(KeepMask)) if mode == "keep" else (lambda: torch.ones(B, dtype=torch.float64))
+        out = model(input_ids=ids, attention_mask=torch.ones_like(ids, dtype=torch.bool), labels=labels,
+                    images=images, pil_images=[None] * B, gen_mask=mk(), seg_mask=mk(), depth_mask=mk())
+        out.loss.backward()
+        res[f"{mode}_loss"] = np.float64(out.loss.item())
+        res[f"{mode}_layer_losses"] = np.array([c[1] for c in captured], dtype=np.float64)
+        res[f"{mode}_layer_shapes"] = json.dumps([c[0] for c in captured])
+        for j, c in enumerate(captured):
+            res[f"{mode}_pred{j}"] = c[2]
+        if mode == "keep":
+            lg = out.logits
+            res["logits_shape"] = np.array(lg.shape)
+            res["logits_sub"] = lg[:, ::41, ::997].detach().numpy().copy()
+            res["logits_lse_sub"] = torch.logsumexp(lg, -1)[:, ::7].detach().numpy().copy()
+            hs = out.hidden_states
+            res["n_hidden_states"] = np.array(len(hs))
+            for li in (0, 2, 3, 4):
+                res[f"hidden{li}_sub"] = hs[li][:, ::13, ::3].detach().numpy().copy()
+            res["depth_embs_len"] = np.array(len(out.depth_embs[0]))
+            res["depth_preds_shape"] = np.array(out.depth_preds[0].shape)
+            res["seg_emb_sub"] = sub(out.seg_embs[0], 2048)
+            res["gen_emb_sub"] = sub(out.image_embs[0], 1024)
+        grads = {}
+        for n, p in model.named_parameters():
+            if p.requires_grad:
+                grads[n] = None if p.grad is None else p.grad
+        res[f"{mode}_grad_none"] = json.dumps(sorted(k for k, v in grads.items() if v is None))
+        for n, g in grads.items():
+            if g is not None:
+                res[f"{mode}_gradnorm::{n}"] = np.float64(g.double().norm().item())
+                if mode == "keep":
+                    res[f"keep_gradsub::{n}"] = sub(g, 256)
+    res["manifest"] = json.dumps({k: list(s) for k, s in shapes.items()})
+    res["trainable"] = json.dumps(sorted(n for n, p in model.named_parameters() if p.requires_grad))
+    res["input_ids"] = ids.numpy()
+    res["labels"] = labels.numpy()
+    res["cfg"] = json.dumps(TINY_LLAMA)
+    np.savez_compressed(os.path.join(OUT, "tiny_llama_e2e.npz"), **res)
+    print("tiny_llama: keep loss", res["keep_loss"], "released loss", res["released_loss"])
+    print("layer losses (keep):\n", res["keep_layer_losses"], res["keep_layer_shapes"])
+    return model
+
+
+def run_units():
+    """Unit fixtures straight from the reference functions."""
+    from ola_vlm.ola_utils import calculate_contrastive_loss
+    from ola_vlm.model.language_model.base_ola_vlm import BaseOLA_VLM
+    from ola_vlm.model.multimodal_projector.resampler import TaskTokenResampler
+    res = {}
+    fake = types.SimpleNamespace(contrastive_loss_weight=0.3)
+    cases = {"gen": (3, 1, 1024), "depth": (3, 40, 1024), "seg": (3, 96, 6, 6)}
+    for name, shp in cases.items():
+        p = WT.tensor(f"unit_pred_{name}", shp, 1.3).requires_grad_(True)
+        t = WT.tensor(f"unit_tgt_{name}", shp, 1.0)
+        mask = torch.tensor([1.0, 0.0, 1.0])
+        s = torch.tensor(2.0, requires_grad=True)
+        e, l1, c = BaseOLA_VLM._emb_loss(fake, p, mask, t, s)
+        e.backward()
+        res[f"{name}_out"] = np.array([e.item(), l1.item(), c.item()], dtype=np.float64)
+        res[f"{name}_dpred"] = p.grad.numpy().copy()
+        res[f"{name}_dscale"] = np.float64(s.grad.item())
+        res[f"{name}_con"] = calculate_contrastive_loss(p.detach(), t, s.detach()).numpy().copy()
+    # saturating logit scale (clamp at 100) and no-contrastive variant
+    p = WT.tensor("unit_pred_sat", (4, 8, 16), 1.0)
+    t = WT.tensor("unit_tgt_sat", (4, 8, 16), 1.0)
+    res["sat_con"] = calculate_contrastive_loss(p, t, torch.tensor(5.0)).numpy().copy()
+    e, l1, c = BaseOLA_VLM._emb_loss(fake, p, torch.ones(4), t, None)
+    res["nocon_out"] = np.array([float(e), float(l1), float(c)], dtype=np.float64)
+    # TaskTokenResampler: gen-like (1 query from 8 latents) and seg-like (16 queries tiled from 8... uses mean path)
+    for name, (dim, nq, emb, out_dim, nlat) in {"rs_gen": (64, 1, 48, 64, 8), "rs_tile": (32, 16, 48, 40, 8),
+                                               "rs_same": (32, 12, 48, 40, 12), "rs_mean": (32, 6, 48, 40, 4)}.items():
+        m = TaskTokenResampler(dim=dim, depth=1, dim_head=32, num_queries=nq, heads=4, embedding_dim=emb,
+                               output_dim=out_dim, ff_mult=1)
+        shapes = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+        m.load_state_dict({k: WT.param(f"{name}.{k}", s) for k, s in shapes.items()})
+        x = WT.tensor(f"{name}.x", (2, 50, emb))
+        lat = WT.tensor(f"{name}.lat", (2, nlat, emb))
+        res[f"{name}_out"] = m(x, lat).detach().numpy().copy()
+        res[f"{name}_manifest"] = json.dumps({k: list(s) for k, s in shapes.items()})
+    np.savez_compressed(os.path.join(OUT, "units.npz"), **res)
+    print("units written:", sorted(res)[:8], "...")
+
+
+if __name__ == "__main__":
+    os.makedirs(OUT, exist_ok=True)
+    torch.manual_seed(0)
+    setup_reference()
+    run_units()
+    run_tiny_llama()

@@ -1,0 +1,483 @@
+"""CPU oracle for the VisPer-LM PT train step (TEST INFRASTRUCTURE — never shipped, never measured
+as the product).
+
+A plain-PyTorch (CPU, any float dtype) restatement of the reference's pre-training forward:
+CLIP-ViT tower -> mlp2x_gelu projector -> image/task-token splice -> Llama/Phi-3 decoder ->
+lm_head + NTP cross-entropy -> TaskTokenResampler heads at selected decoder layers ->
+smooth-L1 + InfoNCE embedding losses.  Backward comes from torch autograd over these functions.
+
+Only `tests/`, `__graft_entry__.smoke()` and `bench.py`'s `cpu_baseline` leg may import this
+module.  The product path (`visper_lm_amd`) must never import it.
+
+Every function cites the reference file:line it restates (paths relative to /root/reference,
+or the installed HF transformers copy for third-party math).
+
+Pinning: checked against golden vectors produced by importing the reference itself in the build
+container (`oracle/gen_golden.py` -> `tests/golden/*.npz`, test: `tests/test_oracle_golden.py`).
+The ConvNeXt tower is NOT restated here (timm/open_clip absent: "parity unpinned").
+
+Weights are a flat dict {reference state-dict name: tensor}.
+"""
+from __future__ import annotations
+
+import math
+from types import SimpleNamespace
+from typing import Dict, List, Optional
+
+import torch
+import torch.nn.functional as F
+
+IGNORE_INDEX = -100          # ola_vlm/constants.py:7
+IMAGE_TOKEN_INDEX = -200     # ola_vlm/constants.py:8
+
+
+# ----------------------------------------------------------------------------------------------
+# configuration helpers
+# ----------------------------------------------------------------------------------------------
+def make_config(**kw) -> SimpleNamespace:
+    """Config with the keys the reference copies onto `model.config`
+    (ola_vlm/train/ola_vlm_train.py:1123-1229) + HF Llama/Phi-3/CLIP hyper-parameters."""
+    d = dict(
+        arch="llama",                     # "llama" | "phi3"
+        vocab_size=128256, hidden_size=4096, intermediate_size=14336, num_hidden_layers=32,
+        num_attention_heads=32, num_key_value_heads=8, rms_norm_eps=1e-5, rope_theta=500000.0,
+        sliding_window=None,
+        # vision tower (CLIP-ViT-L/14-336)
+        vit_hidden=1024, vit_inter=4096, vit_layers=24, vit_heads=16, vit_image=336, vit_patch=14,
+        vit_eps=1e-5, mm_vision_select_layer=-2, mm_vision_select_feature="patch",
+        mm_projector_type="mlp2x_gelu",
+        # distillation
+        aux_mode="gen-depth-seg", num_task_tokens=8, contrastive_loss_weight=0.3,
+        use_contrastive=True, pass_text_to_aux=True,
+        image_gen=dict(depth=1, dim_head=32, num_heads=4, num_tokens=1, output_dim=1024, ff_mult=1,
+                       img_layer_indices="20", img_loss_weight=0.5),
+        image_depth=dict(depth=1, dim_head=32, num_heads=4, num_tokens=576, output_dim=1024, ff_mult=1,
+                         depth_layer_indices="18", depth_loss_weight=0.5),
+        image_seg=dict(depth=1, dim_head=32, num_heads=4, num_tokens=576, output_dim=1536, ff_mult=1,
+                       seg_layer_indices="18", seg_loss_weight=0.5),
+        tokenizer_model_max_length=4096, tokenizer_padding_side="right",
+        zero_masks=False,                 # True = as-released `mask.zero_()` quirk
+    )
+    d.update(kw)
+    return SimpleNamespace(**d)
+
+
+def num_sys_tokens(cfg) -> int:
+    """ola_llama.py:65-69 (38 Llama-3 / 26 small-vocab) ; ola_phi3.py:68 (13)."""
+    if cfg.arch == "phi3":
+        return 13
+    return 26 if cfg.vocab_size < 128000 else 38
+
+
+def layer_indices(spec: str) -> List[int]:
+    """base_ola_vlm.py:97-102 — '18-20' -> [17, 19] (1-based CLI -> 0-based into layer_states)."""
+    return [int(i) - 1 for i in str(spec).split("-")]
+
+
+# ----------------------------------------------------------------------------------------------
+# CLIP ViT tower  (clip_encoder.py:37-59 -> HF modeling_clip.py CLIPVisionTransformer)
+# ----------------------------------------------------------------------------------------------
+def quick_gelu(x):
+    return x * torch.sigmoid(1.702 * x)
+
+
+def vit_prefix(W) -> str:
+    """transformers==4.41.1 (reference pin) nests CLIPVisionModel.vision_model; 5.x flattens it."""
+    a = "model.vision_tower.vision_tower.vision_model."
+    return a if (a + "embeddings.class_embedding") in W else "model.vision_tower.vision_tower."
+
+
+def clip_vit_features(images: torch.Tensor, W: Dict[str, torch.Tensor], cfg, prefix=None) -> torch.Tensor:
+    """Frozen CLIP-ViT forward up to hidden_states[select_layer], CLS dropped.
+
+    clip_encoder.py:37-45 (feature_select), :47-59 (forward, no_grad);
+    HF CLIPVisionEmbeddings (patch conv stride=patch, no bias; CLS; learned pos-emb),
+    pre_layrnorm, CLIPEncoderLayer (LN -> MHA(+bias, scale d^-0.5) -> +res -> LN -> fc1 ->
+    quick_gelu -> fc2 -> +res).  hidden_states[k] = input of layer k, so select_layer=-2 needs
+    the first (L-1) layers only."""
+    p = prefix or vit_prefix(W)
+    dt = W[p + "embeddings.patch_embedding.weight"].dtype
+    x = images.to(dt)
+    B = x.shape[0]
+    pe = F.conv2d(x, W[p + "embeddings.patch_embedding.weight"], stride=cfg.vit_patch)   # (B,C,g,g)
+    pe = pe.flatten(2).transpose(1, 2)
+    cls = W[p + "embeddings.class_embedding"].expand(B, 1, -1)
+    h = torch.cat([cls, pe], dim=1) + W[p + "embeddings.position_embedding.weight"][None]
+    C = h.shape[-1]
+    h = F.layer_norm(h, (C,), W[p + "pre_layrnorm.weight"], W[p + "pre_layrnorm.bias"], cfg.vit_eps)
+    nh = cfg.vit_heads
+    hd = C // nh
+    sel = cfg.mm_vision_select_layer
+    n_run = cfg.vit_layers + 1 + sel if sel < 0 else sel      # index into hidden_states
+    for l in range(n_run):
+        q = p + f"encoder.layers.{l}."
+        r = h
+        y = F.layer_norm(h, (C,), W[q + "layer_norm1.weight"], W[q + "layer_norm1.bias"], cfg.vit_eps)
+        N = y.shape[1]
+        qq = F.linear(y, W[q + "self_attn.q_proj.weight"], W[q + "self_attn.q_proj.bias"]).view(B, N, nh, hd).transpose(1, 2)
+        kk = F.linear(y, W[q + "self_attn.k_proj.weight"], W[q + "self_attn.k_proj.bias"]).view(B, N, nh, hd).transpose(1, 2)
+        vv = F.linear(y, W[q + "self_attn.v_proj.weight"], W[q + "self_attn.v_proj.bias"]).view(B, N, nh, hd).transpose(1, 2)
+        att = torch.matmul(qq, kk.transpose(-1, -2)) * (hd ** -0.5)
+        att = torch.softmax(att, dim=-1, dtype=torch.float32).to(qq.dtype)
+        o = torch.matmul(att, vv).transpose(1, 2).reshape(B, N, C)
+        o = F.linear(o, W[q + "self_attn.out_proj.weight"], W[q + "self_attn.out_proj.bias"])
+        h = r + o
+        r = h
+        y = F.layer_norm(h, (C,), W[q + "layer_norm2.weight"], W[q + "layer_norm2.bias"], cfg.vit_eps)
+        y = quick_gelu(F.linear(y, W[q + "mlp.fc1.weight"], W[q + "mlp.fc1.bias"]))
+        y = F.linear(y, W[q + "mlp.fc2.weight"], W[q + "mlp.fc2.bias"])
+        h = r + y
+    if cfg.mm_vision_select_feature == "patch":
+        h = h[:, 1:]
+    return h.to(images.dtype)
+
+
+def mm_projector(x, W, prefix="model.mm_projector."):
+    """multimodal_projector/builder.py:53-60 mlp2x_gelu: Linear -> GELU(erf) -> Linear."""
+    y = F.linear(x, W[prefix + "0.weight"], W[prefix + "0.bias"])
+    y = F.gelu(y)
+    return F.linear(y, W[prefix + "2.weight"], W[prefix + "2.bias"])
+
+
+def encode_images(images, W, cfg):
+    """ola_arch.py:187-190."""
+    with torch.no_grad():
+        feats = clip_vit_features(images, W, cfg)
+    return mm_projector(feats.to(images.dtype), W)
+
+
+# ----------------------------------------------------------------------------------------------
+# sequence splice  (ola_arch.py:224-254, 256-444)
+# ----------------------------------------------------------------------------------------------
+def task_token_rows(W, cfg) -> List[torch.Tensor]:
+    """append_special_tokens (ola_arch.py:224-254): per task in token_order, 8 rows:
+    depth/seg = mean over (num_tokens/8)-row groups of the (num_tokens,H) parameter; gen = raw."""
+    rows = []
+    n = cfg.num_task_tokens
+    for t in cfg.aux_mode.split("-"):
+        name = f"model.special_{t}_tokens"
+        if n > 0 and name in W:
+            tk = W[name]
+            if t in ("depth", "seg"):
+                tk = tk.view(n, tk.shape[0] // n, tk.shape[1]).mean(dim=1)
+            rows.append(tk)
+    return rows
+
+
+def prepare_inputs_labels_for_multimodal(input_ids, attention_mask, labels, image_features, W, cfg):
+    """ola_arch.py:256-444 restated for the tensor-`images` path (one feature block per sample).
+
+    Returns (position_ids, attention_mask, inputs_embeds, labels) after splice / truncate / pad."""
+    embed = W["model.embed_tokens.weight"]
+    B = input_ids.shape[0]
+    if attention_mask is None:
+        attention_mask = torch.ones_like(input_ids, dtype=torch.bool)
+    attention_mask = attention_mask.bool()
+    if labels is None:
+        labels = torch.full_like(input_ids, IGNORE_INDEX)
+    new_embeds, new_labels = [], []
+    img_idx = 0
+    for b in range(B):
+        ids = input_ids[b][attention_mask[b]]
+        lab = labels[b][attention_mask[b]]
+        pos = (ids == IMAGE_TOKEN_INDEX).nonzero().flatten().tolist()
+        if len(pos) == 0:
+            new_embeds.append(torch.cat([embed[ids], image_features[img_idx][0:0]], dim=0))
+            new_labels.append(lab)
+            img_idx += 1
+            continue
+        bounds = [-1] + pos + [ids.shape[0]]
+        pe, pl = [], []
+        for i in range(len(bounds) - 1):
+            seg_ids = ids[bounds[i] + 1: bounds[i + 1]]
+            pe.append(embed[seg_ids])
+            pl.append(lab[bounds[i] + 1: bounds[i + 1]])
+            if i < len(pos):
+                f = image_features[img_idx]
+                img_idx += 1
+                pe.append(f)
+                pl.append(torch.full((f.shape[0],), IGNORE_INDEX, dtype=lab.dtype))
+                for tk in task_token_rows(W, cfg):
+                    pe.append(tk.to(f.dtype))
+                    pl.append(torch.full((tk.shape[0],), IGNORE_INDEX, dtype=lab.dtype))
+        new_embeds.append(torch.cat(pe, dim=0))
+        new_labels.append(torch.cat(pl, dim=0))
+    mx = cfg.tokenizer_model_max_length
+    if mx is not None:
+        new_embeds = [x[:mx] for x in new_embeds]
+        new_labels = [x[:mx] for x in new_labels]
+    L = max(x.shape[0] for x in new_embeds)
+    H = new_embeds[0].shape[1]
+    out = torch.zeros(B, L, H, dtype=new_embeds[0].dtype)
+    out_l = torch.full((B, L), IGNORE_INDEX, dtype=labels.dtype)
+    am = torch.zeros(B, L, dtype=torch.bool)
+    pid = torch.zeros(B, L, dtype=torch.long)
+    left = cfg.tokenizer_padding_side == "left"
+    rows = []
+    for b, (e, l) in enumerate(zip(new_embeds, new_labels)):
+        n = e.shape[0]
+        padz = torch.zeros(L - n, H, dtype=e.dtype)
+        if left:
+            rows.append(torch.cat([padz, e], 0))
+            if n > 0:
+                out_l[b, L - n:] = l; am[b, L - n:] = True; pid[b, L - n:] = torch.arange(n)
+        else:
+            rows.append(torch.cat([e, padz], 0))
+            if n > 0:
+                out_l[b, :n] = l; am[b, :n] = True; pid[b, :n] = torch.arange(n)
+    return pid, am, torch.stack(rows, 0), out_l
+
+
+# ----------------------------------------------------------------------------------------------
+# decoder  (ola_llama.py:105-119 -> HF LlamaModel / Phi3Model)
+# ----------------------------------------------------------------------------------------------
+def rms_norm(x, w, eps):
+    """HF LlamaRMSNorm (modeling_llama.py:53-68): fp32 variance, cast back, * weight."""
+    dt = x.dtype
+    xf = x.float()
+    xf = xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + eps)
+    return w * xf.to(dt)
+
+
+def rope_tables(position_ids, head_dim, theta, dtype):
+    """HF LlamaRotaryEmbedding.forward: fp32 angles, cos/sin cast to the activation dtype."""
+    inv = 1.0 / (theta ** (torch.arange(0, head_dim, 2, dtype=torch.float32) / head_dim))
+    fr = position_ids[:, :, None].float() * inv[None, None, :]
+    emb = torch.cat([fr, fr], dim=-1)
+    return emb.cos().to(dtype), emb.sin().to(dtype)
+
+
+def _rot_half(x):
+    h = x.shape[-1] // 2
+    return torch.cat([-x[..., h:], x[..., :h]], dim=-1)
+
+
+def decoder_forward(inputs_embeds, position_ids, attention_mask, W, cfg, prefix="model."):
+    """32x [RMSNorm -> QKV -> RoPE -> causal softmax(fp32) attention -> O -> +res -> RMSNorm ->
+    SwiGLU -> +res], final RMSNorm.  Returns (hidden_post_norm, layer_states) with
+    layer_states[i] = residual stream after layer i+1, the LAST one replaced by the post-norm
+    state — exactly `outputs[-1][1:]` of HF with output_hidden_states=True (ola_llama.py:117-119)."""
+    x = inputs_embeds
+    B, S, H = x.shape
+    nh, nkv = cfg.num_attention_heads, cfg.num_key_value_heads
+    hd = H // nh
+    if position_ids is None:
+        position_ids = torch.arange(S)[None].expand(B, S)
+    cos, sin = rope_tables(position_ids, hd, cfg.rope_theta, x.dtype)
+    cos, sin = cos[:, None], sin[:, None]
+    neg = torch.finfo(x.dtype).min
+    causal = torch.ones(S, S, dtype=torch.bool).tril()
+    if cfg.sliding_window is not None:
+        causal = causal & ~torch.ones(S, S, dtype=torch.bool).tril(-int(cfg.sliding_window))
+    allow = causal[None, None]
+    if attention_mask is not None:
+        allow = allow & attention_mask.bool()[:, None, None, :]
+    bias = torch.zeros(allow.shape, dtype=x.dtype).masked_fill(~allow, neg)
+    states = []
+    for l in range(cfg.num_hidden_layers):
+        p = f"{prefix}layers.{l}."
+        r = x
+        y = rms_norm(x, W[p + "input_layernorm.weight"], cfg.rms_norm_eps)
+        if cfg.arch == "phi3":
+            qkv = F.linear(y, W[p + "self_attn.qkv_proj.weight"])
+            q, k, v = qkv.split([nh * hd, nkv * hd, nkv * hd], dim=-1)
+        else:
+            q = F.linear(y, W[p + "self_attn.q_proj.weight"])
+            k = F.linear(y, W[p + "self_attn.k_proj.weight"])
+            v = F.linear(y, W[p + "self_attn.v_proj.weight"])
+        q = q.view(B, S, nh, hd).transpose(1, 2)
+        k = k.view(B, S, nkv, hd).transpose(1, 2)
+        v = v.view(B, S, nkv, hd).transpose(1, 2)
+        q = q * cos + _rot_half(q) * sin
+        k = k * cos + _rot_half(k) * sin
+        rep = nh // nkv
+        if rep > 1:
+            k = k[:, :, None].expand(B, nkv, rep, S, hd).reshape(B, nh, S, hd)
+            v = v[:, :, None].expand(B, nkv, rep, S, hd).reshape(B, nh, S, hd)
+        att = torch.matmul(q, k.transpose(2, 3)) * (hd ** -0.5) + bias
+        att = torch.softmax(att, dim=-1, dtype=torch.float32).to(q.dtype)
+        o = torch.matmul(att, v).transpose(1, 2).reshape(B, S, nh * hd)
+        x = r + F.linear(o, W[p + "self_attn.o_proj.weight"])
+        r = x
+        y = rms_norm(x, W[p + "post_attention_layernorm.weight"], cfg.rms_norm_eps)
+        if cfg.arch == "phi3":
+            gu = F.linear(y, W[p + "mlp.gate_up_proj.weight"])
+            g, u = gu.chunk(2, dim=-1)
+        else:
+            g = F.linear(y, W[p + "mlp.gate_proj.weight"])
+            u = F.linear(y, W[p + "mlp.up_proj.weight"])
+        x = r + F.linear(F.silu(g) * u, W[p + "mlp.down_proj.weight"])
+        states.append(x)
+    hidden = rms_norm(x, W[prefix + "norm.weight"], cfg.rms_norm_eps)
+    states[-1] = hidden
+    return hidden, states
+
+
+def ntp_loss(hidden, labels, W, cfg):
+    """ola_llama.py:121-136: lm_head (no bias) -> .float() -> shifted CE, mean over labels != -100."""
+    logits = F.linear(hidden, W["lm_head.weight"]).float()
+    sl = logits[:, :-1].reshape(-1, logits.shape[-1])
+    tl = labels[:, 1:].reshape(-1)
+    return logits, F.cross_entropy(sl, tl, ignore_index=IGNORE_INDEX)
+
+
+# ----------------------------------------------------------------------------------------------
+# heads  (resampler.py:9-75,167-224; gen_head.py:39-65; oneformer_head.py:224-258; da_v2_head.py:418-457)
+# ----------------------------------------------------------------------------------------------
+def task_token_resampler(x, latents, W, pfx, hcfg):
+    """TaskTokenResampler.forward (resampler.py:202-224) with depth==len(layers) Perceiver blocks."""
+    nq = hcfg["num_tokens"]
+    heads = hcfg["num_heads"]
+    dh = hcfg["dim_head"]
+    if latents.shape[1] != nq:
+        if nq > 1 and nq % latents.shape[1] == 0:
+            latents = latents.repeat(1, nq // latents.shape[1], 1)
+        else:
+            latents = latents.mean(dim=1, keepdim=True).repeat(1, nq, 1)
+    lat = F.linear(latents, W[pfx + "proj_in.weight"], W[pfx + "proj_in.bias"])
+    x = F.linear(x, W[pfx + "proj_in.weight"], W[pfx + "proj_in.bias"])
+    D = lat.shape[-1]
+    for d in range(hcfg["depth"]):
+        a = f"{pfx}layers.{d}.0."
+        f = f"{pfx}layers.{d}.1."
+        # PerceiverAttention.forward resampler.py:46-75
+        xn = F.layer_norm(x, (D,), W[a + "norm1.weight"], W[a + "norm1.bias"])
+        ln = F.layer_norm(lat, (D,), W[a + "norm2.weight"], W[a + "norm2.bias"])
+        b, l, _ = ln.shape
+        q = F.linear(ln, W[a + "to_q.weight"])
+        kv = F.linear(torch.cat([xn, ln], dim=-2), W[a + "to_kv.weight"])
+        k, v = kv.chunk(2, dim=-1)
+        sp = lambda t: t.view(b, t.shape[1], heads, -1).transpose(1, 2)
+        q, k, v = sp(q), sp(k), sp(v)
+        sc = 1.0 / math.sqrt(math.sqrt(dh))
+        w = (q * sc) @ (k * sc).transpose(-2, -1)
+        w = torch.softmax(w.float(), dim=-1).type(w.dtype)
+        o = (w @ v).permute(0, 2, 1, 3).reshape(b, l, -1)
+        lat = F.linear(o, W[a + "to_out.weight"]) + lat
+        # FeedForward resampler.py:9-16: LN -> Linear(no bias) -> GELU -> Linear(no bias)
+        y = F.layer_norm(lat, (D,), W[f + "0.weight"], W[f + "0.bias"])
+        y = F.linear(F.gelu(F.linear(y, W[f + "1.weight"])), W[f + "3.weight"])
+        lat = y + lat
+    out = F.linear(lat, W[pfx + "proj_out.weight"], W[pfx + "proj_out.bias"])
+    Do = out.shape[-1]
+    return F.layer_norm(out, (Do,), W[pfx + "norm_out.weight"], W[pfx + "norm_out.bias"])
+
+
+def head_inputs(state, task, W, cfg):
+    """forward_emb_predictor token selection (base_ola_vlm.py:413-441)."""
+    order = cfg.aux_mode.split("-")
+    ns = num_sys_tokens(cfg)
+    nt = cfg.num_task_tokens
+    k = order.index(task)
+    s0 = ns + 576 + nt * k
+    end = ns + 576 + nt * len(order)
+    x = state[:, :ns + 576]
+    if nt == 0 or state.shape[1] < 600:
+        if cfg.pass_text_to_aux:
+            x = state
+    else:
+        x = torch.cat([x, state[:, s0:s0 + nt]], dim=1)
+        if cfg.pass_text_to_aux:
+            x = torch.cat([x, state[:, end:]], dim=1)
+    if task != "gen":
+        lat = W[f"model.special_{task}_tokens"][None].repeat(x.shape[0], 1, 1)
+    else:
+        lat = x[:, -nt:] if not cfg.pass_text_to_aux else x[:, ns + 576: ns + 576 + nt]
+    return x, lat
+
+
+def _mlp_relu(x, W, p):
+    """da_v2_head.py:331-335 build_mlp: Linear -> ReLU -> Linear."""
+    return F.linear(F.relu(F.linear(x, W[p + "0.weight"], W[p + "0.bias"])), W[p + "2.weight"], W[p + "2.bias"])
+
+
+def head_forward(state, task, i, W, cfg):
+    """One head instance i of `task` on one layer state -> (loss_input_pred, extras)."""
+    x, lat = head_inputs(state, task, W, cfg)
+    name = {"gen": "image_gen_heads", "seg": "image_seg_heads", "depth": "image_depth_heads"}[task]
+    hcfg = {"gen": cfg.image_gen, "seg": cfg.image_seg, "depth": cfg.image_depth}[task]
+    v = task_token_resampler(x, lat.to(x.dtype), W, f"{name}.{i}.projector.", hcfg)
+    if task == "gen":
+        return v, None
+    if task == "seg":
+        b, n, c = v.shape
+        g = int(math.sqrt(n))
+        return v.permute(0, 2, 1).reshape(b, c, g, g), None          # oneformer_head.py:250-258
+    feats = [_mlp_relu(v, W, f"{name}.{i}.linear_{j}.") for j in (1, 2, 3)] + [v]   # da_v2_head.py:444-457
+    return feats[0], feats                                            # loss uses lin1(v): base_ola_vlm.py:369
+
+
+# ----------------------------------------------------------------------------------------------
+# embedding losses  (base_ola_vlm.py:289-320 ; ola_utils.py:96-125)
+# ----------------------------------------------------------------------------------------------
+def contrastive_loss(preds, targets, logit_scale, rank=0, gathered_targets=None):
+    """calculate_contrastive_loss (ola_utils.py:108-125). `gathered_targets` = rank-ordered
+    concatenation of every rank's L2-normalised targets (dist_collect :96-106)."""
+    Bn = preds.shape[0]
+    labels = torch.arange(Bn) + Bn * rank
+    p = F.normalize(preds.flatten(1), dim=-1)
+    t = F.normalize(targets.flatten(1), dim=-1)
+    allt = t if gathered_targets is None else gathered_targets
+    logits = p @ allt.t()
+    sc = torch.clamp(logit_scale.exp(), max=100)
+    return F.cross_entropy(logits * sc, labels, reduction="none")
+
+
+def emb_loss(preds, mask, targets, logit_scale, w_contrastive, rank=0, gathered_targets=None):
+    """_emb_loss (base_ola_vlm.py:289-320) incl. the outer-product mask broadcast."""
+    targets = targets.to(preds.dtype)
+    m = mask.view(preds.shape[0], *([1] * (preds.ndim - 1))).float()
+    sl1 = F.smooth_l1_loss(preds.float(), targets.float(), reduction="none")
+    con = contrastive_loss(preds, targets, logit_scale, rank, gathered_targets) if logit_scale is not None else 0
+    sl1 = (sl1 * m).mean()
+    con = (w_contrastive * con * m).mean()
+    return sl1 + con, sl1, con
+
+
+# ----------------------------------------------------------------------------------------------
+# whole forward (ola_llama.py:79-188)
+# ----------------------------------------------------------------------------------------------
+def forward(W, batch, cfg, rank=0, gathered=None, need_logits=True):
+    """batch: input_ids, attention_mask, labels, images, {gen,depth,seg}_target, {gen,depth,seg}_mask.
+    Returns dict(loss, text_loss, logits, per-task loss triples, embeddings, layer_states...)."""
+    feats = encode_images(batch["images"], W, cfg)
+    pid, am, emb, labels = prepare_inputs_labels_for_multimodal(
+        batch["input_ids"], batch.get("attention_mask"), batch.get("labels"), feats, W, cfg)
+    hidden, states = decoder_forward(emb, pid, am, W, cfg)
+    logits, text_loss = ntp_loss(hidden, labels, W, cfg)
+    out = dict(text_loss=text_loss, logits=logits if need_logits else None, labels=labels,
+               inputs_embeds=emb, image_features=feats, hidden=hidden, layer_states=states,
+               layer_losses={})
+    total = text_loss
+    ns = num_sys_tokens(cfg)
+    modes = cfg.aux_mode.split("-")
+    spec = {"depth": ("image_depth", "depth_layer_indices", "depth_loss_weight", "depth_logit_scale"),
+            "seg": ("image_seg", "seg_layer_indices", "seg_loss_weight", "seg_logit_scale"),
+            "gen": ("image_gen", "img_layer_indices", "img_loss_weight", "gen_logit_scale")}
+    for task in ("depth", "seg", "gen"):                      # call order: ola_llama.py:139-141
+        if task not in modes or states[0].shape[1] <= ns:
+            continue
+        cname, ikey, wkey, sname = spec[task]
+        hcfg = getattr(cfg, cname)
+        tloss = 0
+        embs = []
+        for i, idx in enumerate(layer_indices(hcfg[ikey])):
+            pred, extra = head_forward(states[idx], task, i, W, cfg)
+            embs.append(extra if extra is not None else pred)
+            tgt = batch.get(f"{task}_target")
+            if tgt is None:
+                continue
+            mask = batch[f"{task}_mask"].float()
+            if cfg.zero_masks:
+                mask = torch.zeros_like(mask)                  # base_ola_vlm.py:472-473,498-499,525-526
+            scale = W.get(sname) if cfg.use_contrastive else None
+            g = None if gathered is None else gathered[task]
+            l, s, c = emb_loss(pred, mask, tgt, scale, cfg.contrastive_loss_weight, rank, g)
+            out["layer_losses"][(task, idx)] = (l, s, c)
+            tloss = tloss + l * hcfg[wkey]
+        out[f"{task}_loss"] = tloss
+        out[f"{task}_embs"] = embs
+    for task in ("seg", "depth", "gen"):                      # sum order: ola_llama.py:143-144
+        total = total + out.get(f"{task}_loss", 0)
+    out["loss"] = total
+    return out

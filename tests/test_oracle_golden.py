@@ -1,0 +1,124 @@
+"""Pin the CPU oracle (oracle/visper_oracle.py) to golden vectors produced by the reference itself
+(oracle/gen_golden.py).  fp32, CPU only."""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import cases, weights as WT, visper_oracle as O
+
+
+def _close(a, b, rtol=2e-4, atol=2e-5):
+    a = np.asarray(a, dtype=np.float64); b = np.asarray(b, dtype=np.float64)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    err = np.abs(a - b).max() if a.size else 0.0
+    assert np.allclose(a, b, rtol=rtol, atol=atol), f"max abs err {err}, ref max {np.abs(b).max()}"
+
+
+@pytest.mark.parametrize("name,shp", [("gen", (3, 1, 1024)), ("depth", (3, 40, 1024)), ("seg", (3, 96, 6, 6))])
+def test_emb_loss_units(name, shp):
+    g = cases.load_golden("units.npz")
+    p = WT.tensor(f"unit_pred_{name}", shp, 1.3).requires_grad_(True)
+    t = WT.tensor(f"unit_tgt_{name}", shp, 1.0)
+    s = torch.tensor(2.0, requires_grad=True)
+    e, l1, c = O.emb_loss(p, torch.tensor([1.0, 0.0, 1.0]), t, s, 0.3)
+    e.backward()
+    _close([e.item(), l1.item(), c.item()], g[f"{name}_out"], 1e-5, 1e-7)
+    _close(p.grad.numpy(), g[f"{name}_dpred"], 1e-4, 1e-9)
+    _close(s.grad.item(), g[f"{name}_dscale"], 1e-4, 1e-8)
+    _close(O.contrastive_loss(p.detach(), t, s.detach()).numpy(), g[f"{name}_con"], 1e-5, 1e-6)
+
+
+def test_contrastive_saturation_and_nocontrastive():
+    g = cases.load_golden("units.npz")
+    p = WT.tensor("unit_pred_sat", (4, 8, 16), 1.0)
+    t = WT.tensor("unit_tgt_sat", (4, 8, 16), 1.0)
+    _close(O.contrastive_loss(p, t, torch.tensor(5.0)).numpy(), g["sat_con"], 1e-5, 1e-6)
+    e, l1, c = O.emb_loss(p, torch.ones(4), t, None, 0.3)
+    _close([float(e), float(l1), float(c)], g["nocon_out"], 1e-6, 1e-8)
+
+
+@pytest.mark.parametrize("name,dims", [("rs_gen", (64, 1, 48, 64, 8)), ("rs_tile", (32, 16, 48, 40, 8)),
+                                       ("rs_same", (32, 12, 48, 40, 12)), ("rs_mean", (32, 6, 48, 40, 4))])
+def test_task_token_resampler(name, dims):
+    g = cases.load_golden("units.npz")
+    dim, nq, emb, out_dim, nlat = dims
+    man = json.loads(str(g[f"{name}_manifest"]))
+    W = {f"h.{k}": WT.param(f"{name}.{k}", s) for k, s in man.items()}
+    x = WT.tensor(f"{name}.x", (2, 50, emb))
+    lat = WT.tensor(f"{name}.lat", (2, nlat, emb))
+    out = O.task_token_resampler(x, lat, W, "h.", dict(num_tokens=nq, num_heads=4, dim_head=32, depth=1))
+    _close(out.numpy(), g[f"{name}_out"], 1e-4, 1e-5)
+
+
+@pytest.fixture(scope="module")
+def tiny():
+    cfg, W, batch, g = cases.tiny_llama_case()
+    tr = json.loads(str(g["trainable"]))
+    for k in tr:
+        W[k] = W[k].clone().requires_grad_(True)
+    out = O.forward(W, batch, cfg)
+    out["loss"].backward()
+    return cfg, W, batch, g, out, tr
+
+
+def test_e2e_manifest_names(tiny):
+    cfg, W, batch, g, out, tr = tiny
+    man = json.loads(str(g["manifest"]))
+    # every parameter the oracle touches exists in the reference state dict with the same shape
+    for k, v in W.items():
+        assert tuple(man[k]) == tuple(v.shape), k
+    assert int(g["n_hidden_states"]) == cfg.num_hidden_layers + 1
+
+
+def test_e2e_forward_matches_reference(tiny):
+    cfg, W, batch, g, out, tr = tiny
+    _close(out["loss"].item(), g["keep_loss"], 1e-5, 1e-6)
+    lg = out["logits"]
+    assert tuple(lg.shape) == tuple(g["logits_shape"])
+    _close(lg[:, ::41, ::997].detach().numpy(), g["logits_sub"], 1e-3, 2e-5)
+    _close(torch.logsumexp(lg, -1)[:, ::7].detach().numpy(), g["logits_lse_sub"], 1e-5, 1e-5)
+    hs = [out["inputs_embeds"]] + out["layer_states"]
+    for li in (0, 2, 3, 4):
+        _close(hs[li][:, ::13, ::3].detach().numpy(), g[f"hidden{li}_sub"], 1e-3, 2e-5)
+    ll = g["keep_layer_losses"]
+    shapes = json.loads(str(g["keep_layer_shapes"]))
+    # reference call order: depth layers, seg layers, gen layers (ola_llama.py:139-141)
+    mine = [out["layer_losses"][("depth", 2)], out["layer_losses"][("seg", 1)], out["layer_losses"][("seg", 2)],
+            out["layer_losses"][("gen", 3)]]
+    assert [len(s) for s in shapes] == [3, 4, 4, 3]
+    for i, trip in enumerate(mine):
+        _close([float(x) for x in trip], ll[i], 2e-5, 1e-6)
+    _close(cases.sub(out["seg_embs"][0], 2048), g["seg_emb_sub"], 1e-3, 2e-5)
+    _close(cases.sub(out["gen_embs"][0], 1024), g["gen_emb_sub"], 1e-3, 2e-5)
+    assert int(g["depth_embs_len"]) == len(out["depth_embs"][0]) == 4
+
+
+def test_e2e_gradients_match_reference(tiny):
+    cfg, W, batch, g, out, tr = tiny
+    none_ref = set(json.loads(str(g["keep_grad_none"])))
+    for k in tr:
+        gr = W[k].grad
+        if k in none_ref:
+            assert gr is None or float(gr.abs().sum()) == 0.0, k
+            continue
+        assert gr is not None, k
+        ref_norm = float(g[f"keep_gradnorm::{k}"])
+        assert abs(float(gr.double().norm()) - ref_norm) <= 2e-4 * ref_norm + 1e-9, (k, float(gr.double().norm()), ref_norm)
+        _close(cases.sub(gr, 256), g[f"keep_gradsub::{k}"], 2e-3, 1e-4 * ref_norm / max(1.0, gr.numel() ** 0.5) + 1e-9)
+
+
+def test_e2e_as_released_mask_zeroing(tiny):
+    cfg, W, batch, g, _, tr = tiny
+    import copy
+    cfg2 = copy.copy(cfg); cfg2.zero_masks = True
+    W2 = {k: v.detach().clone().requires_grad_(k in tr) for k, v in W.items()}
+    out = O.forward(W2, batch, cfg2)
+    out["loss"].backward()
+    _close(out["loss"].item(), g["released_loss"], 1e-5, 1e-6)
+    _close(out["loss"].item(), out["text_loss"].item(), 0, 0)
+    assert np.all(g["released_layer_losses"] == 0.0)
+    for k in tr:
+        if "_heads." in k or "logit_scale" in k:
+            assert W2[k].grad is None or float(W2[k].grad.abs().sum()) == 0.0, k
