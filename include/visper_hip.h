@@ -1,0 +1,123 @@
+/* visper_hip.h — C ABI of libvisper_hip.so: the MI355X (gfx950) kernels behind the VisPer-LM
+ * pre-training step (NTP + per-layer embedding distillation).
+ *
+ * The reference (SHI-Labs/VisPer-LM) has NO native code and no FFI: every op below replaces a
+ * PyTorch/HF call site on the hot path.  Each prototype cites the reference
+ * call site it stands in for (paths relative to /root/reference; "HF:" = transformers==4.41.1, the
+ * reference's pinned dependency).  INTEGRATION.md shows the ctypes binding a maintainer adds.
+ *
+ * Conventions
+ *  - plain pointers + sizes; all tensors are device pointers owned by the caller (PyTorch caching
+ *    allocator); the library never allocates, frees or retains device memory.
+ *  - bf16 tensors are `void*` (raw uint16 bit patterns); fp32 are `float*`; ld* = leading dimension in
+ *    ELEMENTS; every call is asynchronous on `stream` (a hipStream_t passed as void*).
+ *  - return 0 on success, negative VP_ERR_* otherwise; vp_last_error_string() (thread-local) explains.
+ *    Nothing throws or aborts across the ABI.
+ */
+#ifndef VISPER_HIP_H
+#define VISPER_HIP_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* vp_stream_t; /* hipStream_t */
+
+#define VP_OK 0
+#define VP_ERR_BAD_ARG (-1)
+#define VP_ERR_UNSUPPORTED_SHAPE (-2)
+#define VP_ERR_HIP (-3)
+
+/* epilogue / activation kinds */
+#define VP_EPI_NONE 0
+#define VP_EPI_GELU 1       /* erf GELU: multimodal_projector/builder.py:57, resampler.py:14 */
+#define VP_EPI_QUICK_GELU 2 /* HF: CLIPMLP quick_gelu */
+#define VP_EPI_RELU 3       /* aux_heads/da_v2_head.py:331-335 build_mlp */
+
+const char* vp_last_error_string(void);
+int vp_version(void);
+int vp_device_info(int* cu_count, int* wave_size, long* lds_bytes_per_cu);
+
+/* ---- GEMM: C[M,N] = epi(A[M,K] . B[N,K]^T + bias[N]) + residual[M,N]   (bf16 in, fp32 MFMA accumulate)
+ * replaces every nn.Linear / F.linear on the path: HF LlamaAttention/LlamaMLP q,k,v,o,gate,up,down
+ * (HF modeling_llama.py), CLIP q,k,v,out,fc1,fc2 (HF modeling_clip.py), lm_head (ola_llama.py:121),
+ * mm_projector (multimodal_projector/builder.py:53-60), resampler proj_in/to_q/to_kv/to_out/FF/proj_out
+ * (multimodal_projector/resampler.py:9-16,40-44,186-190), depth MLPs (aux_heads/da_v2_head.py:439-442).
+ * out_f32=1 writes fp32 (used for weight gradients). force_generic=1 selects the bounds-checked kernel. */
+int vp_gemm_bf16(int M, int N, int K, const void* A, long lda, const void* B, long ldb, void* C, long ldc,
+                 const void* bias, const void* residual, long ldr, int epilogue, int out_f32, int force_generic,
+                 vp_stream_t stream);
+int vp_transpose_bf16(int rows, int cols, const void* in, long ld_in, void* out, long ld_out, vp_stream_t stream);
+
+/* ---- norms.  HF LlamaRMSNorm (modeling_llama.py:53-68); nn.LayerNorm in CLIP and the resampler
+ * (resampler.py:12,37-38,189).  rstd/mean: fp32 [M] saved for backward. */
+int vp_rmsnorm_fwd(int M, int H, const void* x, long ldx, const void* w, float eps, void* y, long ldy, float* rstd,
+                   vp_stream_t stream);
+int vp_rmsnorm_bwd(int M, int H, const void* dy, const void* x, const void* w, const float* rstd, const void* dres,
+                   void* dx, long ld, vp_stream_t stream);
+int vp_layernorm_fwd(int M, int H, const void* x, long ldx, const void* w, const void* b, float eps, void* y, long ldy,
+                     float* mean, float* rstd, vp_stream_t stream);
+int vp_layernorm_bwd_dx(int M, int H, const void* dy, const void* x, const void* w, const float* mean,
+                        const float* rstd, const void* dres, void* dx, long ld, vp_stream_t stream);
+int vp_layernorm_bwd_wb_partial(int M, int H, const void* dy, const void* x, const float* mean, const float* rstd,
+                                float* pw, float* pb, long ld, int rows_per_block, vp_stream_t stream);
+
+/* ---- elementwise.  RoPE rotate-half (HF modeling_llama.py:138-160), SwiGLU (HF LlamaMLP :175-177),
+ * GELU / ReLU fwd+bwd for the trainable projector/heads, residual adds. */
+int vp_rope(long T, int S, int nheads, int head_dim, void* x, long ld, const float* cos_t, const float* sin_t,
+            const int* pos, int inverse, vp_stream_t stream);
+int vp_swiglu_fwd(long M, int F, const void* gate_up, long ldg, void* out, long ldo, vp_stream_t stream);
+int vp_swiglu_bwd(long M, int F, const void* dact, long ldd, const void* gate_up, void* dgate_up, long ldg,
+                  vp_stream_t stream);
+int vp_act_fwd(int kind, long n, const void* x, void* y, vp_stream_t stream);
+int vp_act_bwd(int kind, long n, const void* dy, const void* x, void* dx, vp_stream_t stream);
+int vp_add_bf16(long n, const void* a, const void* b, void* out, vp_stream_t stream);
+int vp_add2d_bf16(long R, int C, void* dst, long ldd, const void* src, long lds, vp_stream_t stream);
+int vp_copy2d_bf16(long R, int C, void* dst, long ldd, const void* src, long lds, vp_stream_t stream);
+/* bias gradients (column sums), two deterministic stages */
+int vp_colsum_partial(long M, int N, const void* x, long ld, float* part, int rows_per_block, vp_stream_t stream);
+int vp_colsum_finish(int nslab, int N, const float* part, float* out, float scale, int accumulate, vp_stream_t stream);
+
+/* ---- sequence splice (ola_arch.py:224-254 append_special_tokens, :345-429 embed/concat/pad) as a row
+ * gather driven by a host-built index table, and its backward as a gather-sum. */
+int vp_gather_rows(long n_out, int H, const void* const* srcs, const long* lds, int nsrc, const int* kind,
+                   const int* row, void* out, long ldo, vp_stream_t stream);
+int vp_gather_sum_rows(long n_out, int cnt, int H, const void* src, long lds, int src_f32, const int* idx, float scale,
+                       void* out, long ldo, int out_f32, int accumulate, vp_stream_t stream);
+
+int vp_cast_f32_to_bf16(long n, const float* x, void* y, vp_stream_t stream);
+int vp_cast_bf16_to_f32(long n, const void* x, float* y, int accumulate, vp_stream_t stream);
+int vp_sum_f32(long n, const float* x, float* out, float scale, vp_stream_t stream);
+
+/* ---- attention.  HF LlamaAttention eager path (modeling_llama.py:191-214: QK^T/sqrt(d) + causal mask,
+ * fp32 softmax, PV), HF CLIPAttention (non-causal), PerceiverAttention (resampler.py:46-75; scale d^-1/4
+ * on q and k == d^-1/2 on the product).  Tensors are [B,S,H,D] views (strides in elements). */
+int vp_attn_fwd(int B, int Hq, int Hkv, int Sq, int Skv, int D, const void* q, long q_bs, long q_ts, const void* k,
+                long k_bs, long k_ts, const void* v, long v_bs, long v_ts, void* o, long o_bs, long o_ts, float* lse,
+                const int* kv_len, int causal, int window, float scale, vp_stream_t stream);
+int vp_attn_bwd(int B, int Hq, int Hkv, int Sq, int Skv, int D, const void* q, long q_bs, long q_ts, const void* k,
+                long k_bs, long k_ts, const void* v, long v_bs, long v_ts, const void* o, long o_bs, long o_ts,
+                const float* lse, const void* dout, long do_bs, long do_ts, void* dq, long dq_bs, long dq_ts, void* dk,
+                long dk_bs, long dk_ts, void* dv, long dv_bs, long dv_ts, float* delta, const int* kv_len, int causal,
+                int window, float scale, vp_stream_t stream);
+
+/* ---- losses.  NTP CE (ola_llama.py:121-136: logits.float(), shifted CrossEntropyLoss, ignore -100);
+ * embedding distillation (base_ola_vlm.py:289-320 _emb_loss; ola_utils.py:108-125
+ * calculate_contrastive_loss; :96-106 dist_collect -> tgt_all is the rank-ordered all-gather). */
+int vp_ce_fwd_bwd(long rows, int V, void* logits, long ld, const long* labels, float* row_loss, float grad_scale,
+                  int write_grad, vp_stream_t stream);
+int vp_emb_loss_nblk(long D);
+int vp_emb_loss_fwd(int B, int Bw, long D, int rank, const void* pred, const void* tgt_all, const float* mask,
+                    const float* logit_scale, float w_contrastive, float* out3, float* coef, float* part,
+                    vp_stream_t stream);
+int vp_emb_loss_bwd(int B, int Bw, long D, int rank, const void* pred, const void* tgt_all, const float* coef,
+                    float grad_out, void* dpred, vp_stream_t stream);
+
+/* ---- optimizer.  HF Trainer `adamw_torch` (ola_vlm_train.py:124; torch.optim.AdamW semantics) fused over
+ * the flat fp32 master buffer, bf16 shadow refreshed in the same pass. */
+int vp_adamw(long n, float* p, const float* g, float* m, float* v, void* bf16_shadow, float lr, float beta1, float beta2,
+             float eps, float weight_decay, int step, float grad_scale, vp_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,317 @@
+"""GPU parity of every C-ABI kernel against a CPU fp32 restatement (oracle functions where the op is a
+reference op, plain torch math otherwise).  Inputs are bf16-rounded on the host so both sides see the
+same values; tolerances are stated per test (bf16 outputs: ~2^-8 relative)."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+BF = torch.bfloat16
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from visper_lm_amd import ops as o
+    return o
+
+
+def rnd(*shape, scale=1.0, seed=0):
+    g = torch.Generator().manual_seed(seed + sum(shape) * 7919 + len(shape))
+    return (torch.randn(*shape, generator=g) * scale).to(BF)
+
+
+def dev(t):
+    return t.cuda()
+
+
+def close(got, ref, rtol=2e-2, atol=None, what=""):
+    got = got.detach().float().cpu()
+    ref = ref.detach().float().cpu()
+    assert got.shape == ref.shape, (what, got.shape, ref.shape)
+    if atol is None:
+        atol = 1e-2 * float(ref.abs().max()) + 1e-6
+    err = (got - ref).abs()
+    tol = atol + rtol * ref.abs()
+    bad = err > tol
+    assert not bool(bad.any()), f"{what}: {int(bad.sum())}/{bad.numel()} off; max err {float(err.max()):.4g} (ref max {float(ref.abs().max()):.4g})"
+
+
+# ------------------------------------------------------------------------------------------------ GEMM
+@pytest.mark.parametrize("M,N,K,generic", [(256, 256, 256, False), (300, 200, 128, False), (128, 128, 64, False),
+                                           (77, 50, 40, True), (300, 200, 128, True), (1, 1024, 64, False),
+                                           (577 * 2, 1024, 1024, False)])
+def test_gemm_plain(ops, M, N, K, generic):
+    a, w = rnd(M, K, seed=1), rnd(N, K, scale=0.1, seed=2)
+    ref = a.float() @ w.float().t()
+    out = ops.gemm(dev(a), dev(w), force_generic=generic)
+    close(out, ref, what=f"gemm {M}x{N}x{K}")
+    out32 = ops.gemm(dev(a), dev(w), out_f32=True, force_generic=generic)
+    close(out32, ref, rtol=1e-3, atol=1e-3 * float(ref.abs().max()), what="gemm f32 out")
+
+
+@pytest.mark.parametrize("epi", [0, 1, 2, 3])
+def test_gemm_epilogues(ops, epi):
+    M, N, K = 200, 328, 192
+    a, w, b, r = rnd(M, K, seed=3), rnd(N, K, scale=0.1, seed=4), rnd(N, seed=5), rnd(M, N, seed=6)
+    y = a.float() @ w.float().t() + b.float()
+    y = y.to(BF).float()
+    if epi == 1:
+        y = F.gelu(y)
+    elif epi == 2:
+        y = y * torch.sigmoid(1.702 * y)
+    elif epi == 3:
+        y = F.relu(y)
+    ref = y.to(BF).float() + r.float()
+    out = ops.gemm(dev(a), dev(w), bias=dev(b), residual=dev(r), epi=epi)
+    close(out, ref, what=f"gemm epi {epi}")
+
+
+def test_gemm_strided_views(ops):
+    # A is a column slice of a wider buffer, C is written into a column slice (fused-QKV style)
+    M, K, N = 192, 128, 64
+    big = rnd(M, 3 * K, seed=7)
+    w = rnd(N, K, scale=0.1, seed=8)
+    a = big[:, K:2 * K]
+    ref = a.float() @ w.float().t()
+    bigd = dev(big)
+    outbuf = torch.zeros(M, 3 * N, device="cuda", dtype=BF)
+    ops.gemm(bigd[:, K:2 * K], dev(w), out=outbuf[:, N:2 * N])
+    close(outbuf[:, N:2 * N], ref, what="strided gemm")
+    assert float(outbuf[:, :N].abs().max()) == 0 and float(outbuf[:, 2 * N:].abs().max()) == 0
+
+
+def test_transpose(ops):
+    x = rnd(130, 75, seed=9)
+    out = ops.transpose(dev(x))
+    assert torch.equal(out.cpu(), x.t().contiguous())
+
+
+# ------------------------------------------------------------------------------------------------ norms
+@pytest.mark.parametrize("M,H", [(37, 64), (19, 1024), (9, 4096), (5, 1536)])
+def test_rmsnorm(ops, M, H):
+    from oracle import visper_oracle as O
+    x, w, dy, dres = rnd(M, H, seed=10), (1 + 0.1 * rnd(H, seed=11).float()).to(BF), rnd(M, H, seed=12), rnd(M, H, seed=13)
+    xr = x.float().requires_grad_(True)
+    y_ref = O.rms_norm(xr, w.float(), 1e-5)
+    y_ref.backward(dy.float())
+    y, rstd = ops.rmsnorm_fwd(dev(x), dev(w), 1e-5)
+    close(y, y_ref, what="rmsnorm fwd")
+    dx = ops.rmsnorm_bwd(dev(dy), dev(x), dev(w), rstd, dres=dev(dres))
+    close(dx, xr.grad + dres.float(), what="rmsnorm bwd")
+
+
+@pytest.mark.parametrize("M,H", [(37, 64), (19, 1024), (300, 1536)])
+def test_layernorm(ops, M, H):
+    x, w, b, dy = rnd(M, H, seed=14), (1 + 0.1 * rnd(H, seed=15).float()).to(BF), rnd(H, scale=0.1, seed=16), rnd(M, H, seed=17)
+    xr, wr, br = x.float().requires_grad_(True), w.float().requires_grad_(True), b.float().requires_grad_(True)
+    y_ref = F.layer_norm(xr, (H,), wr, br, 1e-5)
+    y_ref.backward(dy.float())
+    y, mean, rstd = ops.layernorm_fwd(dev(x), dev(w), dev(b), 1e-5)
+    close(y, y_ref, what="layernorm fwd")
+    dx, dw, db = ops.layernorm_bwd(dev(dy), dev(x), dev(w), mean, rstd)
+    close(dx, xr.grad, what="layernorm dx")
+    close(dw, wr.grad, rtol=1e-2, what="layernorm dw")
+    close(db, br.grad, rtol=1e-2, what="layernorm db")
+
+
+# ------------------------------------------------------------------------------------------------ elementwise
+def test_rope_fwd_and_inverse(ops):
+    from oracle import visper_oracle as O
+    B, S, nh, hd = 2, 50, 3, 64
+    x = rnd(B, S, nh * hd + 32, seed=18)                  # row-strided buffer, rope on the first nh*hd columns
+    pos = torch.arange(S)[None].expand(B, S)
+    cos, sin = O.rope_tables(pos, hd, 10000.0, BF)
+    q = x[..., :nh * hd].reshape(B, S, nh, hd).transpose(1, 2).float()
+    c, s = cos[:, None].float(), sin[:, None].float()
+    ref = (q * c + O._rot_half(q) * s).transpose(1, 2).reshape(B, S, nh * hd)
+    cs, sn = ops.rope_tables(S, hd, 10000.0, "cuda")
+    xd = dev(x).reshape(B * S, -1)
+    ops.rope_(xd, B * S, S, nh, hd, cs, sn)
+    close(xd[:, :nh * hd].reshape(B, S, -1), ref, what="rope fwd")
+    assert torch.equal(xd[:, nh * hd:].cpu(), x.reshape(B * S, -1)[:, nh * hd:])
+    # inverse == autograd transpose of the rotation
+    g = rnd(B, S, nh * hd, seed=19)
+    qq = torch.randn(B, nh, S, hd, requires_grad=True)
+    (qq * c + O._rot_half(qq) * s).backward(g.reshape(B, S, nh, hd).transpose(1, 2).float())
+    gd = dev(g).reshape(B * S, -1).clone()
+    ops.rope_(gd, B * S, S, nh, hd, cs, sn, inverse=True)
+    close(gd.reshape(B, S, nh, hd), qq.grad.transpose(1, 2), what="rope inverse")
+
+
+def test_swiglu(ops):
+    M, Fd = 33, 136
+    gu, d = rnd(M, 2 * Fd, seed=20), rnd(M, Fd, seed=21)
+    gr = gu.float().requires_grad_(True)
+    ref = F.silu(gr[:, :Fd]) * gr[:, Fd:]
+    ref.backward(d.float())
+    close(ops.swiglu_fwd(dev(gu)), ref, what="swiglu fwd")
+    close(ops.swiglu_bwd(dev(d), dev(gu)), gr.grad, what="swiglu bwd")
+
+
+@pytest.mark.parametrize("kind", [1, 3])
+def test_act(ops, kind):
+    x, d = rnd(40, 64, seed=22), rnd(40, 64, seed=23)
+    xr = x.float().requires_grad_(True)
+    ref = F.gelu(xr) if kind == 1 else F.relu(xr)
+    ref.backward(d.float())
+    close(ops.act_fwd(dev(x), kind), ref, what="act fwd")
+    close(ops.act_bwd(dev(d), dev(x), kind), xr.grad, what="act bwd")
+
+
+def test_add_colsum_cast(ops):
+    a, b = rnd(70, 64, seed=24), rnd(70, 64, seed=25)
+    close(ops.add(dev(a), dev(b)), a.float() + b.float(), what="add")
+    close(ops.colsum(dev(a)), a.float().sum(0), rtol=1e-3, what="colsum")
+    x32 = torch.randn(1000)
+    assert torch.equal(ops.cast_to_bf16(x32.cuda()).cpu(), x32.to(BF))
+    close(ops.sum_f32(x32.cuda(), 0.5), x32.sum()[None] * 0.5, rtol=1e-4, atol=1e-3, what="sum")
+    dst = dev(rnd(20, 96, seed=26)); src = dev(rnd(20, 64, seed=27))
+    ref = dst.clone().float().cpu(); ref[:, 16:80] += src.float().cpu()
+    ops.add2d_(dst[:, 16:80], src)
+    close(dst, ref, what="add2d")
+
+
+def test_gather_and_gather_sum(ops):
+    H = 64
+    s0, s1, s2 = rnd(10, H, seed=28), rnd(7, H, seed=29), rnd(5, H, seed=30)
+    kind = torch.tensor([0, 1, -1, 2, 0, 1, 2, -1, 0], dtype=torch.int32)
+    row = torch.tensor([3, 6, 0, 4, 9, 0, 1, 0, 0], dtype=torch.int32)
+    out = torch.empty(len(kind), H, device="cuda", dtype=BF)
+    ops.gather_rows([dev(s0), dev(s1), dev(s2)], kind.cuda(), row.cuda(), H, out)
+    srcs = [s0, s1, s2]
+    ref = torch.stack([srcs[k][r] if k >= 0 else torch.zeros(H, dtype=BF) for k, r in zip(kind.tolist(), row.tolist())])
+    assert torch.equal(out.cpu(), ref)
+    idx = torch.tensor([[0, 1, 2], [3, -1, 9], [4, 4, 4]], dtype=torch.int32)
+    o2 = torch.empty(3, H, device="cuda", dtype=torch.float32)
+    ops.gather_sum_rows(dev(s0), idx.cuda().flatten(), 3, 0.5, o2)
+    ref2 = torch.stack([sum(s0[i].float() for i in r if i >= 0) * 0.5 for r in idx.tolist()])
+    close(o2, ref2, rtol=1e-4, what="gather_sum")
+
+
+def test_adamw(ops):
+    n = 5000
+    p0, g = torch.randn(n), torch.randn(n)
+    pr = p0.clone().requires_grad_(True)
+    opt = torch.optim.AdamW([pr], lr=1e-2, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.1)
+    p, m, v = p0.clone().cuda(), torch.zeros(n).cuda(), torch.zeros(n).cuda()
+    sh = torch.empty(n, device="cuda", dtype=BF)
+    for step in (1, 2, 3):
+        pr.grad = g.clone() * step
+        opt.step()
+        ops.adamw_(p, (g * step).cuda(), m, v, sh, 1e-2, 0.9, 0.999, 1e-8, 0.1, step)
+    close(p, pr.detach(), rtol=1e-5, atol=1e-6, what="adamw")
+    assert torch.equal(sh.cpu(), p.cpu().to(BF))
+
+
+# ------------------------------------------------------------------------------------------------ attention
+def attn_ref(q, k, v, causal, kv_len=None, window=0):
+    """q [B,Sq,Hq,D], k,v [B,Skv,Hkv,D] fp32 -> o [B,Sq,Hq,D] with HF-eager semantics."""
+    B, Sq, Hq, D = q.shape
+    Skv, Hkv = k.shape[1], k.shape[2]
+    rep = Hq // Hkv
+    qq = q.transpose(1, 2)
+    kk = k.transpose(1, 2).repeat_interleave(rep, dim=1)
+    vv = v.transpose(1, 2).repeat_interleave(rep, dim=1)
+    s = qq @ kk.transpose(-1, -2) / math.sqrt(D)
+    i = torch.arange(Sq)[:, None] + (Skv - Sq)
+    j = torch.arange(Skv)[None, :]
+    allow = torch.ones(Sq, Skv, dtype=torch.bool)
+    if causal:
+        allow &= j <= i
+    if window > 0:
+        allow &= j > i - window
+    allow = allow[None, None].expand(B, 1, Sq, Skv).clone()
+    if kv_len is not None:
+        for b in range(B):
+            allow[b, :, :, kv_len[b]:] = False
+    s = s.masked_fill(~allow, float("-inf"))
+    return (torch.softmax(s, -1) @ vv).transpose(1, 2)
+
+
+@pytest.mark.parametrize("B,Hq,Hkv,Sq,Skv,D,causal", [
+    (2, 4, 2, 128, 128, 128, True),       # Llama-style GQA causal
+    (1, 4, 4, 200, 200, 64, True),        # ragged length causal
+    (2, 4, 4, 577, 577, 64, False),       # ViT
+    (2, 4, 4, 1, 100, 32, False),         # gen head: one query
+    (2, 4, 4, 70, 210, 32, False),        # resampler cross attention
+    (1, 2, 2, 150, 150, 96, True),        # Phi-3 head dim
+    (1, 8, 2, 320, 320, 128, True),
+])
+def test_attention_fwd_bwd(ops, B, Hq, Hkv, Sq, Skv, D, causal):
+    q, k, v, do = rnd(B, Sq, Hq, D, seed=31), rnd(B, Skv, Hkv, D, seed=32), rnd(B, Skv, Hkv, D, seed=33), rnd(B, Sq, Hq, D, seed=34)
+    qr, kr, vr = (t.float().requires_grad_(True) for t in (q, k, v))
+    ref = attn_ref(qr, kr, vr, causal)
+    ref.backward(do.float())
+    qd, kd, vd = dev(q), dev(k), dev(v)
+    o, lse = ops.attn_fwd(qd, kd, vd, causal)
+    close(o, ref, what="attn fwd")
+    dq, dk, dv = ops.attn_bwd(qd, kd, vd, o, lse, dev(do), causal)
+    close(dq, qr.grad, rtol=3e-2, what="attn dq")
+    close(dk, kr.grad, rtol=3e-2, what="attn dk")
+    close(dv, vr.grad, rtol=3e-2, what="attn dv")
+
+
+def test_attention_fused_qkv_views_and_kvlen(ops):
+    B, S, Hq, Hkv, D = 2, 96, 4, 2, 64
+    qkv = rnd(B, S, (Hq + 2 * Hkv) * D, seed=35)
+    kv_len = [96, 61]
+    q = qkv[..., :Hq * D].reshape(B, S, Hq, D)
+    k = qkv[..., Hq * D:(Hq + Hkv) * D].reshape(B, S, Hkv, D)
+    v = qkv[..., (Hq + Hkv) * D:].reshape(B, S, Hkv, D)
+    ref = attn_ref(q.float(), k.float(), v.float(), True, kv_len=kv_len)
+    d = dev(qkv)
+    qd = d[..., :Hq * D].view(B, S, Hq, D)
+    kd = d[..., Hq * D:(Hq + Hkv) * D].view(B, S, Hkv, D)
+    vd = d[..., (Hq + Hkv) * D:].view(B, S, Hkv, D)
+    o, lse = ops.attn_fwd(qd, kd, vd, True, kv_len=torch.tensor(kv_len, dtype=torch.int32).cuda())
+    close(o, ref, what="attn fused-qkv kvlen")
+
+
+def test_attention_sliding_window(ops):
+    B, S, H, D = 1, 200, 2, 32
+    q, k, v = rnd(B, S, H, D, seed=36), rnd(B, S, H, D, seed=37), rnd(B, S, H, D, seed=38)
+    ref = attn_ref(q.float(), k.float(), v.float(), True, window=70)
+    o, _ = ops.attn_fwd(dev(q), dev(k), dev(v), True, window=70)
+    close(o, ref, what="attn window")
+
+
+# ------------------------------------------------------------------------------------------------ losses
+def test_ce(ops):
+    rows, V = 37, 1000
+    lg = rnd(rows, V, scale=2.0, seed=39)
+    labels = torch.randint(0, V, (rows,))
+    labels[::5] = -100
+    n = int((labels != -100).sum())
+    lr = lg.float().requires_grad_(True)
+    ref = F.cross_entropy(lr, labels, ignore_index=-100, reduction="sum")
+    (ref / n).backward()
+    lgd = dev(lg)
+    rl = ops.ce_fwd_bwd(lgd, labels.cuda(), 1.0 / n)
+    close(rl.sum()[None], ref[None], rtol=1e-4, atol=1e-3, what="ce loss")
+    close(lgd, lr.grad, rtol=2e-2, atol=2e-3 * float(lr.grad.abs().max()), what="ce dlogits")
+
+
+@pytest.mark.parametrize("B,world,rank,shape,mask", [(3, 1, 0, (3, 40, 1024), [1., 0., 1.]), (2, 4, 2, (2, 96, 24), [1., 1.]),
+                                                     (8, 1, 0, (8, 1, 1024), [1.] * 8), (4, 2, 1, (4, 1536, 6, 6), [1., 1., 0., 1.])])
+def test_emb_loss(ops, B, world, rank, shape, mask):
+    from oracle import visper_oracle as O
+    D = math.prod(shape[1:])
+    pred = rnd(*shape, scale=1.3, seed=40)
+    tg_all = rnd(B * world, D, seed=41)
+    tgt = tg_all[rank * B:(rank + 1) * B].reshape(shape)
+    pr = pred.float().requires_grad_(True)
+    ls = torch.tensor(2.0, requires_grad=True)
+    gathered = F.normalize(tg_all.float(), dim=-1)
+    e, s1, c = O.emb_loss(pr, torch.tensor(mask), tgt.float(), ls, 0.3, rank=rank, gathered_targets=gathered)
+    (e * 0.5).backward()
+    out3, coef = ops.emb_loss_fwd(dev(pred).reshape(B, D), dev(tg_all), torch.tensor(mask).cuda(), torch.tensor([2.0]).cuda(), 0.3,
+                                  rank=rank)
+    close(out3, torch.stack([e, s1, c]).detach(), rtol=2e-3, atol=1e-5, what="emb loss fwd")
+    dp = ops.emb_loss_bwd(dev(pred).reshape(B, D), dev(tg_all), coef, 0.5, rank=rank)
+    close(dp.reshape(shape), pr.grad, rtol=3e-2, atol=2e-2 * float(pr.grad.abs().max()), what="emb loss dpred")
+    close(coef[-1:] * 0.5, ls.grad[None], rtol=5e-3, atol=1e-6, what="dlogit_scale")

@@ -1,0 +1,86 @@
+"""ctypes binding of libvisper_hip.so (the C ABI declared in include/visper_hip.h).
+
+The product path has NO CPU fallback: if the library is missing, or a call returns non-zero,
+this module raises.  `import torch` happens first so the HIP runtime that PyTorch already loaded
+(libamdhip64.so.7) is the one the kernels launch on (same streams, same device memory)."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch  # noqa: F401  (must be loaded before the library: shares its HIP runtime)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libvisper_hip.so")
+
+i, l, f, p = C.c_int, C.c_long, C.c_float, C.c_void_p
+
+# name -> argtypes (every function returns int unless listed in _RET)
+_SIGS = {
+    "vp_version": [],
+    "vp_device_info": [p, p, p],
+    "vp_gemm_bf16": [i, i, i, p, l, p, l, p, l, p, p, l, i, i, i, p],
+    "vp_transpose_bf16": [i, i, p, l, p, l, p],
+    "vp_rmsnorm_fwd": [i, i, p, l, p, f, p, l, p, p],
+    "vp_rmsnorm_bwd": [i, i, p, p, p, p, p, p, l, p],
+    "vp_layernorm_fwd": [i, i, p, l, p, p, f, p, l, p, p, p],
+    "vp_layernorm_bwd_dx": [i, i, p, p, p, p, p, p, p, l, p],
+    "vp_layernorm_bwd_wb_partial": [i, i, p, p, p, p, p, p, l, i, p],
+    "vp_rope": [l, i, i, i, p, l, p, p, p, i, p],
+    "vp_swiglu_fwd": [l, i, p, l, p, l, p],
+    "vp_swiglu_bwd": [l, i, p, l, p, p, l, p],
+    "vp_act_fwd": [i, l, p, p, p],
+    "vp_act_bwd": [i, l, p, p, p, p],
+    "vp_add_bf16": [l, p, p, p, p],
+    "vp_add2d_bf16": [l, i, p, l, p, l, p],
+    "vp_copy2d_bf16": [l, i, p, l, p, l, p],
+    "vp_colsum_partial": [l, i, p, l, p, i, p],
+    "vp_colsum_finish": [i, i, p, p, f, i, p],
+    "vp_gather_rows": [l, i, p, p, i, p, p, p, l, p],
+    "vp_gather_sum_rows": [l, i, i, p, l, i, p, f, p, l, i, i, p],
+    "vp_cast_f32_to_bf16": [l, p, p, p],
+    "vp_cast_bf16_to_f32": [l, p, p, i, p],
+    "vp_sum_f32": [l, p, p, f, p],
+    "vp_attn_fwd": [i, i, i, i, i, i, p, l, l, p, l, l, p, l, l, p, l, l, p, p, i, i, f, p],
+    "vp_attn_bwd": [i, i, i, i, i, i, p, l, l, p, l, l, p, l, l, p, l, l, p, p, l, l, p, l, l, p, l, l, p, l, l, p, p,
+                    i, i, f, p],
+    "vp_ce_fwd_bwd": [l, i, p, l, p, p, f, i, p],
+    "vp_emb_loss_nblk": [l],
+    "vp_emb_loss_fwd": [i, i, l, i, p, p, p, p, f, p, p, p, p],
+    "vp_emb_loss_bwd": [i, i, l, i, p, p, p, f, p, p],
+    "vp_adamw": [l, p, p, p, p, p, f, f, f, f, f, i, f, p],
+}
+EXPORTS = ["vp_last_error_string"] + list(_SIGS)
+
+_lib = None
+
+
+def load():
+    """Load the library (raises if it has not been built: run `python __graft_entry__.py` / build())."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"{LIB_PATH} not found — the HIP extension is not built (no CPU fallback exists). "
+                               "Run __graft_entry__.build().")
+        lib = C.CDLL(LIB_PATH)
+        lib.vp_last_error_string.restype = C.c_char_p
+        lib.vp_last_error_string.argtypes = []
+        for name, args in _SIGS.items():
+            fn = getattr(lib, name)
+            fn.argtypes = args
+            fn.restype = C.c_int
+        _lib = lib
+    return _lib
+
+
+def call(name, *args):
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        raise RuntimeError(f"{name} failed ({rc}): {lib.vp_last_error_string().decode()}")
+    return rc
+
+
+def raw(name, *args):
+    """Call returning the raw int (for query functions such as vp_emb_loss_nblk / vp_version)."""
+    return getattr(load(), name)(*args)

@@ -1,0 +1,308 @@
+"""Tensor-level wrappers over the C ABI (include/visper_hip.h).  PyTorch provides device memory and
+streams only; every computation is a libvisper_hip kernel.  All tensors must live on the current HIP
+device; bf16 unless stated.  No CPU fallback: a CPU tensor raises."""
+from __future__ import annotations
+
+import ctypes as C
+import math
+
+import torch
+
+from . import _lib
+
+EPI_NONE, EPI_GELU, EPI_QUICK_GELU, EPI_RELU = 0, 1, 2, 3
+BF16 = torch.bfloat16
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("visper_lm_amd ops need device tensors (there is no CPU path)")
+    return C.c_void_p(t.data_ptr())
+
+
+def _rows2d(t):
+    """(rows, cols, ld) of a tensor viewed as 2-D with a contiguous last dim."""
+    assert t.stride(-1) == 1, "last dim must be contiguous"
+    if t.dim() == 1:
+        return 1, t.shape[0], t.shape[0]
+    if t.dim() == 2:
+        return t.shape[0], t.shape[1], t.stride(0)
+    assert t.is_contiguous(), "3-D+ tensors must be contiguous"
+    return t.numel() // t.shape[-1], t.shape[-1], t.shape[-1]
+
+
+# ------------------------------------------------------------------------------------------------
+def gemm(a, w, bias=None, residual=None, epi=EPI_NONE, out=None, out_f32=False, force_generic=False):
+    """out[M,N] = epi(a[M,K] @ w[N,K]^T + bias) + residual."""
+    M, K, lda = _rows2d(a)
+    N, K2, ldb = _rows2d(w)
+    assert K == K2, (a.shape, w.shape)
+    assert a.dtype == BF16 and w.dtype == BF16
+    if out is None:
+        out = torch.empty(*a.shape[:-1], N, device=a.device, dtype=torch.float32 if out_f32 else BF16)
+    _, _, ldc = _rows2d(out)
+    ldr = 0
+    if residual is not None:
+        _, _, ldr = _rows2d(residual)
+    _lib.call("vp_gemm_bf16", M, N, K, _p(a), lda, _p(w), ldb, _p(out), ldc, _p(bias), _p(residual), ldr, epi,
+              1 if out.dtype == torch.float32 else 0, 1 if force_generic else 0, _stream())
+    return out
+
+
+def transpose(x, out=None):
+    """2-D transpose (bf16)."""
+    R, Cc, ldi = _rows2d(x)
+    if out is None:
+        out = torch.empty(Cc, R, device=x.device, dtype=BF16)
+    _lib.call("vp_transpose_bf16", R, Cc, _p(x), ldi, _p(out), out.stride(0), _stream())
+    return out
+
+
+def rmsnorm_fwd(x, w, eps, save_rstd=True):
+    M, H, ldx = _rows2d(x)
+    y = torch.empty(x.shape, device=x.device, dtype=BF16)
+    rstd = torch.empty(M, device=x.device, dtype=torch.float32) if save_rstd else None
+    _lib.call("vp_rmsnorm_fwd", M, H, _p(x), ldx, _p(w), eps, _p(y), H, _p(rstd), _stream())
+    return y, rstd
+
+
+def rmsnorm_bwd(dy, x, w, rstd, dres=None):
+    M, H, ld = _rows2d(x)
+    assert dy.is_contiguous() and x.is_contiguous()
+    dx = torch.empty_like(x)
+    _lib.call("vp_rmsnorm_bwd", M, H, _p(dy), _p(x), _p(w), _p(rstd), _p(dres), _p(dx), ld, _stream())
+    return dx
+
+
+def layernorm_fwd(x, w, b, eps=1e-5, save_stats=True):
+    M, H, ldx = _rows2d(x)
+    y = torch.empty(x.shape, device=x.device, dtype=BF16)
+    mean = torch.empty(M, device=x.device, dtype=torch.float32) if save_stats else None
+    rstd = torch.empty(M, device=x.device, dtype=torch.float32) if save_stats else None
+    _lib.call("vp_layernorm_fwd", M, H, _p(x), ldx, _p(w), _p(b), eps, _p(y), H, _p(mean), _p(rstd), _stream())
+    return y, mean, rstd
+
+
+def layernorm_bwd(dy, x, w, mean, rstd, dres=None, want_wb=True):
+    """-> dx (bf16), dw (f32), db (f32)."""
+    M, H, ld = _rows2d(x)
+    assert dy.is_contiguous() and x.is_contiguous()
+    dx = torch.empty_like(x)
+    _lib.call("vp_layernorm_bwd_dx", M, H, _p(dy), _p(x), _p(w), _p(mean), _p(rstd), _p(dres), _p(dx), ld, _stream())
+    if not want_wb:
+        return dx, None, None
+    rpb = max(1, (M + 255) // 256)
+    nslab = (M + rpb - 1) // rpb
+    pw = torch.empty(nslab, H, device=x.device, dtype=torch.float32)
+    pb = torch.empty(nslab, H, device=x.device, dtype=torch.float32)
+    _lib.call("vp_layernorm_bwd_wb_partial", M, H, _p(dy), _p(x), _p(mean), _p(rstd), _p(pw), _p(pb), ld, rpb, _stream())
+    dw = torch.empty(H, device=x.device, dtype=torch.float32)
+    db = torch.empty(H, device=x.device, dtype=torch.float32)
+    _lib.call("vp_colsum_finish", nslab, H, _p(pw), _p(dw), 1.0, 0, _stream())
+    _lib.call("vp_colsum_finish", nslab, H, _p(pb), _p(db), 1.0, 0, _stream())
+    return dx, dw, db
+
+
+def rope_tables(S, head_dim, theta, device):
+    """cos/sin [S, head_dim/2] fp32, rounded to bf16 first (HF casts the tables to the activation dtype)."""
+    inv = 1.0 / (theta ** (torch.arange(0, head_dim, 2, dtype=torch.float32) / head_dim))
+    fr = torch.arange(S, dtype=torch.float32)[:, None] * inv[None, :]
+    return (fr.cos().to(BF16).float().to(device).contiguous(), fr.sin().to(BF16).float().to(device).contiguous())
+
+
+def rope_(x2d, T, S, nheads, head_dim, cos_t, sin_t, pos=None, inverse=False):
+    """In-place rotate-half RoPE on a [T, >= nheads*head_dim] row-strided slice."""
+    _lib.call("vp_rope", T, S, nheads, head_dim, _p(x2d), x2d.stride(0), _p(cos_t), _p(sin_t), _p(pos), 1 if inverse else 0,
+              _stream())
+    return x2d
+
+
+def swiglu_fwd(gate_up):
+    M, F2, ldg = _rows2d(gate_up)
+    F = F2 // 2
+    out = torch.empty(*gate_up.shape[:-1], F, device=gate_up.device, dtype=BF16)
+    _lib.call("vp_swiglu_fwd", M, F, _p(gate_up), ldg, _p(out), F, _stream())
+    return out
+
+
+def swiglu_bwd(dact, gate_up):
+    M, F2, ldg = _rows2d(gate_up)
+    F = F2 // 2
+    _, _, ldd = _rows2d(dact)
+    dgu = torch.empty_like(gate_up)
+    _lib.call("vp_swiglu_bwd", M, F, _p(dact), ldd, _p(gate_up), _p(dgu), ldg, _stream())
+    return dgu
+
+
+def act_fwd(x, kind):
+    assert x.is_contiguous()
+    y = torch.empty_like(x)
+    _lib.call("vp_act_fwd", kind, x.numel(), _p(x), _p(y), _stream())
+    return y
+
+
+def act_bwd(dy, x, kind):
+    assert x.is_contiguous() and dy.is_contiguous()
+    dx = torch.empty_like(x)
+    _lib.call("vp_act_bwd", kind, x.numel(), _p(dy), _p(x), _p(dx), _stream())
+    return dx
+
+
+def add(a, b, out=None):
+    assert a.is_contiguous() and b.is_contiguous()
+    if out is None:
+        out = torch.empty_like(a)
+    _lib.call("vp_add_bf16", a.numel(), _p(a), _p(b), _p(out), _stream())
+    return out
+
+
+def add2d_(dst, src):
+    R, Cc, ldd = _rows2d(dst)
+    _, _, lds = _rows2d(src)
+    _lib.call("vp_add2d_bf16", R, Cc, _p(dst), ldd, _p(src), lds, _stream())
+    return dst
+
+
+def copy2d_(dst, src):
+    R, Cc, ldd = _rows2d(dst)
+    _, _, lds = _rows2d(src)
+    _lib.call("vp_copy2d_bf16", R, Cc, _p(dst), ldd, _p(src), lds, _stream())
+    return dst
+
+
+def colsum(x, out=None, accumulate=False, scale=1.0):
+    """fp32 column sums of a bf16 [M,N] matrix (bias gradient)."""
+    M, N, ld = _rows2d(x)
+    rpb = max(1, (M + 255) // 256)
+    nslab = (M + rpb - 1) // rpb
+    part = torch.empty(nslab, N, device=x.device, dtype=torch.float32)
+    _lib.call("vp_colsum_partial", M, N, _p(x), ld, _p(part), rpb, _stream())
+    if out is None:
+        out = torch.empty(N, device=x.device, dtype=torch.float32)
+        accumulate = False
+    _lib.call("vp_colsum_finish", nslab, N, _p(part), _p(out), scale, 1 if accumulate else 0, _stream())
+    return out
+
+
+def gather_rows(srcs, kind, row, H, out):
+    """out[i] = srcs[kind[i]][row[i]] (kind<0 -> zeros).  srcs: list of <=4 2-D bf16 tensors; kind,row int32."""
+    n = out.numel() // H
+    arr_p = (C.c_void_p * len(srcs))(*[t.data_ptr() for t in srcs])
+    arr_l = (C.c_long * len(srcs))(*[_rows2d(t)[2] for t in srcs])
+    _lib.call("vp_gather_rows", n, H, arr_p, arr_l, len(srcs), _p(kind), _p(row), _p(out), H, _stream())
+    return out
+
+
+def gather_sum_rows(src, idx, cnt, scale, out, accumulate=False):
+    """out[i] = scale * sum_k src[idx[i*cnt+k]] (idx<0 skipped). src bf16/f32 2-D, out bf16/f32 2-D."""
+    n, H, ldo = _rows2d(out)
+    _, _, lds = _rows2d(src)
+    _lib.call("vp_gather_sum_rows", n, cnt, H, _p(src), lds, 1 if src.dtype == torch.float32 else 0, _p(idx), scale, _p(out), ldo,
+              1 if out.dtype == torch.float32 else 0, 1 if accumulate else 0, _stream())
+    return out
+
+
+def cast_to_bf16(x, out=None):
+    if out is None:
+        out = torch.empty(x.shape, device=x.device, dtype=BF16)
+    _lib.call("vp_cast_f32_to_bf16", x.numel(), _p(x), _p(out), _stream())
+    return out
+
+
+def cast_to_f32(x, out=None, accumulate=False):
+    if out is None:
+        out = torch.empty(x.shape, device=x.device, dtype=torch.float32)
+        accumulate = False
+    _lib.call("vp_cast_bf16_to_f32", x.numel(), _p(x), _p(out), 1 if accumulate else 0, _stream())
+    return out
+
+
+def sum_f32(x, scale=1.0, out=None):
+    if out is None:
+        out = torch.empty(1, device=x.device, dtype=torch.float32)
+    _lib.call("vp_sum_f32", x.numel(), _p(x), _p(out), scale, _stream())
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+def _bshd(t):
+    """strides (batch, token) of a [B,S,H,D] view whose (H,D) block is contiguous."""
+    B, S, H, D = t.shape
+    assert t.stride(3) == 1 and t.stride(2) == D, "heads must be contiguous within a token row"
+    return t.stride(0), t.stride(1)
+
+
+def attn_fwd(q, k, v, causal, scale=None, window=0, kv_len=None, out=None):
+    """q [B,Sq,Hq,D], k/v [B,Skv,Hkv,D] (views allowed) -> o [B,Sq,Hq,D], lse2 [B,Hq,Sq] (log2 domain)."""
+    B, Sq, Hq, D = q.shape
+    _, Skv, Hkv, _ = k.shape
+    if scale is None:
+        scale = 1.0 / math.sqrt(D)
+    if out is None:
+        out = torch.empty(B, Sq, Hq, D, device=q.device, dtype=BF16)
+    lse = torch.empty(B, Hq, Sq, device=q.device, dtype=torch.float32)
+    qb, qt = _bshd(q); kb, kt = _bshd(k); vb, vt = _bshd(v); ob, ot = _bshd(out)
+    _lib.call("vp_attn_fwd", B, Hq, Hkv, Sq, Skv, D, _p(q), qb, qt, _p(k), kb, kt, _p(v), vb, vt, _p(out), ob, ot, _p(lse),
+              _p(kv_len), 1 if causal else 0, window, scale, _stream())
+    return out, lse
+
+
+def attn_bwd(q, k, v, o, lse, dout, causal, scale=None, window=0, kv_len=None, dq=None, dk=None, dv=None):
+    B, Sq, Hq, D = q.shape
+    _, Skv, Hkv, _ = k.shape
+    if scale is None:
+        scale = 1.0 / math.sqrt(D)
+    if dq is None:
+        dq = torch.empty(B, Sq, Hq, D, device=q.device, dtype=BF16)
+    if dk is None:
+        dk = torch.empty(B, Skv, Hkv, D, device=q.device, dtype=BF16)
+    if dv is None:
+        dv = torch.empty(B, Skv, Hkv, D, device=q.device, dtype=BF16)
+    delta = torch.empty(B, Hq, Sq, device=q.device, dtype=torch.float32)
+    qb, qt = _bshd(q); kb, kt = _bshd(k); vb, vt = _bshd(v); ob, ot = _bshd(o); gb, gt = _bshd(dout)
+    dqb, dqt = _bshd(dq); dkb, dkt = _bshd(dk); dvb, dvt = _bshd(dv)
+    _lib.call("vp_attn_bwd", B, Hq, Hkv, Sq, Skv, D, _p(q), qb, qt, _p(k), kb, kt, _p(v), vb, vt, _p(o), ob, ot, _p(lse),
+              _p(dout), gb, gt, _p(dq), dqb, dqt, _p(dk), dkb, dkt, _p(dv), dvb, dvt, _p(delta), _p(kv_len),
+              1 if causal else 0, window, scale, _stream())
+    return dq, dk, dv
+
+
+# ------------------------------------------------------------------------------------------------
+def ce_fwd_bwd(logits, labels, grad_scale, write_grad=True):
+    """logits [rows, V] bf16 (overwritten with dlogits when write_grad), labels int64 [rows] -> row_loss f32 [rows]."""
+    rows, V, ld = _rows2d(logits)
+    row_loss = torch.empty(rows, device=logits.device, dtype=torch.float32)
+    _lib.call("vp_ce_fwd_bwd", rows, V, _p(logits), ld, _p(labels), _p(row_loss), grad_scale, 1 if write_grad else 0, _stream())
+    return row_loss
+
+
+def emb_loss_fwd(pred, tgt_all, mask, logit_scale, w_con, rank=0):
+    """pred [B, D] bf16, tgt_all [Bw, D] bf16 (rank-ordered gather), mask f32 [B], logit_scale f32 [1] or None.
+    -> out3 f32 [3] = (emb_loss, sl1, contrastive), coef (saved for backward)."""
+    B, D = pred.shape
+    Bw = tgt_all.shape[0]
+    nblk = _lib.raw("vp_emb_loss_nblk", D)
+    njc = (Bw + 7) // 8
+    part = torch.empty(njc * nblk * 88, device=pred.device, dtype=torch.float32)
+    coef = torch.empty(2 * B + B * Bw + 1, device=pred.device, dtype=torch.float32)
+    out3 = torch.empty(3, device=pred.device, dtype=torch.float32)
+    _lib.call("vp_emb_loss_fwd", B, Bw, D, rank, _p(pred), _p(tgt_all), _p(mask), _p(logit_scale), w_con, _p(out3), _p(coef),
+              _p(part), _stream())
+    return out3, coef
+
+
+def emb_loss_bwd(pred, tgt_all, coef, grad_out, rank=0):
+    B, D = pred.shape
+    dpred = torch.empty_like(pred)
+    _lib.call("vp_emb_loss_bwd", B, tgt_all.shape[0], D, rank, _p(pred), _p(tgt_all), _p(coef), grad_out, _p(dpred), _stream())
+    return dpred
+
+
+def adamw_(p, g, m, v, shadow, lr, beta1, beta2, eps, wd, step, grad_scale=1.0):
+    _lib.call("vp_adamw", p.numel(), _p(p), _p(g), _p(m), _p(v), _p(shadow), lr, beta1, beta2, eps, wd, step, grad_scale, _stream())
