@@ -135,8 +135,8 @@ def build_llama(tiny):
 
 
 TINY_LLAMA = dict(
-    vocab_size=128256, hidden_size=64, intermediate_size=128, num_hidden_layers=4, num_attention_heads=4,
-    num_key_value_heads=2, vit_hidden=64, vit_inter=128, vit_layers=3, vit_heads=4, aux_mode="gen-depth-seg",
+    vocab_size=128256, hidden_size=128, intermediate_size=256, num_hidden_layers=4, num_attention_heads=4,
+    num_key_value_heads=2, vit_hidden=128, vit_inter=256, vit_layers=3, vit_heads=4, aux_mode="gen-depth-seg",
     image_gen=dict(depth=1, dim_head=32, num_heads=4, num_tokens=1, output_dim=1024, ff_mult=1,
                    img_layer_indices="4", img_loss_weight=0.5),
     image_seg=dict(depth=1, dim_head=32, num_heads=4, num_tokens=576, output_dim=1536, ff_mult=1,

@@ -1,0 +1,85 @@
+"""Configuration object for the VisPer-LM PT step.  Mirrors the attribute names the reference copies onto
+`model.config` (ola_vlm/train/ola_vlm_train.py:1123-1229) plus the HF Llama / Phi-3 / CLIP hyper-parameters
+(hard-coded presets: the HF hub configs are not part of the reference and there is no network)."""
+from __future__ import annotations
+
+import copy
+
+IGNORE_INDEX = -100        # ola_vlm/constants.py:7
+IMAGE_TOKEN_INDEX = -200   # ola_vlm/constants.py:8
+
+
+class VisperConfig:
+    """Attribute bag with HF-config-like semantics (`hasattr`, `getattr(cfg, k, default)`, `to_dict`)."""
+
+    model_type = "ola_llama"
+
+    def __init__(self, **kw):
+        d = dict(
+            arch="llama",
+            vocab_size=128256, hidden_size=4096, intermediate_size=14336, num_hidden_layers=32,
+            num_attention_heads=32, num_key_value_heads=8, rms_norm_eps=1e-5, rope_theta=500000.0,
+            sliding_window=None, max_position_embeddings=8192,
+            # CLIP-ViT-L/14-336 tower (multimodal_encoder/clip_encoder.py)
+            mm_vision_tower="openai/clip-vit-large-patch14-336",
+            vit_hidden=1024, vit_inter=4096, vit_layers=24, vit_heads=16, vit_image=336, vit_patch=14, vit_eps=1e-5,
+            mm_vision_select_layer=-2, mm_vision_select_feature="patch", mm_projector_type="mlp2x_gelu",
+            mm_hidden_size=1024,
+            # distillation (ola_vlm_train.py:1149-1229)
+            aux_mode="gen-depth-seg", num_task_tokens=8, contrastive_loss_weight=0.3, use_contrastive=True,
+            pass_text_to_aux=True, task_token_format="emb",
+            image_gen=dict(depth=1, dim_head=32, num_heads=4, num_tokens=1, output_dim=1024, ff_mult=1,
+                           img_layer_indices="20", img_loss_weight=0.5),
+            image_depth=dict(depth=1, dim_head=32, num_heads=4, num_tokens=576, output_dim=1024, ff_mult=1,
+                             depth_layer_indices="18", depth_loss_weight=0.5),
+            image_seg=dict(depth=1, dim_head=32, num_heads=4, num_tokens=576, output_dim=1536, ff_mult=1,
+                           seg_layer_indices="18", seg_loss_weight=0.5),
+            tokenizer_model_max_length=4096, tokenizer_padding_side="right",
+            zero_masks=False,      # True reproduces the as-released `mask.zero_()` (base_ola_vlm.py:472-473,...)
+        )
+        d.update(kw)
+        if "mm_hidden_size" not in kw:
+            d["mm_hidden_size"] = d["vit_hidden"]
+        self.__dict__.update(d)
+
+    def to_dict(self):
+        return copy.deepcopy(self.__dict__)
+
+    def __repr__(self):
+        return f"VisperConfig({self.__dict__})"
+
+    @property
+    def head_dim(self):
+        return self.hidden_size // self.num_attention_heads
+
+    @property
+    def num_sys_tokens(self):
+        """ola_llama.py:65-69 / ola_phi3.py:68."""
+        if self.arch == "phi3":
+            return 13
+        return 26 if self.vocab_size < 128000 else 38
+
+    @property
+    def token_order(self):
+        return self.aux_mode.split("-") if self.aux_mode else []
+
+
+def llama3_8b(**kw) -> VisperConfig:
+    """BASELINE.json configs[1]: CLIP-ViT-L/14-336 + Llama-3-8B, one distillation layer per task (d18_s18_g20)."""
+    return VisperConfig(**kw)
+
+
+def phi3_mini(**kw) -> VisperConfig:
+    """BASELINE.json configs[4]: Phi-3-mini-4k (H 3072, 32 MHA heads x 96, FF 8192, V 32064, theta 1e4, window 2047)."""
+    d = dict(arch="phi3", vocab_size=32064, hidden_size=3072, intermediate_size=8192, num_hidden_layers=32,
+             num_attention_heads=32, num_key_value_heads=32, rope_theta=10000.0, sliding_window=2047,
+             max_position_embeddings=4096)
+    d.update(kw)
+    c = VisperConfig(**d)
+    c.model_type = "ola_phi3"
+    return c
+
+
+def layer_indices(spec) -> list:
+    """base_ola_vlm.py:97-102: '18-20' -> [17, 19]."""
+    return [int(i) - 1 for i in str(spec).split("-")]

@@ -1,0 +1,733 @@
+"""The MI355X-native VisPer-LM pre-training step (NTP + per-layer embedding distillation).
+
+`Engine` owns device-resident weights laid out for the HIP kernels and runs one fused forward+backward
+of the reference's hot path entirely through the C ABI (ops.py -> libvisper_hip.so):
+
+  CLIP-ViT tower (frozen, fwd only)                                   clip_encoder.py:47-59
+  -> mlp2x_gelu projector (trainable)                                 ola_arch.py:187-190, builder.py:53-60
+  -> token/image/task-token splice                                    ola_arch.py:224-254, 256-444
+  -> Llama-3 / Phi-3 decoder, every layer state tapped on demand      ola_llama.py:105-119
+  -> lm_head + shifted cross-entropy (row-chunked, logits never kept) ola_llama.py:121-136
+  -> TaskTokenResampler heads + smooth-L1/InfoNCE losses              base_ola_vlm.py:289-320, 413-534
+  -> backward: dgrad-only through the frozen decoder (PT stage: ola_vlm_train.py:1127-1131,1147),
+     wgrad for projector / heads / task tokens / logit scales.
+
+Data layout in HBM (sized for 288 GB): frozen decoder weights are kept twice — [out,in] for forward and
+the pre-transposed [in,out] copy for dgrad — so both directions run the same K-contiguous MFMA GEMM;
+q/k/v and gate/up are fused into single weights; activations needed by backward are kept (no recompute:
+~1.5 GB/layer at B=8,S=2048).  Trainable parameters live in one flat fp32 master buffer (+ bf16 shadow,
+fp32 grads, Adam moments) so the DP all-reduce and the fused AdamW are one launch each.
+"""
+from __future__ import annotations
+
+import math
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from . import ops
+from .config import IGNORE_INDEX, IMAGE_TOKEN_INDEX, layer_indices
+
+BF16 = torch.bfloat16
+F32 = torch.float32
+N_IMG_TOK = 576   # the reference hard-codes 576 image tokens in the head slicing (base_ola_vlm.py:415-418)
+
+TASK_SPEC = {   # task -> (config attr, layer key, weight key, logit-scale name, heads module name)
+    "depth": ("image_depth", "depth_layer_indices", "depth_loss_weight", "depth_logit_scale", "image_depth_heads"),
+    "seg": ("image_seg", "seg_layer_indices", "seg_loss_weight", "seg_logit_scale", "image_seg_heads"),
+    "gen": ("image_gen", "img_layer_indices", "img_loss_weight", "gen_logit_scale", "image_gen_heads"),
+}
+
+
+def is_trainable(name: str) -> bool:
+    """PT-stage trainable set: projector, heads, task tokens, logit scales (ola_vlm_train.py:1127-1131, 1239-1242)."""
+    return ("mm_projector" in name or "_heads." in name or "special_" in name or name.endswith("logit_scale"))
+
+
+class ParamStore:
+    """Flat fp32 master / bf16 shadow / fp32 grad buffers for the trainable set (one all-reduce, one AdamW)."""
+
+    def __init__(self, shapes: "OrderedDict[str, tuple]", device):
+        self.index = OrderedDict()
+        off = 0
+        for name, shp in shapes.items():
+            n = int(np.prod(shp)) if len(shp) else 1
+            self.index[name] = (off, n, tuple(shp))
+            off += (n + 63) // 64 * 64
+        self.total = max(off, 64)
+        self.master = torch.zeros(self.total, device=device, dtype=F32)
+        self.shadow = torch.zeros(self.total, device=device, dtype=BF16)
+        self.grad = torch.zeros(self.total, device=device, dtype=F32)
+        self.exp_avg = None
+        self.exp_avg_sq = None
+        self.step = 0
+
+    def _v(self, buf, name):
+        off, n, shp = self.index[name]
+        return buf[off:off + n].view(shp if len(shp) else (1,))
+
+    def w(self, name):        # bf16 kernel-side view
+        return self._v(self.shadow, name)
+
+    def p(self, name):        # fp32 master view
+        return self._v(self.master, name)
+
+    def g(self, name):        # fp32 grad view
+        return self._v(self.grad, name)
+
+    def __contains__(self, name):
+        return name in self.index
+
+    def refresh_shadow(self):
+        ops.cast_to_bf16(self.master, out=self.shadow)
+
+    def zero_grad(self):
+        self.grad.zero_()
+
+    def adamw_step(self, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, grad_scale=1.0):
+        """HF `adamw_torch` (ola_vlm_train.py:124) on the whole flat buffer; refreshes the bf16 shadow in-kernel."""
+        if self.exp_avg is None:
+            self.exp_avg = torch.zeros_like(self.master)
+            self.exp_avg_sq = torch.zeros_like(self.master)
+        self.step += 1
+        ops.adamw_(self.master, self.grad, self.exp_avg, self.exp_avg_sq, self.shadow, lr, betas[0], betas[1], eps,
+                   weight_decay, self.step, grad_scale)
+
+
+def _tp(w):
+    """Device transpose of a 2-D bf16 weight (pre-transposed dgrad copy)."""
+    return ops.transpose(w.contiguous())
+
+
+class Engine:
+    def __init__(self, cfg, device="cuda", lm_chunk_rows=2048):
+        if not torch.cuda.is_available():
+            raise RuntimeError("visper_lm_amd.Engine needs a HIP device: there is no CPU fallback path")
+        self.cfg = cfg
+        self.dev = torch.device(device)
+        self.lm_chunk_rows = lm_chunk_rows
+        self.rank, self.world = 0, 1
+        self.fz = {}           # frozen, kernel-ready weights
+        self.ps = None         # ParamStore
+        self._rope = {}
+        self._plan_cache = {}
+        self.keep_logits = False
+
+    # ------------------------------------------------------------------------------------------ weights
+    def load_weights(self, W):
+        """W: {reference state-dict name: tensor}. Frozen weights -> bf16 device buffers (fused / pre-transposed);
+        trainable ones -> ParamStore."""
+        cfg, dev = self.cfg, self.dev
+        d = lambda t: t.detach().to(device=dev, dtype=BF16).contiguous()
+        fz = self.fz = {}
+        # ---- CLIP tower (both transformers naming generations: with / without ".vision_model")
+        vp = "model.vision_tower.vision_tower.vision_model."
+        if vp + "embeddings.class_embedding" not in W:
+            vp = "model.vision_tower.vision_tower."
+        self.vit_prefix = vp
+        if vp + "embeddings.class_embedding" in W:
+            C = cfg.vit_hidden
+            pw = W[vp + "embeddings.patch_embedding.weight"].reshape(C, -1)
+            kp = (pw.shape[1] + 63) // 64 * 64
+            pwp = torch.zeros(C, kp, dtype=pw.dtype)
+            pwp[:, :pw.shape[1]] = pw
+            fz["vit.patch_w"] = d(pwp)
+            pos = W[vp + "embeddings.position_embedding.weight"]
+            fz["vit.pos"] = d(pos[1:])
+            fz["vit.cls_pos"] = d((W[vp + "embeddings.class_embedding"].to(BF16) + pos[0].to(BF16)))
+            for nm in ("pre_layrnorm.weight", "pre_layrnorm.bias"):
+                fz["vit." + nm] = d(W[vp + nm])
+            for l in range(self.vit_layers_run()):
+                q = vp + f"encoder.layers.{l}."
+                o = f"vit.{l}."
+                fz[o + "wqkv"] = d(torch.cat([W[q + f"self_attn.{x}_proj.weight"] for x in "qkv"], 0))
+                fz[o + "bqkv"] = d(torch.cat([W[q + f"self_attn.{x}_proj.bias"] for x in "qkv"], 0))
+                for a, b in (("wo", "self_attn.out_proj.weight"), ("bo", "self_attn.out_proj.bias"),
+                             ("ln1w", "layer_norm1.weight"), ("ln1b", "layer_norm1.bias"), ("ln2w", "layer_norm2.weight"),
+                             ("ln2b", "layer_norm2.bias"), ("w1", "mlp.fc1.weight"), ("b1", "mlp.fc1.bias"),
+                             ("w2", "mlp.fc2.weight"), ("b2", "mlp.fc2.bias")):
+                    fz[o + a] = d(W[q + b])
+        # ---- decoder
+        fz["embed"] = d(W["model.embed_tokens.weight"])
+        fz["norm"] = d(W["model.norm.weight"])
+        fz["lm_head"] = d(W["lm_head.weight"])
+        fz["lm_head_T"] = _tp(fz["lm_head"])
+        for l in range(cfg.num_hidden_layers):
+            p = f"model.layers.{l}."
+            o = f"dec.{l}."
+            if cfg.arch == "phi3":
+                wqkv, wgu = W[p + "self_attn.qkv_proj.weight"], W[p + "mlp.gate_up_proj.weight"]
+            else:
+                wqkv = torch.cat([W[p + f"self_attn.{x}_proj.weight"] for x in "qkv"], 0)
+                wgu = torch.cat([W[p + "mlp.gate_proj.weight"], W[p + "mlp.up_proj.weight"]], 0)
+            fz[o + "wqkv"] = d(wqkv)
+            fz[o + "wgu"] = d(wgu)
+            fz[o + "wo"] = d(W[p + "self_attn.o_proj.weight"])
+            fz[o + "wd"] = d(W[p + "mlp.down_proj.weight"])
+            for k in ("wqkv", "wgu", "wo", "wd"):
+                fz[o + k + "_T"] = _tp(fz[o + k])
+            fz[o + "ln1"] = d(W[p + "input_layernorm.weight"])
+            fz[o + "ln2"] = d(W[p + "post_attention_layernorm.weight"])
+        # ---- trainable
+        shapes = OrderedDict((k, tuple(v.shape)) for k, v in W.items() if is_trainable(k))
+        self.ps = ParamStore(shapes, dev)
+        for k in shapes:
+            self.ps.p(k).copy_(W[k].detach().to(device=dev, dtype=F32).reshape(self.ps.p(k).shape))
+        self.ps.refresh_shadow()
+        self._build_static()
+
+    def vit_layers_run(self):
+        sel = self.cfg.mm_vision_select_layer
+        return self.cfg.vit_layers + 1 + sel if sel < 0 else sel
+
+    def _build_static(self):
+        cfg = self.cfg
+        self.tasks = []          # [(task, head_i, layer_idx)]
+        for task in ("depth", "seg", "gen"):                      # reference call order: ola_llama.py:139-141
+            if task in cfg.token_order and hasattr(cfg, TASK_SPEC[task][0]):
+                hc = getattr(cfg, TASK_SPEC[task][0])
+                for i, idx in enumerate(layer_indices(hc[TASK_SPEC[task][1]])):
+                    self.tasks.append((task, i, idx))
+        self.tapped = sorted({idx for _, _, idx in self.tasks})
+
+    def rope(self, S):
+        if S not in self._rope:
+            self._rope[S] = ops.rope_tables(S, self.cfg.head_dim, self.cfg.rope_theta, self.dev)
+        return self._rope[S]
+
+    # ------------------------------------------------------------------------------------------ ViT
+    def vit_forward(self, images):
+        """Frozen CLIP tower -> hidden_states[select_layer][:, 1:]  as [B*576, C] bf16 (no grad)."""
+        cfg, fz = self.cfg, self.fz
+        B = images.shape[0]
+        g = cfg.vit_image // cfg.vit_patch
+        P, C, nh = cfg.vit_patch, cfg.vit_hidden, cfg.vit_heads
+        N = g * g + 1
+        # im2col (pure data movement; conv stride == kernel): [B*g*g, 3*P*P] zero-padded to the GEMM K multiple
+        cols = images.to(BF16).view(B, 3, g, P, g, P).permute(0, 2, 4, 1, 3, 5).reshape(B * g * g, 3 * P * P)
+        kp = fz["vit.patch_w"].shape[1]
+        a = torch.zeros(B * g * g, kp, device=self.dev, dtype=BF16)
+        a[:, :3 * P * P] = cols
+        h = torch.empty(B, N, C, device=self.dev, dtype=BF16)
+        for b in range(B):       # patch rows + learned positions (residual epilogue), CLS row precomputed
+            ops.gemm(a[b * g * g:(b + 1) * g * g], fz["vit.patch_w"], residual=fz["vit.pos"], out=h[b, 1:])
+        h[:, 0] = fz["vit.cls_pos"]
+        x, _, _ = ops.layernorm_fwd(h.view(B * N, C), fz["vit.pre_layrnorm.weight"], fz["vit.pre_layrnorm.bias"], cfg.vit_eps,
+                                    save_stats=False)
+        hd = C // nh
+        for l in range(self.vit_layers_run()):
+            o = f"vit.{l}."
+            y, _, _ = ops.layernorm_fwd(x, fz[o + "ln1w"], fz[o + "ln1b"], cfg.vit_eps, save_stats=False)
+            qkv = ops.gemm(y, fz[o + "wqkv"], bias=fz[o + "bqkv"]).view(B, N, 3 * C)
+            att, _ = ops.attn_fwd(qkv[..., :C].view(B, N, nh, hd), qkv[..., C:2 * C].view(B, N, nh, hd),
+                                  qkv[..., 2 * C:].view(B, N, nh, hd), causal=False)
+            x = ops.gemm(att.view(B * N, C), fz[o + "wo"], bias=fz[o + "bo"], residual=x)
+            y, _, _ = ops.layernorm_fwd(x, fz[o + "ln2w"], fz[o + "ln2b"], cfg.vit_eps, save_stats=False)
+            y = ops.gemm(y, fz[o + "w1"], bias=fz[o + "b1"], epi=ops.EPI_QUICK_GELU)
+            x = ops.gemm(y, fz[o + "w2"], bias=fz[o + "b2"], residual=x)
+        x = x.view(B, N, C)
+        if cfg.mm_vision_select_feature == "patch":
+            x = x[:, 1:]
+        return x.contiguous().view(-1, C)
+
+    # ------------------------------------------------------------------------------------------ linear helpers
+    def _wgrad(self, x2d, dy2d, gview, accumulate=False):
+        """gview[N,K] (fp32) (+)= dy^T @ x  via two zero-padded transposes + the NT GEMM."""
+        M = x2d.shape[0]
+        Mp = (M + 63) // 64 * 64
+        N, K = dy2d.shape[1], x2d.shape[1]
+        dyT = torch.zeros(N, Mp, device=self.dev, dtype=BF16) if Mp != M else torch.empty(N, Mp, device=self.dev, dtype=BF16)
+        xT = torch.zeros(K, Mp, device=self.dev, dtype=BF16) if Mp != M else torch.empty(K, Mp, device=self.dev, dtype=BF16)
+        ops.transpose(dy2d, out=dyT)
+        ops.transpose(x2d, out=xT)
+        g2 = gview.view(N, K)
+        if accumulate:
+            tmp = ops.gemm(dyT, xT, out_f32=True)
+            ops._lib.call("vp_colsum_finish", 1, N * K, ops._p(tmp), ops._p(g2), 1.0, 1, ops._stream())
+        else:
+            ops.gemm(dyT, xT, out=g2)
+
+    def _lin_bwd(self, x2d, dy2d, wname, bname=None, need_dx=True):
+        ps = self.ps
+        dx = None
+        if need_dx:
+            dx = ops.gemm(dy2d, _tp(ps.w(wname)))
+        self._wgrad(x2d, dy2d, ps.g(wname))
+        if bname is not None:
+            ops.colsum(dy2d, out=ps.g(bname))
+        return dx
+
+    def _acc(self, gview, src_f32, scale=1.0):
+        """gview += scale * src (fp32, flat)."""
+        n = src_f32.numel()
+        ops._lib.call("vp_colsum_finish", 1, n, ops._p(src_f32), ops._p(gview), scale, 1, ops._stream())
+
+    # ------------------------------------------------------------------------------------------ splice plan (host)
+    def build_plan(self, input_ids, attention_mask, labels):
+        """Host restatement of prepare_inputs_labels_for_multimodal's index bookkeeping (ola_arch.py:256-444):
+        returns gather tables instead of concatenating tensors.  Right padding only."""
+        cfg = self.cfg
+        if cfg.tokenizer_padding_side != "right":
+            raise NotImplementedError("left padding is not supported by the MI355X splice (reference default is right)")
+        ids = input_ids.detach().cpu().numpy().astype(np.int64)
+        B, T = ids.shape
+        am = np.ones((B, T), bool) if attention_mask is None else attention_mask.detach().cpu().numpy().astype(bool)
+        lab = np.full((B, T), IGNORE_INDEX, np.int64) if labels is None else labels.detach().cpu().numpy().astype(np.int64)
+        key = (ids.tobytes(), am.tobytes(), lab.tobytes())
+        if key in self._plan_cache:
+            return self._plan_cache[key]
+        order = cfg.token_order
+        nt = cfg.num_task_tokens
+        n_tok_rows = nt * len(order) if nt > 0 else 0
+        seqs = []
+        img_idx = 0
+        for b in range(B):
+            idb, lb = ids[b][am[b]], lab[b][am[b]]
+            kind, row, lo = [], [], []
+            pos = np.nonzero(idb == IMAGE_TOKEN_INDEX)[0]
+            if len(pos) == 0:
+                kind += [0] * len(idb); row += idb.tolist(); lo += lb.tolist()
+                img_idx += 1                                        # reference consumes one (empty) feature slot
+            else:
+                bounds = [-1] + pos.tolist() + [len(idb)]
+                for i in range(len(bounds) - 1):
+                    seg = idb[bounds[i] + 1:bounds[i + 1]]
+                    kind += [0] * len(seg); row += seg.tolist(); lo += lb[bounds[i] + 1:bounds[i + 1]].tolist()
+                    if i < len(pos):
+                        kind += [1] * N_IMG_TOK
+                        row += list(range(img_idx * N_IMG_TOK, (img_idx + 1) * N_IMG_TOK))
+                        lo += [IGNORE_INDEX] * N_IMG_TOK
+                        img_idx += 1
+                        kind += [2] * n_tok_rows; row += list(range(n_tok_rows)); lo += [IGNORE_INDEX] * n_tok_rows
+            mx = cfg.tokenizer_model_max_length
+            if mx is not None:
+                kind, row, lo = kind[:mx], row[:mx], lo[:mx]
+            seqs.append((kind, row, lo))
+        n_img = img_idx
+        S = max(len(s[0]) for s in seqs)
+        S_pad = S
+        kind = np.full((B, S_pad), -1, np.int32)
+        row = np.zeros((B, S_pad), np.int32)
+        lab2 = np.full((B, S_pad), IGNORE_INDEX, np.int64)
+        lens = np.zeros(B, np.int32)
+        for b, (k, r, lo) in enumerate(seqs):
+            n = len(k)
+            kind[b, :n], row[b, :n], lab2[b, :n], lens[b] = k, r, lo, n
+        shift = np.full((B, S_pad), IGNORE_INDEX, np.int64)
+        shift[:, :-1] = lab2[:, 1:]
+        # backward tables
+        img_dst = np.full(n_img * N_IMG_TOK, -1, np.int32)          # image-feature row -> row of the [B*S] sequence
+        tok_src = np.full((max(n_tok_rows, 1), B), -1, np.int32)     # task-token row j -> its position in every sample
+        for b in range(B):
+            for s in range(lens[b]):
+                if kind[b, s] == 1:
+                    img_dst[row[b, s]] = b * S_pad + s
+                elif kind[b, s] == 2:
+                    tok_src[row[b, s], b] = b * S_pad + s
+        dev = self.dev
+        plan = dict(B=B, S=S_pad, n_img=n_img, kind=torch.from_numpy(kind.reshape(-1)).to(dev), row=torch.from_numpy(row.reshape(-1)).to(dev),
+                    labels=torch.from_numpy(lab2), shift_labels=torch.from_numpy(shift.reshape(-1)).to(dev),
+                    n_valid=int((shift != IGNORE_INDEX).sum()), lens=torch.from_numpy(lens).to(dev), lens_host=lens,
+                    img_dst=torch.from_numpy(img_dst).to(dev), tok_src=torch.from_numpy(tok_src.reshape(-1)).to(dev),
+                    n_tok_rows=n_tok_rows, full=bool((lens == S_pad).all()),
+                    attention_mask=torch.from_numpy(np.arange(S_pad)[None, :] < lens[:, None]))
+        plan["heads"] = self._head_tables(plan)
+        if len(self._plan_cache) > 8:
+            self._plan_cache.clear()
+        self._plan_cache[key] = plan
+        return plan
+
+    def _head_tables(self, plan):
+        """forward_emb_predictor's token selection (base_ola_vlm.py:413-441) as per-task row tables into [B*S]."""
+        cfg = self.cfg
+        B, S = plan["B"], plan["S"]
+        ns, nt, order = cfg.num_sys_tokens, cfg.num_task_tokens, cfg.token_order
+        out = {}
+        for task in {t for t, _, _ in self.tasks}:
+            k = order.index(task)
+            s0 = ns + N_IMG_TOK + nt * k
+            end = ns + N_IMG_TOK + nt * len(order)
+            if nt == 0 or S < 600:
+                sel = list(range(S)) if cfg.pass_text_to_aux else list(range(min(S, ns + N_IMG_TOK)))
+            else:
+                sel = list(range(ns + N_IMG_TOK)) + list(range(s0, s0 + nt))
+                if cfg.pass_text_to_aux:
+                    sel += list(range(end, S))
+            sel = np.asarray(sel, np.int32)
+            rows = (np.arange(B, dtype=np.int32)[:, None] * S + sel[None, :]).reshape(-1)
+            if cfg.pass_text_to_aux:
+                lat_x = np.arange(ns + N_IMG_TOK, ns + N_IMG_TOK + nt)           # positions inside x
+            else:
+                lat_x = np.arange(len(sel) - nt, len(sel))
+            out[task] = dict(n_x=len(sel), rows=torch.from_numpy(rows).to(self.dev), sel=sel, lat_x=lat_x)
+        return out
+
+    # ------------------------------------------------------------------------------------------ the step
+    def train_step(self, batch, compute_grads=True):
+        """One fused forward+backward.  Returns dict(loss, text_loss, per-task losses, layer_losses, ...) of device
+        scalars (fp32 tensors); gradients of the trainable set are in self.ps.grad (zeroed first)."""
+        cfg, fz, ps, dev = self.cfg, self.fz, self.ps, self.dev
+        H = cfg.hidden_size
+        plan = self.build_plan(batch["input_ids"], batch.get("attention_mask"), batch.get("labels"))
+        B, S = plan["B"], plan["S"]
+        M = B * S
+        if compute_grads:
+            ps.zero_grad()
+        out = {"plan": plan}
+
+        # ---- vision tower + projector (a1..a3)
+        feats = self.vit_forward(batch["images"])                                  # [n_img*576, C]
+        z1 = ops.gemm(feats, ps.w("model.mm_projector.0.weight"), bias=ps.w("model.mm_projector.0.bias"))
+        a1 = ops.act_fwd(z1, ops.EPI_GELU)
+        img = ops.gemm(a1, ps.w("model.mm_projector.2.weight"), bias=ps.w("model.mm_projector.2.bias"))
+        out["image_features"] = img
+
+        # ---- task-token rows (a4): depth/seg = group means of the (576,H) parameter, gen = raw rows
+        nt = cfg.num_task_tokens
+        tok_rows = None
+        if plan["n_tok_rows"] > 0:
+            tok_rows = torch.empty(plan["n_tok_rows"], H, device=dev, dtype=BF16)
+            for k, task in enumerate(cfg.token_order):
+                name = f"model.special_{task}_tokens"
+                src = ps.w(name)
+                if task == "gen":
+                    ops.copy2d_(tok_rows[k * nt:(k + 1) * nt], src)
+                else:
+                    grp = src.shape[0] // nt
+                    idx = torch.arange(src.shape[0], device=dev, dtype=torch.int32)
+                    ops.gather_sum_rows(src, idx, grp, 1.0 / grp, tok_rows[k * nt:(k + 1) * nt])
+        # ---- splice (a5)
+        x = torch.empty(M, H, device=dev, dtype=BF16)
+        srcs = [fz["embed"], img] + ([tok_rows] if tok_rows is not None else [])
+        ops.gather_rows(srcs, plan["kind"], plan["row"], H, x)
+        out["inputs_embeds"] = x.view(B, S, H)
+
+        # ---- decoder (a6)
+        nh, nkv, hd = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim
+        Fi = cfg.intermediate_size
+        cos_t, sin_t = self.rope(S)
+        kv_len = None if plan["full"] else plan["lens"]
+        window = int(cfg.sliding_window) if cfg.sliding_window else 0
+        L = cfg.num_hidden_layers
+        saved = []
+        states = {}
+        for l in range(L):
+            o = f"dec.{l}."
+            xn, rstd1 = ops.rmsnorm_fwd(x, fz[o + "ln1"], cfg.rms_norm_eps)
+            qkv = ops.gemm(xn, fz[o + "wqkv"])
+            ops.rope_(qkv, M, S, nh + nkv, hd, cos_t, sin_t)
+            q4 = qkv.view(B, S, -1)[..., :nh * hd].view(B, S, nh, hd)
+            k4 = qkv.view(B, S, -1)[..., nh * hd:(nh + nkv) * hd].view(B, S, nkv, hd)
+            v4 = qkv.view(B, S, -1)[..., (nh + nkv) * hd:].view(B, S, nkv, hd)
+            att, lse = ops.attn_fwd(q4, k4, v4, causal=True, window=window, kv_len=kv_len)
+            h1 = ops.gemm(att.view(M, nh * hd), fz[o + "wo"], residual=x)
+            hn, rstd2 = ops.rmsnorm_fwd(h1, fz[o + "ln2"], cfg.rms_norm_eps)
+            gu = ops.gemm(hn, fz[o + "wgu"])
+            act = ops.swiglu_fwd(gu)
+            xo = ops.gemm(act, fz[o + "wd"], residual=h1)
+            if compute_grads:
+                saved.append((x, rstd1, qkv, att, lse, h1, rstd2, gu))
+            if l in self.tapped and l != L - 1:
+                states[l] = xo
+            x = xo
+        hidden, rstd_f = ops.rmsnorm_fwd(x, fz["norm"], cfg.rms_norm_eps)
+        if (L - 1) in self.tapped:
+            states[L - 1] = hidden              # layer_states[-1] is the post-norm state (ola_llama.py:117-119)
+        out["hidden"] = hidden.view(B, S, H)
+
+        # ---- lm_head + NTP loss (a7), row-chunked; dlogits -> d_hidden in the same sweep
+        n_valid = plan["n_valid"]
+        gscale = 1.0 / n_valid if n_valid > 0 else float("nan")
+        d_hidden = torch.empty(M, H, device=dev, dtype=BF16) if compute_grads else None
+        row_loss = torch.empty(M, device=dev, dtype=F32)
+        logits_keep = [] if self.keep_logits else None
+        R = self.lm_chunk_rows
+        for r0 in range(0, M, R):
+            r1 = min(M, r0 + R)
+            lg = ops.gemm(hidden[r0:r1], fz["lm_head"])
+            if logits_keep is not None:
+                logits_keep.append(lg.clone())
+            row_loss[r0:r1] = ops.ce_fwd_bwd(lg, plan["shift_labels"][r0:r1], gscale, write_grad=compute_grads)
+            if compute_grads:
+                ops.gemm(lg, fz["lm_head_T"], out=d_hidden[r0:r1])
+        text_loss = ops.sum_f32(row_loss, gscale)
+        out["text_loss"] = text_loss
+        if logits_keep is not None:
+            out["logits"] = torch.cat(logits_keep, 0).view(B, S, -1)
+
+        # ---- heads + embedding losses (a8..a14), forward and backward back-to-back per head
+        d_state = {}
+        task_loss = {}
+        out["layer_losses"] = {}
+        out["embs"] = {}
+        dx_parts = {l: [] for l in self.tapped}
+        ns = cfg.num_sys_tokens
+        run_heads = len(self.tasks) > 0 and S > ns
+        if run_heads:
+            targets = self._prepare_targets(batch)
+            for task, i, idx in self.tasks:
+                res = self._head_fwd_bwd(task, i, idx, states[idx], plan, batch, targets, compute_grads)
+                if res["loss3"] is not None:
+                    out["layer_losses"][(task, idx)] = res["loss3"]
+                    w_t = getattr(cfg, TASK_SPEC[task][0])[TASK_SPEC[task][2]]
+                    task_loss[task] = res["loss3"][0:1] * w_t if task not in task_loss else task_loss[task] + res["loss3"][0:1] * w_t
+                out["embs"].setdefault(task, []).append(res["emb"])
+                if compute_grads and res["dx"] is not None:
+                    dx_parts[idx].append((task, res["dx"]))
+        loss = text_loss.clone()
+        for task in ("seg", "depth", "gen"):                                 # sum order: ola_llama.py:143-144
+            if task in task_loss:
+                loss = loss + task_loss[task]
+                out[f"{task}_loss"] = task_loss[task]
+        out["loss"] = loss
+        if not compute_grads:
+            return out
+
+        # ---- scatter head input grads back to their layer states
+        for l, parts in dx_parts.items():
+            if not parts:
+                continue
+            tot = sum(p.shape[0] for _, p in parts)
+            cat = torch.empty(tot, H, device=dev, dtype=BF16)
+            off = 0
+            for _, p in parts:
+                cat[off:off + p.shape[0]] = p
+                off += p.shape[0]
+            ikey = ("inv", l, tuple(t for t, _ in parts))
+            if ikey not in plan:                         # inverse row table: state row -> row of `cat` per head (or -1)
+                inv = np.full((M, len(parts)), -1, np.int32)
+                off = 0
+                for j, (task, p) in enumerate(parts):
+                    rows = plan["heads"][task]["rows"].cpu().numpy()
+                    inv[rows, j] = off + np.arange(p.shape[0], dtype=np.int32)
+                    off += p.shape[0]
+                plan[ikey] = torch.from_numpy(inv.reshape(-1)).to(dev)
+            ds = torch.empty(M, H, device=dev, dtype=BF16)
+            ops.gather_sum_rows(cat, plan[ikey], len(parts), 1.0, ds)
+            d_state[l] = ds
+
+        # ---- decoder backward (dgrad only: LLM frozen)
+        if (L - 1) in d_state:
+            ops.add(d_hidden, d_state[L - 1], out=d_hidden)
+        dx = ops.rmsnorm_bwd(d_hidden, x, fz["norm"], rstd_f)
+        del d_hidden
+        for l in range(L - 1, -1, -1):
+            o = f"dec.{l}."
+            x_in, rstd1, qkv, att, lse, h1, rstd2, gu = saved[l]
+            if l in d_state and l != L - 1:
+                ops.add(dx, d_state[l], out=dx)
+            d_act = ops.gemm(dx, fz[o + "wd_T"])
+            d_gu = ops.swiglu_bwd(d_act, gu)
+            del d_act
+            d_hn = ops.gemm(d_gu, fz[o + "wgu_T"])
+            del d_gu
+            d_h1 = ops.rmsnorm_bwd(d_hn, h1, fz[o + "ln2"], rstd2, dres=dx)
+            d_att = ops.gemm(d_h1, fz[o + "wo_T"])
+            dqkv = torch.empty_like(qkv)
+            q4 = qkv.view(B, S, -1)[..., :nh * hd].view(B, S, nh, hd)
+            k4 = qkv.view(B, S, -1)[..., nh * hd:(nh + nkv) * hd].view(B, S, nkv, hd)
+            v4 = qkv.view(B, S, -1)[..., (nh + nkv) * hd:].view(B, S, nkv, hd)
+            dq4 = dqkv.view(B, S, -1)[..., :nh * hd].view(B, S, nh, hd)
+            dk4 = dqkv.view(B, S, -1)[..., nh * hd:(nh + nkv) * hd].view(B, S, nkv, hd)
+            dv4 = dqkv.view(B, S, -1)[..., (nh + nkv) * hd:].view(B, S, nkv, hd)
+            ops.attn_bwd(q4, k4, v4, att, lse, d_att.view(B, S, nh, hd), causal=True, window=window, kv_len=kv_len,
+                         dq=dq4, dk=dk4, dv=dv4)
+            ops.rope_(dqkv, M, S, nh + nkv, hd, cos_t, sin_t, inverse=True)
+            d_xn = ops.gemm(dqkv, fz[o + "wqkv_T"])
+            dx = ops.rmsnorm_bwd(d_xn, x_in, fz[o + "ln1"], rstd1, dres=d_h1)
+            saved[l] = None
+        out["d_inputs_embeds"] = dx.view(B, S, H)
+
+        # ---- splice backward: image rows -> projector, task-token rows -> special-token parameters
+        d_img = torch.empty(plan["n_img"] * N_IMG_TOK, H, device=dev, dtype=BF16)
+        ops.gather_sum_rows(dx, plan["img_dst"], 1, 1.0, d_img)
+        if plan["n_tok_rows"] > 0:
+            d_tok = torch.empty(plan["n_tok_rows"], H, device=dev, dtype=F32)
+            ops.gather_sum_rows(dx, plan["tok_src"], B, 1.0, d_tok)
+            for k, task in enumerate(cfg.token_order):
+                name = f"model.special_{task}_tokens"
+                g = ps.g(name)
+                if task == "gen":
+                    self._acc(g, d_tok[k * nt:(k + 1) * nt].contiguous())
+                else:
+                    grp = g.shape[0] // nt
+                    idx = (torch.arange(g.shape[0], device=dev, dtype=torch.int32) // grp + k * nt).to(torch.int32)
+                    ops.gather_sum_rows(d_tok, idx, 1, 1.0 / grp, g, accumulate=True)
+        # ---- projector backward
+        d_a1 = self._lin_bwd(a1, d_img, "model.mm_projector.2.weight", "model.mm_projector.2.bias", need_dx=True)
+        d_z1 = ops.act_bwd(d_a1, z1, ops.EPI_GELU)
+        self._lin_bwd(feats, d_z1, "model.mm_projector.0.weight", "model.mm_projector.0.bias", need_dx=False)
+        return out
+
+    # ------------------------------------------------------------------------------------------ targets
+    def _prepare_targets(self, batch):
+        """Frozen-teacher features are inputs.  Flatten to [B, D] in the PREDICTION's memory order
+        (seg targets (B,C,24,24) are re-laid out to (B,576,C) once so the loss kernel streams both linearly), then
+        all-gather across DP ranks for the contrastive negatives (ola_utils.py:96-106), once per task per step."""
+        out = {}
+        for task in {t for t, _, _ in self.tasks}:
+            tg = batch.get(f"{task}_target")
+            if tg is None:
+                out[task] = None
+                continue
+            tg = tg.to(device=self.dev, dtype=BF16)
+            Bn = tg.shape[0]
+            if task == "seg" and tg.dim() == 4:
+                Cc = tg.shape[1]
+                flat = torch.empty(Bn, tg.shape[2] * tg.shape[3], Cc, device=self.dev, dtype=BF16)
+                t3 = tg.reshape(Bn, Cc, -1).contiguous()
+                for b in range(Bn):
+                    ops.transpose(t3[b], out=flat[b])
+                flat = flat.view(Bn, -1)
+            else:
+                flat = tg.reshape(Bn, -1).contiguous()
+            if self.world > 1:
+                import torch.distributed as dist
+                allt = torch.empty(self.world * Bn, flat.shape[1], device=self.dev, dtype=BF16)
+                dist.all_gather_into_tensor(allt, flat)
+            else:
+                allt = flat
+            mask = batch.get(f"{task}_mask")
+            mask = torch.ones(Bn, device=self.dev, dtype=F32) if mask is None else mask.to(device=self.dev, dtype=F32)
+            if self.cfg.zero_masks:
+                mask = torch.zeros_like(mask)
+            out[task] = (allt, mask)
+        return out
+
+    # ------------------------------------------------------------------------------------------ one head
+    def _head_fwd_bwd(self, task, i, idx, state, plan, batch, targets, compute_grads):
+        """TaskToken{Gen,Seg,Depth}Head on one layer state: forward, loss, and (eagerly) backward.
+        resampler.py:202-224 / :46-75 / :9-16 ; gen_head.py:39-65 ; oneformer_head.py:224-258 ; da_v2_head.py:418-457."""
+        cfg, ps, dev = self.cfg, self.ps, self.dev
+        cname, _, wkey, sname, hname = TASK_SPEC[task]
+        hc = getattr(cfg, cname)
+        B, S, H = plan["B"], plan["S"], cfg.hidden_size
+        tb = plan["heads"][task]
+        n, nq, heads, dh = tb["n_x"], hc["num_tokens"], hc["num_heads"], hc["dim_head"]
+        inner = heads * dh
+        pf = f"{hname}.{i}.projector."
+        assert hc["depth"] == 1, "reference scripts use depth=1 resampler heads"
+        a, f = pf + "layers.0.0.", pf + "layers.0.1."
+        T = n + nq
+        # -- inputs: [x_b ; latents_b] per batch, contiguous (kv_input = cat(x, latents): resampler.py:59)
+        xin = torch.empty(B, T, H, device=dev, dtype=BF16)
+        xg = torch.empty(B * n, H, device=dev, dtype=BF16)
+        ops.gather_rows([state], torch.zeros(B * n, device=dev, dtype=torch.int32), tb["rows"], H, xg)
+        xin[:, :n] = xg.view(B, n, H)
+        if task == "gen":
+            lat0 = xg.view(B, n, H)[:, tb["lat_x"][0]:tb["lat_x"][-1] + 1]              # 8 hidden rows (base_ola_vlm.py:437-439)
+        else:
+            lat0 = ps.w(f"model.special_{task}_tokens")[None].expand(B, -1, -1)
+        nl = lat0.shape[1]
+        if nl == nq:
+            xin[:, n:] = lat0
+            mode = "same"
+        elif nq > 1 and nq % nl == 0:
+            xin[:, n:] = lat0.repeat(1, nq // nl, 1)
+            mode = "tile"
+        else:                                                                           # mean over the latents (resampler.py:212)
+            latc = lat0.contiguous().view(B * nl, H)
+            idxm = torch.arange(B * nl, device=dev, dtype=torch.int32)
+            mean = torch.empty(B, H, device=dev, dtype=BF16)
+            ops.gather_sum_rows(latc, idxm, nl, 1.0 / nl, mean)
+            xin[:, n:] = mean[:, None].expand(B, nq, H)
+            mode = "mean"
+        xin2 = xin.view(B * T, H)
+        Dm = ps.w(pf + "proj_in.weight").shape[0]
+        P = ops.gemm(xin2, ps.w(pf + "proj_in.weight"), bias=ps.w(pf + "proj_in.bias")).view(B, T, Dm)
+        # -- norm1 on x rows, norm2 on latent rows
+        Nn = torch.empty(B, T, Dm, device=dev, dtype=BF16)
+        Px = P[:, :n].contiguous().view(B * n, Dm)
+        Pl = P[:, n:].contiguous().view(B * nq, Dm)
+        nx, mx_, rx = ops.layernorm_fwd(Px, ps.w(a + "norm1.weight"), ps.w(a + "norm1.bias"))
+        nlat, ml_, rl = ops.layernorm_fwd(Pl, ps.w(a + "norm2.weight"), ps.w(a + "norm2.bias"))
+        Nn[:, :n] = nx.view(B, n, Dm)
+        Nn[:, n:] = nlat.view(B, nq, Dm)
+        wqkv = torch.cat([ps.w(a + "to_q.weight"), ps.w(a + "to_kv.weight")], 0).contiguous()     # [3*inner, Dm]
+        QKV = ops.gemm(Nn.view(B * T, Dm), wqkv).view(B, T, 3 * inner)
+        q4 = QKV[:, n:, :inner].unflatten(-1, (heads, dh))
+        k4 = QKV[:, :, inner:2 * inner].unflatten(-1, (heads, dh))
+        v4 = QKV[:, :, 2 * inner:].unflatten(-1, (heads, dh))
+        att, lse = ops.attn_fwd(q4, k4, v4, causal=False, scale=1.0 / math.sqrt(dh))
+        att2 = att.view(B * nq, inner)
+        lat1 = ops.gemm(att2, ps.w(a + "to_out.weight"), residual=Pl)
+        y, mf, rf = ops.layernorm_fwd(lat1, ps.w(f + "0.weight"), ps.w(f + "0.bias"))
+        zf = ops.gemm(y, ps.w(f + "1.weight"))
+        af = ops.act_fwd(zf, ops.EPI_GELU)
+        lat2 = ops.gemm(af, ps.w(f + "3.weight"), residual=lat1)
+        po = ops.gemm(lat2, ps.w(pf + "proj_out.weight"), bias=ps.w(pf + "proj_out.bias"))
+        vout, mo, ro = ops.layernorm_fwd(po, ps.w(pf + "norm_out.weight"), ps.w(pf + "norm_out.bias"))
+        Do = vout.shape[-1]
+        emb = vout.view(B, nq, Do)
+        pred = vout
+        if task == "depth":                                        # loss on linear_1(visual_feats): base_ola_vlm.py:369
+            l1 = f"{hname}.{i}.linear_1."
+            zd = ops.gemm(vout, ps.w(l1 + "0.weight"), bias=ps.w(l1 + "0.bias"))
+            ad = ops.act_fwd(zd, ops.EPI_RELU)
+            pred = ops.gemm(ad, ps.w(l1 + "2.weight"), bias=ps.w(l1 + "2.bias"))
+        res = dict(emb=emb if task != "depth" else pred.view(B, nq, -1), loss3=None, dx=None)
+        tg = targets.get(task)
+        if tg is None:
+            return res
+        allt, mask = tg
+        pred2 = pred.view(B, -1)
+        scale = ps.p(sname) if (cfg.use_contrastive and sname in ps) else None
+        loss3, coef = ops.emb_loss_fwd(pred2, allt, mask, scale, cfg.contrastive_loss_weight, rank=self.rank)
+        res["loss3"] = loss3
+        if not compute_grads:
+            return res
+        w_t = float(hc[wkey])
+        # ---------------- backward ----------------
+        dpred = ops.emb_loss_bwd(pred2, allt, coef, w_t, rank=self.rank).view(B * nq, -1)
+        if scale is not None:
+            self._acc(ps.g(sname), coef[-1:], w_t)
+        if task == "depth":
+            d_ad = self._lin_bwd(ad, dpred, l1 + "2.weight", l1 + "2.bias")
+            d_zd = ops.act_bwd(d_ad, zd, ops.EPI_RELU)
+            dvout = self._lin_bwd(vout, d_zd, l1 + "0.weight", l1 + "0.bias")
+        else:
+            dvout = dpred
+        d_po, dw, db = ops.layernorm_bwd(dvout, po, ps.w(pf + "norm_out.weight"), mo, ro)
+        ps.g(pf + "norm_out.weight").copy_(dw); ps.g(pf + "norm_out.bias").copy_(db)
+        d_lat2 = self._lin_bwd(lat2, d_po, pf + "proj_out.weight", pf + "proj_out.bias")
+        d_af = self._lin_bwd(af, d_lat2, f + "3.weight")
+        d_zf = ops.act_bwd(d_af, zf, ops.EPI_GELU)
+        d_y = self._lin_bwd(y, d_zf, f + "1.weight")
+        d_lat1, dw, db = ops.layernorm_bwd(d_y, lat1, ps.w(f + "0.weight"), mf, rf, dres=d_lat2)
+        ps.g(f + "0.weight").copy_(dw); ps.g(f + "0.bias").copy_(db)
+        d_att = self._lin_bwd(att2, d_lat1, a + "to_out.weight")
+        dQKV = torch.zeros(B, T, 3 * inner, device=dev, dtype=BF16)
+        ops.attn_bwd(q4, k4, v4, att, lse, d_att.view(B, nq, heads, dh), causal=False, scale=1.0 / math.sqrt(dh),
+                     dq=dQKV[:, n:, :inner].unflatten(-1, (heads, dh)), dk=dQKV[:, :, inner:2 * inner].unflatten(-1, (heads, dh)),
+                     dv=dQKV[:, :, 2 * inner:].unflatten(-1, (heads, dh)))
+        dQKV2 = dQKV.view(B * T, 3 * inner)
+        dNn = ops.gemm(dQKV2, _tp(wqkv)).view(B, T, Dm)
+        gq = torch.empty(3 * inner, Dm, device=dev, dtype=F32)
+        self._wgrad(Nn.view(B * T, Dm), dQKV2, gq)
+        ps.g(a + "to_q.weight").copy_(gq[:inner]); ps.g(a + "to_kv.weight").copy_(gq[inner:])
+        dPx, dw, db = ops.layernorm_bwd(dNn[:, :n].contiguous().view(B * n, Dm), Px, ps.w(a + "norm1.weight"), mx_, rx)
+        ps.g(a + "norm1.weight").copy_(dw); ps.g(a + "norm1.bias").copy_(db)
+        dPl, dw, db = ops.layernorm_bwd(dNn[:, n:].contiguous().view(B * nq, Dm), Pl, ps.w(a + "norm2.weight"), ml_, rl,
+                                        dres=d_lat1)          # + residual path lat1 = to_out(.) + Pl
+        ps.g(a + "norm2.weight").copy_(dw); ps.g(a + "norm2.bias").copy_(db)
+        dP = torch.empty(B, T, Dm, device=dev, dtype=BF16)
+        dP[:, :n] = dPx.view(B, n, Dm)
+        dP[:, n:] = dPl.view(B, nq, Dm)
+        dxin = self._lin_bwd(xin2, dP.view(B * T, Dm), pf + "proj_in.weight", pf + "proj_in.bias").view(B, T, H)
+        dxg = dxin[:, :n].contiguous()                                                  # grads of the gathered state rows
+        dlat_in = dxin[:, n:]                                                           # [B, nq, H]
+        # latents' gradient: fold the tile / mean expansion, then route to hidden rows (gen) or the parameter
+        if mode == "same":
+            dlat0 = dlat_in.float()
+        elif mode == "tile":
+            dlat0 = dlat_in.float().reshape(B, nq // nl, nl, H).sum(1)
+        else:
+            dlat0 = (dlat_in.float().sum(1, keepdim=True) / nl).expand(B, nl, H)
+        if task == "gen":
+            lo = int(tb["lat_x"][0])
+            dxg[:, lo:lo + nl] = (dxg[:, lo:lo + nl].float() + dlat0).to(BF16)
+        else:
+            self._acc(ps.g(f"model.special_{task}_tokens"), dlat0.sum(0).contiguous())
+        res["dx"] = dxg.view(B * n, H)
+        return res
