@@ -1,0 +1,211 @@
+"""bench.py — train-step images/sec of the VisPer-LM PT step (NTP + distillation) on MI355X.
+
+Workload (BASELINE.json configs[1]): CLIP-ViT-L/14-336 + Llama-3-8B, bf16, batch 8 per GPU,
+post-splice seq_len 2048 (text T=1449, one 336x336 image at column 38, 3x8 task tokens), one distillation head per
+task (depth@18, seg@18, gen@20), random-init weights and synthetic data/targets resident in HBM.
+A step = ViT fwd + projector fwd/bwd + splice + 32-layer decoder fwd + dgrad bwd + lm_head/CE fwd/bwd + 3 heads
+fwd/bwd + embedding losses + (N>1: RCCL grad all-reduce, contrastive target all-gather) + fused AdamW.
+
+  python bench.py --gpus 1 --steps 5 --warmup 2
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (dominant kernel = the bf16 MFMA
+GEMM, timed live with HIP events on its launch stream) and `cpu_baseline` (the CPU oracle timed on a bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+STEP_TF_PER_IMAGE = 65.84       # SURVEY §8d / BASELINE.md §2: algorithmic PT-step TFLOP per image (config 2)
+PEAK_BF16_TF = 2500.0           # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md)
+
+
+def make_batch(cfg, B, T, rank, device):
+    g = torch.Generator().manual_seed(1234 + rank)
+    ids = torch.randint(0, 1000, (B, T), generator=g)
+    ids[:, cfg.num_sys_tokens] = -200
+    labels = ids.clone()
+    labels[:, :cfg.num_sys_tokens + 7] = -100
+    gd = torch.Generator(device=device).manual_seed(1234 + rank)
+    rn = lambda *s: torch.randn(*s, device=device, dtype=torch.bfloat16, generator=gd)
+    batch = dict(input_ids=ids, labels=labels, attention_mask=torch.ones_like(ids, dtype=torch.bool),
+                 images=rn(B, 3, cfg.vit_image, cfg.vit_image))
+    order = cfg.token_order
+    if "gen" in order:
+        batch["gen_target"] = rn(B, 1, cfg.image_gen["output_dim"]); batch["gen_mask"] = torch.ones(B, device=device)
+    if "depth" in order:
+        batch["depth_target"] = rn(B, 576, cfg.image_depth["output_dim"]); batch["depth_mask"] = torch.ones(B, device=device)
+    if "seg" in order:
+        batch["seg_target"] = rn(B, cfg.image_seg["output_dim"], 24, 24); batch["seg_mask"] = torch.ones(B, device=device)
+    return batch
+
+
+def cpu_baseline(cfg, budget_s=25.0):
+    """The CPU oracle (a port of the reference's PyTorch path) timed on a bounded sample of config-1 shapes
+    (B=2, text 128 -> S=711, bf16): ViT-L tower fwd once, ONE Llama-3-8B-width decoder layer fwd+dgrad (x num layers),
+    lm_head+CE fwd+bwd once, one seg head fwd+bwd once; composed into a step time."""
+    from oracle import visper_oracle as O
+    torch.set_num_threads(os.cpu_count() or 1)
+    dt = torch.bfloat16
+    B, S, H = 2, 711, cfg.hidden_size
+    ocfg = O.make_config(**{k: v for k, v in cfg.to_dict().items() if k in vars(O.make_config())})
+    g = torch.Generator().manual_seed(0)
+    rn = lambda *s: (torch.randn(*s, generator=g) * 0.02).to(dt)
+    t_all = time.time()
+    # (a) ViT tower
+    W = {}
+    from visper_lm_amd.params import param_shapes
+    shapes = param_shapes(cfg, vit_nested=True)
+    for k, s in shapes.items():
+        if "vision_tower" in k:
+            W[k] = rn(*s) if len(s) > 1 else (torch.ones(s, dtype=dt) if k.endswith("weight") else torch.zeros(s, dtype=dt))
+    img = torch.randn(B, 3, cfg.vit_image, cfg.vit_image, generator=g).to(dt)
+    t0 = time.time()
+    with torch.no_grad():
+        O.clip_vit_features(img, W, ocfg)
+    t_vit = time.time() - t0
+    # (b) one decoder layer, fwd + dgrad
+    one = O.make_config(**{**vars(ocfg), "num_hidden_layers": 1})
+    Wd = {k.replace("model.layers.0.", "model.layers.0."): (rn(*s) if len(s) > 1 else torch.ones(s, dtype=dt))
+          for k, s in shapes.items() if k.startswith("model.layers.0.") or k == "model.norm.weight"}
+    x = (torch.randn(B, S, H, generator=g)).to(dt).requires_grad_(True)
+    reps, t_layer = 0, 0.0
+    while reps < 2 and (time.time() - t_all) < budget_s:
+        t0 = time.time()
+        h, st = O.decoder_forward(x, None, None, Wd, one)
+        h.float().sum().backward()
+        t_layer += time.time() - t0
+        reps += 1
+    t_layer /= max(reps, 1)
+    # (c) lm_head + CE
+    Wl = {"lm_head.weight": rn(cfg.vocab_size, H)}
+    hid = torch.randn(B, S, H, generator=g).to(dt).requires_grad_(True)
+    labels = torch.randint(0, 1000, (B, S), generator=g)
+    t0 = time.time()
+    _, loss = O.ntp_loss(hid, labels, Wl, ocfg)
+    loss.backward()
+    t_lm = time.time() - t0
+    # (d) one seg head fwd+bwd + loss
+    Wh = {k: (rn(*s).requires_grad_(True) if len(s) > 1 else torch.ones(s, dtype=dt).requires_grad_(True)) for k, s in shapes.items()
+          if k.startswith("image_seg_heads.0.") or k == "model.special_seg_tokens"}
+    Wh["seg_logit_scale"] = torch.tensor(2.0, requires_grad=True)
+    st = torch.randn(B, S, H, generator=g).to(dt).requires_grad_(True)
+    scfg = O.make_config(**{**vars(ocfg), "aux_mode": "seg"})
+    t0 = time.time()
+    pred, _ = O.head_forward(st, "seg", 0, Wh, scfg)
+    tgt = torch.randn(B, cfg.image_seg["output_dim"], 24, 24, generator=g).to(dt)
+    l, _, _ = O.emb_loss(pred, torch.ones(B), tgt, Wh["seg_logit_scale"], 0.3)
+    l.backward()
+    t_head = time.time() - t0
+    step = t_vit + cfg.num_hidden_layers * t_layer + t_lm + t_head
+    return {"value": B / step, "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": (f"oracle bf16 at config-1 shapes (B=2, S=711): ViT-L fwd {t_vit:.2f}s + {cfg.num_hidden_layers} x one Llama-3-8B "
+                       f"layer fwd+dgrad {t_layer:.2f}s + lm_head/CE {t_lm:.2f}s + seg head {t_head:.2f}s = {step:.1f}s/step (composed)")}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=8)
+    ap.add_argument("--text-len", type=int, default=1449)          # -> post-splice S = 2048 with 3 tasks
+    ap.add_argument("--layers", type=int, default=None, help="debug only: fewer decoder layers (result marked invalid)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--lr", type=float, default=1e-3)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a MI355X: the product path has no CPU fallback")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from visper_lm_amd import ops
+    from visper_lm_amd.config import llama3_8b
+    from visper_lm_amd.engine import Engine
+
+    cfg = llama3_8b()
+    if args.layers:
+        cfg.num_hidden_layers = args.layers
+        cfg.image_gen["img_layer_indices"] = str(min(20, args.layers))
+        cfg.image_depth["depth_layer_indices"] = str(min(18, args.layers))
+        cfg.image_seg["seg_layer_indices"] = str(min(18, args.layers))
+    eng = Engine(cfg, device=dev)
+    eng.set_distributed(rank, world)
+    eng.init_random(seed=0)                       # identical weights on every rank
+    batch = make_batch(cfg, args.batch, args.text_len, rank, dev)
+
+    def step():
+        out = eng.train_step(batch)
+        eng.optimizer_step(lr=args.lr)
+        return out
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        out = step()
+    fence()
+    ops.GEMM_PROF = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    fence()
+    dt = time.perf_counter() - t0
+    prof, ops.GEMM_PROF = ops.GEMM_PROF, None
+    if dist is not None:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t)
+    S = out["plan"]["S"]
+    loss = float(out["loss"])
+    ms = dt / args.steps * 1e3
+    value = args.batch * world * args.steps / dt
+
+    # roofline of the dominant kernel (bf16 MFMA GEMM): algorithmic 2*M*N*K per launch / event-timed duration
+    g_ms = sum(e0.elapsed_time(e1) for e0, e1, _, _ in prof)
+    g_fl = sum(f for _, _, f, _ in prof)
+    achieved = g_fl / (g_ms * 1e-3) / 1e12 if g_ms > 0 else 0.0
+    roof = {"bound": "mfma", "kernel": "gemm_nt_128 (bf16 MFMA 16x16x32, 128x128x64 tiles)", "achieved": round(achieved, 1),
+            "peak": PEAK_BF16_TF, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TF, 4), "traffic": None,
+            "launches_per_step": len(prof) // max(args.steps, 1), "gemm_ms_per_step": round(g_ms / args.steps, 2),
+            "gemm_tflop_per_step": round(g_fl / args.steps / 1e12, 2),
+            "step_frac_of_peak": round(value / world * STEP_TF_PER_IMAGE / PEAK_BF16_TF, 4)}
+    if rank == 0:
+        res = {"metric": "train-step images/sec (NTP+distill), ViT-L+Llama3-8B seq2048", "value": round(value, 4), "unit": "images/s",
+               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 2), "higher_is_better": True,
+               "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic (random-init weights, random images/tokens/targets)",
+               "config": {"workload": "configs[1]: CLIP-ViT-L/14-336 + Llama-3-8B PT step, 3 distill heads (d18,s18,g20), 336px",
+                          "global_batch": args.batch * world, "per_gpu_batch": args.batch, "seq_len": S, "text_len": args.text_len,
+                          "parallelism": f"dp{world}", "decoder_layers": cfg.num_hidden_layers, "loss": round(loss, 4),
+                          "valid": args.layers is None},
+               "roofline": roof}
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(cfg)
+        print(json.dumps(res), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

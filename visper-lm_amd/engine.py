@@ -100,6 +100,25 @@ def _tp(w):
     return ops.transpose(w.contiguous())
 
 
+class LazyRandomWeights:
+    """Mapping name -> freshly generated bf16 device tensor (random init, see params.init_value); lets an 8 B-parameter
+    model be initialised layer by layer on the GPU without a host copy.  Deterministic for a given seed and access order."""
+
+    def __init__(self, cfg, device, seed=0, vit_nested=True):
+        from .params import param_shapes
+        self.shapes = param_shapes(cfg, vit_nested=vit_nested)
+        self.device = torch.device(device)
+        self.gen = torch.Generator(device=self.device)
+        self.gen.manual_seed(seed)
+
+    def __contains__(self, k):
+        return k in self.shapes
+
+    def __getitem__(self, k):
+        from .params import init_value
+        return init_value(k, self.shapes[k], self.gen, self.device, BF16)
+
+
 class Engine:
     def __init__(self, cfg, device="cuda", lm_chunk_rows=2048):
         if not torch.cuda.is_available():
@@ -112,6 +131,7 @@ class Engine:
         self.ps = None         # ParamStore
         self._rope = {}
         self._plan_cache = {}
+        self._pending = []
         self.keep_logits = False
 
     # ------------------------------------------------------------------------------------------ weights
@@ -130,7 +150,7 @@ class Engine:
             C = cfg.vit_hidden
             pw = W[vp + "embeddings.patch_embedding.weight"].reshape(C, -1)
             kp = (pw.shape[1] + 63) // 64 * 64
-            pwp = torch.zeros(C, kp, dtype=pw.dtype)
+            pwp = torch.zeros(C, kp, dtype=pw.dtype, device=pw.device)
             pwp[:, :pw.shape[1]] = pw
             fz["vit.patch_w"] = d(pwp)
             pos = W[vp + "embeddings.position_embedding.weight"]
@@ -169,13 +189,46 @@ class Engine:
                 fz[o + k + "_T"] = _tp(fz[o + k])
             fz[o + "ln1"] = d(W[p + "input_layernorm.weight"])
             fz[o + "ln2"] = d(W[p + "post_attention_layernorm.weight"])
-        # ---- trainable
-        shapes = OrderedDict((k, tuple(v.shape)) for k, v in W.items() if is_trainable(k))
+        # ---- trainable.  Flat-buffer order: [heads + logit scales | projector + task tokens] so the first block's
+        # gradients (final as soon as the heads' backward is done) can be all-reduced under the decoder backward.
+        allshapes = getattr(W, "shapes", None) or OrderedDict((k, tuple(v.shape)) for k, v in W.items())
+        tr = [k for k in allshapes if is_trainable(k)]
+        early = [k for k in tr if ("_heads." in k or k.endswith("logit_scale"))]
+        late = [k for k in tr if k not in set(early)]
+        shapes = OrderedDict((k, tuple(allshapes[k])) for k in early + late)
         self.ps = ParamStore(shapes, dev)
+        self.ps.split = self.ps.index[late[0]][0] if late else self.ps.total
         for k in shapes:
             self.ps.p(k).copy_(W[k].detach().to(device=dev, dtype=F32).reshape(self.ps.p(k).shape))
         self.ps.refresh_shadow()
         self._build_static()
+
+    def init_random(self, seed=0):
+        """Random-init weights of the configured architecture, generated on the device (bench / smoke runs)."""
+        self.load_weights(LazyRandomWeights(self.cfg, self.dev, seed))
+
+    def set_distributed(self, rank, world):
+        self.rank, self.world = rank, world
+
+    def _allreduce_async(self, lo, hi):
+        """Sum-all-reduce grad[lo:hi] on RCCL's own stream (it waits for the kernels already queued on the compute
+        stream, then runs concurrently with whatever we launch next); joined in finish_grads()."""
+        import torch.distributed as dist
+        if hi > lo:
+            self._pending.append(dist.all_reduce(self.ps.grad[lo:hi], async_op=True))
+
+    def finish_grads(self):
+        """Join outstanding gradient all-reduces (the compute stream waits; the host does not)."""
+        for w in self._pending:
+            w.wait()
+        self._pending = []
+
+    def optimizer_step(self, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+        """Mean-reduce over DP ranks is folded into AdamW's grad_scale (ZeRO-2 / DDP averaging semantics)."""
+        if self.world > 1:
+            self._allreduce_async(self.ps.split, self.ps.total)
+            self.finish_grads()
+        self.ps.adamw_step(lr, betas, eps, weight_decay, grad_scale=1.0 / self.world)
 
     def vit_layers_run(self):
         sel = self.cfg.mm_vision_select_layer
@@ -475,6 +528,8 @@ class Engine:
                 out["embs"].setdefault(task, []).append(res["emb"])
                 if compute_grads and res["dx"] is not None:
                     dx_parts[idx].append((task, res["dx"]))
+        if compute_grads and self.world > 1:
+            self._allreduce_async(0, self.ps.split)          # heads + logit scales: overlap with the decoder backward
         loss = text_loss.clone()
         for task in ("seg", "depth", "gen"):                                 # sum order: ola_llama.py:143-144
             if task in task_loss:

@@ -12,6 +12,7 @@ from . import _lib
 
 EPI_NONE, EPI_GELU, EPI_QUICK_GELU, EPI_RELU = 0, 1, 2, 3
 BF16 = torch.bfloat16
+GEMM_PROF = None   # bench.py sets this to a list: every GEMM launch is bracketed by HIP events on its own stream
 
 
 def _stream():
@@ -50,8 +51,14 @@ def gemm(a, w, bias=None, residual=None, epi=EPI_NONE, out=None, out_f32=False, 
     ldr = 0
     if residual is not None:
         _, _, ldr = _rows2d(residual)
+    if GEMM_PROF is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     _lib.call("vp_gemm_bf16", M, N, K, _p(a), lda, _p(w), ldb, _p(out), ldc, _p(bias), _p(residual), ldr, epi,
               1 if out.dtype == torch.float32 else 0, 1 if force_generic else 0, _stream())
+    if GEMM_PROF is not None:
+        e1.record()
+        GEMM_PROF.append((e0, e1, 2.0 * M * N * K, (M, N, K)))
     return out
 
 

@@ -1,0 +1,124 @@
+"""State-dict manifest of the reference PT-stage model (names and shapes exactly as the reference modules
+create them — SURVEY §5.4 — so reference checkpoints round-trip) and an on-device random initialiser.
+
+Names follow OlaLlavaLlamaForCausalLM / OlaLlavaPhi3ForCausalLM (ola_llama.py / ola_phi3.py), OlaLlavaMetaModel
+(ola_arch.py:45,67-94,127), init_heads (base_ola_vlm.py:104-168), TaskTokenResampler (resampler.py:167-200),
+TaskToken{Gen,Depth}Head / OneFormerTaskTokenSegHead, HF CLIPVisionModel.  The frozen DPT decoder
+(`da_v2_head.*`, base_ola_vlm.py:139) is visualisation-only and out of scope."""
+from __future__ import annotations
+
+from collections import OrderedDict
+
+from .config import layer_indices
+
+
+def _resampler(pfx, dim, emb, out_dim, hc, sh):
+    inner = hc["num_heads"] * hc["dim_head"]
+    sh[pfx + "proj_in.weight"] = (dim, emb); sh[pfx + "proj_in.bias"] = (dim,)
+    sh[pfx + "proj_out.weight"] = (out_dim, dim); sh[pfx + "proj_out.bias"] = (out_dim,)
+    sh[pfx + "norm_out.weight"] = (out_dim,); sh[pfx + "norm_out.bias"] = (out_dim,)
+    for d in range(hc["depth"]):
+        a, f = f"{pfx}layers.{d}.0.", f"{pfx}layers.{d}.1."
+        for n in ("norm1", "norm2"):
+            sh[a + n + ".weight"] = (dim,); sh[a + n + ".bias"] = (dim,)
+        sh[a + "to_q.weight"] = (inner, dim); sh[a + "to_kv.weight"] = (2 * inner, dim); sh[a + "to_out.weight"] = (dim, inner)
+        ff = int(dim * hc["ff_mult"])
+        sh[f + "0.weight"] = (dim,); sh[f + "0.bias"] = (dim,)
+        sh[f + "1.weight"] = (ff, dim); sh[f + "3.weight"] = (dim, ff)
+
+
+def param_shapes(cfg, vit_nested=True, with_vit=True) -> "OrderedDict[str, tuple]":
+    """{name: shape}.  vit_nested=True uses transformers==4.41.1 naming (`...vision_tower.vision_model.*`, the
+    reference's pin); False uses the flattened 5.x naming the golden fixtures were generated under."""
+    sh = OrderedDict()
+    H, V, F = cfg.hidden_size, cfg.vocab_size, cfg.intermediate_size
+    nh, nkv, hd = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim
+    order = cfg.token_order
+    nt = cfg.num_task_tokens
+    if "gen" in order and hasattr(cfg, "image_gen"):
+        sh["gen_logit_scale"] = ()
+    if "depth" in order and hasattr(cfg, "image_depth"):
+        sh["depth_logit_scale"] = ()
+    if "seg" in order and hasattr(cfg, "image_seg"):
+        sh["seg_logit_scale"] = ()
+    if "gen" in order and hasattr(cfg, "image_gen"):
+        hc = cfg.image_gen
+        for i in range(len(layer_indices(hc["img_layer_indices"]))):
+            _resampler(f"image_gen_heads.{i}.projector.", hc["output_dim"], H, hc["output_dim"], hc, sh)   # gen_head.py:48-57
+    if "depth" in order and hasattr(cfg, "image_depth"):
+        hc = cfg.image_depth
+        for i in range(len(layer_indices(hc["depth_layer_indices"]))):
+            _resampler(f"image_depth_heads.{i}.projector.", H, H, hc["output_dim"], hc, sh)                 # da_v2_head.py:427-436 (dim = llm hidden)
+            for j in (1, 2, 3):
+                p = f"image_depth_heads.{i}.linear_{j}."
+                sh[p + "0.weight"] = (hc["output_dim"], hc["output_dim"]); sh[p + "0.bias"] = (hc["output_dim"],)
+                sh[p + "2.weight"] = (hc["output_dim"], hc["output_dim"]); sh[p + "2.bias"] = (hc["output_dim"],)
+    if "seg" in order and hasattr(cfg, "image_seg"):
+        hc = cfg.image_seg
+        for i in range(len(layer_indices(hc["seg_layer_indices"]))):
+            _resampler(f"image_seg_heads.{i}.projector.", hc["output_dim"], H, hc["output_dim"], hc, sh)    # oneformer_head.py:233-242
+    if nt > 0:
+        if "depth" in order:
+            sh["model.special_depth_tokens"] = (cfg.image_depth["num_tokens"], H)
+        if "seg" in order:
+            sh["model.special_seg_tokens"] = (cfg.image_seg["num_tokens"], H)
+        if "gen" in order:
+            sh["model.special_gen_tokens"] = (nt, H)
+    sh["model.embed_tokens.weight"] = (V, H)
+    for l in range(cfg.num_hidden_layers):
+        p = f"model.layers.{l}."
+        if cfg.arch == "phi3":
+            sh[p + "self_attn.o_proj.weight"] = (H, nh * hd)
+            sh[p + "self_attn.qkv_proj.weight"] = ((nh + 2 * nkv) * hd, H)
+            sh[p + "mlp.gate_up_proj.weight"] = (2 * F, H)
+            sh[p + "mlp.down_proj.weight"] = (H, F)
+        else:
+            sh[p + "self_attn.q_proj.weight"] = (nh * hd, H)
+            sh[p + "self_attn.k_proj.weight"] = (nkv * hd, H)
+            sh[p + "self_attn.v_proj.weight"] = (nkv * hd, H)
+            sh[p + "self_attn.o_proj.weight"] = (H, nh * hd)
+            sh[p + "mlp.gate_proj.weight"] = (F, H)
+            sh[p + "mlp.up_proj.weight"] = (F, H)
+            sh[p + "mlp.down_proj.weight"] = (H, F)
+        sh[p + "input_layernorm.weight"] = (H,)
+        sh[p + "post_attention_layernorm.weight"] = (H,)
+    sh["model.norm.weight"] = (H,)
+    if with_vit:
+        vp = "model.vision_tower.vision_tower." + ("vision_model." if vit_nested else "")
+        C, I = cfg.vit_hidden, cfg.vit_inter
+        g = cfg.vit_image // cfg.vit_patch
+        sh[vp + "embeddings.class_embedding"] = (C,)
+        sh[vp + "embeddings.patch_embedding.weight"] = (C, 3, cfg.vit_patch, cfg.vit_patch)
+        sh[vp + "embeddings.position_embedding.weight"] = (g * g + 1, C)
+        sh[vp + "pre_layrnorm.weight"] = (C,); sh[vp + "pre_layrnorm.bias"] = (C,)
+        for l in range(cfg.vit_layers):
+            q = vp + f"encoder.layers.{l}."
+            for n in ("k_proj", "v_proj", "q_proj", "out_proj"):
+                sh[q + f"self_attn.{n}.weight"] = (C, C); sh[q + f"self_attn.{n}.bias"] = (C,)
+            sh[q + "layer_norm1.weight"] = (C,); sh[q + "layer_norm1.bias"] = (C,)
+            sh[q + "mlp.fc1.weight"] = (I, C); sh[q + "mlp.fc1.bias"] = (I,)
+            sh[q + "mlp.fc2.weight"] = (C, I); sh[q + "mlp.fc2.bias"] = (C,)
+            sh[q + "layer_norm2.weight"] = (C,); sh[q + "layer_norm2.bias"] = (C,)
+        sh[vp + "post_layernorm.weight"] = (C,); sh[vp + "post_layernorm.bias"] = (C,)
+    sh["model.mm_projector.0.weight"] = (H, cfg.mm_hidden_size); sh["model.mm_projector.0.bias"] = (H,)
+    sh["model.mm_projector.2.weight"] = (H, H); sh["model.mm_projector.2.bias"] = (H,)
+    sh["lm_head.weight"] = (V, H)
+    return sh
+
+
+def init_value(name, shape, gen, device, dtype):
+    """Random init mirroring the reference's module defaults closely enough for a throughput run:
+    logit scales 2.0 (base_ola_vlm.py:113), task tokens ~N(0,1) (ola_arch.py:80-94), norm weights 1 / biases 0,
+    linear & embedding weights ~N(0, 0.02) (HF initializer_range)."""
+    import torch
+    if name.endswith("logit_scale"):
+        return torch.full((), 2.0, device=device, dtype=dtype)
+    if "special_" in name:
+        return torch.randn(shape, device=device, dtype=dtype, generator=gen)
+    if len(shape) == 1:
+        if name.endswith("bias"):
+            return torch.zeros(shape, device=device, dtype=dtype)
+        if name.endswith("class_embedding"):
+            return torch.randn(shape, device=device, dtype=dtype, generator=gen) * 0.02
+        return torch.ones(shape, device=device, dtype=dtype)
+    return torch.randn(shape, device=device, dtype=dtype, generator=gen) * 0.02
