@@ -71,6 +71,16 @@ def test_gemm_epilogues(ops, epi):
     close(out, ref, what=f"gemm epi {epi}")
 
 
+@pytest.mark.parametrize("M,N,K", [(512, 512, 128), (700, 300, 192), (256, 1024, 64)])
+def test_gemm_256_tile_kernel(ops, M, N, K):
+    a, w, b, r = rnd(M, K, seed=50), rnd(N, K, scale=0.1, seed=51), rnd(N, seed=52), rnd(M, N, seed=53)
+    ref = (a.float() @ w.float().t() + b.float()).to(BF).float() + r.float()
+    out = ops.gemm(dev(a), dev(w), bias=dev(b), residual=dev(r), force_generic=3)
+    close(out, ref, what=f"gemm256 {M}x{N}x{K}")
+    out2 = ops.gemm(dev(a), dev(w), bias=dev(b), residual=dev(r), force_generic=2)
+    close(out2, ref, what=f"gemm128 {M}x{N}x{K}")
+
+
 def test_gemm_strided_views(ops):
     # A is a column slice of a wider buffer, C is written into a column slice (fused-QKV style)
     M, K, N = 192, 128, 64

@@ -166,6 +166,95 @@ __global__ __launch_bounds__(256) void gemm_nt_128(GemmArgs p) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// large-problem path: 256x256x64 block tile, 8 waves (2 x 4, each 128x64 = 8x4 MFMA tiles), 2 LDS buffers
+// (2 x 64 KB): tile t+1 is DMA'd into the other buffer at the START of computing tile t, so its
+// global_load_lds has a whole tile of MFMA work to land under and the single barrier per K-tile (which
+// carries vmcnt(0)) never stalls on it.  1 block / CU (128 KB LDS), 2 waves / SIMD.
+// ------------------------------------------------------------------------------------------------
+template <bool OUT_F32>
+__global__ __launch_bounds__(512) void gemm_nt_256(GemmArgs p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  bf16_t* smem = (bf16_t*)smem_raw;                    // [buf 0: A 256x64 | B 256x64][buf 1: ...]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+  const int tiles_m = (p.M + 255) >> 8, tiles_n = (p.N + 255) >> 8;
+  const int nwg = tiles_m * tiles_n;
+  const int id = xcd_remap(blockIdx.x, nwg);
+  const int GROUP_M = 8;
+  const int width = GROUP_M * tiles_n;
+  const int group = id / width;
+  const int first_m = group * GROUP_M;
+  const int gsz = min(tiles_m - first_m, GROUP_M);
+  const int tm = first_m + (id % width) % gsz;
+  const int tn = (id % width) / gsz;
+  const int m0 = tm << 8, n0 = tn << 8;
+
+  const bf16_t* srcA[4];
+  const bf16_t* srcB[4];
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int q = it * 512 + tid;
+    const int row = q >> 3;
+    const int gc = (q & 7) ^ ((row >> 1) & 7);
+    srcA[it] = p.A + (long)min(m0 + row, p.M - 1) * p.lda + gc * 8;
+    srcB[it] = p.B + (long)min(n0 + row, p.N - 1) * p.ldb + gc * 8;
+  }
+  const int wr = wave >> 2, wc = wave & 3;
+  const int fr = lane & 15, g = lane >> 4;
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nt = p.K >> 6;
+#define ISSUE_TILE(T, BUF)                                                         \
+  {                                                                                \
+    bf16_t* As_ = smem + (BUF) * 32768;                                            \
+    bf16_t* Bs_ = As_ + 16384;                                                     \
+    _Pragma("unroll") for (int it = 0; it < 4; ++it) {                             \
+      GLDS16(srcA[it] + (long)(T) * 64, As_ + (it * 512 + wave * 64) * 8);         \
+      GLDS16(srcB[it] + (long)(T) * 64, Bs_ + (it * 512 + wave * 64) * 8);         \
+    }                                                                              \
+  }
+  ISSUE_TILE(0, 0);
+  __syncthreads();
+  for (int t = 0; t < nt; ++t) {
+    const int cur = t & 1;
+    if (t + 1 < nt) ISSUE_TILE(t + 1, cur ^ 1);
+    const bf16_t* As = smem + cur * 32768;
+    const bf16_t* Bs = As + 16384;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 xf[8], wf[4];
+      const int cg = ks * 4 + g;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int r = wc * 64 + j * 16 + fr;
+        wf[j] = *(const bf16x8*)(Bs + r * 64 + ((cg ^ ((r >> 1) & 7)) << 3));
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int r = wr * 128 + i * 16 + fr;
+        xf[i] = *(const bf16x8*)(As + r * 64 + ((cg ^ ((r >> 1) & 7)) << 3));
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], xf[i], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+#undef ISSUE_TILE
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      store4<OUT_F32>(p, m0 + wr * 128 + i * 16 + fr, n0 + wc * 64 + j * 16 + g * 4, acc[i][j]);
+}
+
+// ------------------------------------------------------------------------------------------------
 // generic path: any M, N, K, any alignment (register-staged, zero-filled K tail). 64x64x32 tile.
 // ------------------------------------------------------------------------------------------------
 template <bool OUT_F32>
@@ -245,9 +334,19 @@ int vp_gemm_bf16(int M, int N, int K, const void* A, long lda, const void* B, lo
   VP_REQUIRE(epilogue >= 0 && epilogue <= 3, VP_ERR_BAD_ARG, "vp_gemm_bf16: bad epilogue %d", epilogue);
   GemmArgs p{(const bf16_t*)A, (const bf16_t*)B, C, (const bf16_t*)bias, (const bf16_t*)residual, M, N, K,
              lda, ldb, ldc, ldr, epilogue};
-  const bool fast = !force_generic && (K % 64 == 0) && (lda % 8 == 0) && (ldb % 8 == 0) &&
+  const bool fast = (force_generic != 1) && (K % 64 == 0) && (lda % 8 == 0) && (ldb % 8 == 0) &&
                     ((((uintptr_t)A) | ((uintptr_t)B)) & 15) == 0;
-  if (fast) {
+  const long big_tiles = (long)((M + 255) / 256) * ((N + 255) / 256);
+  if (fast && force_generic != 2 && (force_generic == 3 || (big_tiles >= 192 && M >= 256 && N >= 256))) {
+    static bool attr_done = false;
+    if (!attr_done) {
+      (void)hipFuncSetAttribute((const void*)gemm_nt_256<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+      (void)hipFuncSetAttribute((const void*)gemm_nt_256<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+      attr_done = true;
+    }
+    if (out_f32) hipLaunchKernelGGL(gemm_nt_256<true>, dim3((unsigned)big_tiles), dim3(512), 131072, stream, p);
+    else hipLaunchKernelGGL(gemm_nt_256<false>, dim3((unsigned)big_tiles), dim3(512), 131072, stream, p);
+  } else if (fast) {
     const int grid = ((M + 127) / 128) * ((N + 127) / 128);
     if (out_f32) hipLaunchKernelGGL(gemm_nt_128<true>, dim3(grid), dim3(256), 0, stream, p);
     else hipLaunchKernelGGL(gemm_nt_128<false>, dim3(grid), dim3(256), 0, stream, p);

@@ -120,7 +120,7 @@ class LazyRandomWeights:
 
 
 class Engine:
-    def __init__(self, cfg, device="cuda", lm_chunk_rows=2048):
+    def __init__(self, cfg, device="cuda", lm_chunk_rows=8192):
         if not torch.cuda.is_available():
             raise RuntimeError("visper_lm_amd.Engine needs a HIP device: there is no CPU fallback path")
         self.cfg = cfg

@@ -40,7 +40,8 @@ def _rows2d(t):
 
 # ------------------------------------------------------------------------------------------------
 def gemm(a, w, bias=None, residual=None, epi=EPI_NONE, out=None, out_f32=False, force_generic=False):
-    """out[M,N] = epi(a[M,K] @ w[N,K]^T + bias) + residual."""
+    """out[M,N] = epi(a[M,K] @ w[N,K]^T + bias) + residual.
+    force_generic: 0 auto | 1 bounds-checked generic kernel | 2 force the 128-tile kernel | 3 force the 256-tile kernel."""
     M, K, lda = _rows2d(a)
     N, K2, ldb = _rows2d(w)
     assert K == K2, (a.shape, w.shape)
@@ -55,7 +56,7 @@ def gemm(a, w, bias=None, residual=None, epi=EPI_NONE, out=None, out_f32=False, 
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
     _lib.call("vp_gemm_bf16", M, N, K, _p(a), lda, _p(w), ldb, _p(out), ldc, _p(bias), _p(residual), ldr, epi,
-              1 if out.dtype == torch.float32 else 0, 1 if force_generic else 0, _stream())
+              1 if out.dtype == torch.float32 else 0, int(force_generic), _stream())
     if GEMM_PROF is not None:
         e1.record()
         GEMM_PROF.append((e0, e1, 2.0 * M * N * K, (M, N, K)))
