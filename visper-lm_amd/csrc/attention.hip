@@ -2,15 +2,23 @@
 //   * Llama/Phi-3 decoder: causal, GQA, D=128/96            (fwd + bwd; LLM is frozen -> dgrad only)
 //   * CLIP-ViT: non-causal, N=577, D=64                      (fwd only)
 //   * Perceiver resampler heads: cross-attention, D=32       (fwd + bwd)
-// Design (CDNA4, 64-lane waves): every kernel keeps the *query* (or key) index on the lane axis so
-// softmax statistics are lane-local, and builds the second GEMM's operand directly from the first GEMM's
-// accumulator registers (no LDS round trip for P / dS): a 16x16x32 MFMA contracts over 32 "k slots"
-// (g = lane>>4, j = 0..7); A and B only have to agree on which key each slot means, so slot (g,j) is
-// mapped to key 16*(j>>2) + 4g + (j&3) — exactly the (row = 4g + r) layout two stacked C tiles have.
-// The operand that is contracted over tokens (V in fwd, Q/dO in dK/dV, K in dQ) is staged *transposed*
-// in LDS ([d][token], token pairs packed into dwords) so its fragments are two 8-byte reads.
-// Row-major tiles are padded (+8 elements) -> conflict-free ds_read_b128; transposed tiles use a
-// stride of 2*odd 8-byte slots -> conflict-free ds_read_b64.
+// Design (CDNA4, 64-lane waves):
+//  - every kernel keeps the *query* (fwd, dQ) or *key* (dK/dV) index on the lane axis so softmax statistics
+//    are lane-local, and builds the second GEMM's operand directly from the first GEMM's accumulator
+//    registers (no LDS round trip for P / dS): a 16x16x32 MFMA contracts over 32 "k slots" (g = lane>>4,
+//    j = 0..7); A and B only have to agree on which token each slot means, so slot (g,j) is mapped to token
+//    16*(j>>2) + 4g + (j&3) — exactly the (row = 4g + r) layout two stacked C tiles have.
+//  - all LDS tiles are plain row-major [token][feature] (stride D+16 elements: conflict-free for both read
+//    kinds).  Fragments contracted over features are ds_read_b128; fragments contracted over TOKENS (V in
+//    fwd, Q/dO in dK/dV, K in dQ) come from the gfx950 hardware transpose read ds_read_b64_tr_b16
+//    (lane 4a+b supplies the address of row a, features 4b..4b+3; it receives column (lane&15) of that
+//    4x16 block), so nothing is ever staged transposed.
+//  - the next K/V (or Q/dO) tile is prefetched HBM->registers while the current tile is being consumed, and
+//    written to LDS after the compute barrier (issue-early / write-late), so HBM latency hides under MFMA.
+//  - 8 waves (512 threads) x 16 rows per block at <= 128 VGPRs: the kernels are VALU-issue bound (softmax /
+//    dS arithmetic ~ as many issue cycles as the MFMAs), so they want 4 waves per SIMD to hide dependent-issue
+//    latency more than they want bigger per-wave tiles (LDS is only ~10 % busy).  exp2 is the raw v_exp_f32
+//    with scale*log2(e) folded into one FMA; the O rescale is skipped while the running max grows < 2^8.
 // Log-sum-exp is kept in the log2 domain: lse2 = m + log2(l) with scores pre-multiplied by scale*log2(e).
 #include "common.h"
 
@@ -25,6 +33,9 @@ struct AttnParams {
 };
 
 #define LOG2E 1.4426950408889634f
+#define RESCALE_THR 8.0f     // log2 units: skip the O/l rescale while the running max grows by < 2^8 (wave-uniform)
+static __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }   // raw v_exp_f32
+typedef __attribute__((ext_vector_type(4))) short s16x4;
 static __device__ __forceinline__ bf16x8 zero8() { return bf16x8{0, 0, 0, 0, 0, 0, 0, 0}; }
 
 // 8 fp32 (two C tiles' registers) -> one bf16x8 MFMA operand
@@ -34,142 +45,162 @@ static __device__ __forceinline__ bf16x8 pack8(const f32x4& a, const f32x4& b) {
   r[4] = (short)f2bf(b[0]); r[5] = (short)f2bf(b[1]); r[6] = (short)f2bf(b[2]); r[7] = (short)f2bf(b[3]);
   return r;
 }
-// transposed-tile fragment: tokens (4g..4g+3) and (16+4g..) of feature row `d`
-static __device__ __forceinline__ bf16x8 tfrag(const bf16_t* t, int ldt, int d, int tok0, int g) {
-  const bf16x4 lo = *(const bf16x4*)(t + d * ldt + tok0 + 4 * g);
-  const bf16x4 hi = *(const bf16x4*)(t + d * ldt + tok0 + 16 + 4 * g);
+
+// Token-contracted fragment from a ROW-MAJOR tile t[token][feature] (stride ld): this lane (fr = lane&15,
+// g = lane>>4) receives feature f0+fr of tokens tok0+4g+{0..3} and tok0+16+4g+{0..3}  (== k slots (g, 0..7)).
+static __device__ __forceinline__ bf16x8 trfrag(const bf16_t* t, int ld, int tok0, int f0, int lane) {
+  const int g = lane >> 4, a = (lane & 15) >> 2, b = lane & 3;
+  const bf16_t* p0 = t + (tok0 + 4 * g + a) * ld + f0 + 4 * b;
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p0);
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p0 + 16 * ld));
   return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 }
 
-// Stage R token rows x D features (global, token stride ts) into LDS row-major (stride D+8); rows >= limit -> 0.
-template <int D, int R>
-static __device__ __forceinline__ void stage_rows(bf16_t* lds, const bf16_t* gbase, long ts, int row0, int limit) {
-  constexpr int CH = D / 8;
-  for (int it = threadIdx.x; it < R * CH; it += 256) {
-    const int r = it / CH, c = it % CH;
-    bf16x8 v = zero8();
-    if (row0 + r < limit) v = *(const bf16x8*)(gbase + (long)(row0 + r) * ts + c * 8);
-    *(bf16x8*)(lds + r * (D + 8) + c * 8) = v;
-  }
-}
-// Stage the same tile transposed: ldsT[d][token] (stride LDT), token pairs packed per dword.
-// Optionally also writes the row-major image from the same loads (ROWMAJOR != nullptr).
-template <int D, int R, int LDT>
-static __device__ __forceinline__ void stage_transposed(bf16_t* ldsT, bf16_t* rowmajor, const bf16_t* gbase, long ts, int row0,
-                                                        int limit) {
-  constexpr int CH = D / 8, NP = R / 2;
-  for (int it = threadIdx.x; it < NP * CH; it += 256) {
-    const int pr = it % NP, c = it / NP;
-    const int r0 = 2 * pr;
-    bf16x8 a = zero8(), b = zero8();
-    if (row0 + r0 < limit) a = *(const bf16x8*)(gbase + (long)(row0 + r0) * ts + c * 8);
-    if (row0 + r0 + 1 < limit) b = *(const bf16x8*)(gbase + (long)(row0 + r0 + 1) * ts + c * 8);
-    if (rowmajor) {
-      *(bf16x8*)(rowmajor + r0 * (D + 8) + c * 8) = a;
-      *(bf16x8*)(rowmajor + (r0 + 1) * (D + 8) + c * 8) = b;
-    }
+// R token rows x D features prefetched into registers (HBM latency hides under the current tile's MFMAs),
+// then written to the row-major LDS tile.  Loads are UNCONDITIONAL (row index clamped to limit-1): a
+// predicated load makes hipcc branch around it and wait vmcnt(0) per element, serialising the L2 round
+// trips.  Out-of-range rows therefore hold a copy of the last valid row; every consumer masks them
+// (scores of keys >= kv_len / queries >= Sq are forced to p = 0) so they never reach an output.
+template <int D, int R, int NT = 512>
+struct TileRegs {
+  static constexpr int CH = D / 8;
+  static constexpr int N = (R * CH + NT - 1) / NT;
+  bf16x8 v[N];
+  __device__ __forceinline__ void load(const bf16_t* gbase, long ts, int row0, int limit) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const uint32_t w = (uint32_t)(uint16_t)a[j] | ((uint32_t)(uint16_t)b[j] << 16);
-      *(uint32_t*)(ldsT + (c * 8 + j) * LDT + r0) = w;
+    for (int i = 0; i < N; ++i) {
+      const int it = threadIdx.x + i * NT;
+      const int itc = (R * CH) % NT == 0 ? it : min(it, R * CH - 1);
+      const int r = itc / CH, c = itc % CH;
+      v[i] = *(const bf16x8*)(gbase + (long)min(row0 + r, limit - 1) * ts + c * 8);
     }
   }
-}
+  __device__ __forceinline__ void store(bf16_t* lds, int ld) const {
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      const int it = threadIdx.x + i * NT;
+      const int r = it / CH, c = it % CH;
+      if (it < R * CH) *(bf16x8*)(lds + r * ld + c * 8) = v[i];
+    }
+  }
+};
 
 // ================================================================================================
-// forward
+// forward: block = 128 queries (8 waves x 16), loops 64-key tiles
 // ================================================================================================
 template <int D, bool CAUSAL>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
-  constexpr int LDK = D + 8, LDV = 72, NKS = D / 32, NDB = D / 16;
-  __shared__ __attribute__((aligned(16))) bf16_t Ks[64 * LDK];
-  __shared__ __attribute__((aligned(16))) bf16_t Vt[D * LDV];
+__global__ __launch_bounds__(512) void attn_fwd_kernel(AttnParams p) {
+  constexpr int LD = D + 16, NKS = D / 32, NDB = D / 16;
+  __shared__ __attribute__((aligned(16))) bf16_t Ks[64 * LD];
+  __shared__ __attribute__((aligned(16))) bf16_t Vs[64 * LD];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, fr = lane & 15, g = lane >> 4;
-  const int nqb = (p.Sq + 63) >> 6;
+  const int nqb = (p.Sq + 127) >> 7;
   const int qb = nqb - 1 - (int)blockIdx.x;            // heavy (late) causal blocks first
   const int h = blockIdx.y, b = blockIdx.z, hk = h / (p.Hq / p.Hkv);
-  const int q0 = qb * 64, qrow = q0 + wave * 16 + fr;
+  const int q0 = qb * 128, qw0 = q0 + wave * 16;
+  const int qrow = qw0 + fr;
   const int kvlen = p.kv_len ? min(p.kv_len[b], p.Skv) : p.Skv;
   const int off = p.Skv - p.Sq;
   const float c = p.scale * LOG2E;
 
   bf16x8 qf[NKS];
   {
-    const bf16_t* qp = p.q + (long)b * p.q_bs + (long)qrow * p.q_ts + (long)h * D;
+    const bf16_t* qp = p.q + (long)b * p.q_bs + (long)min(qrow, p.Sq - 1) * p.q_ts + (long)h * D;   // clamped: rows >= Sq never stored
 #pragma unroll
-    for (int ks = 0; ks < NKS; ++ks) qf[ks] = (qrow < p.Sq) ? *(const bf16x8*)(qp + ks * 32 + g * 8) : zero8();
+    for (int ks = 0; ks < NKS; ++ks) qf[ks] = *(const bf16x8*)(qp + ks * 32 + g * 8);
   }
   f32x4 oacc[NDB];
 #pragma unroll
   for (int d = 0; d < NDB; ++d) oacc[d] = f32x4{0.f, 0.f, 0.f, 0.f};
-  float m = -1e30f, l = 0.f;
+  float m = -1e30f, l = 0.f;          // m is kept PRE-scaled: m = c * max(raw score)
 
   int kend = kvlen;
-  if (CAUSAL) kend = min(kend, q0 + 64 + off);
+  if (CAUSAL) kend = min(kend, q0 + 128 + off);
   int kstart = 0;
   if (p.window > 0) kstart = max(0, (q0 + off - p.window + 1)) & ~63;
   const bf16_t* kbase = p.k + (long)b * p.k_bs + (long)hk * D;
   const bf16_t* vbase = p.v + (long)b * p.v_bs + (long)hk * D;
 
+  TileRegs<D, 64> kr, vr;
+  if (kstart < kend) {
+    kr.load(kbase, p.k_ts, kstart, p.Skv);
+    vr.load(vbase, p.v_ts, kstart, p.Skv);
+    kr.store(Ks, LD);
+    vr.store(Vs, LD);
+  }
+  __syncthreads();
   for (int k0 = kstart; k0 < kend; k0 += 64) {
-    __syncthreads();
-    stage_rows<D, 64>(Ks, kbase, p.k_ts, k0, p.Skv);
-    stage_transposed<D, 64, LDV>(Vt, nullptr, vbase, p.v_ts, k0, p.Skv);
-    __syncthreads();
-
-    f32x4 st[4];
-#pragma unroll
-    for (int kt = 0; kt < 4; ++kt) {
-      st[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int ks = 0; ks < NKS; ++ks) {
-        const bf16x8 kf = *(const bf16x8*)(Ks + (kt * 16 + fr) * LDK + ks * 32 + g * 8);
-        st[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], st[kt], 0, 0, 0);
-      }
+    const bool more = k0 + 64 < kend;
+    if (more) {
+      kr.load(kbase, p.k_ts, k0 + 64, p.Skv);
+      vr.load(vbase, p.v_ts, k0 + 64, p.Skv);
     }
-    // st[kt][r]: key = k0 + 16kt + 4g + r, query = qrow
-    const bool need_mask = (k0 + 64 > kvlen) || (CAUSAL && (k0 + 63 > q0 + wave * 16 + off)) || (p.window > 0);
-    float mx = -INFINITY;
+    // wave-uniform skip of tiles that are entirely above this wave's causal diagonal
+    const bool active = !CAUSAL || (k0 <= qw0 + 15 + off);
+    if (active) {
+      f32x4 st[4];
 #pragma unroll
-    for (int kt = 0; kt < 4; ++kt)
+      for (int kt = 0; kt < 4; ++kt) {
+        st[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float s = st[kt][r] * c;
-        if (need_mask) {
-          const int key = k0 + kt * 16 + 4 * g + r;
-          if (key >= kvlen || (CAUSAL && key > qrow + off) || (p.window > 0 && key <= qrow + off - p.window)) s = -INFINITY;
+        for (int ks = 0; ks < NKS; ++ks) {
+          const bf16x8 kf = *(const bf16x8*)(Ks + (kt * 16 + fr) * LD + ks * 32 + g * 8);
+          st[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], st[kt], 0, 0, 0);
         }
-        st[kt][r] = s;
-        mx = fmaxf(mx, s);
       }
-    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float mnew = fmaxf(m, mx);
-    const float alpha = exp2f(m - mnew);
-    float rs = 0.f;
+      // st[kt][r]: raw score of key k0 + 16kt + 4g + r against query qrow
+      const bool need_mask = (k0 + 64 > kvlen) || (CAUSAL && (k0 + 63 > qw0 + off)) || (p.window > 0);
+      if (need_mask) {
 #pragma unroll
-    for (int kt = 0; kt < 4; ++kt)
+        for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float e = exp2f(st[kt][r] - mnew);
-        st[kt][r] = e;
-        rs += e;
+          for (int r = 0; r < 4; ++r) {
+            const int key = k0 + kt * 16 + 4 * g + r;
+            if (key >= kvlen || (CAUSAL && key > qrow + off) || (p.window > 0 && key <= qrow + off - p.window)) st[kt][r] = -INFINITY;
+          }
       }
-    rs += __shfl_xor(rs, 16, 64);
-    rs += __shfl_xor(rs, 32, 64);
-    l = l * alpha + rs;
-    m = mnew;
+      float mx = fmaxf(fmaxf(st[0][0], st[0][1]), fmaxf(st[0][2], st[0][3]));
 #pragma unroll
-    for (int d = 0; d < NDB; ++d) oacc[d] *= alpha;
+      for (int kt = 1; kt < 4; ++kt) mx = fmaxf(mx, fmaxf(fmaxf(st[kt][0], st[kt][1]), fmaxf(st[kt][2], st[kt][3])));
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      mx *= c;
+      if (!__all(mx <= m + RESCALE_THR)) {            // rare after the first tiles: rescale everything held at the old max
+        const float mnew = fmaxf(m, mx);
+        const float alpha = fast_exp2(m - mnew);
+        l *= alpha;
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      const bf16x8 pf = pack8(st[2 * kk], st[2 * kk + 1]);
+        for (int d = 0; d < NDB; ++d) oacc[d] *= alpha;
+        m = mnew;
+      }
+      float rs = 0.f;
 #pragma unroll
-      for (int d = 0; d < NDB; ++d) {
-        const bf16x8 vf = tfrag(Vt, LDV, d * 16 + fr, kk * 32, g);
-        oacc[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, oacc[d], 0, 0, 0);
+      for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float e = fast_exp2(fmaf(st[kt][r], c, -m));
+          st[kt][r] = e;
+          rs += e;
+        }
+      rs += __shfl_xor(rs, 16, 64);
+      rs += __shfl_xor(rs, 32, 64);
+      l += rs;
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        const bf16x8 pf = pack8(st[2 * kk], st[2 * kk + 1]);
+#pragma unroll
+        for (int d = 0; d < NDB; ++d) {
+          const bf16x8 vf = trfrag(Vs, LD, kk * 32, d * 16, lane);
+          oacc[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, oacc[d], 0, 0, 0);
+        }
       }
     }
+    __syncthreads();
+    if (more) {
+      kr.store(Ks, LD);
+      vr.store(Vs, LD);
+    }
+    __syncthreads();
   }
   if (qrow < p.Sq) {
     const float inv = l > 0.f ? 1.f / l : 0.f;
@@ -206,19 +237,17 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(AttnParams p) {
 }
 
 // ================================================================================================
-// backward: dK, dV  (block = 64 keys of one kv head; loops the GQA group's q heads and 32-query tiles)
+// backward: dK, dV  (block = 128 keys of one kv head, 16 per wave; loops the GQA group's q heads and 32-query tiles)
 // ================================================================================================
 template <int D, bool CAUSAL>
-__global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnParams p) {
-  constexpr int LDR = D + 8, LDT = 40, NKS = D / 32, NDB = D / 16;
-  __shared__ __attribute__((aligned(16))) bf16_t Qs[32 * LDR];
-  __shared__ __attribute__((aligned(16))) bf16_t dOs[32 * LDR];
-  __shared__ __attribute__((aligned(16))) bf16_t Qt[D * LDT];
-  __shared__ __attribute__((aligned(16))) bf16_t dOt[D * LDT];
+__global__ __launch_bounds__(512) void attn_bwd_dkdv_kernel(AttnParams p) {
+  constexpr int LD = D + 16, NKS = D / 32, NDB = D / 16;
+  __shared__ __attribute__((aligned(16))) bf16_t Qs[32 * LD];
+  __shared__ __attribute__((aligned(16))) bf16_t dOs[32 * LD];
   __shared__ float lse_s[32], delta_s[32];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, fr = lane & 15, g = lane >> 4;
   const int hk = blockIdx.y, b = blockIdx.z;
-  const int k0 = blockIdx.x * 64, key = k0 + wave * 16 + fr;
+  const int k0 = blockIdx.x * 128, kw0 = k0 + wave * 16, key = kw0 + fr;
   const int kvlen = p.kv_len ? min(p.kv_len[b], p.Skv) : p.Skv;
   const int off = p.Skv - p.Sq;
   const int rep = p.Hq / p.Hkv;
@@ -226,12 +255,13 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnParams p) {
 
   bf16x8 kf[NKS], vf[NKS];
   {
-    const bf16_t* kp = p.k + (long)b * p.k_bs + (long)key * p.k_ts + (long)hk * D;
-    const bf16_t* vp = p.v + (long)b * p.v_bs + (long)key * p.v_ts + (long)hk * D;
+    const int keyc = min(key, p.Skv - 1);                   // clamped; keys >= kv_len are masked (p = 0) and not stored
+    const bf16_t* kp = p.k + (long)b * p.k_bs + (long)keyc * p.k_ts + (long)hk * D;
+    const bf16_t* vp = p.v + (long)b * p.v_bs + (long)keyc * p.v_ts + (long)hk * D;
 #pragma unroll
     for (int ks = 0; ks < NKS; ++ks) {
-      kf[ks] = (key < p.Skv) ? *(const bf16x8*)(kp + ks * 32 + g * 8) : zero8();
-      vf[ks] = (key < p.Skv) ? *(const bf16x8*)(vp + ks * 32 + g * 8) : zero8();
+      kf[ks] = *(const bf16x8*)(kp + ks * 32 + g * 8);
+      vf[ks] = *(const bf16x8*)(vp + ks * 32 + g * 8);
     }
   }
   f32x4 dk[NDB], dv[NDB];
@@ -240,25 +270,35 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnParams p) {
 
   int qstart = 0, qend = p.Sq;
   if (CAUSAL) qstart = max(0, k0 - off) & ~31;
-  if (p.window > 0) qend = min(p.Sq, k0 + 64 - off + p.window);
+  if (p.window > 0) qend = min(p.Sq, k0 + 128 - off + p.window);
   if (k0 >= kvlen) qend = qstart;                      // whole key tile is padding: gradients are zero
+  const int ntq = qend > qstart ? (qend - qstart + 31) / 32 : 0;
+  const int nit = ntq * rep;                           // flattened (head, q tile) iteration space
 
-  for (int hh = 0; hh < rep; ++hh) {
-    const int h = hk * rep + hh;
-    const bf16_t* qbase = p.q + (long)b * p.q_bs + (long)h * D;
-    const bf16_t* dobase = p.dout + (long)b * p.do_bs + (long)h * D;
-    const float* lse = p.lse + ((long)b * p.Hq + h) * p.Sq;
-    const float* dl = p.delta + ((long)b * p.Hq + h) * p.Sq;
-    for (int q0 = qstart; q0 < qend; q0 += 32) {
-      __syncthreads();
-      stage_transposed<D, 32, LDT>(Qt, Qs, qbase, p.q_ts, q0, p.Sq);
-      stage_transposed<D, 32, LDT>(dOt, dOs, dobase, p.do_ts, q0, p.Sq);
-      if (threadIdx.x < 32) {
-        const int qq = q0 + threadIdx.x;
-        lse_s[threadIdx.x] = qq < p.Sq ? lse[qq] : 0.f;
-        delta_s[threadIdx.x] = qq < p.Sq ? dl[qq] : 0.f;
-      }
-      __syncthreads();
+  TileRegs<D, 32> qr, dor;
+  float lse_r = 0.f, del_r = 0.f;
+  auto prefetch = [&](int it) {
+    const int h = hk * rep + it / ntq, q0 = qstart + (it % ntq) * 32;
+    qr.load(p.q + (long)b * p.q_bs + (long)h * D, p.q_ts, q0, p.Sq);
+    dor.load(p.dout + (long)b * p.do_bs + (long)h * D, p.do_ts, q0, p.Sq);
+    const int qq = min(q0 + (int)(threadIdx.x & 31), p.Sq - 1);
+    const long si = ((long)b * p.Hq + h) * p.Sq + qq;
+    lse_r = p.lse[si];
+    del_r = p.delta[si];
+  };
+  auto commit = [&]() {
+    qr.store(Qs, LD);
+    dor.store(dOs, LD);
+    if (threadIdx.x < 32) { lse_s[threadIdx.x] = lse_r; delta_s[threadIdx.x] = del_r; }
+  };
+  if (nit > 0) { prefetch(0); commit(); }
+  __syncthreads();
+  for (int it = 0; it < nit; ++it) {
+    if (it + 1 < nit) prefetch(it + 1);
+    const int q0 = qstart + (it % ntq) * 32;
+    // wave-uniform skip: every query of this tile is below this wave's first key (causal) -> all p = 0
+    const bool active = !CAUSAL || (q0 + 31 + off >= kw0);
+    if (active) {
       f32x4 s[2], dp[2];
 #pragma unroll
       for (int qt = 0; qt < 2; ++qt) {
@@ -266,21 +306,25 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnParams p) {
         dp[qt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks) {
-          const bf16x8 qa = *(const bf16x8*)(Qs + (qt * 16 + fr) * LDR + ks * 32 + g * 8);
-          const bf16x8 da = *(const bf16x8*)(dOs + (qt * 16 + fr) * LDR + ks * 32 + g * 8);
+          const bf16x8 qa = *(const bf16x8*)(Qs + (qt * 16 + fr) * LD + ks * 32 + g * 8);
+          const bf16x8 da = *(const bf16x8*)(dOs + (qt * 16 + fr) * LD + ks * 32 + g * 8);
           s[qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa, kf[ks], s[qt], 0, 0, 0);
           dp[qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(da, vf[ks], dp[qt], 0, 0, 0);
         }
       }
       // s[qt][r]: query = q0 + 16qt + 4g + r, key = this lane's key
+      const bool need_mask = (q0 + 32 > p.Sq) || (kw0 + 16 > kvlen) || (CAUSAL && (kw0 + 15 > q0 + off)) || (p.window > 0);
 #pragma unroll
       for (int qt = 0; qt < 2; ++qt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int ql = qt * 16 + 4 * g + r, qg = q0 + ql;
-          const bool ok = qg < p.Sq && key < kvlen && (!CAUSAL || key <= qg + off) &&
-                          (p.window <= 0 || key > qg + off - p.window);
-          const float pv = ok ? exp2f(s[qt][r] * c - lse_s[ql]) : 0.f;
+          const int ql = qt * 16 + 4 * g + r;
+          float pv = fast_exp2(fmaf(s[qt][r], c, -lse_s[ql]));
+          if (need_mask) {
+            const int qg = q0 + ql;
+            const bool ok = qg < p.Sq && key < kvlen && (!CAUSAL || key <= qg + off) && (p.window <= 0 || key > qg + off - p.window);
+            pv = ok ? pv : 0.f;
+          }
           s[qt][r] = pv;
           dp[qt][r] = pv * (dp[qt][r] - delta_s[ql]);
         }
@@ -288,12 +332,15 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnParams p) {
       const bf16x8 dsf = pack8(dp[0], dp[1]);
 #pragma unroll
       for (int d = 0; d < NDB; ++d) {
-        const bf16x8 ta = tfrag(dOt, LDT, d * 16 + fr, 0, g);
+        const bf16x8 ta = trfrag(dOs, LD, 0, d * 16, lane);
         dv[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ta, pf, dv[d], 0, 0, 0);
-        const bf16x8 tq = tfrag(Qt, LDT, d * 16 + fr, 0, g);
+        const bf16x8 tq = trfrag(Qs, LD, 0, d * 16, lane);
         dk[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tq, dsf, dk[d], 0, 0, 0);
       }
     }
+    __syncthreads();
+    if (it + 1 < nit) commit();
+    __syncthreads();
   }
   if (key < p.Skv) {
     bf16_t* dkp = p.dk + (long)b * p.dk_bs + (long)key * p.dk_ts + (long)hk * D;
@@ -310,84 +357,105 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnParams p) {
 }
 
 // ================================================================================================
-// backward: dQ  (block = 64 queries of one q head; loops 64-key tiles)
+// backward: dQ  (block = 128 queries of one q head, 16 per wave; loops 64-key tiles)
 // ================================================================================================
 template <int D, bool CAUSAL>
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
-  constexpr int LDR = D + 8, LDT = 72, NKS = D / 32, NDB = D / 16;
-  __shared__ __attribute__((aligned(16))) bf16_t Ks[64 * LDR];
-  __shared__ __attribute__((aligned(16))) bf16_t Vs[64 * LDR];
-  __shared__ __attribute__((aligned(16))) bf16_t Kt[D * LDT];
+__global__ __launch_bounds__(512) void attn_bwd_dq_kernel(AttnParams p) {
+  constexpr int LD = D + 16, NKS = D / 32, NDB = D / 16;
+  __shared__ __attribute__((aligned(16))) bf16_t Ks[64 * LD];
+  __shared__ __attribute__((aligned(16))) bf16_t Vs[64 * LD];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, fr = lane & 15, g = lane >> 4;
-  const int nqb = (p.Sq + 63) >> 6;
+  const int nqb = (p.Sq + 127) >> 7;
   const int qb = nqb - 1 - (int)blockIdx.x;
   const int h = blockIdx.y, b = blockIdx.z, hk = h / (p.Hq / p.Hkv);
-  const int q0 = qb * 64, qrow = q0 + wave * 16 + fr;
+  const int q0 = qb * 128, qw0 = q0 + wave * 16, qrow = qw0 + fr;
   const int kvlen = p.kv_len ? min(p.kv_len[b], p.Skv) : p.Skv;
   const int off = p.Skv - p.Sq;
   const float c = p.scale * LOG2E;
 
   bf16x8 qf[NKS], dof[NKS];
+  const int qrc = min(qrow, p.Sq - 1);                        // clamped (unconditional loads)
   {
-    const bf16_t* qp = p.q + (long)b * p.q_bs + (long)qrow * p.q_ts + (long)h * D;
-    const bf16_t* dp_ = p.dout + (long)b * p.do_bs + (long)qrow * p.do_ts + (long)h * D;
+    const bf16_t* qp = p.q + (long)b * p.q_bs + (long)qrc * p.q_ts + (long)h * D;
+    const bf16_t* dp_ = p.dout + (long)b * p.do_bs + (long)qrc * p.do_ts + (long)h * D;
 #pragma unroll
     for (int ks = 0; ks < NKS; ++ks) {
-      qf[ks] = (qrow < p.Sq) ? *(const bf16x8*)(qp + ks * 32 + g * 8) : zero8();
-      dof[ks] = (qrow < p.Sq) ? *(const bf16x8*)(dp_ + ks * 32 + g * 8) : zero8();
+      qf[ks] = *(const bf16x8*)(qp + ks * 32 + g * 8);
+      dof[ks] = *(const bf16x8*)(dp_ + ks * 32 + g * 8);
     }
   }
-  const long sidx = ((long)b * p.Hq + h) * p.Sq + qrow;
-  const float lse = qrow < p.Sq ? p.lse[sidx] : 0.f;
-  const float dlt = qrow < p.Sq ? p.delta[sidx] : 0.f;
+  const long sidx = ((long)b * p.Hq + h) * p.Sq + qrc;
+  const float lse = p.lse[sidx], dlt = p.delta[sidx];
   f32x4 dq[NDB];
 #pragma unroll
   for (int d = 0; d < NDB; ++d) dq[d] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   int kend = kvlen;
-  if (CAUSAL) kend = min(kend, q0 + 64 + off);
+  if (CAUSAL) kend = min(kend, q0 + 128 + off);
   int kstart = 0;
   if (p.window > 0) kstart = max(0, (q0 + off - p.window + 1)) & ~63;
   const bf16_t* kbase = p.k + (long)b * p.k_bs + (long)hk * D;
   const bf16_t* vbase = p.v + (long)b * p.v_bs + (long)hk * D;
 
+  TileRegs<D, 64> kr, vr;
+  if (kstart < kend) {
+    kr.load(kbase, p.k_ts, kstart, p.Skv);
+    vr.load(vbase, p.v_ts, kstart, p.Skv);
+    kr.store(Ks, LD);
+    vr.store(Vs, LD);
+  }
+  __syncthreads();
   for (int k0 = kstart; k0 < kend; k0 += 64) {
-    __syncthreads();
-    stage_transposed<D, 64, LDT>(Kt, Ks, kbase, p.k_ts, k0, p.Skv);
-    stage_rows<D, 64>(Vs, vbase, p.v_ts, k0, p.Skv);
-    __syncthreads();
-    f32x4 st[4], dpt[4];
+    const bool more = k0 + 64 < kend;
+    if (more) {
+      kr.load(kbase, p.k_ts, k0 + 64, p.Skv);
+      vr.load(vbase, p.v_ts, k0 + 64, p.Skv);
+    }
+    const bool active = !CAUSAL || (k0 <= qw0 + 15 + off);
+    if (active) {
+      const bool need_mask = (qw0 + 16 > p.Sq) || (k0 + 64 > kvlen) || (CAUSAL && (k0 + 63 > qw0 + off)) || (p.window > 0);
 #pragma unroll
-    for (int kt = 0; kt < 4; ++kt) {
-      st[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
-      dpt[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int kk = 0; kk < 2; ++kk) {
+        f32x4 st[2], dpt[2];
 #pragma unroll
-      for (int ks = 0; ks < NKS; ++ks) {
-        const bf16x8 ka = *(const bf16x8*)(Ks + (kt * 16 + fr) * LDR + ks * 32 + g * 8);
-        const bf16x8 va = *(const bf16x8*)(Vs + (kt * 16 + fr) * LDR + ks * 32 + g * 8);
-        st[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka, qf[ks], st[kt], 0, 0, 0);
-        dpt[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va, dof[ks], dpt[kt], 0, 0, 0);
+        for (int t = 0; t < 2; ++t) {
+          const int kt = 2 * kk + t;
+          st[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+          dpt[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int ks = 0; ks < NKS; ++ks) {
+            const bf16x8 ka = *(const bf16x8*)(Ks + (kt * 16 + fr) * LD + ks * 32 + g * 8);
+            const bf16x8 va = *(const bf16x8*)(Vs + (kt * 16 + fr) * LD + ks * 32 + g * 8);
+            st[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka, qf[ks], st[t], 0, 0, 0);
+            dpt[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va, dof[ks], dpt[t], 0, 0, 0);
+          }
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float pv = fast_exp2(fmaf(st[t][r], c, -lse));
+            if (need_mask) {
+              const int key = k0 + (2 * kk + t) * 16 + 4 * g + r;
+              const bool ok = qrow < p.Sq && key < kvlen && (!CAUSAL || key <= qrow + off) && (p.window <= 0 || key > qrow + off - p.window);
+              pv = ok ? pv : 0.f;
+            }
+            dpt[t][r] = pv * (dpt[t][r] - dlt);
+          }
+        const bf16x8 dsf = pack8(dpt[0], dpt[1]);
+#pragma unroll
+        for (int d = 0; d < NDB; ++d) {
+          const bf16x8 ktf = trfrag(Ks, LD, kk * 32, d * 16, lane);
+          dq[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ktf, dsf, dq[d], 0, 0, 0);
+        }
       }
     }
-#pragma unroll
-    for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int key = k0 + kt * 16 + 4 * g + r;
-        const bool ok = qrow < p.Sq && key < kvlen && (!CAUSAL || key <= qrow + off) &&
-                        (p.window <= 0 || key > qrow + off - p.window);
-        const float pv = ok ? exp2f(st[kt][r] * c - lse) : 0.f;
-        dpt[kt][r] = pv * (dpt[kt][r] - dlt);
-      }
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      const bf16x8 dsf = pack8(dpt[2 * kk], dpt[2 * kk + 1]);
-#pragma unroll
-      for (int d = 0; d < NDB; ++d) {
-        const bf16x8 ktf = tfrag(Kt, LDT, d * 16 + fr, kk * 32, g);
-        dq[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ktf, dsf, dq[d], 0, 0, 0);
-      }
+    __syncthreads();
+    if (more) {
+      kr.store(Ks, LD);
+      vr.store(Vs, LD);
     }
+    __syncthreads();
   }
   if (qrow < p.Sq) {
     bf16_t* dqp = p.dq + (long)b * p.dq_bs + (long)qrow * p.dq_ts + (long)h * D;
@@ -406,22 +474,22 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
 // ================================================================================================
 template <int D>
 static int launch_fwd(const AttnParams& p, int causal, hipStream_t s) {
-  dim3 grid((p.Sq + 63) / 64, p.Hq, p.B);
-  if (causal) hipLaunchKernelGGL((attn_fwd_kernel<D, true>), grid, dim3(256), 0, s, p);
-  else hipLaunchKernelGGL((attn_fwd_kernel<D, false>), grid, dim3(256), 0, s, p);
+  dim3 grid((p.Sq + 127) / 128, p.Hq, p.B);
+  if (causal) hipLaunchKernelGGL((attn_fwd_kernel<D, true>), grid, dim3(512), 0, s, p);
+  else hipLaunchKernelGGL((attn_fwd_kernel<D, false>), grid, dim3(512), 0, s, p);
   return vp_check_launch("vp_attn_fwd");
 }
 template <int D>
 static int launch_bwd(const AttnParams& p, int causal, hipStream_t s) {
   const long rows = (long)p.B * p.Hq * p.Sq;
   hipLaunchKernelGGL((attn_delta_kernel<D>), dim3((unsigned)min(8192L, (rows + 3) / 4)), dim3(256), 0, s, p);
-  dim3 g1((p.Skv + 63) / 64, p.Hkv, p.B), g2((p.Sq + 63) / 64, p.Hq, p.B);
+  dim3 g1((p.Skv + 127) / 128, p.Hkv, p.B), g2((p.Sq + 127) / 128, p.Hq, p.B);
   if (causal) {
-    hipLaunchKernelGGL((attn_bwd_dkdv_kernel<D, true>), g1, dim3(256), 0, s, p);
-    hipLaunchKernelGGL((attn_bwd_dq_kernel<D, true>), g2, dim3(256), 0, s, p);
+    hipLaunchKernelGGL((attn_bwd_dkdv_kernel<D, true>), g1, dim3(512), 0, s, p);
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<D, true>), g2, dim3(512), 0, s, p);
   } else {
-    hipLaunchKernelGGL((attn_bwd_dkdv_kernel<D, false>), g1, dim3(256), 0, s, p);
-    hipLaunchKernelGGL((attn_bwd_dq_kernel<D, false>), g2, dim3(256), 0, s, p);
+    hipLaunchKernelGGL((attn_bwd_dkdv_kernel<D, false>), g1, dim3(512), 0, s, p);
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<D, false>), g2, dim3(512), 0, s, p);
   }
   return vp_check_launch("vp_attn_bwd");
 }
