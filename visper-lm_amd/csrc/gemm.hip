@@ -46,8 +46,8 @@ __device__ __forceinline__ void store4(const GemmArgs& p, int m, int n, f32x4 ac
       float x = v[r];
       if (p.bias) x += bf2f(p.bias[n + r]);
       if (!OUT_F32) x = bfround(x);
-      if (p.epi != EPI_NONE) {
-        x = apply_epi(x, p.epi);
+      if ((p.epi & 0xff) != EPI_NONE) {
+        x = apply_epi(x, p.epi & 0xff);
         if (!OUT_F32) x = bfround(x);
       }
       if (p.res) {
@@ -72,6 +72,69 @@ __device__ __forceinline__ void store4(const GemmArgs& p, int m, int n, f32x4 ac
     } else {
       for (int r = 0; r < nv; ++r) c[r] = f2bf(v[r]);
     }
+  }
+}
+
+
+// Coalesced epilogue for the 256-tile kernels (bf16 output): every wave stages its 128x64 accumulator block
+// through its own LDS slice (two 64-row passes, 144-byte padded rows) and writes/reads global memory as 16-byte
+// pieces with 8 lanes covering one full 128-byte row segment — the MFMA register layout alone only yields 8-byte
+// pieces scattered over 16 rows per instruction, which measured ~30 % of the whole kernel at K = 4096.
+// Same rounding points as store4: (acc + bias) -> bf16 -> act -> bf16 (in registers), + residual -> bf16 (on the way out).
+__device__ __forceinline__ void epilogue_256_bf16(const GemmArgs& p, bf16_t* wave_lds, const f32x4 (&acc)[8][4], int mrow0, int ncol0,
+                                                  int lane) {
+  constexpr int RS = 72;                      // row stride (elements): 64 + 8 pad
+  const int fr = lane & 15, g = lane >> 4;
+  const int epi = p.epi & 0xff;
+  float bias4[4][4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int n = ncol0 + j * 16 + g * 4 + r;
+      bias4[j][r] = (p.bias && n < p.N) ? bf2f(p.bias[n]) : 0.f;
+    }
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+#pragma unroll
+    for (int ii = 0; ii < 4; ++ii) {
+      const int i = half * 4 + ii;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        bf16x4 o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float x = bfround(acc[i][j][r] + bias4[j][r]);
+          if (epi != EPI_NONE) x = bfround(apply_epi(x, epi));
+          o[r] = (short)f2bf(x);
+        }
+        *(bf16x4*)(wave_lds + (ii * 16 + fr) * RS + j * 16 + g * 4) = o;
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // wave-private slice: our own writes are visible to our own reads
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int rl = it * 8 + (lane >> 3), c8 = (lane & 7) * 8;
+      const int m = mrow0 + half * 64 + rl, n = ncol0 + c8;
+      bf16x8 v = *(const bf16x8*)(wave_lds + rl * RS + c8);
+      if (m < p.M && n < p.N) {
+        bf16_t* cptr = (bf16_t*)p.C + (long)m * p.ldc + n;
+        const bool full = (n + 8 <= p.N) && ((((uintptr_t)cptr) & 15) == 0);
+        if (p.res) {
+          const bf16_t* rptr = p.res + (long)m * p.ldr + n;
+          if (full && ((((uintptr_t)rptr) & 15) == 0)) {
+            const bf16x8 rv = *(const bf16x8*)rptr;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (short)f2bf(bf2f((bf16_t)v[e]) + bf2f((bf16_t)rv[e]));
+          } else {
+            for (int e = 0; e < 8 && n + e < p.N; ++e) v[e] = (short)f2bf(bf2f((bf16_t)v[e]) + bf2f(rptr[e]));
+          }
+        }
+        if (full) *(bf16x8*)cptr = v;
+        else for (int e = 0; e < 8 && n + e < p.N; ++e) cptr[e] = (bf16_t)v[e];
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // reads done before the slice is overwritten by the next pass
   }
 }
 
@@ -166,15 +229,209 @@ __global__ __launch_bounds__(256) void gemm_nt_128(GemmArgs p) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// large-problem path: 256x256x64 block tile, 8 waves (2 x 4, each 128x64 = 8x4 MFMA tiles), 2 LDS buffers
-// (2 x 64 KB): tile t+1 is DMA'd into the other buffer at the START of computing tile t, so its
-// global_load_lds has a whole tile of MFMA work to land under and the single barrier per K-tile (which
-// carries vmcnt(0)) never stalls on it.  1 block / CU (128 KB LDS), 2 waves / SIMD.
+// large-problem path: PERSISTENT 256x256x64 kernel.  One 512-thread block per CU (8 waves = 2 x 4, each
+// 128x64 = 8x4 MFMA tiles), 2 LDS buffers (2 x 64 KB).  The K-tile stream never stops: tile t+1 is DMA'd
+// (global_load_lds) into the other buffer at the START of computing tile t, and at a block's LAST K-tile the
+// DMA already fetches the first K-tile of the block's NEXT output tile, so there is no prologue bubble between
+// output tiles, the epilogue's stores drain under the next tile's MFMAs, and the end-of-tile write bursts of
+// the 256 CUs stop being synchronised.  (Ablation: with one block per output tile the turnover — exposed first
+// load + store drain + relaunch — cost ~28 % of the kernel at K = 4096.)  The epilogue stages C through the LDS
+// buffer that was just consumed (XOR-swizzled 128-byte rows) to emit 16-byte, 128-byte-row-coalesced accesses.
 // ------------------------------------------------------------------------------------------------
+struct TileCoord {
+  int m0, n0;
+};
+__device__ __forceinline__ TileCoord tile_coord_256(int v, int tiles_m, int tiles_n) {
+  const int nwg = tiles_m * tiles_n;
+  const int id = xcd_remap(v, nwg);
+  const int GROUP_M = 8;
+  const int width = GROUP_M * tiles_n;
+  const int group = id / width;
+  const int first_m = group * GROUP_M;
+  const int gsz = min(tiles_m - first_m, GROUP_M);
+  return TileCoord{(first_m + (id % width) % gsz) << 8, ((id % width) / gsz) << 8};
+}
+
+// swizzled C staging: per wave a [64 rows][64 cols] bf16 slice (8 KB), 16-byte chunk index ^= row & 7
+__device__ __forceinline__ void epilogue_256_swz(const GemmArgs& p, bf16_t* wave_lds, const f32x4 (&acc)[8][4], int mrow0, int ncol0,
+                                                 int lane) {
+  const int fr = lane & 15, g = lane >> 4;
+  const int epi = p.epi & 0xff;
+  float bias4[4][4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int n = ncol0 + j * 16 + g * 4 + r;
+      bias4[j][r] = (p.bias && n < p.N) ? bf2f(p.bias[n]) : 0.f;
+    }
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+#pragma unroll
+    for (int ii = 0; ii < 4; ++ii) {
+      const int i = half * 4 + ii;
+      const int row = ii * 16 + fr;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        bf16x4 o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float x = bfround(acc[i][j][r] + bias4[j][r]);
+          if (epi != EPI_NONE) x = bfround(apply_epi(x, epi));
+          o[r] = (short)f2bf(x);
+        }
+        const int chunk = (j * 2 + (g >> 1)) ^ (row & 7);
+        *(bf16x4*)(wave_lds + row * 64 + chunk * 8 + (g & 1) * 4) = o;
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // wave-private slice: own writes visible to own reads
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int rl = it * 8 + (lane >> 3), ch = lane & 7;
+      const int m = mrow0 + half * 64 + rl, n = ncol0 + ch * 8;
+      bf16x8 v = *(const bf16x8*)(wave_lds + rl * 64 + ((ch ^ (rl & 7)) << 3));
+      if (m < p.M && n < p.N) {
+        bf16_t* cptr = (bf16_t*)p.C + (long)m * p.ldc + n;
+        const bool full = (n + 8 <= p.N) && ((((uintptr_t)cptr) & 15) == 0);
+        if (p.res) {
+          const bf16_t* rptr = p.res + (long)m * p.ldr + n;
+          if (full && ((((uintptr_t)rptr) & 15) == 0)) {
+            const bf16x8 rv = *(const bf16x8*)rptr;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (short)f2bf(bf2f((bf16_t)v[e]) + bf2f((bf16_t)rv[e]));
+          } else {
+            for (int e = 0; e < 8 && n + e < p.N; ++e) v[e] = (short)f2bf(bf2f((bf16_t)v[e]) + bf2f(rptr[e]));
+          }
+        }
+        if (full) *(bf16x8*)cptr = v;
+        else for (int e = 0; e < 8 && n + e < p.N; ++e) cptr[e] = (bf16_t)v[e];
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // reads done before the slice is overwritten by the next pass
+  }
+}
+
 template <bool OUT_F32>
 __global__ __launch_bounds__(512) void gemm_nt_256(GemmArgs p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   bf16_t* smem = (bf16_t*)smem_raw;                    // [buf 0: A 256x64 | B 256x64][buf 1: ...]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tiles_m = (p.M + 255) >> 8, tiles_n = (p.N + 255) >> 8;
+  const int ntiles = tiles_m * tiles_n;
+  const int wr = wave >> 2, wc = wave & 3;
+  const int fr = lane & 15, g = lane >> 4;
+  const int nt = p.K >> 6;
+
+  // per-thread staging geometry (same for every tile): 4 chunks per operand, LDS chunk q = (row q>>3, slot q&7)
+  long offA[4], offB[4];
+  int rowi[4], gci[4];
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int q = it * 512 + tid;
+    rowi[it] = q >> 3;
+    gci[it] = ((q & 7) ^ ((rowi[it] >> 1) & 7)) * 8;
+  }
+#define SET_TILE(TC)                                                               \
+  _Pragma("unroll") for (int it = 0; it < 4; ++it) {                               \
+    offA[it] = (long)min((TC).m0 + rowi[it], p.M - 1) * p.lda + gci[it];           \
+    offB[it] = (long)min((TC).n0 + rowi[it], p.N - 1) * p.ldb + gci[it];           \
+  }
+#define ISSUE_TILE(T, BUF)                                                         \
+  {                                                                                \
+    bf16_t* As_ = smem + (BUF) * 32768;                                            \
+    bf16_t* Bs_ = As_ + 16384;                                                     \
+    _Pragma("unroll") for (int it = 0; it < 4; ++it) {                             \
+      GLDS16(p.A + offA[it] + (long)(T) * 64, As_ + (it * 512 + wave * 64) * 8);   \
+      GLDS16(p.B + offB[it] + (long)(T) * 64, Bs_ + (it * 512 + wave * 64) * 8);   \
+    }                                                                              \
+  }
+  int v = blockIdx.x;
+  TileCoord tc = tile_coord_256(v, tiles_m, tiles_n);
+  SET_TILE(tc);
+  ISSUE_TILE(0, 0);
+  __syncthreads();
+  int cur = 0;
+  while (true) {
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int vnext = v + gridDim.x;
+    const TileCoord tcur = tc;
+    for (int t = 0; t < nt; ++t) {
+      if (t + 1 < nt) {
+        ISSUE_TILE(t + 1, cur ^ 1);
+      } else if (vnext < ntiles) {                     // keep the DMA stream going: first K-tile of the next output tile
+        tc = tile_coord_256(vnext, tiles_m, tiles_n);
+        SET_TILE(tc);
+        ISSUE_TILE(0, cur ^ 1);
+      }
+      const bf16_t* As = smem + cur * 32768;
+      const bf16_t* Bs = As + 16384;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        bf16x8 xf[8], wf[4];
+        const int cg = ks * 4 + g;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int r = wc * 64 + j * 16 + fr;
+          wf[j] = *(const bf16x8*)(Bs + r * 64 + ((cg ^ ((r >> 1) & 7)) << 3));
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int r = wr * 128 + i * 16 + fr;
+          xf[i] = *(const bf16x8*)(As + r * 64 + ((cg ^ ((r >> 1) & 7)) << 3));
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], xf[i], acc[i][j], 0, 0, 0);
+      }
+      __syncthreads();
+      cur ^= 1;
+    }
+    // buf[cur] now holds (or is receiving) the next tile's first K-tile; buf[cur ^ 1] was just consumed -> C staging
+    if (!OUT_F32) {
+      epilogue_256_swz(p, smem + (cur ^ 1) * 32768 + wave * 4096, acc, tcur.m0 + wr * 128, tcur.n0 + wc * 64, lane);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          store4<OUT_F32>(p, tcur.m0 + wr * 128 + i * 16 + fr, tcur.n0 + wc * 64 + j * 16 + g * 4, acc[i][j]);
+    }
+    if (vnext >= ntiles) break;
+    v = vnext;
+    __syncthreads();             // every wave is done with the staging slice before the next DMA may land in it
+  }
+#undef SET_TILE
+#undef ISSUE_TILE
+}
+
+// ------------------------------------------------------------------------------------------------
+// ping-pong variant of the 256x256x64 kernel.  The plain kernel above re-synchronises all 8 waves once per
+// K-tile, so both waves of a SIMD read LDS at the same time and then both issue MFMAs at the same time: the
+// matrix pipe idles during every read phase (PMC: MFMA busy ~49 %).  Here the two wave groups (wr = 0 / 1,
+// one wave of each per SIMD) run one phase apart: a K-tile is 4 phases per wave — R0 (ds_read the ks=0
+// fragments), M0 (32 MFMAs), R1, M1 — separated by raw s_barriers, and group 1 starts one barrier late, so
+// in every barrier interval one group is in an M phase while the other is in an R phase.  global_load_lds
+// of tile t+1 is issued in R0(t) (its buffer was last read in R1(t-1), one full interval earlier even for
+// the late group) and waited for (vmcnt(0)) at the end of R1(t) — two intervals before anyone reads it.
+// ------------------------------------------------------------------------------------------------
+#define VP_SB() __builtin_amdgcn_sched_barrier(0)
+#define VP_BAR()                      \
+  do {                                \
+    VP_SB();                          \
+    __builtin_amdgcn_s_barrier();     \
+    VP_SB();                          \
+  } while (0)
+
+template <bool OUT_F32>
+__global__ __launch_bounds__(512) void gemm_nt_256pp(GemmArgs p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  bf16_t* smem = (bf16_t*)smem_raw;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
   const int tiles_m = (p.M + 255) >> 8, tiles_n = (p.N + 255) >> 8;
@@ -199,7 +456,7 @@ __global__ __launch_bounds__(512) void gemm_nt_256(GemmArgs p) {
     srcA[it] = p.A + (long)min(m0 + row, p.M - 1) * p.lda + gc * 8;
     srcB[it] = p.B + (long)min(n0 + row, p.N - 1) * p.ldb + gc * 8;
   }
-  const int wr = wave >> 2, wc = wave & 3;
+  const int wr = __builtin_amdgcn_readfirstlane(wave >> 2), wc = wave & 3;
   const int fr = lane & 15, g = lane >> 4;
   f32x4 acc[8][4];
 #pragma unroll
@@ -217,41 +474,201 @@ __global__ __launch_bounds__(512) void gemm_nt_256(GemmArgs p) {
       GLDS16(srcB[it] + (long)(T) * 64, Bs_ + (it * 512 + wave * 64) * 8);         \
     }                                                                              \
   }
+#define READ_FRAGS(KS)                                                             \
+  {                                                                                \
+    const int cg = (KS) * 4 + g;                                                   \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                \
+      const int r = wc * 64 + j * 16 + fr;                                         \
+      wf[j] = *(const bf16x8*)(Bs + r * 64 + ((cg ^ ((r >> 1) & 7)) << 3));        \
+    }                                                                              \
+    _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                \
+      const int r = wr * 128 + i * 16 + fr;                                        \
+      xf[i] = *(const bf16x8*)(As + r * 64 + ((cg ^ ((r >> 1) & 7)) << 3));        \
+    }                                                                              \
+  }
+#define MFMA_PHASE()                                                               \
+  {                                                                                \
+    __builtin_amdgcn_s_setprio(1);                                                 \
+    _Pragma("unroll") for (int i = 0; i < 8; ++i)                                  \
+      _Pragma("unroll") for (int j = 0; j < 4; ++j)                                \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], xf[i], acc[i][j], 0, 0, 0); \
+    __builtin_amdgcn_s_setprio(0);                                                 \
+  }
+  const int dbg = p.epi >> 8;             // dev-only ablation switches (tools/gemm_bench.py): 1 no glds, 2 no ds_read, 4 no mfma
   ISSUE_TILE(0, 0);
-  __syncthreads();
+  if (nt > 1) ISSUE_TILE(1, 1);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  VP_BAR();
+  if (wr == 1) VP_BAR();                 // stagger: the second wave group runs one phase behind
+  bf16x8 xf[8], wf[4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) xf[i] = bf16x8{1, 2, 3, 4, 5, 6, 7, 8};
+#pragma unroll
+  for (int j = 0; j < 4; ++j) wf[j] = bf16x8{1, 2, 3, 4, 5, 6, 7, 8};
   for (int t = 0; t < nt; ++t) {
     const int cur = t & 1;
-    if (t + 1 < nt) ISSUE_TILE(t + 1, cur ^ 1);
     const bf16_t* As = smem + cur * 32768;
     const bf16_t* Bs = As + 16384;
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      bf16x8 xf[8], wf[4];
-      const int cg = ks * 4 + g;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int r = wc * 64 + j * 16 + fr;
-        wf[j] = *(const bf16x8*)(Bs + r * 64 + ((cg ^ ((r >> 1) & 7)) << 3));
-      }
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int r = wr * 128 + i * 16 + fr;
-        xf[i] = *(const bf16x8*)(As + r * 64 + ((cg ^ ((r >> 1) & 7)) << 3));
-      }
-#pragma unroll
-      for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], xf[i], acc[i][j], 0, 0, 0);
-    }
-    __syncthreads();
+    // ---- R0
+    if (t >= 1 && t + 1 < nt && !(dbg & 1)) ISSUE_TILE(t + 1, cur ^ 1);
+    if (!(dbg & 2)) READ_FRAGS(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    VP_BAR();
+    // ---- M0
+    if (!(dbg & 4)) MFMA_PHASE();
+    VP_BAR();
+    // ---- R1
+    if (!(dbg & 2)) READ_FRAGS(1);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    VP_BAR();
+    // ---- M1
+    if (!(dbg & 4)) MFMA_PHASE();
+    VP_BAR();
   }
+  if (wr == 0) VP_BAR();
 #undef ISSUE_TILE
+#undef READ_FRAGS
+#undef MFMA_PHASE
+  if ((dbg & 8) && acc[0][0][0] != 12345.f) return;     // dev-only: skip the epilogue
 #pragma unroll
   for (int i = 0; i < 8; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j)
       store4<OUT_F32>(p, m0 + wr * 128 + i * 16 + fr, n0 + wc * 64 + j * 16 + g * 4, acc[i][j]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// "skewed" 256x256x64 kernel (default for large problems).  Ablation of the ping-pong kernel above showed what a
+// K-tile costs when nothing overlaps: MFMA ~265 us, L2->LDS DMA ~135 us (at the 34 TB/s L2 roof), ds_reads
+// ~110 us (at the LDS roof), and ~240 cycles per workgroup barrier.  So: ONE barrier per K-tile (it only
+// guards LDS buffer reuse), and the two wave groups run the same R0 M0 R1 M1 phase string skewed by half a
+// K-tile *in program order*: group 0 does [R0 M0 R1 M1] between barriers, group 1 does [M1' R0 M0 R1]
+// (M1' = the MFMAs of the previous tile's second half, whose fragments it carried across the barrier in
+// registers).  Right after every barrier one group starts with MFMAs and the other with ds_reads, so the
+// matrix pipe, the LDS and the L2 DMA stream stay busy together without any extra synchronisation.
+// ------------------------------------------------------------------------------------------------
+template <bool OUT_F32>
+__global__ __launch_bounds__(512) void gemm_nt_256sk(GemmArgs p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  bf16_t* smem = (bf16_t*)smem_raw;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+  const int tiles_m = (p.M + 255) >> 8, tiles_n = (p.N + 255) >> 8;
+  const int nwg = tiles_m * tiles_n;
+  const int id = xcd_remap(blockIdx.x, nwg);
+  const int GROUP_M = 8;
+  const int width = GROUP_M * tiles_n;
+  const int group = id / width;
+  const int first_m = group * GROUP_M;
+  const int gsz = min(tiles_m - first_m, GROUP_M);
+  const int tm = first_m + (id % width) % gsz;
+  const int tn = (id % width) / gsz;
+  const int m0 = tm << 8, n0 = tn << 8;
+
+  const bf16_t* srcA[4];
+  const bf16_t* srcB[4];
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int q = it * 512 + tid;
+    const int row = q >> 3;
+    const int gc = (q & 7) ^ ((row >> 1) & 7);
+    srcA[it] = p.A + (long)min(m0 + row, p.M - 1) * p.lda + gc * 8;
+    srcB[it] = p.B + (long)min(n0 + row, p.N - 1) * p.ldb + gc * 8;
+  }
+  const int wr = __builtin_amdgcn_readfirstlane(wave >> 2), wc = wave & 3;
+  const int fr = lane & 15, g = lane >> 4;
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nt = p.K >> 6;
+#define ISSUE_TILE(T, BUF)                                                         \
+  {                                                                                \
+    bf16_t* As_ = smem + (BUF) * 32768;                                            \
+    bf16_t* Bs_ = As_ + 16384;                                                     \
+    _Pragma("unroll") for (int it = 0; it < 4; ++it) {                             \
+      GLDS16(srcA[it] + (long)(T) * 64, As_ + (it * 512 + wave * 64) * 8);         \
+      GLDS16(srcB[it] + (long)(T) * 64, Bs_ + (it * 512 + wave * 64) * 8);         \
+    }                                                                              \
+  }
+#define READ_FRAGS(XF, WF, KS)                                                     \
+  {                                                                                \
+    const int cg = (KS) * 4 + g;                                                   \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                \
+      const int r = wc * 64 + j * 16 + fr;                                         \
+      WF[j] = *(const bf16x8*)(Bs + r * 64 + ((cg ^ ((r >> 1) & 7)) << 3));        \
+    }                                                                              \
+    _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                \
+      const int r = wr * 128 + i * 16 + fr;                                        \
+      XF[i] = *(const bf16x8*)(As + r * 64 + ((cg ^ ((r >> 1) & 7)) << 3));        \
+    }                                                                              \
+  }
+#define MFMA_PHASE(XF, WF)                                                         \
+  {                                                                                \
+    __builtin_amdgcn_s_setprio(1);                                                 \
+    _Pragma("unroll") for (int i = 0; i < 8; ++i)                                  \
+      _Pragma("unroll") for (int j = 0; j < 4; ++j)                                \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(WF[j], XF[i], acc[i][j], 0, 0, 0); \
+    __builtin_amdgcn_s_setprio(0);                                                 \
+  }
+  ISSUE_TILE(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  VP_BAR();
+  if (wr == 0) {
+    for (int t = 0; t < nt; ++t) {
+      const int cur = t & 1;
+      const bf16_t* As = smem + cur * 32768;
+      const bf16_t* Bs = As + 16384;
+      bf16x8 xf[8], wf[4];
+      if (t + 1 < nt) ISSUE_TILE(t + 1, cur ^ 1);
+      READ_FRAGS(xf, wf, 0);
+      VP_SB();
+      MFMA_PHASE(xf, wf);
+      VP_SB();
+      READ_FRAGS(xf, wf, 1);
+      VP_SB();
+      MFMA_PHASE(xf, wf);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      VP_BAR();
+    }
+  } else {
+    bf16x8 xh[8], wh[4];                 // second-half fragments carried across the barrier
+#pragma unroll
+    for (int i = 0; i < 8; ++i) xh[i] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) wh[j] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+    for (int t = 0; t < nt; ++t) {
+      const int cur = t & 1;
+      const bf16_t* As = smem + cur * 32768;
+      const bf16_t* Bs = As + 16384;
+      bf16x8 xf[8], wf[4];
+      if (t + 1 < nt) ISSUE_TILE(t + 1, cur ^ 1);
+      MFMA_PHASE(xh, wh);                // M1 of tile t-1 (zeros at t = 0)
+      VP_SB();
+      READ_FRAGS(xf, wf, 0);
+      VP_SB();
+      MFMA_PHASE(xf, wf);
+      VP_SB();
+      READ_FRAGS(xh, wh, 1);
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // our LDS reads are done before anyone may overwrite the buffer
+      VP_BAR();
+    }
+    MFMA_PHASE(xh, wh);
+  }
+#undef ISSUE_TILE
+#undef READ_FRAGS
+#undef MFMA_PHASE
+  if (!OUT_F32) {
+    epilogue_256_bf16(p, smem + wave * (64 * 72), acc, m0 + wr * 128, n0 + wc * 64, lane);
+  } else {
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        store4<OUT_F32>(p, m0 + wr * 128 + i * 16 + fr, n0 + wc * 64 + j * 16 + g * 4, acc[i][j]);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -331,21 +748,40 @@ int vp_gemm_bf16(int M, int N, int K, const void* A, long lda, const void* B, lo
   VP_REQUIRE(M > 0 && N > 0 && K > 0, VP_ERR_BAD_ARG, "vp_gemm_bf16: non-positive dims %d %d %d", M, N, K);
   VP_REQUIRE(A && B && C, VP_ERR_BAD_ARG, "vp_gemm_bf16: null operand");
   VP_REQUIRE(lda >= K && ldb >= K && ldc >= N, VP_ERR_BAD_ARG, "vp_gemm_bf16: leading dims too small");
-  VP_REQUIRE(epilogue >= 0 && epilogue <= 3, VP_ERR_BAD_ARG, "vp_gemm_bf16: bad epilogue %d", epilogue);
+  VP_REQUIRE((epilogue & 0xff) >= 0 && (epilogue & 0xff) <= 3, VP_ERR_BAD_ARG, "vp_gemm_bf16: bad epilogue %d", epilogue);
   GemmArgs p{(const bf16_t*)A, (const bf16_t*)B, C, (const bf16_t*)bias, (const bf16_t*)residual, M, N, K,
              lda, ldb, ldc, ldr, epilogue};
   const bool fast = (force_generic != 1) && (K % 64 == 0) && (lda % 8 == 0) && (ldb % 8 == 0) &&
                     ((((uintptr_t)A) | ((uintptr_t)B)) & 15) == 0;
   const long big_tiles = (long)((M + 255) / 256) * ((N + 255) / 256);
-  if (fast && force_generic != 2 && (force_generic == 3 || (big_tiles >= 192 && M >= 256 && N >= 256))) {
+  if (fast && force_generic == 5) {
+    static bool attr_sk = false;
+    if (!attr_sk) {
+      (void)hipFuncSetAttribute((const void*)gemm_nt_256sk<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+      (void)hipFuncSetAttribute((const void*)gemm_nt_256sk<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+      attr_sk = true;
+    }
+    if (out_f32) hipLaunchKernelGGL(gemm_nt_256sk<true>, dim3((unsigned)big_tiles), dim3(512), 131072, stream, p);
+    else hipLaunchKernelGGL(gemm_nt_256sk<false>, dim3((unsigned)big_tiles), dim3(512), 131072, stream, p);
+  } else if (fast && force_generic == 4) {
+    static bool attr_pp = false;
+    if (!attr_pp) {
+      (void)hipFuncSetAttribute((const void*)gemm_nt_256pp<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+      (void)hipFuncSetAttribute((const void*)gemm_nt_256pp<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+      attr_pp = true;
+    }
+    if (out_f32) hipLaunchKernelGGL(gemm_nt_256pp<true>, dim3((unsigned)big_tiles), dim3(512), 131072, stream, p);
+    else hipLaunchKernelGGL(gemm_nt_256pp<false>, dim3((unsigned)big_tiles), dim3(512), 131072, stream, p);
+  } else if (fast && force_generic != 2 && (force_generic == 3 || (big_tiles >= 192 && M >= 256 && N >= 256))) {
     static bool attr_done = false;
     if (!attr_done) {
       (void)hipFuncSetAttribute((const void*)gemm_nt_256<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
       (void)hipFuncSetAttribute((const void*)gemm_nt_256<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
       attr_done = true;
     }
-    if (out_f32) hipLaunchKernelGGL(gemm_nt_256<true>, dim3((unsigned)big_tiles), dim3(512), 131072, stream, p);
-    else hipLaunchKernelGGL(gemm_nt_256<false>, dim3((unsigned)big_tiles), dim3(512), 131072, stream, p);
+    const unsigned pgrid = (unsigned)(big_tiles < 256 ? big_tiles : 256);      // persistent: one block per CU
+    if (out_f32) hipLaunchKernelGGL(gemm_nt_256<true>, dim3(pgrid), dim3(512), 131072, stream, p);
+    else hipLaunchKernelGGL(gemm_nt_256<false>, dim3(pgrid), dim3(512), 131072, stream, p);
   } else if (fast) {
     const int grid = ((M + 127) / 128) * ((N + 127) / 128);
     if (out_f32) hipLaunchKernelGGL(gemm_nt_128<true>, dim3(grid), dim3(256), 0, stream, p);
