@@ -25,3 +25,23 @@ def test_trainable_set_matches_reference_pt_stage():
     ref_tr = set(json.loads(str(g["trainable"])))
     mine = {k for k in param_shapes(VisperConfig(**vars(ocfg)), vit_nested=False) if is_trainable(k)}
     assert mine == ref_tr
+
+
+def test_api_mirror_state_dict_keys_cpu():
+    """The nn.Module mirror (constructed on CPU, no compute) exposes exactly the reference's state-dict keys/shapes
+    under the pinned transformers==4.41.1 naming, and the PT-stage requires_grad pattern."""
+    import torch
+    from visper_lm_amd.model import OlaLlavaLlamaForCausalLM, OlaLlavaLlamaConfig
+    ocfg, W, batch, g = cases.tiny_llama_case()
+    model = OlaLlavaLlamaForCausalLM(OlaLlavaLlamaConfig(**vars(ocfg)), device="cpu", init="empty")
+    ref = {k: tuple(v) for k, v in json.loads(str(g["manifest"])).items() if not k.startswith("da_v2_head.")}
+    ref = {(k.replace("model.vision_tower.vision_tower.", "model.vision_tower.vision_tower.vision_model.")
+            if k.startswith("model.vision_tower.vision_tower.") else k): v for k, v in ref.items()}
+    sd = model.state_dict()
+    assert set(sd) == set(ref), sorted(set(sd) ^ set(ref))[:8]
+    for k, v in sd.items():
+        assert tuple(v.shape) == ref[k], k
+    tr = {n for n, p in model.named_parameters() if p.requires_grad}
+    assert tr == set(json.loads(str(g["trainable"])))
+    assert model.get_model().mm_projector[2].weight.shape == (ocfg.hidden_size, ocfg.hidden_size)
+    assert model.image_seg_heads[1].projector.proj_in.weight.shape == (1536, ocfg.hidden_size)

@@ -1,0 +1,68 @@
+"""Drop-in API mirror on the GPU: reference-named classes, state-dict round trip, `.loss.backward()` semantics."""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def setup():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from oracle import cases
+    from visper_lm_amd.model import OlaLlavaLlamaForCausalLM, OlaLlavaLlamaConfig
+    ocfg, W, batch, g = cases.tiny_llama_case()
+    cfg = OlaLlavaLlamaConfig(**vars(ocfg))
+    model = OlaLlavaLlamaForCausalLM(cfg, init="empty")
+    # the golden fixture's names use the flattened (transformers 5.x) CLIP prefix; the mirror uses the 4.41.1 (pinned) nesting
+    sd = {k.replace("model.vision_tower.vision_tower.", "model.vision_tower.vision_tower.vision_model.")
+          if k.startswith("model.vision_tower.vision_tower.") else k: v for k, v in W.items()}
+    missing = model.load_state_dict(sd, strict=True)
+    model.reload_frozen()
+    return model, cfg, batch, g
+
+
+def test_reference_surface(setup):
+    model, cfg, batch, g = setup
+    assert model.NUM_SYS_TOKENS == 38 and model.get_model() is model.model
+    assert model.get_vision_tower() is model.model.vision_tower
+    assert model.model.mm_projector[0].weight.shape == (cfg.hidden_size, cfg.mm_hidden_size)
+    assert model.token_order == ["gen", "depth", "seg"] and model.num_task_tokens == 8
+    assert model.depth_tokens.shape == (576, cfg.hidden_size) and model.gen_tokens.shape == (8, cfg.hidden_size)
+    assert model.seg_layer_indices == [1, 2] and model.img_gen_loss_weight == 0.5
+    tr = {n for n, p in model.named_parameters() if p.requires_grad}
+    assert tr == set(json.loads(str(g["trainable"])))
+
+
+def test_forward_backward_like_reference(setup):
+    model, cfg, batch, g = setup
+    B = batch["input_ids"].shape[0]
+    out = model(input_ids=batch["input_ids"], attention_mask=batch["attention_mask"], labels=batch["labels"],
+                images=batch["images"].cuda(), gen_mask=torch.ones(B).cuda(), seg_mask=torch.ones(B).cuda(), depth_mask=torch.ones(B).cuda(),
+                gen_target=batch["gen_target"].cuda(), depth_target=batch["depth_target"].cuda(), seg_target=batch["seg_target"].cuda())
+    assert abs(float(out.loss) - float(g["keep_loss"])) < 1e-2 * float(g["keep_loss"])
+    assert len(out.seg_embs) == 2 and len(out.image_embs) == 1 and len(out.depth_embs) == 1
+    out.loss.backward()
+    none_ref = set(json.loads(str(g["keep_grad_none"])))
+    for n, p in model.named_parameters():
+        if not p.requires_grad:
+            assert p.grad is None
+            continue
+        ref = float(g[f"keep_gradnorm::{n}"]) if n not in none_ref else 0.0
+        got = float(p.grad.float().norm())
+        assert abs(got - ref) <= 0.08 * ref + 1e-6, (n, got, ref)
+
+
+def test_encode_images_and_prepare_inputs(setup):
+    model, cfg, batch, g = setup
+    feats = model.encode_images(batch["images"].cuda())
+    assert feats.shape == (2, 576, cfg.hidden_size)
+    r = model.prepare_inputs_labels_for_multimodal(batch["input_ids"], None, batch["attention_mask"], None, batch["labels"],
+                                                   batch["images"].cuda())
+    assert r[0] is None and r[4].shape == (2, 658, cfg.hidden_size) and r[5].shape == (2, 658)
+    ref = g["hidden0_sub"]
+    got = r[4].float().cpu()[:, ::13, ::3].numpy()
+    assert np.allclose(got, ref, rtol=3e-2, atol=3e-2)

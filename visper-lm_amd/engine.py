@@ -131,7 +131,7 @@ class Engine:
         self.ps = None         # ParamStore
         self._rope = {}
         self._plan_cache = {}
-        self._pending = []
+        self._red = None
         self.keep_logits = False
 
     # ------------------------------------------------------------------------------------------ weights
@@ -210,24 +210,20 @@ class Engine:
     def set_distributed(self, rank, world):
         self.rank, self.world = rank, world
 
-    def _allreduce_async(self, lo, hi):
-        """Sum-all-reduce grad[lo:hi] on RCCL's own stream (it waits for the kernels already queued on the compute
-        stream, then runs concurrently with whatever we launch next); joined in finish_grads()."""
-        import torch.distributed as dist
-        if hi > lo:
-            self._pending.append(dist.all_reduce(self.ps.grad[lo:hi], async_op=True))
+    def _reducer(self):
+        from .parallel import GradReducer
+        if self._red is None or self._red.g is not self.ps.grad:
+            self._red = GradReducer(self.ps.grad, self.ps.split)
+        return self._red
 
     def finish_grads(self):
         """Join outstanding gradient all-reduces (the compute stream waits; the host does not)."""
-        for w in self._pending:
-            w.wait()
-        self._pending = []
+        if self.world > 1:
+            self._reducer().finish()
 
     def optimizer_step(self, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
         """Mean-reduce over DP ranks is folded into AdamW's grad_scale (ZeRO-2 / DDP averaging semantics)."""
-        if self.world > 1:
-            self._allreduce_async(self.ps.split, self.ps.total)
-            self.finish_grads()
+        self.finish_grads()
         self.ps.adamw_step(lr, betas, eps, weight_decay, grad_scale=1.0 / self.world)
 
     def vit_layers_run(self):
@@ -416,6 +412,40 @@ class Engine:
             out[task] = dict(n_x=len(sel), rows=torch.from_numpy(rows).to(self.dev), sel=sel, lat_x=lat_x)
         return out
 
+    # ------------------------------------------------------------------------------------------ embed
+    def _embed(self, images, plan):
+        """CLIP tower -> mlp2x_gelu projector -> task-token rows -> splice gather.  Returns x [B*S,H] and the projector
+        activations its backward needs."""
+        cfg, fz, ps, dev = self.cfg, self.fz, self.ps, self.dev
+        H = cfg.hidden_size
+        feats = self.vit_forward(images)                                           # [n_img*576, C]
+        z1 = ops.gemm(feats, ps.w("model.mm_projector.0.weight"), bias=ps.w("model.mm_projector.0.bias"))
+        a1 = ops.act_fwd(z1, ops.EPI_GELU)
+        img = ops.gemm(a1, ps.w("model.mm_projector.2.weight"), bias=ps.w("model.mm_projector.2.bias"))
+        # task-token rows (a4): depth/seg = group means of the (576,H) parameter, gen = raw rows
+        nt = cfg.num_task_tokens
+        tok_rows = None
+        if plan["n_tok_rows"] > 0:
+            tok_rows = torch.empty(plan["n_tok_rows"], H, device=dev, dtype=BF16)
+            for k, task in enumerate(cfg.token_order):
+                src = ps.w(f"model.special_{task}_tokens")
+                if task == "gen":
+                    ops.copy2d_(tok_rows[k * nt:(k + 1) * nt], src)
+                else:
+                    grp = src.shape[0] // nt
+                    idx = torch.arange(src.shape[0], device=dev, dtype=torch.int32)
+                    ops.gather_sum_rows(src, idx, grp, 1.0 / grp, tok_rows[k * nt:(k + 1) * nt])
+        x = torch.empty(plan["B"] * plan["S"], H, device=dev, dtype=BF16)
+        srcs = [fz["embed"], img] + ([tok_rows] if tok_rows is not None else [])
+        ops.gather_rows(srcs, plan["kind"], plan["row"], H, x)
+        return x, feats, z1, a1, img
+
+    def splice_forward(self, input_ids, attention_mask, labels, images):
+        """prepare_inputs_labels_for_multimodal's tensor outputs (ola_arch.py:256-444): (inputs_embeds [B,S,H], plan)."""
+        plan = self.build_plan(input_ids, attention_mask, labels)
+        x, *_ = self._embed(images.to(self.dev), plan)
+        return x.view(plan["B"], plan["S"], -1), plan
+
     # ------------------------------------------------------------------------------------------ the step
     def train_step(self, batch, compute_grads=True):
         """One fused forward+backward.  Returns dict(loss, text_loss, per-task losses, layer_losses, ...) of device
@@ -429,32 +459,11 @@ class Engine:
             ps.zero_grad()
         out = {"plan": plan}
 
-        # ---- vision tower + projector (a1..a3)
-        feats = self.vit_forward(batch["images"])                                  # [n_img*576, C]
-        z1 = ops.gemm(feats, ps.w("model.mm_projector.0.weight"), bias=ps.w("model.mm_projector.0.bias"))
-        a1 = ops.act_fwd(z1, ops.EPI_GELU)
-        img = ops.gemm(a1, ps.w("model.mm_projector.2.weight"), bias=ps.w("model.mm_projector.2.bias"))
+        # ---- vision tower + projector + splice (a1..a5)
+        x, feats, z1, a1, img = self._embed(batch["images"], plan)
         out["image_features"] = img
-
-        # ---- task-token rows (a4): depth/seg = group means of the (576,H) parameter, gen = raw rows
-        nt = cfg.num_task_tokens
-        tok_rows = None
-        if plan["n_tok_rows"] > 0:
-            tok_rows = torch.empty(plan["n_tok_rows"], H, device=dev, dtype=BF16)
-            for k, task in enumerate(cfg.token_order):
-                name = f"model.special_{task}_tokens"
-                src = ps.w(name)
-                if task == "gen":
-                    ops.copy2d_(tok_rows[k * nt:(k + 1) * nt], src)
-                else:
-                    grp = src.shape[0] // nt
-                    idx = torch.arange(src.shape[0], device=dev, dtype=torch.int32)
-                    ops.gather_sum_rows(src, idx, grp, 1.0 / grp, tok_rows[k * nt:(k + 1) * nt])
-        # ---- splice (a5)
-        x = torch.empty(M, H, device=dev, dtype=BF16)
-        srcs = [fz["embed"], img] + ([tok_rows] if tok_rows is not None else [])
-        ops.gather_rows(srcs, plan["kind"], plan["row"], H, x)
         out["inputs_embeds"] = x.view(B, S, H)
+        nt = cfg.num_task_tokens
 
         # ---- decoder (a6)
         nh, nkv, hd = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim
@@ -529,7 +538,7 @@ class Engine:
                 if compute_grads and res["dx"] is not None:
                     dx_parts[idx].append((task, res["dx"]))
         if compute_grads and self.world > 1:
-            self._allreduce_async(0, self.ps.split)          # heads + logit scales: overlap with the decoder backward
+            self._reducer().start_early()                    # heads + logit scales: overlap with the decoder backward
         loss = text_loss.clone()
         for task in ("seg", "depth", "gen"):                                 # sum order: ola_llama.py:143-144
             if task in task_loss:
@@ -637,12 +646,8 @@ class Engine:
                 flat = flat.view(Bn, -1)
             else:
                 flat = tg.reshape(Bn, -1).contiguous()
-            if self.world > 1:
-                import torch.distributed as dist
-                allt = torch.empty(self.world * Bn, flat.shape[1], device=self.dev, dtype=BF16)
-                dist.all_gather_into_tensor(allt, flat)
-            else:
-                allt = flat
+            from .parallel import all_gather_rows
+            allt = all_gather_rows(flat) if self.world > 1 else flat
             mask = batch.get(f"{task}_mask")
             mask = torch.ones(Bn, device=self.dev, dtype=F32) if mask is None else mask.to(device=self.dev, dtype=F32)
             if self.cfg.zero_masks:

@@ -1,0 +1,228 @@
+"""OlaLlavaLlamaForCausalLM / OlaLlavaPhi3ForCausalLM / BaseOLA_VLM mirrors
+(ola_vlm/model/language_model/ola_llama.py:39-247, ola_phi3.py, base_ola_vlm.py:38-168,289-320,413-534).
+
+The modules hold nn.Parameters under the reference's state-dict names (so reference checkpoints load with
+`load_state_dict`) and expose the reference's forward signature.  The whole forward+backward of a step runs on the
+HIP engine inside ONE autograd node: `out.loss.backward()` delivers `.grad` for the PT-stage trainable set
+(projector, heads, task tokens, logit scales) exactly like the reference's autograd would."""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import List, Optional, Tuple
+
+import torch
+import torch.nn as nn
+
+from ..config import VisperConfig, phi3_mini
+from ..engine import Engine, is_trainable
+from ..params import param_shapes, init_value
+from .builders import ParamTree, CLIPVisionTower
+from .ola_arch import OlaLlavaMetaModel, OlaLlavaMetaForCausalLM
+
+
+@dataclass
+class OlaCausalLLMOutputWithPast:
+    """ola_llama.py:39-44 (CausalLMOutputWithPast + the four embedding fields)."""
+    loss: Optional[torch.Tensor] = None
+    logits: Optional[torch.Tensor] = None
+    past_key_values: Optional[Tuple] = None
+    hidden_states: Optional[Tuple] = None
+    attentions: Optional[Tuple] = None
+    image_embs: Optional[List[torch.Tensor]] = None
+    seg_embs: Optional[List[torch.Tensor]] = None
+    depth_embs: Optional[List[torch.Tensor]] = None
+    depth_preds: Optional[List[torch.Tensor]] = None
+
+
+class OlaLlavaLlamaConfig(VisperConfig):
+    model_type = "ola_llama"
+
+
+class OlaLlavaPhi3Config(VisperConfig):
+    model_type = "ola_phi3"
+
+    def __init__(self, **kw):
+        super().__init__(**{**phi3_mini().to_dict(), **kw})
+
+
+class OlaLlavaLlamaModel(OlaLlavaMetaModel, ParamTree):
+    config_class = OlaLlavaLlamaConfig
+
+
+class OlaLlavaPhi3Model(OlaLlavaMetaModel, ParamTree):
+    config_class = OlaLlavaPhi3Config
+
+
+class _VisperStep(torch.autograd.Function):
+    """One fused forward+backward on the engine; backward hands the already-computed gradients to autograd."""
+
+    @staticmethod
+    def forward(ctx, owner, batch, *params):
+        eng = owner._get_engine()
+        out = eng.train_step(batch, compute_grads=any(ctx.needs_input_grad[2:]))   # (grad mode is off inside Function.forward)
+        owner._last = out
+        ctx.owner = owner
+        ctx.names = owner._trainable_names
+        return out["loss"].reshape(())
+
+    @staticmethod
+    def backward(ctx, gout):
+        eng = ctx.owner._get_engine()
+        eng.finish_grads()
+        grads = []
+        for n, p in zip(ctx.names, ctx.owner._trainable_params):
+            g = eng.ps.g(n).reshape(p.shape) * gout
+            grads.append(g.to(p.dtype) if p.requires_grad else None)
+        return (None, None, *grads)
+
+
+class BaseOLA_VLM:
+    """base_ola_vlm.py:38-168 attribute surface (mode, layer indices, loss weights, logit scales) + engine plumbing."""
+
+    def init_heads(self, config):                      # base_ola_vlm.py:104-168 (parameters come from the manifest)
+        from ..config import layer_indices
+        self.mode = getattr(config, "aux_mode", "gen-depth-seg")
+        self.pass_text_to_aux_head = getattr(config, "pass_text_to_aux", True)
+        self.use_ce = getattr(config, "use_ce", False)
+        self.contrastive_loss_weight = config.contrastive_loss_weight
+        if "gen" in self.mode and hasattr(config, "image_gen"):
+            self.img_layer_indices = layer_indices(config.image_gen["img_layer_indices"])
+            self.img_gen_loss_weight = config.image_gen["img_loss_weight"]
+        if "depth" in self.mode and hasattr(config, "image_depth"):
+            self.depth_layer_indices = layer_indices(config.image_depth["depth_layer_indices"])
+            self.img_depth_loss_weight = config.image_depth["depth_loss_weight"]
+            self.use_intermediate_depth = config.image_depth.get("use_intermediate_depth", True)
+        if "seg" in self.mode and hasattr(config, "image_seg"):
+            self.seg_layer_indices = layer_indices(config.image_seg["seg_layer_indices"])
+            self.img_seg_loss_weight = config.image_seg["seg_loss_weight"]
+
+    def init_target_models(self, config):              # base_ola_vlm.py:56-95
+        """The frozen teachers (unCLIP image encoder, DINOv2-L, OneFormer Swin-L) are OUT OF SCOPE:
+        their features are inputs.  Override _get_gen_feats/_get_dav2_feats/_get_seg_targets or pass *_target tensors."""
+        return None
+
+    def _get_gen_feats(self, pil_images, device):
+        raise NotImplementedError("frozen unCLIP teacher is out of scope: pass gen_target= or override _get_gen_feats")
+
+    def _get_dav2_feats(self, pil_images, device):
+        raise NotImplementedError("frozen DINOv2 teacher is out of scope: pass depth_target= or override _get_dav2_feats")
+
+    def _get_seg_targets(self, pil_images, seg_preds):
+        raise NotImplementedError("frozen OneFormer teacher is out of scope: pass seg_target= or override _get_seg_targets")
+
+    # ---- engine plumbing
+    def _get_engine(self) -> Engine:
+        if self._engine is None:
+            dev = next(self.parameters()).device
+            eng = Engine(self.config, device=dev)
+            eng.load_weights({k: v for k, v in self.state_dict().items()})
+            self._engine = eng
+            self._trainable_names = [n for n in eng.ps.index]
+            named = dict(self.named_parameters())
+            self._trainable_params = [named[n] for n in self._trainable_names]
+        return self._engine
+
+    def _sync_trainable(self):
+        """nn.Parameters are the source of truth (an external optimizer may have stepped them): refresh the engine's
+        fp32 master + bf16 shadow (one flat cast kernel)."""
+        eng = self._get_engine()
+        for n, p in zip(self._trainable_names, self._trainable_params):
+            eng.ps.p(n).copy_(p.detach().reshape(eng.ps.p(n).shape))
+        eng.ps.refresh_shadow()
+
+    def reload_frozen(self):
+        """Call after load_state_dict(): rebuilds the engine's fused / pre-transposed frozen weights."""
+        self._engine = None
+
+
+class _OlaCausalLMBase(OlaLlavaMetaForCausalLM, BaseOLA_VLM, nn.Module):
+    model_cls = OlaLlavaLlamaModel
+
+    def __init__(self, config, device="cuda", dtype=torch.bfloat16, init="random", seed=0):
+        nn.Module.__init__(self)
+        self.config = config
+        self.vocab_size = config.vocab_size
+        self.NUM_SYS_TOKENS = config.num_sys_tokens                   # ola_llama.py:65-69 / ola_phi3.py:68
+        self.steps = 0
+        self._engine = None
+        self._last = None
+        self.model = self.model_cls()
+        self.model.config = config
+        shapes = param_shapes(config, vit_nested=True)
+        gen = torch.Generator(device=device).manual_seed(seed) if init == "random" else None
+        top = ParamTree()
+        for name, shp in shapes.items():
+            tgt, rel = (self.model, name[len("model."):]) if name.startswith("model.") else (top, name)
+            if rel.startswith("vision_tower.") and "vision_tower" not in self.model._modules:
+                tower = CLIPVisionTower(config.mm_vision_tower, args=config)
+                tower.__dict__["_owner"] = self          # plain attribute: NOT a registered child (would create a module cycle)
+                self.model.add_module("vision_tower", tower)
+            tgt.add(rel, shp, device, dtype if len(shp) else torch.float32, requires_grad=is_trainable(name))
+            if gen is not None:
+                p = dict(tgt.named_parameters())[rel]
+                p.data.copy_(init_value(name, shp, gen, device, p.dtype))
+        for k, m in list(top._modules.items()):                      # image_*_heads, lm_head
+            self.add_module(k, m)
+        for k, p in list(top._parameters.items()):                   # *_logit_scale
+            self.register_parameter(k, p)
+        self.model.initialize_special_tokens(config)
+        self.init_heads(config)
+
+    def get_model(self):
+        return self.model
+
+    def _collect_targets(self, pil_images, kw, B, dev):
+        t = {}
+        for task, getter in (("gen", "_get_gen_feats"), ("depth", "_get_dav2_feats"), ("seg", "_get_seg_targets")):
+            if task not in self.config.token_order:
+                continue
+            if kw.get(f"{task}_target") is not None:
+                t[task] = kw[f"{task}_target"]
+            elif pil_images is not None:
+                if task == "gen":
+                    t[task] = self._get_gen_feats(pil_images, dev)
+                elif task == "depth":
+                    t[task] = self._get_dav2_feats(pil_images, dev)[0][0][0]      # mean-of-4 DINOv2 feature (base_ola_vlm.py:355)
+                else:
+                    t[task] = self._get_seg_targets(pil_images, None)
+        return t
+
+    def forward(self, input_ids=None, attention_mask=None, position_ids=None, past_key_values=None, inputs_embeds=None,
+                labels=None, use_cache=None, output_attentions=None, output_hidden_states=None, images=None,
+                image_sizes=None, return_dict=None, pil_images=None, gen_mask=None, seg_mask=None, depth_mask=None, **kwargs):
+        """ola_llama.py:190-244 signature.  Extra kwargs: gen_target / depth_target / seg_target (precomputed frozen-teacher
+        features), output_logits=True to materialise `logits`."""
+        if inputs_embeds is not None or past_key_values is not None or use_cache:
+            raise NotImplementedError("the MI355X path covers the training forward (input_ids + images); generation is out of scope")
+        self._sync_trainable()
+        eng = self._get_engine()
+        dev = eng.dev
+        B = input_ids.shape[0]
+        batch = dict(input_ids=input_ids, attention_mask=attention_mask, labels=labels, images=images.to(dev))
+        for task, tg in self._collect_targets(pil_images, kwargs, B, dev).items():
+            batch[f"{task}_target"] = tg
+            m = {"gen": gen_mask, "seg": seg_mask, "depth": depth_mask}[task]
+            batch[f"{task}_mask"] = torch.ones(B, device=dev) if m is None else m
+        eng.keep_logits = bool(kwargs.get("output_logits", False))
+        if labels is not None:
+            loss = _VisperStep.apply(self, batch, *self._trainable_params)
+        else:
+            self._last = eng.train_step(batch, compute_grads=False)
+            loss = None
+        out = self._last
+        embs = out.get("embs", {})
+        return OlaCausalLLMOutputWithPast(loss=loss, logits=out.get("logits"), hidden_states=(out["hidden"],),
+                                          image_embs=embs.get("gen", []), seg_embs=embs.get("seg", []),
+                                          depth_embs=embs.get("depth", []), depth_preds=[])
+
+    _forward = forward
+
+
+class OlaLlavaLlamaForCausalLM(_OlaCausalLMBase):
+    config_class = OlaLlavaLlamaConfig
+    model_cls = OlaLlavaLlamaModel
+
+
+class OlaLlavaPhi3ForCausalLM(_OlaCausalLMBase):
+    config_class = OlaLlavaPhi3Config
+    model_cls = OlaLlavaPhi3Model

@@ -1,0 +1,51 @@
+"""Data-parallel exchange points of the PT step over torch.distributed — backend "nccl" (= RCCL over
+xGMI) on MI355X, "gloo" in the CPU tests.  One process per GPU; exactly two collectives per step:
+
+  1. all_gather_rows: the frozen-teacher target features, once per task per step (the reference re-gathers the
+     normalised targets in every layer call: ola_utils.py:96-106,118-119) -> rank-ordered [world*B, D].
+  2. GradReducer: sum-all-reduce of the flat fp32 gradient buffer in two pieces — heads + logit scales as soon as the
+     heads' backward is done (their all-reduce runs on RCCL's stream underneath the whole decoder backward), projector +
+     task tokens at the end.  The 1/world mean is folded into the fused AdamW (grad_scale).  Replaces DeepSpeed ZeRO-2's
+     bucketed reduce-scatter (scripts/zero2.json:16-22, overlap_comm:false).
+"""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+
+
+def world_info():
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def all_gather_rows(flat: torch.Tensor) -> torch.Tensor:
+    """[B, D] on every rank -> [world*B, D], rank r's rows at r*B..(r+1)*B (dist_collect order, ola_utils.py:104-106)."""
+    rank, world = world_info()
+    if world == 1:
+        return flat
+    out = torch.empty(world * flat.shape[0], flat.shape[1], device=flat.device, dtype=flat.dtype)
+    dist.all_gather_into_tensor(out, flat.contiguous())
+    return out
+
+
+class GradReducer:
+    def __init__(self, flat_grad: torch.Tensor, split: int):
+        self.g, self.split, self.pending = flat_grad, split, []
+
+    def _launch(self, lo, hi):
+        _, world = world_info()
+        if world > 1 and hi > lo:
+            self.pending.append(dist.all_reduce(self.g[lo:hi], op=dist.ReduceOp.SUM, async_op=True))
+
+    def start_early(self):
+        """heads + logit-scale gradients are final: reduce them while the decoder backward runs."""
+        self._launch(0, self.split)
+
+    def finish(self):
+        """reduce the late block (projector + task tokens) and join everything (stream-side wait on GPU)."""
+        self._launch(self.split, self.g.numel())
+        for w in self.pending:
+            w.wait()
+        self.pending = []
