@@ -672,6 +672,163 @@ __global__ __launch_bounds__(512) void gemm_nt_256sk(GemmArgs p) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// 4-wave variant: 256x256 block tile, each wave owns 128x128 (8x8 MFMA tiles, 256 accumulator registers -> one wave
+// per SIMD with the whole 512-register file).  Per K step of 32 a wave reads 16 fragments for 64 MFMAs, i.e. 1/3 fewer
+// LDS bytes per flop than the 8-wave kernel (the ablation showed LDS/L2 data movement, not scheduling, is the limiter).
+// LDS is a 4-deep ring of 32-K stages (4 x 32 KB); stage s+3 is DMA'd while stage s is computed, fragments of stage
+// s+1 are prefetched into a second register set under the MFMAs of stage s, and the DMA queue is never drained
+// (counted s_waitcnt vmcnt(8): the newest stage stays in flight across every barrier).  One raw s_barrier per stage.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void epilogue_w4_swz(const GemmArgs& p, bf16_t* wave_lds, const f32x4 (&acc)[8][8], int mrow0, int ncol0,
+                                                int lane) {
+  const int fr = lane & 15, g = lane >> 4;
+  const int epi = p.epi & 0xff;
+#pragma unroll
+  for (int pass = 0; pass < 4; ++pass) {            // 32 rows (two m-tiles) x 128 cols per pass: [32][128] bf16 = 8 KB per wave
+#pragma unroll
+    for (int ii = 0; ii < 2; ++ii) {
+      const int i = pass * 2 + ii;
+      const int row = ii * 16 + fr;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        bf16x4 o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int n = ncol0 + j * 16 + g * 4 + r;
+          float x = acc[i][j][r] + ((p.bias && n < p.N) ? bf2f(p.bias[n]) : 0.f);
+          x = bfround(x);
+          if (epi != EPI_NONE) x = bfround(apply_epi(x, epi));
+          o[r] = (short)f2bf(x);
+        }
+        const int chunk = (j * 2 + (g >> 1)) ^ (row & 15);
+        *(bf16x4*)(wave_lds + row * 128 + chunk * 8 + (g & 1) * 4) = o;
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int rl = it * 4 + (lane >> 4), ch = lane & 15;
+      const int m = mrow0 + pass * 32 + rl, n = ncol0 + ch * 8;
+      bf16x8 v = *(const bf16x8*)(wave_lds + rl * 128 + ((ch ^ (rl & 15)) << 3));
+      if (m < p.M && n < p.N) {
+        bf16_t* cptr = (bf16_t*)p.C + (long)m * p.ldc + n;
+        const bool full = (n + 8 <= p.N) && ((((uintptr_t)cptr) & 15) == 0);
+        if (p.res) {
+          const bf16_t* rptr = p.res + (long)m * p.ldr + n;
+          if (full && ((((uintptr_t)rptr) & 15) == 0)) {
+            const bf16x8 rv = *(const bf16x8*)rptr;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (short)f2bf(bf2f((bf16_t)v[e]) + bf2f((bf16_t)rv[e]));
+          } else {
+            for (int e = 0; e < 8 && n + e < p.N; ++e) v[e] = (short)f2bf(bf2f((bf16_t)v[e]) + bf2f(rptr[e]));
+          }
+        }
+        if (full) *(bf16x8*)cptr = v;
+        else for (int e = 0; e < 8 && n + e < p.N; ++e) cptr[e] = (bf16_t)v[e];
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
+}
+
+template <bool OUT_F32>
+__global__ __launch_bounds__(256) void gemm_nt_256w4(GemmArgs p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  bf16_t* smem = (bf16_t*)smem_raw;                    // 4 stages x [A 256x32 | B 256x32]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tiles_m = (p.M + 255) >> 8, tiles_n = (p.N + 255) >> 8;
+  const TileCoord tc = tile_coord_256(blockIdx.x, tiles_m, tiles_n);
+  const int m0 = tc.m0, n0 = tc.n0;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int fr = lane & 15, g = lane >> 4;
+  const int ns = p.K >> 5;
+
+  const bf16_t* srcA[4];
+  const bf16_t* srcB[4];
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int q = it * 256 + tid;
+    const int row = q >> 2;
+    const int gc = (q & 3) ^ ((row >> 2) & 3);
+    srcA[it] = p.A + (long)min(m0 + row, p.M - 1) * p.lda + gc * 8;
+    srcB[it] = p.B + (long)min(n0 + row, p.N - 1) * p.ldb + gc * 8;
+  }
+#define ISSUE_STAGE(S, SLOT)                                                       \
+  {                                                                                \
+    const long ko_ = (long)min((S), ns - 1) * 32;                                  \
+    bf16_t* As_ = smem + (SLOT) * 16384;                                           \
+    bf16_t* Bs_ = As_ + 8192;                                                      \
+    _Pragma("unroll") for (int it = 0; it < 4; ++it) {                             \
+      GLDS16(srcA[it] + ko_, As_ + (it * 256 + wave * 64) * 8);                    \
+      GLDS16(srcB[it] + ko_, Bs_ + (it * 256 + wave * 64) * 8);                    \
+    }                                                                              \
+  }
+#define READ_STAGE(SLOT, XF, WF)                                                   \
+  {                                                                                \
+    const bf16_t* As_ = smem + (SLOT) * 16384;                                     \
+    const bf16_t* Bs_ = As_ + 8192;                                                \
+    _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                \
+      const int r = wc * 128 + j * 16 + fr;                                        \
+      WF[j] = *(const bf16x8*)(Bs_ + r * 32 + ((g ^ ((r >> 2) & 3)) << 3));        \
+    }                                                                              \
+    _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                \
+      const int r = wr * 128 + i * 16 + fr;                                        \
+      XF[i] = *(const bf16x8*)(As_ + r * 32 + ((g ^ ((r >> 2) & 3)) << 3));        \
+    }                                                                              \
+  }
+#define MFMA_STAGE(XF, WF)                                                         \
+  _Pragma("unroll") for (int i = 0; i < 8; ++i)                                    \
+    _Pragma("unroll") for (int j = 0; j < 8; ++j)                                  \
+      acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(WF[j], XF[i], acc[i][j], 0, 0, 0);
+
+  f32x4 acc[8][8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  ISSUE_STAGE(0, 0);
+  ISSUE_STAGE(1, 1);
+  ISSUE_STAGE(2, 2);
+  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                // stages 0 and 1 landed (this wave's parts)
+  VP_BAR();
+  bf16x8 xa[8], wa[8], xb[8], wb[8];
+  READ_STAGE(0, xa, wa);
+  // stage s:  barrier | DMA stage s+3 | prefetch fragments of stage s+1 | 64 MFMAs on stage s | wait until only the
+  // newest stage is still in flight (=> this wave's part of stage s+2 has landed before the next barrier)
+  for (int s = 0; s < ns; s += 2) {
+    VP_BAR();
+    ISSUE_STAGE(s + 3, (s + 3) & 3);
+    READ_STAGE((s + 1) & 3, xb, wb);
+    VP_SB();
+    MFMA_STAGE(xa, wa);
+    VP_SB();
+    asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+    VP_BAR();
+    ISSUE_STAGE(s + 4, (s + 4) & 3);
+    if (s + 2 < ns) READ_STAGE((s + 2) & 3, xa, wa);
+    VP_SB();
+    MFMA_STAGE(xb, wb);
+    VP_SB();
+    asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+  }
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");     // drain the (dummy) tail DMAs before LDS is reused
+  VP_BAR();
+#undef ISSUE_STAGE
+#undef READ_STAGE
+#undef MFMA_STAGE
+  if (!OUT_F32) {
+    epilogue_w4_swz(p, smem + wave * 4096, acc, m0 + wr * 128, n0 + wc * 128, lane);
+  } else {
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        store4<OUT_F32>(p, m0 + wr * 128 + i * 16 + fr, n0 + wc * 128 + j * 16 + g * 4, acc[i][j]);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // generic path: any M, N, K, any alignment (register-staged, zero-filled K tail). 64x64x32 tile.
 // ------------------------------------------------------------------------------------------------
 template <bool OUT_F32>
@@ -754,7 +911,16 @@ int vp_gemm_bf16(int M, int N, int K, const void* A, long lda, const void* B, lo
   const bool fast = (force_generic != 1) && (K % 64 == 0) && (lda % 8 == 0) && (ldb % 8 == 0) &&
                     ((((uintptr_t)A) | ((uintptr_t)B)) & 15) == 0;
   const long big_tiles = (long)((M + 255) / 256) * ((N + 255) / 256);
-  if (fast && force_generic == 5) {
+  if (fast && force_generic == 6) {
+    static bool attr_w4 = false;
+    if (!attr_w4) {
+      (void)hipFuncSetAttribute((const void*)gemm_nt_256w4<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+      (void)hipFuncSetAttribute((const void*)gemm_nt_256w4<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+      attr_w4 = true;
+    }
+    if (out_f32) hipLaunchKernelGGL(gemm_nt_256w4<true>, dim3((unsigned)big_tiles), dim3(256), 131072, stream, p);
+    else hipLaunchKernelGGL(gemm_nt_256w4<false>, dim3((unsigned)big_tiles), dim3(256), 131072, stream, p);
+  } else if (fast && force_generic == 5) {
     static bool attr_sk = false;
     if (!attr_sk) {
       (void)hipFuncSetAttribute((const void*)gemm_nt_256sk<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
