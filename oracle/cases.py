@@ -36,11 +36,12 @@ def load_golden(name):
     return np.load(os.path.join(GOLDEN, name), allow_pickle=False)
 
 
-def tiny_llama_case():
-    """(cfg, W, batch, golden) for tests/golden/tiny_llama_e2e.npz."""
-    g = load_golden("tiny_llama_e2e.npz")
+def tiny_llama_case(arch="llama"):
+    """(cfg, W, batch, golden) for tests/golden/tiny_{llama,phi3}_e2e.npz."""
+    g = load_golden(f"tiny_{arch}_e2e.npz")
     t = json.loads(str(g["cfg"]))
-    cfg = O.make_config(arch="llama", vocab_size=t["vocab_size"], hidden_size=t["hidden_size"],
+    extra = dict(rope_theta=10000.0, sliding_window=t.get("sliding_window")) if arch == "phi3" else {}
+    cfg = O.make_config(arch=arch, **extra, vocab_size=t["vocab_size"], hidden_size=t["hidden_size"],
                         intermediate_size=t["intermediate_size"], num_hidden_layers=t["num_hidden_layers"],
                         num_attention_heads=t["num_attention_heads"], num_key_value_heads=t["num_key_value_heads"],
                         vit_hidden=t["vit_hidden"], vit_inter=t["vit_inter"], vit_layers=t["vit_layers"],
@@ -48,7 +49,8 @@ def tiny_llama_case():
                         image_seg=t["image_seg"], image_depth=t["image_depth"])
     manifest = json.loads(str(g["manifest"]))
     W = {k: WT.param(k, s) for k, s in manifest.items() if not k.startswith("da_v2_head.")}
-    batch = make_batch(2, 59, 38)
+    B, T, col = json.loads(str(g["batch"])) if "batch" in g else (2, 59, 38)
+    batch = make_batch(B, T, col)
     assert np.array_equal(batch["input_ids"].numpy(), g["input_ids"])
     return cfg, W, batch, g
 

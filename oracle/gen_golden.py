@@ -91,20 +91,27 @@ def sub(t, n=4096):
     return f[::step][:n].numpy().copy()
 
 
-def build_llama(tiny):
-    from ola_vlm.model.language_model.ola_llama import OlaLlavaLlamaForCausalLM, OlaLlavaLlamaConfig
+def build_llama(tiny, arch="llama"):
     from ola_vlm.model.multimodal_encoder.clip_encoder import CLIPVisionTower
     from ola_vlm.model.multimodal_projector.builder import build_vision_projector
+    if arch == "phi3":
+        from ola_vlm.model.language_model.ola_phi3 import OlaLlavaPhi3ForCausalLM as OlaLlavaLlamaForCausalLM
+        from ola_vlm.model.language_model.ola_phi3 import OlaLlavaPhi3Config as OlaLlavaLlamaConfig
+        theta, extra = 10000.0, dict(sliding_window=tiny["sliding_window"], pad_token_id=0, resid_pdrop=0.0, embd_pdrop=0.0,
+                                     attention_dropout=0.0)
+    else:
+        from ola_vlm.model.language_model.ola_llama import OlaLlavaLlamaForCausalLM, OlaLlavaLlamaConfig
+        theta, extra = 500000.0, {}
     cfg = OlaLlavaLlamaConfig(vocab_size=tiny["vocab_size"], hidden_size=tiny["hidden_size"],
                               intermediate_size=tiny["intermediate_size"], num_hidden_layers=tiny["num_hidden_layers"],
                               num_attention_heads=tiny["num_attention_heads"],
                               num_key_value_heads=tiny["num_key_value_heads"], rms_norm_eps=1e-5,
-                              max_position_embeddings=4096)
+                              max_position_embeddings=4096, **extra)
     try:
-        cfg.rope_parameters = {"rope_type": "default", "rope_theta": 500000.0}
+        cfg.rope_parameters = {"rope_type": "default", "rope_theta": theta}
     except Exception:
         pass
-    cfg.rope_theta = 500000.0
+    cfg.rope_theta = theta
     cfg._attn_implementation = "eager"
     cfg.aux_mode = tiny["aux_mode"]
     cfg.num_task_tokens = 8
@@ -159,12 +166,24 @@ def make_batch(B, T, img_col, vocab_hi=1000):
     return ids, labels, images, tg, td, ts
 
 
-def _fresh_tiny_llama(B):
+TINY_PHI3 = dict(
+    vocab_size=32064, hidden_size=128, intermediate_size=256, num_hidden_layers=4, num_attention_heads=4,
+    num_key_value_heads=4, sliding_window=300, vit_hidden=128, vit_inter=256, vit_layers=3, vit_heads=4, aux_mode="gen-depth-seg",
+    image_gen=dict(depth=1, dim_head=32, num_heads=4, num_tokens=1, output_dim=1024, ff_mult=1,
+                   img_layer_indices="4", img_loss_weight=0.5),
+    image_seg=dict(depth=1, dim_head=32, num_heads=4, num_tokens=576, output_dim=1536, ff_mult=1,
+                   seg_layer_indices="2-3", seg_loss_weight=0.5),
+    image_depth=dict(depth=1, dim_head=32, num_heads=4, num_tokens=576, output_dim=1024, ff_mult=1,
+                     depth_layer_indices="3", depth_loss_weight=0.5),
+)
+
+
+def _fresh_tiny_llama(B, tiny=None, arch="llama"):
     """A NEW reference model per forward: under transformers 5.x (installed here; the reference pins
     4.41.1) the outer model's first `output_hidden_states=True` call leaves duplicate recorder hooks on
     the nested CLIP tower, so from the SECOND call on `hidden_states` has 2L+1 entries and
     `hidden_states[-2]` silently selects a different layer.  Only a first call has the pinned semantics."""
-    model, cfg = build_llama(TINY_LLAMA)
+    model, cfg = build_llama(tiny or TINY_LLAMA, arch)
     # PT-stage trainability (ola_vlm_train.py:1127-1131,1147): LLM + tower frozen.
     shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
     sd = {k: WT.param(k, s) for k, s in shapes.items() if not k.startswith("da_v2_head.")}
@@ -177,13 +196,14 @@ def _fresh_tiny_llama(B):
     return model, shapes
 
 
-def run_tiny_llama():
-    B, T = 2, 59
-    ids, labels, images, tg, td, ts = make_batch(B, T, 38)
+def run_tiny_llama(arch="llama"):
+    tiny = TINY_LLAMA if arch == "llama" else TINY_PHI3
+    B, T, col = (2, 59, 38) if arch == "llama" else (2, 54, 13)
+    ids, labels, images, tg, td, ts = make_batch(B, T, col)
     captured = []
     res = {}
     for mode in ("keep", "released"):
-        model, shapes = _fresh_tiny_llama(B)
+        model, shapes = _fresh_tiny_llama(B, tiny, arch)
         model._get_gen_feats = lambda pil, dev: tg
         model._get_seg_targets = lambda pil, h: ts
         model._get_dav2_feats = lambda pil, dev: ([(td, None)], torch.zeros(B, 336, 336))
@@ -233,9 +253,10 @@ def run_tiny_llama():
     res["trainable"] = json.dumps(sorted(n for n, p in model.named_parameters() if p.requires_grad))
     res["input_ids"] = ids.numpy()
     res["labels"] = labels.numpy()
-    res["cfg"] = json.dumps(TINY_LLAMA)
-    np.savez_compressed(os.path.join(OUT, "tiny_llama_e2e.npz"), **res)
-    print("tiny_llama: keep loss", res["keep_loss"], "released loss", res["released_loss"])
+    res["cfg"] = json.dumps(tiny)
+    res["batch"] = json.dumps([B, T, col])
+    np.savez_compressed(os.path.join(OUT, f"tiny_{arch}_e2e.npz"), **res)
+    print(f"tiny_{arch}: keep loss", res["keep_loss"], "released loss", res["released_loss"])
     print("layer losses (keep):\n", res["keep_layer_losses"], res["keep_layer_shapes"])
     return model
 
@@ -284,5 +305,10 @@ if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
     setup_reference()
-    run_units()
-    run_tiny_llama()
+    which = sys.argv[1:] or ["units", "llama", "phi3"]
+    if "units" in which:
+        run_units()
+    if "llama" in which:
+        run_tiny_llama("llama")
+    if "phi3" in which:
+        run_tiny_llama("phi3")

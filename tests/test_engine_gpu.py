@@ -123,3 +123,26 @@ def test_smoke_entry():
         pytest.skip("needs a GPU")
     import __graft_entry__ as ge
     ge.smoke()
+
+
+def test_phi3_path_matches_oracle_and_reference_golden():
+    """BASELINE configs[4] path: OlaLlavaPhi3 (fused qkv/gate_up weights, NUM_SYS_TOKENS 13, sliding-window attention)."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from oracle import cases, visper_oracle as O
+    from visper_lm_amd.config import VisperConfig
+    from visper_lm_amd.engine import Engine
+    ocfg, W, batch, g = cases.tiny_llama_case("phi3")
+    eng = Engine(VisperConfig(**vars(ocfg)))
+    eng.load_weights(W)
+    out = eng.train_step(_to_gpu_batch(batch))
+    assert rel(out["loss"], g["keep_loss"]) < 1e-2, (float(out["loss"]), float(g["keep_loss"]))
+    names = [("depth", 2), ("seg", 1), ("seg", 2), ("gen", 3)]
+    for i, key in enumerate(names):
+        mine = out["layer_losses"][key].float().cpu().numpy()
+        assert np.allclose(mine, g["keep_layer_losses"][i], rtol=3e-2, atol=3e-3), (key, mine, g["keep_layer_losses"][i])
+    none_ref = set(json.loads(str(g["keep_grad_none"])))
+    for k in eng.ps.index:
+        got = float(eng.ps.g(k).float().norm())
+        ref = 0.0 if k in none_ref else float(g[f"keep_gradnorm::{k}"])
+        assert abs(got - ref) <= 0.1 * ref + 1e-6, (k, got, ref)

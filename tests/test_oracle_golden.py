@@ -122,3 +122,34 @@ def test_e2e_as_released_mask_zeroing(tiny):
     for k in tr:
         if "_heads." in k or "logit_scale" in k:
             assert W2[k].grad is None or float(W2[k].grad.abs().sum()) == 0.0, k
+
+
+# ------------------------------------------------------------------------------------------------ Phi-3 (config 5 path)
+@pytest.fixture(scope="module")
+def tiny_phi3():
+    cfg, W, batch, g = cases.tiny_llama_case("phi3")
+    tr = json.loads(str(g["trainable"]))
+    for k in tr:
+        W[k] = W[k].clone().requires_grad_(True)
+    out = O.forward(W, batch, cfg)
+    out["loss"].backward()
+    return cfg, W, batch, g, out, tr
+
+
+def test_phi3_e2e_forward_and_grads_match_reference(tiny_phi3):
+    """OlaLlavaPhi3ForCausalLM: fused qkv_proj / gate_up_proj, NUM_SYS_TOKENS = 13, sliding window 300 < S = 653."""
+    cfg, W, batch, g, out, tr = tiny_phi3
+    assert O.num_sys_tokens(cfg) == 13 and cfg.sliding_window == 300
+    _close(out["loss"].item(), g["keep_loss"], 1e-5, 1e-6)
+    lg = out["logits"]
+    assert tuple(lg.shape) == tuple(g["logits_shape"])
+    _close(lg[:, ::41, ::997].detach().numpy(), g["logits_sub"], 1e-3, 2e-5)
+    mine = [out["layer_losses"][("depth", 2)], out["layer_losses"][("seg", 1)], out["layer_losses"][("seg", 2)], out["layer_losses"][("gen", 3)]]
+    for i, trip in enumerate(mine):
+        _close([float(x.detach()) for x in trip], g["keep_layer_losses"][i], 2e-5, 1e-6)
+    none_ref = set(json.loads(str(g["keep_grad_none"])))
+    for k in tr:
+        if k in none_ref:
+            continue
+        ref_norm = float(g[f"keep_gradnorm::{k}"])
+        assert abs(float(W[k].grad.double().norm()) - ref_norm) <= 2e-4 * ref_norm + 1e-9, k
