@@ -37,7 +37,7 @@ def make_batch(cfg, B, T, rank, device):
     gd = torch.Generator(device=device).manual_seed(1234 + rank)
     rn = lambda *s: torch.randn(*s, device=device, dtype=torch.bfloat16, generator=gd)
     batch = dict(input_ids=ids, labels=labels, attention_mask=torch.ones_like(ids, dtype=torch.bool),
-                 images=rn(B, 3, cfg.vit_image, cfg.vit_image))
+                 images=rn(B, 3, cfg.cnx_image if cfg.is_convnext else cfg.vit_image, cfg.cnx_image if cfg.is_convnext else cfg.vit_image))
     order = cfg.token_order
     if "gen" in order:
         batch["gen_target"] = rn(B, 1, cfg.image_gen["output_dim"]); batch["gen_mask"] = torch.ones(B, device=device)
@@ -143,6 +143,8 @@ def main():
     ap.add_argument("--text-len", type=int, default=1449)          # -> post-splice S = 2048 with 3 tasks
     ap.add_argument("--layers", type=int, default=None, help="debug only: fewer decoder layers (result marked invalid)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", default="llama3_8b", choices=["llama3_8b", "convnext", "phi3"],
+                    help="llama3_8b = BASELINE configs[1] (the headline metric); convnext = configs[3]; phi3 = configs[4] (secondary)")
     ap.add_argument("--lr", type=float, default=1e-3)
     args = ap.parse_args()
 
@@ -160,10 +162,19 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from visper_lm_amd import ops
-    from visper_lm_amd.config import llama3_8b
+    from visper_lm_amd.config import llama3_8b, llama3_8b_convnext, phi3_mini
     from visper_lm_amd.engine import Engine
 
-    cfg = llama3_8b()
+    step_tf = STEP_TF_PER_IMAGE
+    if args.workload == "convnext":
+        cfg, step_tf = llama3_8b_convnext(), 69.07
+    elif args.workload == "phi3":
+        cfg, step_tf = phi3_mini(), 71.94
+        cfg.image_depth = dict(cfg.image_depth); cfg.image_gen = dict(cfg.image_gen); cfg.image_seg = dict(cfg.image_seg)
+        if args.text_len == 1449:
+            args.text_len, args.batch = 3497, min(args.batch, 4)      # post-splice S = 4096
+    else:
+        cfg = llama3_8b()
     if args.layers:
         cfg.num_hidden_layers = args.layers
         cfg.image_gen["img_layer_indices"] = str(min(20, args.layers))
@@ -212,17 +223,19 @@ def main():
             "peak": PEAK_BF16_TF, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TF, 4), "traffic": None,
             "launches_per_step": len(prof) // max(args.steps, 1), "gemm_ms_per_step": round(g_ms / args.steps, 2),
             "gemm_tflop_per_step": round(g_fl / args.steps / 1e12, 2),
-            "step_frac_of_peak": round(value / world * STEP_TF_PER_IMAGE / PEAK_BF16_TF, 4)}
+            "step_frac_of_peak": round(value / world * step_tf / PEAK_BF16_TF, 4)}
     if rank == 0:
-        res = {"metric": "train-step images/sec (NTP+distill), ViT-L+Llama3-8B seq2048", "value": round(value, 4), "unit": "images/s",
+        res = {"metric": "train-step images/sec (NTP+distill), ViT-L+Llama3-8B seq2048" if args.workload == "llama3_8b" else f"train-step images/sec (NTP+distill), {args.workload}", "value": round(value, 4), "unit": "images/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 2), "higher_is_better": True,
                "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic (random-init weights, random images/tokens/targets)",
-               "config": {"workload": "configs[1]: CLIP-ViT-L/14-336 + Llama-3-8B PT step, 3 distill heads (d18,s18,g20), 336px",
+               "config": {"workload": {"llama3_8b": "configs[1]: CLIP-ViT-L/14-336 + Llama-3-8B PT step, 3 distill heads (d18,s18,g20), 336px",
+                                       "convnext": "configs[3]: CLIP-ConvNeXt-XXL (768px) + Llama-3-8B PT step, 3 distill heads",
+                                       "phi3": "configs[4]: CLIP-ViT-L/14-336 + Phi-3-mini PT step, 3 distill heads, seq 4096"}[args.workload],
                           "global_batch": args.batch * world, "per_gpu_batch": args.batch, "seq_len": S, "text_len": args.text_len,
                           "parallelism": f"dp{world}", "decoder_layers": cfg.num_hidden_layers, "loss": round(loss, 4),
                           "valid": args.layers is None},
                "roofline": roof}
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.workload == "llama3_8b":
             res["cpu_baseline"] = cpu_baseline(cfg)
         print(json.dumps(res), flush=True)
     if dist is not None:

@@ -75,6 +75,9 @@ int vp_act_bwd(int kind, long n, const void* dy, const void* x, void* dx, vp_str
 int vp_add_bf16(long n, const void* a, const void* b, void* out, vp_stream_t stream);
 int vp_add2d_bf16(long R, int C, void* dst, long ldd, const void* src, long lds, vp_stream_t stream);
 int vp_copy2d_bf16(long R, int C, void* dst, long ldd, const void* src, long lds, vp_stream_t stream);
+/* depthwise 7x7 conv, NHWC, zero pad 3 — timm ConvNeXtBlock.conv_dw of the CLIP-ConvNeXt-XXL tower
+ * (multimodal_encoder/clip_convnext_encoder.py:161-165).  w is tap-major [49, C]. */
+int vp_dwconv7x7_nhwc(int B, int H, int W, int C, const void* x, const void* w, const void* bias, void* y, vp_stream_t stream);
 /* bias gradients (column sums), two deterministic stages */
 int vp_colsum_partial(long M, int N, const void* x, long ld, float* part, int rows_per_block, vp_stream_t stream);
 int vp_colsum_finish(int nslab, int N, const float* part, float* out, float scale, int accumulate, vp_stream_t stream);

@@ -46,6 +46,7 @@ def make_config(**kw) -> SimpleNamespace:
         vit_hidden=1024, vit_inter=4096, vit_layers=24, vit_heads=16, vit_image=336, vit_patch=14,
         vit_eps=1e-5, mm_vision_select_layer=-2, mm_vision_select_feature="patch",
         mm_projector_type="mlp2x_gelu",
+        cnx_dims=(384, 768, 1536, 3072), cnx_depths=(3, 4, 30, 3), cnx_eps=1e-5, cnx_image=768,   # CLIP-ConvNeXt-XXL (config 4)
         # distillation
         aux_mode="gen-depth-seg", num_task_tokens=8, contrastive_loss_weight=0.3,
         use_contrastive=True, pass_text_to_aux=True,
@@ -132,6 +133,36 @@ def clip_vit_features(images: torch.Tensor, W: Dict[str, torch.Tensor], cfg, pre
     return h.to(images.dtype)
 
 
+def convnext_features(images, W, cfg, prefix="model.vision_tower.vision_tower."):
+    """CLIP-ConvNeXt trunk exactly as the reference drives it (clip_convnext_encoder.py:150-174): stem -> stages ->
+    norm_pre (identity for the CLIP trunks) -> flatten(2,3).permute(0,2,1).
+    UNPINNED: timm / open_clip are not installed and there is no network, so this follows the public ConvNeXt definition
+    (timm convnext.py: stem = Conv 4x4/s4 + LayerNorm2d; stage i>0 starts with LayerNorm2d + Conv 2x2/s2; block =
+    dwconv7x7 -> LayerNorm -> Linear(C,4C) -> GELU -> Linear(4C,C) -> * gamma -> + shortcut; norm_eps 1e-5 for xxlarge)."""
+    p = prefix
+    eps = cfg.cnx_eps
+
+    def ln2d(x, w, b):
+        return F.layer_norm(x.permute(0, 2, 3, 1), (x.shape[1],), w, b, eps).permute(0, 3, 1, 2)
+    x = F.conv2d(images.to(W[p + "stem.0.weight"].dtype), W[p + "stem.0.weight"], W[p + "stem.0.bias"], stride=4)
+    x = ln2d(x, W[p + "stem.1.weight"], W[p + "stem.1.bias"])
+    for i, depth in enumerate(cfg.cnx_depths):
+        q = f"{p}stages.{i}."
+        if i > 0:
+            x = ln2d(x, W[q + "downsample.0.weight"], W[q + "downsample.0.bias"])
+            x = F.conv2d(x, W[q + "downsample.1.weight"], W[q + "downsample.1.bias"], stride=2)
+        C = x.shape[1]
+        for j in range(depth):
+            b = f"{q}blocks.{j}."
+            y = F.conv2d(x, W[b + "conv_dw.weight"], W[b + "conv_dw.bias"], padding=3, groups=C)
+            y = y.permute(0, 2, 3, 1)
+            y = F.layer_norm(y, (C,), W[b + "norm.weight"], W[b + "norm.bias"], eps)
+            y = F.linear(F.gelu(F.linear(y, W[b + "mlp.fc1.weight"], W[b + "mlp.fc1.bias"])), W[b + "mlp.fc2.weight"], W[b + "mlp.fc2.bias"])
+            y = y * W[b + "gamma"]
+            x = x + y.permute(0, 3, 1, 2)
+    return x.flatten(2, 3).permute(0, 2, 1).contiguous().to(images.dtype)
+
+
 def mm_projector(x, W, prefix="model.mm_projector."):
     """multimodal_projector/builder.py:53-60 mlp2x_gelu: Linear -> GELU(erf) -> Linear."""
     y = F.linear(x, W[prefix + "0.weight"], W[prefix + "0.bias"])
@@ -142,7 +173,10 @@ def mm_projector(x, W, prefix="model.mm_projector."):
 def encode_images(images, W, cfg):
     """ola_arch.py:187-190."""
     with torch.no_grad():
-        feats = clip_vit_features(images, W, cfg)
+        if "model.vision_tower.vision_tower.stem.0.weight" in W:
+            feats = convnext_features(images, W, cfg)
+        else:
+            feats = clip_vit_features(images, W, cfg)
     return mm_projector(feats.to(images.dtype), W)
 
 

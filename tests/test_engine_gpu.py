@@ -146,3 +146,32 @@ def test_phi3_path_matches_oracle_and_reference_golden():
         got = float(eng.ps.g(k).float().norm())
         ref = 0.0 if k in none_ref else float(g[f"keep_gradnorm::{k}"])
         assert abs(got - ref) <= 0.1 * ref + 1e-6, (k, got, ref)
+
+
+def test_convnext_tower_matches_oracle():
+    """BASELINE configs[3] path (CLIP-ConvNeXt trunk as image encoder).  Oracle is UNPINNED for this tower (timm/open_clip
+    absent): this is a self-consistency check HIP vs the CPU restatement of the public ConvNeXt definition."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from oracle import visper_oracle as O, weights as WT
+    from visper_lm_amd.config import VisperConfig
+    from visper_lm_amd.engine import Engine
+    from visper_lm_amd.params import param_shapes
+    cfg = VisperConfig(mm_vision_tower="CLIP-convnext_tiny-res768", cnx_dims=(64, 64, 128, 192), cnx_depths=(1, 1, 2, 1),
+                       vocab_size=1024, hidden_size=128, intermediate_size=256, num_hidden_layers=1, num_attention_heads=4,
+                       num_key_value_heads=2, aux_mode="", num_task_tokens=0)
+    shapes = param_shapes(cfg)
+    assert cfg.mm_hidden_size == 192 and "model.vision_tower.vision_tower.stages.2.blocks.1.gamma" in shapes
+    W = {k: WT.param(k, s) for k, s in shapes.items()}
+    for k in W:
+        if k.endswith(".gamma"):
+            W[k] = WT.tensor(k, shapes[k], 0.5)                      # layer scale large enough to matter
+    images = WT.tensor("cnx_images", (1, 3, 768, 768))
+    ocfg = O.make_config(**{k: v for k, v in cfg.to_dict().items() if k in vars(O.make_config())})
+    Wq = {k: v.to(BF).float() for k, v in W.items()}
+    ref = O.convnext_features(images.to(BF).float(), Wq, ocfg)       # (1, 576, 192)
+    eng = Engine(cfg)
+    eng.load_weights(W)
+    got = eng.vit_forward(images.cuda()).float().cpu().view(1, 576, 192)
+    err = (got - ref).abs().max() / ref.abs().max()
+    assert err < 3e-2, float(err)

@@ -26,6 +26,7 @@ _SIGS = {
     "vp_layernorm_fwd": [i, i, p, l, p, p, f, p, l, p, p, p],
     "vp_layernorm_bwd_dx": [i, i, p, p, p, p, p, p, p, l, p],
     "vp_layernorm_bwd_wb_partial": [i, i, p, p, p, p, p, p, l, i, p],
+    "vp_dwconv7x7_nhwc": [i, i, i, i, p, p, p, p, p],
     "vp_rope": [l, i, i, i, p, l, p, p, p, i, p],
     "vp_swiglu_fwd": [l, i, p, l, p, l, p],
     "vp_swiglu_bwd": [l, i, p, l, p, p, l, p],

@@ -25,6 +25,8 @@ class VisperConfig:
             vit_hidden=1024, vit_inter=4096, vit_layers=24, vit_heads=16, vit_image=336, vit_patch=14, vit_eps=1e-5,
             mm_vision_select_layer=-2, mm_vision_select_feature="patch", mm_projector_type="mlp2x_gelu",
             mm_hidden_size=1024,
+            # CLIP-ConvNeXt-XXL tower (clip_convnext_encoder.py:92-101), used when "convnext" is in mm_vision_tower
+            cnx_dims=(384, 768, 1536, 3072), cnx_depths=(3, 4, 30, 3), cnx_eps=1e-5, cnx_image=768,
             # distillation (ola_vlm_train.py:1149-1229)
             aux_mode="gen-depth-seg", num_task_tokens=8, contrastive_loss_weight=0.3, use_contrastive=True,
             pass_text_to_aux=True, task_token_format="emb",
@@ -39,7 +41,7 @@ class VisperConfig:
         )
         d.update(kw)
         if "mm_hidden_size" not in kw:
-            d["mm_hidden_size"] = d["vit_hidden"]
+            d["mm_hidden_size"] = d["cnx_dims"][-1] if "convnext" in str(d["mm_vision_tower"]).lower() else d["vit_hidden"]
         self.__dict__.update(d)
 
     def to_dict(self):
@@ -47,6 +49,10 @@ class VisperConfig:
 
     def __repr__(self):
         return f"VisperConfig({self.__dict__})"
+
+    @property
+    def is_convnext(self):
+        return "convnext" in str(self.mm_vision_tower).lower()
 
     @property
     def head_dim(self):
@@ -67,6 +73,13 @@ class VisperConfig:
 def llama3_8b(**kw) -> VisperConfig:
     """BASELINE.json configs[1]: CLIP-ViT-L/14-336 + Llama-3-8B, one distillation layer per task (d18_s18_g20)."""
     return VisperConfig(**kw)
+
+
+def llama3_8b_convnext(**kw) -> VisperConfig:
+    """BASELINE.json configs[3]: CLIP-ConvNeXt-XXL (768 px -> 576 x 3072) + Llama-3-8B."""
+    d = dict(mm_vision_tower="laion/CLIP-convnext_xxlarge-laion2B-s34B-b82K-augreg-soup-res768")
+    d.update(kw)
+    return VisperConfig(**d)
 
 
 def phi3_mini(**kw) -> VisperConfig:

@@ -241,7 +241,54 @@ __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
   }
 }
 
+
+// ---------------------------------------------------------------- depthwise 7x7 conv (ConvNeXt block, NHWC) ----------
+// x, y: [B, Hh, Ww, C] bf16 (channels last); w: [49, C] bf16 (tap-major, so 8 channels of one tap are one 16-byte load);
+// bias: [C].  One thread = 8 channels of one pixel; zero padding 3; fp32 accumulate, one bf16 rounding (torch conv2d).
+// HBM-bound: the 49x input re-reads are served by L1/L2.   timm ConvNeXtBlock.conv_dw (clip_convnext_encoder.py:161-165)
+__global__ __launch_bounds__(256) void dwconv7x7_nhwc_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w,
+                                                             const bf16_t* __restrict__ bias, bf16_t* __restrict__ y, int B, int Hh,
+                                                             int Ww, int C) {
+  const int cv = C >> 3;
+  const long total = (long)B * Hh * Ww * cv;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c8 = (int)(i % cv) * 8;
+    const long pix = i / cv;
+    const int xw = (int)(pix % Ww), yh = (int)((pix / Ww) % Hh);
+    const long b = pix / ((long)Ww * Hh);
+    float acc[8];
+    const bf16x8 bv = *(const bf16x8*)(bias + c8);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = bf2f((bf16_t)bv[e]);
+    for (int dy = 0; dy < 7; ++dy) {
+      const int yy = yh + dy - 3;
+      if (yy < 0 || yy >= Hh) continue;
+#pragma unroll
+      for (int dx = 0; dx < 7; ++dx) {
+        const int xx = xw + dx - 3;
+        if (xx < 0 || xx >= Ww) continue;
+        const bf16x8 xv = *(const bf16x8*)(x + ((b * Hh + yy) * Ww + xx) * C + c8);
+        const bf16x8 wv = *(const bf16x8*)(w + (dy * 7 + dx) * C + c8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] += bf2f((bf16_t)xv[e]) * bf2f((bf16_t)wv[e]);
+      }
+    }
+    bf16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (short)f2bf(acc[e]);
+    *(bf16x8*)(y + pix * C + c8) = o;
+  }
+}
+
 extern "C" {
+
+int vp_dwconv7x7_nhwc(int B, int Hh, int Ww, int C, const void* x, const void* w, const void* bias, void* y, hipStream_t s) {
+  VP_REQUIRE(B > 0 && Hh > 0 && Ww > 0 && C > 0 && C % 8 == 0 && x && w && bias && y, VP_ERR_BAD_ARG, "vp_dwconv7x7_nhwc: bad args");
+  const long total = (long)B * Hh * Ww * (C / 8);
+  hipLaunchKernelGGL(dwconv7x7_nhwc_kernel, dim3((unsigned)min(65536L, (total + 255) / 256)), dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)w,
+                     (const bf16_t*)bias, (bf16_t*)y, B, Hh, Ww, C);
+  return vp_check_launch("vp_dwconv7x7_nhwc");
+}
 
 int vp_rope(long T, int S, int nheads, int hd, void* x, long ld, const float* cos_t, const float* sin_t, const int* pos,
             int inverse, hipStream_t s) {

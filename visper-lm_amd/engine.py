@@ -168,6 +168,32 @@ class Engine:
                              ("ln2b", "layer_norm2.bias"), ("w1", "mlp.fc1.weight"), ("b1", "mlp.fc1.bias"),
                              ("w2", "mlp.fc2.weight"), ("b2", "mlp.fc2.bias")):
                     fz[o + a] = d(W[q + b])
+        # ---- CLIP-ConvNeXt trunk (config 4): channels-last weights, gamma folded into fc2, conv weights as GEMM operands
+        cp = "model.vision_tower.vision_tower."
+        self.has_convnext = (cp + "stem.0.weight") in W
+        if self.has_convnext:
+            sw = W[cp + "stem.0.weight"].reshape(cfg.cnx_dims[0], -1)
+            swp = torch.zeros(sw.shape[0], 64, dtype=sw.dtype, device=sw.device)
+            swp[:, :sw.shape[1]] = sw
+            fz["cnx.stem_w"], fz["cnx.stem_b"] = d(swp), d(W[cp + "stem.0.bias"])
+            fz["cnx.stem_ln_w"], fz["cnx.stem_ln_b"] = d(W[cp + "stem.1.weight"]), d(W[cp + "stem.1.bias"])
+            for i, dep in enumerate(cfg.cnx_depths):
+                q = f"{cp}stages.{i}."
+                if i > 0:
+                    fz[f"cnx.{i}.ds_ln_w"], fz[f"cnx.{i}.ds_ln_b"] = d(W[q + "downsample.0.weight"]), d(W[q + "downsample.0.bias"])
+                    dw_ = W[q + "downsample.1.weight"]                       # [Cout, Cin, 2, 2] -> [Cout, (dy,dx,cin)]
+                    fz[f"cnx.{i}.ds_w"] = d(dw_.permute(0, 2, 3, 1).reshape(dw_.shape[0], -1))
+                    fz[f"cnx.{i}.ds_b"] = d(W[q + "downsample.1.bias"])
+                for j in range(dep):
+                    b_, o = f"{q}blocks.{j}.", f"cnx.{i}.{j}."
+                    C = W[b_ + "gamma"].shape[0]
+                    fz[o + "dw_w"] = d(W[b_ + "conv_dw.weight"].reshape(C, 49).t())     # tap-major [49, C]
+                    fz[o + "dw_b"] = d(W[b_ + "conv_dw.bias"])
+                    fz[o + "ln_w"], fz[o + "ln_b"] = d(W[b_ + "norm.weight"]), d(W[b_ + "norm.bias"])
+                    fz[o + "w1"], fz[o + "b1"] = d(W[b_ + "mlp.fc1.weight"]), d(W[b_ + "mlp.fc1.bias"])
+                    gam = W[b_ + "gamma"].float()
+                    fz[o + "w2"] = d(W[b_ + "mlp.fc2.weight"].float() * gam[:, None])      # layer scale folded (frozen tower)
+                    fz[o + "b2"] = d(W[b_ + "mlp.fc2.bias"].float() * gam)
         # ---- decoder
         fz["embed"] = d(W["model.embed_tokens.weight"])
         fz["norm"] = d(W["model.norm.weight"])
@@ -246,8 +272,50 @@ class Engine:
         return self._rope[S]
 
     # ------------------------------------------------------------------------------------------ ViT
+    def convnext_forward(self, images):
+        """Frozen CLIP-ConvNeXt trunk (clip_convnext_encoder.py:150-174), channels-last end to end:
+        stem 4x4/s4 as im2col GEMM + LN; per block: depthwise 7x7 kernel -> LN -> GEMM(+bias, GELU epilogue) ->
+        GEMM(+bias, +residual; layer-scale folded into the weights); downsample = LN + 2x2/s2 patch gather + GEMM.
+        images [B,3,768,768] -> [B*576, C_last]."""
+        cfg, fz, dev = self.cfg, self.fz, self.dev
+        B, _, Hi, Wi = images.shape
+        g = Hi // 4
+        cols = images.to(BF16).view(B, 3, g, 4, g, 4).permute(0, 2, 4, 1, 3, 5).reshape(B * g * g, 48)
+        a = torch.zeros(B * g * g, 64, device=dev, dtype=BF16)
+        a[:, :48] = cols
+        x = ops.gemm(a, fz["cnx.stem_w"], bias=fz["cnx.stem_b"])
+        x, _, _ = ops.layernorm_fwd(x, fz["cnx.stem_ln_w"], fz["cnx.stem_ln_b"], cfg.cnx_eps, save_stats=False)
+        Hc = Wc = g
+        for i, dep in enumerate(cfg.cnx_depths):
+            C = cfg.cnx_dims[i]
+            if i > 0:
+                Cp = cfg.cnx_dims[i - 1]
+                x, _, _ = ops.layernorm_fwd(x, fz[f"cnx.{i}.ds_ln_w"], fz[f"cnx.{i}.ds_ln_b"], cfg.cnx_eps, save_stats=False)
+                key = ("cnx_ds", B, Hc, Wc)
+                if key not in self._plan_cache:                      # 2x2/s2 patch rows: (b, y2, x2, dy, dx) -> source pixel row
+                    bb = torch.arange(B, device=dev).view(B, 1, 1, 1, 1)
+                    y2 = torch.arange(Hc // 2, device=dev).view(1, -1, 1, 1, 1)
+                    x2 = torch.arange(Wc // 2, device=dev).view(1, 1, -1, 1, 1)
+                    dy = torch.arange(2, device=dev).view(1, 1, 1, 2, 1)
+                    dx = torch.arange(2, device=dev).view(1, 1, 1, 1, 2)
+                    self._plan_cache[key] = ((bb * Hc + 2 * y2 + dy) * Wc + 2 * x2 + dx).reshape(-1).to(torch.int32)
+                rows = self._plan_cache[key]
+                Hc, Wc = Hc // 2, Wc // 2
+                patches = torch.empty(B * Hc * Wc * 4, Cp, device=dev, dtype=BF16)
+                ops.gather_rows([x], torch.zeros(rows.numel(), device=dev, dtype=torch.int32), rows, Cp, patches)
+                x = ops.gemm(patches.view(B * Hc * Wc, 4 * Cp), fz[f"cnx.{i}.ds_w"], bias=fz[f"cnx.{i}.ds_b"])
+            for j in range(dep):
+                o = f"cnx.{i}.{j}."
+                y = ops.dwconv7x7_nhwc(x.view(B, Hc, Wc, C), fz[o + "dw_w"], fz[o + "dw_b"]).view(-1, C)
+                y, _, _ = ops.layernorm_fwd(y, fz[o + "ln_w"], fz[o + "ln_b"], cfg.cnx_eps, save_stats=False)
+                y = ops.gemm(y, fz[o + "w1"], bias=fz[o + "b1"], epi=ops.EPI_GELU)
+                x = ops.gemm(y, fz[o + "w2"], bias=fz[o + "b2"], residual=x)
+        return x                                                      # [B*Hc*Wc, C_last], rows already (b, y, x)
+
     def vit_forward(self, images):
-        """Frozen CLIP tower -> hidden_states[select_layer][:, 1:]  as [B*576, C] bf16 (no grad)."""
+        """Frozen vision tower -> [B*576, C] bf16 (no grad): CLIP-ViT hidden_states[select_layer][:, 1:], or the ConvNeXt trunk."""
+        if getattr(self, "has_convnext", False):
+            return self.convnext_forward(images)
         cfg, fz = self.cfg, self.fz
         B = images.shape[0]
         g = cfg.vit_image // cfg.vit_patch

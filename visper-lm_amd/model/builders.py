@@ -60,10 +60,22 @@ class CLIPVisionTower(ParamTree):
         return self.num_patches_per_side ** 2
 
 
+class CLIPConvNextVisionTower(CLIPVisionTower):
+    """clip_convnext_encoder.py:61-205 (timm ConvNeXt trunk via open_clip): stem -> stages -> norm_pre -> (B, 576, C)."""
+
+    @property
+    def hidden_size(self):
+        return self._owner.config.cnx_dims[-1]
+
+    @property
+    def num_patches_per_side(self):
+        return self._owner.config.cnx_image // 32
+
+
 def build_vision_tower(vision_tower_cfg, **kwargs):
     name = getattr(vision_tower_cfg, "mm_vision_tower", getattr(vision_tower_cfg, "vision_tower", None))
     if name is not None and "convnext" in str(name).lower():
-        raise NotImplementedError("CLIP-ConvNeXt-XXL tower (BASELINE configs[3]) is not built yet: SURVEY §8a a2 / DESIGN.md 'next'")
+        return CLIPConvNextVisionTower(name, args=vision_tower_cfg, **kwargs)
     return CLIPVisionTower(name, args=vision_tower_cfg, **kwargs)
 
 

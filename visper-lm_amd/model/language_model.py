@@ -16,7 +16,7 @@ import torch.nn as nn
 from ..config import VisperConfig, phi3_mini
 from ..engine import Engine, is_trainable
 from ..params import param_shapes, init_value
-from .builders import ParamTree, CLIPVisionTower
+from .builders import ParamTree, CLIPVisionTower, CLIPConvNextVisionTower
 from .ola_arch import OlaLlavaMetaModel, OlaLlavaMetaForCausalLM
 
 
@@ -154,7 +154,7 @@ class _OlaCausalLMBase(OlaLlavaMetaForCausalLM, BaseOLA_VLM, nn.Module):
         for name, shp in shapes.items():
             tgt, rel = (self.model, name[len("model."):]) if name.startswith("model.") else (top, name)
             if rel.startswith("vision_tower.") and "vision_tower" not in self.model._modules:
-                tower = CLIPVisionTower(config.mm_vision_tower, args=config)
+                tower = (CLIPConvNextVisionTower if config.is_convnext else CLIPVisionTower)(config.mm_vision_tower, args=config)
                 tower.__dict__["_owner"] = self          # plain attribute: NOT a registered child (would create a module cycle)
                 self.model.add_module("vision_tower", tower)
             tgt.add(rel, shp, device, dtype if len(shp) else torch.float32, requires_grad=is_trainable(name))

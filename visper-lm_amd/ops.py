@@ -131,6 +131,15 @@ def rope_(x2d, T, S, nheads, head_dim, cos_t, sin_t, pos=None, inverse=False):
     return x2d
 
 
+def dwconv7x7_nhwc(x, w_tap_major, bias):
+    """x [B,H,W,C] bf16 channels-last, w [49,C], bias [C] -> y [B,H,W,C] (zero padding 3)."""
+    B, Hh, Ww, Cc = x.shape
+    assert x.is_contiguous()
+    y = torch.empty_like(x)
+    _lib.call("vp_dwconv7x7_nhwc", B, Hh, Ww, Cc, _p(x), _p(w_tap_major), _p(bias), _p(y), _stream())
+    return y
+
+
 def swiglu_fwd(gate_up):
     M, F2, ldg = _rows2d(gate_up)
     F = F2 // 2

@@ -83,7 +83,24 @@ def param_shapes(cfg, vit_nested=True, with_vit=True) -> "OrderedDict[str, tuple
         sh[p + "input_layernorm.weight"] = (H,)
         sh[p + "post_attention_layernorm.weight"] = (H,)
     sh["model.norm.weight"] = (H,)
-    if with_vit:
+    if with_vit and getattr(cfg, "is_convnext", False):
+        vp = "model.vision_tower.vision_tower."                      # timm ConvNeXt trunk (clip_convnext_encoder.py:119)
+        dims, depths = cfg.cnx_dims, cfg.cnx_depths
+        sh[vp + "stem.0.weight"] = (dims[0], 3, 4, 4); sh[vp + "stem.0.bias"] = (dims[0],)
+        sh[vp + "stem.1.weight"] = (dims[0],); sh[vp + "stem.1.bias"] = (dims[0],)
+        for i, (C, dep) in enumerate(zip(dims, depths)):
+            q = f"{vp}stages.{i}."
+            if i > 0:
+                sh[q + "downsample.0.weight"] = (dims[i - 1],); sh[q + "downsample.0.bias"] = (dims[i - 1],)
+                sh[q + "downsample.1.weight"] = (C, dims[i - 1], 2, 2); sh[q + "downsample.1.bias"] = (C,)
+            for j in range(dep):
+                b = f"{q}blocks.{j}."
+                sh[b + "gamma"] = (C,)
+                sh[b + "conv_dw.weight"] = (C, 1, 7, 7); sh[b + "conv_dw.bias"] = (C,)
+                sh[b + "norm.weight"] = (C,); sh[b + "norm.bias"] = (C,)
+                sh[b + "mlp.fc1.weight"] = (4 * C, C); sh[b + "mlp.fc1.bias"] = (4 * C,)
+                sh[b + "mlp.fc2.weight"] = (C, 4 * C); sh[b + "mlp.fc2.bias"] = (C,)
+    elif with_vit:
         vp = "model.vision_tower.vision_tower." + ("vision_model." if vit_nested else "")
         C, I = cfg.vit_hidden, cfg.vit_inter
         g = cfg.vit_image // cfg.vit_patch
@@ -118,7 +135,7 @@ def init_value(name, shape, gen, device, dtype):
     if len(shape) == 1:
         if name.endswith("bias"):
             return torch.zeros(shape, device=device, dtype=dtype)
-        if name.endswith("class_embedding"):
+        if name.endswith("class_embedding") or name.endswith(".gamma"):
             return torch.randn(shape, device=device, dtype=dtype, generator=gen) * 0.02
         return torch.ones(shape, device=device, dtype=dtype)
     return torch.randn(shape, device=device, dtype=dtype, generator=gen) * 0.02
