@@ -323,7 +323,6 @@ __global__ __launch_bounds__(512) void gemm_nt_256(GemmArgs p) {
   const int nt = p.K >> 6;
 
   // per-thread staging geometry (same for every tile): 4 chunks per operand, LDS chunk q = (row q>>3, slot q&7)
-  long offA[4], offB[4];
   int rowi[4], gci[4];
 #pragma unroll
   for (int it = 0; it < 4; ++it) {
@@ -331,24 +330,21 @@ __global__ __launch_bounds__(512) void gemm_nt_256(GemmArgs p) {
     rowi[it] = q >> 3;
     gci[it] = ((q & 7) ^ ((rowi[it] >> 1) & 7)) * 8;
   }
+  const bf16_t* curA[4];     // this thread's 4 + 4 source rows of the output tile whose K-tiles are being streamed
+  const bf16_t* curB[4];
 #define SET_TILE(TC)                                                               \
   _Pragma("unroll") for (int it = 0; it < 4; ++it) {                               \
-    offA[it] = (long)min((TC).m0 + rowi[it], p.M - 1) * p.lda + gci[it];           \
-    offB[it] = (long)min((TC).n0 + rowi[it], p.N - 1) * p.ldb + gci[it];           \
-  }
-#define ISSUE_TILE(T, BUF)                                                         \
-  {                                                                                \
-    bf16_t* As_ = smem + (BUF) * 32768;                                            \
-    bf16_t* Bs_ = As_ + 16384;                                                     \
-    _Pragma("unroll") for (int it = 0; it < 4; ++it) {                             \
-      GLDS16(p.A + offA[it] + (long)(T) * 64, As_ + (it * 512 + wave * 64) * 8);   \
-      GLDS16(p.B + offB[it] + (long)(T) * 64, Bs_ + (it * 512 + wave * 64) * 8);   \
-    }                                                                              \
+    curA[it] = p.A + (long)min((TC).m0 + rowi[it], p.M - 1) * p.lda + gci[it];     \
+    curB[it] = p.B + (long)min((TC).n0 + rowi[it], p.N - 1) * p.ldb + gci[it];     \
   }
   int v = blockIdx.x;
   TileCoord tc = tile_coord_256(v, tiles_m, tiles_n);
   SET_TILE(tc);
-  ISSUE_TILE(0, 0);
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    GLDS16(curA[it], smem + (it * 512 + wave * 64) * 8);
+    GLDS16(curB[it], smem + 16384 + (it * 512 + wave * 64) * 8);
+  }
   __syncthreads();
   int cur = 0;
   while (true) {
@@ -360,15 +356,22 @@ __global__ __launch_bounds__(512) void gemm_nt_256(GemmArgs p) {
     const int vnext = v + gridDim.x;
     const TileCoord tcur = tc;
     for (int t = 0; t < nt; ++t) {
-      if (t + 1 < nt) {
-        ISSUE_TILE(t + 1, cur ^ 1);
-      } else if (vnext < ntiles) {                     // keep the DMA stream going: first K-tile of the next output tile
-        tc = tile_coord_256(vnext, tiles_m, tiles_n);
-        SET_TILE(tc);
-        ISSUE_TILE(0, cur ^ 1);
+      // source of the NEXT K-tile in the stream: same output tile, or the first K-tile of this block's next output tile
+      // (the very last one re-fetches a valid dummy so the DMA pattern stays branch-free)
+      long koff = (long)(t + 1) * 64;
+      if (t + 1 == nt) {
+        koff = 0;
+        if (vnext < ntiles) {
+          tc = tile_coord_256(vnext, tiles_m, tiles_n);
+          SET_TILE(tc);
+        }
       }
       const bf16_t* As = smem + cur * 32768;
       const bf16_t* Bs = As + 16384;
+      bf16_t* Asn = smem + (cur ^ 1) * 32768;
+      bf16_t* Bsn = Asn + 16384;
+      // 64 MFMAs per K-tile; the 8 LDS-DMA instructions of the next K-tile are spread one per 4 MFMAs over the first half: a global_load_lds
+      // blocks its wave for ~60-100 issue cycles, which the SIMD's other wave covers only if the stalls are not bunched up.
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
         bf16x8 xf[8], wf[4];
@@ -384,10 +387,18 @@ __global__ __launch_bounds__(512) void gemm_nt_256(GemmArgs p) {
           xf[i] = *(const bf16x8*)(As + r * 64 + ((cg ^ ((r >> 1) & 7)) << 3));
         }
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
+        for (int i = 0; i < 8; ++i) {
 #pragma unroll
           for (int j = 0; j < 4; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], xf[i], acc[i][j], 0, 0, 0);
+          if (ks == 0) {                                       // all 8 DMAs in the FIRST half: the second half (32 MFMAs) is landing time
+            const int it = (i >> 1);                           // 0..3
+            if (i & 1) GLDS16(curB[it] + koff, Bsn + (it * 512 + wave * 64) * 8);
+            else GLDS16(curA[it] + koff, Asn + (it * 512 + wave * 64) * 8);
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);   // 4 MFMA ...
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // ... then 1 VMEM read (the LDS-DMA)
+          }
+        }
       }
       __syncthreads();
       cur ^= 1;
@@ -407,7 +418,6 @@ __global__ __launch_bounds__(512) void gemm_nt_256(GemmArgs p) {
     __syncthreads();             // every wave is done with the staging slice before the next DMA may land in it
   }
 #undef SET_TILE
-#undef ISSUE_TILE
 }
 
 // ------------------------------------------------------------------------------------------------
