@@ -146,6 +146,7 @@ def main():
     ap.add_argument("--workload", default="llama3_8b", choices=["llama3_8b", "convnext", "phi3"],
                     help="llama3_8b = BASELINE configs[1] (the headline metric); convnext = configs[3]; phi3 = configs[4] (secondary)")
     ap.add_argument("--lr", type=float, default=1e-3)
+    ap.add_argument("--force-dist", action="store_true", help="initialise the RCCL process group even with one rank (test hook)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -156,7 +157,7 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
-    if world > 1:
+    if world > 1 or args.force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)

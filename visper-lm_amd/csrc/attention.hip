@@ -13,8 +13,9 @@
 //    fwd, Q/dO in dK/dV, K in dQ) come from the gfx950 hardware transpose read ds_read_b64_tr_b16
 //    (lane 4a+b supplies the address of row a, features 4b..4b+3; it receives column (lane&15) of that
 //    4x16 block), so nothing is ever staged transposed.
-//  - the next K/V (or Q/dO) tile is prefetched HBM->registers while the current tile is being consumed, and
-//    written to LDS after the compute barrier (issue-early / write-late), so HBM latency hides under MFMA.
+//  - the next K/V (or Q/dO) tile is prefetched HBM->registers while the current tile is being consumed and written
+//    into the OTHER LDS buffer after the compute (issue-early / write-late, double-buffered LDS): HBM latency hides
+//    under MFMA and there is ONE barrier per tile.
 //  - 8 waves (512 threads) x 16 rows per block at <= 128 VGPRs: the kernels are VALU-issue bound (softmax /
 //    dS arithmetic ~ as many issue cycles as the MFMAs), so they want 4 waves per SIMD to hide dependent-issue
 //    latency more than they want bigger per-wave tiles (LDS is only ~10 % busy).  exp2 is the raw v_exp_f32
@@ -90,9 +91,10 @@ struct TileRegs {
 // ================================================================================================
 template <int D, bool CAUSAL>
 __global__ __launch_bounds__(512) void attn_fwd_kernel(AttnParams p) {
-  constexpr int LD = D + 16, NKS = D / 32, NDB = D / 16;
-  __shared__ __attribute__((aligned(16))) bf16_t Ks[64 * LD];
-  __shared__ __attribute__((aligned(16))) bf16_t Vs[64 * LD];
+  constexpr int LD = D + 16, NKS = D / 32, NDB = D / 16, TILE = 64 * LD;
+  extern __shared__ __attribute__((aligned(16))) unsigned char attn_smem[];
+  bf16_t* const Kbuf = (bf16_t*)attn_smem;             // [2][64*LD]   K tiles (double buffered)
+  bf16_t* const Vbuf = Kbuf + 2 * TILE;                // [2][64*LD]   V tiles
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, fr = lane & 15, g = lane >> 4;
   const int nqb = (p.Sq + 127) >> 7;
   const int qb = nqb - 1 - (int)blockIdx.x;            // heavy (late) causal blocks first
@@ -125,16 +127,19 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(AttnParams p) {
   if (kstart < kend) {
     kr.load(kbase, p.k_ts, kstart, p.Skv);
     vr.load(vbase, p.v_ts, kstart, p.Skv);
-    kr.store(Ks, LD);
-    vr.store(Vs, LD);
+    kr.store(Kbuf, LD);
+    vr.store(Vbuf, LD);
   }
   __syncthreads();
-  for (int k0 = kstart; k0 < kend; k0 += 64) {
+  int cur = 0;
+  for (int k0 = kstart; k0 < kend; k0 += 64, cur ^= 1) {
     const bool more = k0 + 64 < kend;
     if (more) {
       kr.load(kbase, p.k_ts, k0 + 64, p.Skv);
       vr.load(vbase, p.v_ts, k0 + 64, p.Skv);
     }
+    const bf16_t* Ks = Kbuf + cur * TILE;
+    const bf16_t* Vs = Vbuf + cur * TILE;
     // wave-uniform skip of tiles that are entirely above this wave's causal diagonal
     const bool active = !CAUSAL || (k0 <= qw0 + 15 + off);
     if (active) {
@@ -195,10 +200,9 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(AttnParams p) {
         }
       }
     }
-    __syncthreads();
-    if (more) {
-      kr.store(Ks, LD);
-      vr.store(Vs, LD);
+    if (more) {                       // other buffer: last read one iteration ago, i.e. before the previous barrier
+      kr.store(Kbuf + (cur ^ 1) * TILE, LD);
+      vr.store(Vbuf + (cur ^ 1) * TILE, LD);
     }
     __syncthreads();
   }
@@ -242,9 +246,9 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(AttnParams p) {
 template <int D, bool CAUSAL>
 __global__ __launch_bounds__(512) void attn_bwd_dkdv_kernel(AttnParams p) {
   constexpr int LD = D + 16, NKS = D / 32, NDB = D / 16;
-  __shared__ __attribute__((aligned(16))) bf16_t Qs[32 * LD];
-  __shared__ __attribute__((aligned(16))) bf16_t dOs[32 * LD];
-  __shared__ float lse_s[32], delta_s[32];
+  __shared__ __attribute__((aligned(16))) bf16_t Qbuf[2 * 32 * LD];
+  __shared__ __attribute__((aligned(16))) bf16_t dObuf[2 * 32 * LD];
+  __shared__ float lse_buf[2 * 32], delta_buf[2 * 32];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, fr = lane & 15, g = lane >> 4;
   const int hk = blockIdx.y, b = blockIdx.z;
   const int k0 = blockIdx.x * 128, kw0 = k0 + wave * 16, key = kw0 + fr;
@@ -286,15 +290,20 @@ __global__ __launch_bounds__(512) void attn_bwd_dkdv_kernel(AttnParams p) {
     lse_r = p.lse[si];
     del_r = p.delta[si];
   };
-  auto commit = [&]() {
-    qr.store(Qs, LD);
-    dor.store(dOs, LD);
-    if (threadIdx.x < 32) { lse_s[threadIdx.x] = lse_r; delta_s[threadIdx.x] = del_r; }
+  auto commit = [&](int buf) {
+    qr.store(Qbuf + buf * 32 * LD, LD);
+    dor.store(dObuf + buf * 32 * LD, LD);
+    if (threadIdx.x < 32) { lse_buf[buf * 32 + threadIdx.x] = lse_r; delta_buf[buf * 32 + threadIdx.x] = del_r; }
   };
-  if (nit > 0) { prefetch(0); commit(); }
+  if (nit > 0) { prefetch(0); commit(0); }
   __syncthreads();
   for (int it = 0; it < nit; ++it) {
     if (it + 1 < nit) prefetch(it + 1);
+    const int cb = it & 1;
+    const bf16_t* Qs = Qbuf + cb * 32 * LD;
+    const bf16_t* dOs = dObuf + cb * 32 * LD;
+    const float* lse_s = lse_buf + cb * 32;
+    const float* delta_s = delta_buf + cb * 32;
     const int q0 = qstart + (it % ntq) * 32;
     // wave-uniform skip: every query of this tile is below this wave's first key (causal) -> all p = 0
     const bool active = !CAUSAL || (q0 + 31 + off >= kw0);
@@ -338,8 +347,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dkdv_kernel(AttnParams p) {
         dk[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tq, dsf, dk[d], 0, 0, 0);
       }
     }
-    __syncthreads();
-    if (it + 1 < nit) commit();
+    if (it + 1 < nit) commit(cb ^ 1);      // other buffer: last read one iteration ago (before the previous barrier)
     __syncthreads();
   }
   if (key < p.Skv) {
@@ -361,9 +369,10 @@ __global__ __launch_bounds__(512) void attn_bwd_dkdv_kernel(AttnParams p) {
 // ================================================================================================
 template <int D, bool CAUSAL>
 __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(AttnParams p) {
-  constexpr int LD = D + 16, NKS = D / 32, NDB = D / 16;
-  __shared__ __attribute__((aligned(16))) bf16_t Ks[64 * LD];
-  __shared__ __attribute__((aligned(16))) bf16_t Vs[64 * LD];
+  constexpr int LD = D + 16, NKS = D / 32, NDB = D / 16, TILE = 64 * LD;
+  extern __shared__ __attribute__((aligned(16))) unsigned char attn_smem[];
+  bf16_t* const Kbuf = (bf16_t*)attn_smem;
+  bf16_t* const Vbuf = Kbuf + 2 * TILE;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, fr = lane & 15, g = lane >> 4;
   const int nqb = (p.Sq + 127) >> 7;
   const int qb = nqb - 1 - (int)blockIdx.x;
@@ -401,16 +410,19 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(AttnParams p) {
   if (kstart < kend) {
     kr.load(kbase, p.k_ts, kstart, p.Skv);
     vr.load(vbase, p.v_ts, kstart, p.Skv);
-    kr.store(Ks, LD);
-    vr.store(Vs, LD);
+    kr.store(Kbuf, LD);
+    vr.store(Vbuf, LD);
   }
   __syncthreads();
-  for (int k0 = kstart; k0 < kend; k0 += 64) {
+  int cur = 0;
+  for (int k0 = kstart; k0 < kend; k0 += 64, cur ^= 1) {
     const bool more = k0 + 64 < kend;
     if (more) {
       kr.load(kbase, p.k_ts, k0 + 64, p.Skv);
       vr.load(vbase, p.v_ts, k0 + 64, p.Skv);
     }
+    const bf16_t* Ks = Kbuf + cur * TILE;
+    const bf16_t* Vs = Vbuf + cur * TILE;
     const bool active = !CAUSAL || (k0 <= qw0 + 15 + off);
     if (active) {
       const bool need_mask = (qw0 + 16 > p.Sq) || (k0 + 64 > kvlen) || (CAUSAL && (k0 + 63 > qw0 + off)) || (p.window > 0);
@@ -450,10 +462,9 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(AttnParams p) {
         }
       }
     }
-    __syncthreads();
     if (more) {
-      kr.store(Ks, LD);
-      vr.store(Vs, LD);
+      kr.store(Kbuf + (cur ^ 1) * TILE, LD);
+      vr.store(Vbuf + (cur ^ 1) * TILE, LD);
     }
     __syncthreads();
   }
@@ -473,23 +484,38 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(AttnParams p) {
 // C ABI
 // ================================================================================================
 template <int D>
+static constexpr int kv_lds_bytes() { return 4 * 64 * (D + 16) * 2; }     // K,V tiles x 2 buffers
+
+template <int D>
 static int launch_fwd(const AttnParams& p, int causal, hipStream_t s) {
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<D, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kv_lds_bytes<D>());
+    (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<D, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kv_lds_bytes<D>());
+    attr = true;
+  }
   dim3 grid((p.Sq + 127) / 128, p.Hq, p.B);
-  if (causal) hipLaunchKernelGGL((attn_fwd_kernel<D, true>), grid, dim3(512), 0, s, p);
-  else hipLaunchKernelGGL((attn_fwd_kernel<D, false>), grid, dim3(512), 0, s, p);
+  if (causal) hipLaunchKernelGGL((attn_fwd_kernel<D, true>), grid, dim3(512), kv_lds_bytes<D>(), s, p);
+  else hipLaunchKernelGGL((attn_fwd_kernel<D, false>), grid, dim3(512), kv_lds_bytes<D>(), s, p);
   return vp_check_launch("vp_attn_fwd");
 }
 template <int D>
 static int launch_bwd(const AttnParams& p, int causal, hipStream_t s) {
   const long rows = (long)p.B * p.Hq * p.Sq;
   hipLaunchKernelGGL((attn_delta_kernel<D>), dim3((unsigned)min(8192L, (rows + 3) / 4)), dim3(256), 0, s, p);
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<D, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kv_lds_bytes<D>());
+    (void)hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<D, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kv_lds_bytes<D>());
+    attr = true;
+  }
   dim3 g1((p.Skv + 127) / 128, p.Hkv, p.B), g2((p.Sq + 127) / 128, p.Hq, p.B);
   if (causal) {
     hipLaunchKernelGGL((attn_bwd_dkdv_kernel<D, true>), g1, dim3(512), 0, s, p);
-    hipLaunchKernelGGL((attn_bwd_dq_kernel<D, true>), g2, dim3(512), 0, s, p);
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<D, true>), g2, dim3(512), kv_lds_bytes<D>(), s, p);
   } else {
     hipLaunchKernelGGL((attn_bwd_dkdv_kernel<D, false>), g1, dim3(512), 0, s, p);
-    hipLaunchKernelGGL((attn_bwd_dq_kernel<D, false>), g2, dim3(512), 0, s, p);
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<D, false>), g2, dim3(512), kv_lds_bytes<D>(), s, p);
   }
   return vp_check_launch("vp_attn_bwd");
 }
