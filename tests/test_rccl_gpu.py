@@ -1,0 +1,51 @@
+"""RCCL smoke on one GPU (world_size 1, backend nccl = RCCL): the exact torch.distributed calls the DP path issues
+(async all_reduce on slices of the flat fp32 grad buffer, all_gather_into_tensor of bf16 targets) run and are no-ops
+numerically.  Multi-rank semantics are covered on CPU by tests/test_parallel_gloo.py; the 8-GPU run is the driver's."""
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+SCRIPT = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, os.environ["VP_ROOT"])
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+from visper_lm_amd import parallel
+g = torch.arange(1000, device="cuda", dtype=torch.float32)
+w1 = dist.all_reduce(g[0:640], async_op=True); w2 = dist.all_reduce(g[640:1000], async_op=True)
+w1.wait(); w2.wait(); torch.cuda.synchronize()
+assert torch.equal(g.cpu(), torch.arange(1000, dtype=torch.float32))
+t = torch.randn(8, 1024, device="cuda").to(torch.bfloat16)
+out = torch.empty(8, 1024, device="cuda", dtype=torch.bfloat16)
+dist.all_gather_into_tensor(out, t); torch.cuda.synchronize()
+assert torch.equal(out.cpu(), t.cpu())
+x = torch.tensor([3.5], device="cuda", dtype=torch.float64); dist.all_reduce(x, op=dist.ReduceOp.MAX); dist.barrier()
+dist.destroy_process_group()
+print("RCCL_OK")
+'''
+
+
+def test_rccl_calls_world1():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29611", VP_ROOT=root, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-c", SCRIPT], env=env, capture_output=True, text=True, timeout=240)
+    assert "RCCL_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_bench_under_torchrun_world1():
+    """bench.py launched exactly like the driver does for N>1 (torch.distributed.run), with one rank and a shallow debug model."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", "29612", os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "1", "--layers", "2",
+           "--no-cpu-baseline", "--force-dist"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root)
+    assert '"n_gpus": 1' in r.stdout and '"metric"' in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
