@@ -42,9 +42,9 @@ int vp_device_info(int* cu_count, int* wave_size, long* lds_bytes_per_cu);
  * (HF modeling_llama.py), CLIP q,k,v,out,fc1,fc2 (HF modeling_clip.py), lm_head (ola_llama.py:121),
  * mm_projector (multimodal_projector/builder.py:53-60), resampler proj_in/to_q/to_kv/to_out/FF/proj_out
  * (multimodal_projector/resampler.py:9-16,40-44,186-190), depth MLPs (aux_heads/da_v2_head.py:439-442).
- * out_f32=1 writes fp32 (used for weight gradients). force_generic: 0 = auto (256x256 double-buffered tile kernel for
+ * out_f32=1 writes fp32 (used for weight gradients). force_generic: 0 = auto (256x256 8-phase ping-pong kernel for
  * large problems, 128x128 otherwise, bounds-checked generic kernel when K%64 != 0 or rows are not 16-B aligned),
- * 1 = generic, 2 = 128-tile, 3 = 256-tile. */
+ * 1 = generic, 2 = 128-tile, 3 = persistent 256-tile, 4/5/6 = experimental 256-tile variants kept for A/B, 7 = 8-phase. */
 int vp_gemm_bf16(int M, int N, int K, const void* A, long lda, const void* B, long ldb, void* C, long ldc,
                  const void* bias, const void* residual, long ldr, int epilogue, int out_f32, int force_generic,
                  vp_stream_t stream);

@@ -79,6 +79,18 @@ def test_gemm_256_tile_kernel(ops, M, N, K):
     close(out, ref, what=f"gemm256 {M}x{N}x{K}")
     out2 = ops.gemm(dev(a), dev(w), bias=dev(b), residual=dev(r), force_generic=2)
     close(out2, ref, what=f"gemm128 {M}x{N}x{K}")
+    for code in (4, 5, 6, 7):                       # ping-pong / skewed / 4-wave / 8-phase variants
+        o = ops.gemm(dev(a), dev(w), bias=dev(b), residual=dev(r), force_generic=code)
+        close(o, ref, what=f"gemm variant {code} {M}x{N}x{K}")
+
+
+def test_gemm_8phase_large_k_and_edges(ops):
+    """default large-problem kernel: many K-tiles (piece pipeline wraps both buffers), ragged M/N edges, auto dispatch."""
+    M, N, K = 4100, 3080, 1024
+    a, w = rnd(M, K, seed=54), rnd(N, K, scale=0.05, seed=55)
+    ref = a.float() @ w.float().t()
+    close(ops.gemm(dev(a), dev(w)), ref, what="gemm auto (8-phase)")
+    close(ops.gemm(dev(a), dev(w), force_generic=3), ref, what="gemm persistent 256")
 
 
 def test_gemm_strided_views(ops):

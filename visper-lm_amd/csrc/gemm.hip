@@ -839,6 +839,150 @@ __global__ __launch_bounds__(256) void gemm_nt_256w4(GemmArgs p) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// 8-phase ping-pong kernel (two K-tiles = 8 phases per loop trip).  Same 256x256x64 tile / 8 waves / 2 LDS buffers as
+// above; what changes is the *granularity and balance* of the pipeline:
+//   * a phase = [R: <= 12 ds_read_b128 + 2 global_load_lds] barrier [M: 16 MFMAs on one 64x32 quadrant] barrier, and
+//     the second wave group runs one barrier behind, so every barrier interval pairs one group's R with the other's M
+//     and both are ~300 cycles long (the coarse ping-pong above had an 1100-cycle R0 against a 512-cycle M);
+//   * the next K-tile is DMA'd as four 16 KB *pieces* ordered by first use — A rows of the waves' first 64-row half,
+//     B rows of their first 32-column half, the other B half, the other A half — one piece per phase, so every piece
+//     has >= 3 phases to land and the queue is never drained: s_waitcnt vmcnt(4) keeps two pieces in flight across
+//     every barrier (the wait at the end of phase k's R retires exactly the piece phase k+1 reads first).
+// ------------------------------------------------------------------------------------------------
+template <bool OUT_F32>
+__global__ __launch_bounds__(512) void gemm_nt_256p8(GemmArgs p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  bf16_t* smem = (bf16_t*)smem_raw;                    // [buf][A 256x64 | B 256x64]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tiles_m = (p.M + 255) >> 8, tiles_n = (p.N + 255) >> 8;
+  const TileCoord tc = tile_coord_256(blockIdx.x, tiles_m, tiles_n);
+  const int m0 = tc.m0, n0 = tc.n0;
+  const int wr = __builtin_amdgcn_readfirstlane(wave >> 2), wc = wave & 3;
+  const int fr = lane & 15, g = lane >> 4;
+  const int nt = p.K >> 6;
+
+  // staging pieces (128 rows x 64 k = 16 KB = 2 chunks per thread each):
+  //   piece 0: A rows wr'*128 + [0,64)      piece 1: B rows wc'*64 + [0,32)
+  //   piece 2: B rows wc'*64 + [32,64)      piece 3: A rows wr'*128 + [64,128)
+  const bf16_t* src[4][2];
+  int ldsoff[4][2];                                    // element offset inside a buffer of this wave's 1 KB DMA destination
+#pragma unroll
+  for (int pc = 0; pc < 4; ++pc)
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int q = it * 512 + tid;                    // chunk inside the piece: 128 rows x 8 chunks
+      const int pr = q >> 3;                           // piece row 0..127
+      int row;                                         // row inside the operand tile
+      if (pc == 0) row = (pr >> 6) * 128 + (pr & 63);
+      else if (pc == 3) row = (pr >> 6) * 128 + 64 + (pr & 63);
+      else if (pc == 1) row = (pr >> 5) * 64 + (pr & 31);
+      else row = (pr >> 5) * 64 + 32 + (pr & 31);
+      const int gc = (q & 7) ^ ((row >> 1) & 7);
+      const bool isA = (pc == 0 || pc == 3);
+      src[pc][it] = isA ? p.A + (long)min(m0 + row, p.M - 1) * p.lda + gc * 8 : p.B + (long)min(n0 + row, p.N - 1) * p.ldb + gc * 8;
+      // wave-uniform destination: the 8 rows this wave-instruction covers start at piece row (it*512 + wave*64)/8
+      const int pr0 = (it * 512 + wave * 64) >> 3;
+      int row0;
+      if (pc == 0) row0 = (pr0 >> 6) * 128 + (pr0 & 63);
+      else if (pc == 3) row0 = (pr0 >> 6) * 128 + 64 + (pr0 & 63);
+      else if (pc == 1) row0 = (pr0 >> 5) * 64 + (pr0 & 31);
+      else row0 = (pr0 >> 5) * 64 + 32 + (pr0 & 31);
+      ldsoff[pc][it] = (isA ? 0 : 16384) + row0 * 64;
+    }
+#define ISSUE_PIECE(PC, T, BUF)                                                    \
+  {                                                                                \
+    const long ko_ = (long)min((T), nt - 1) * 64;                                  \
+    bf16_t* base_ = smem + (BUF) * 32768;                                          \
+    GLDS16(src[PC][0] + ko_, base_ + ldsoff[PC][0]);                               \
+    GLDS16(src[PC][1] + ko_, base_ + ldsoff[PC][1]);                               \
+  }
+#define RD_A(DST, MH)                                                              \
+  _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                 \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                \
+      const int r = wr * 128 + (MH) * 64 + i * 16 + fr;                            \
+      DST[ks][i] = *(const bf16x8*)(As + r * 64 + (((ks * 4 + g) ^ ((r >> 1) & 7)) << 3)); \
+    }
+#define RD_B(DST, NH)                                                              \
+  _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                 \
+    _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                \
+      const int r = wc * 64 + (NH) * 32 + j * 16 + fr;                             \
+      DST[ks][j] = *(const bf16x8*)(Bs + r * 64 + (((ks * 4 + g) ^ ((r >> 1) & 7)) << 3)); \
+    }
+#define MM(XA, WB, MH, NH)                                                         \
+  {                                                                                \
+    __builtin_amdgcn_s_setprio(1);                                                 \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                               \
+      _Pragma("unroll") for (int i = 0; i < 4; ++i)                                \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j)                              \
+          acc[(MH) * 4 + i][(NH) * 2 + j] =                                        \
+              __builtin_amdgcn_mfma_f32_16x16x32_bf16(WB[ks][j], XA[ks][i], acc[(MH) * 4 + i][(NH) * 2 + j], 0, 0, 0); \
+    __builtin_amdgcn_s_setprio(0);                                                 \
+  }
+#define END_R() asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory"); VP_BAR();
+
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  ISSUE_PIECE(0, 0, 0);
+  ISSUE_PIECE(1, 0, 0);
+  ISSUE_PIECE(2, 0, 0);
+  ISSUE_PIECE(3, 0, 0);
+  asm volatile("s_waitcnt vmcnt(4)" ::: "memory");     // pieces 0,1 of K-tile 0 landed (this wave's parts)
+  VP_BAR();
+  if (wr == 1) VP_BAR();                               // stagger: group 1 runs one barrier behind
+  bf16x8 xa[2][4], wb0[2][2], wb1[2][2];
+  for (int t = 0; t < nt; ++t) {
+    const int cur = t & 1;
+    const bf16_t* As = smem + cur * 32768;
+    const bf16_t* Bs = As + 16384;
+    // ---- phase 1: quadrant (m0, n0)
+    ISSUE_PIECE(0, t + 1, cur ^ 1);
+    RD_B(wb0, 0);
+    RD_A(xa, 0);
+    END_R();
+    MM(xa, wb0, 0, 0);
+    VP_BAR();
+    // ---- phase 2: quadrant (m0, n1)
+    ISSUE_PIECE(1, t + 1, cur ^ 1);
+    RD_B(wb1, 1);
+    END_R();
+    MM(xa, wb1, 0, 1);
+    VP_BAR();
+    // ---- phase 3: quadrant (m1, n1)
+    ISSUE_PIECE(2, t + 1, cur ^ 1);
+    RD_A(xa, 1);
+    END_R();
+    MM(xa, wb1, 1, 1);
+    VP_BAR();
+    // ---- phase 4: quadrant (m1, n0)   (B(n0) fragments are still in registers)
+    ISSUE_PIECE(3, t + 1, cur ^ 1);
+    END_R();
+    MM(xa, wb0, 1, 0);
+    VP_BAR();
+  }
+  if (wr == 0) VP_BAR();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // drain the dummy tail DMAs before LDS is reused
+  VP_BAR();
+#undef ISSUE_PIECE
+#undef RD_A
+#undef RD_B
+#undef MM
+#undef END_R
+  if (!OUT_F32) {
+    epilogue_256_swz(p, smem + wave * 4096, acc, m0 + wr * 128, n0 + wc * 64, lane);
+  } else {
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        store4<OUT_F32>(p, m0 + wr * 128 + i * 16 + fr, n0 + wc * 64 + j * 16 + g * 4, acc[i][j]);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // generic path: any M, N, K, any alignment (register-staged, zero-filled K tail). 64x64x32 tile.
 // ------------------------------------------------------------------------------------------------
 template <bool OUT_F32>
@@ -921,7 +1065,16 @@ int vp_gemm_bf16(int M, int N, int K, const void* A, long lda, const void* B, lo
   const bool fast = (force_generic != 1) && (K % 64 == 0) && (lda % 8 == 0) && (ldb % 8 == 0) &&
                     ((((uintptr_t)A) | ((uintptr_t)B)) & 15) == 0;
   const long big_tiles = (long)((M + 255) / 256) * ((N + 255) / 256);
-  if (fast && force_generic == 6) {
+  if (fast && (force_generic == 7 || (force_generic == 0 && big_tiles >= 192 && M >= 256 && N >= 256))) {   // default large-problem kernel
+    static bool attr_p8 = false;
+    if (!attr_p8) {
+      (void)hipFuncSetAttribute((const void*)gemm_nt_256p8<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+      (void)hipFuncSetAttribute((const void*)gemm_nt_256p8<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+      attr_p8 = true;
+    }
+    if (out_f32) hipLaunchKernelGGL(gemm_nt_256p8<true>, dim3((unsigned)big_tiles), dim3(512), 131072, stream, p);
+    else hipLaunchKernelGGL(gemm_nt_256p8<false>, dim3((unsigned)big_tiles), dim3(512), 131072, stream, p);
+  } else if (fast && force_generic == 6) {
     static bool attr_w4 = false;
     if (!attr_w4) {
       (void)hipFuncSetAttribute((const void*)gemm_nt_256w4<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
