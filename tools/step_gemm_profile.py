@@ -1,0 +1,24 @@
+"""Per-shape GEMM time inside one full train step (dev tool; run through gpurun)."""
+import sys, os, collections
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import bench
+from visper_lm_amd import ops
+from visper_lm_amd.config import llama3_8b
+from visper_lm_amd.engine import Engine
+cfg = llama3_8b(); eng = Engine(cfg); eng.init_random(0)
+batch = bench.make_batch(cfg, 8, 1449, 0, torch.device("cuda"))
+for _ in range(2):
+    eng.train_step(batch); eng.optimizer_step(1e-3)
+torch.cuda.synchronize()
+ops.GEMM_PROF = []
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record(); eng.train_step(batch); eng.optimizer_step(1e-3); e1.record(); torch.cuda.synchronize()
+prof, ops.GEMM_PROF = ops.GEMM_PROF, None
+agg = collections.defaultdict(lambda: [0, 0.0, 0.0])
+for a, b, fl, shp in prof:
+    r = agg[shp]; r[0] += 1; r[1] += a.elapsed_time(b); r[2] += fl
+tot = sum(r[1] for r in agg.values())
+print(f"step {e0.elapsed_time(e1):.1f} ms, GEMM {tot:.1f} ms in {len(prof)} launches")
+for shp, (n, ms, fl) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:22]:
+    print(f"{str(shp):28s} n={n:4d} {ms:8.2f} ms {100*ms/tot:5.1f}%  {fl/ms/1e9:7.0f} TF/s")

@@ -918,7 +918,7 @@ __global__ __launch_bounds__(512) void gemm_nt_256p8(GemmArgs p) {
               __builtin_amdgcn_mfma_f32_16x16x32_bf16(WB[ks][j], XA[ks][i], acc[(MH) * 4 + i][(NH) * 2 + j], 0, 0, 0); \
     __builtin_amdgcn_s_setprio(0);                                                 \
   }
-#define END_R() asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory"); VP_BAR();
+#define END_R() asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); VP_BAR();     /* ds_reads keep flying across the barrier; the MFMAs wait for them */
 
   f32x4 acc[8][4];
 #pragma unroll
@@ -933,32 +933,54 @@ __global__ __launch_bounds__(512) void gemm_nt_256p8(GemmArgs p) {
   asm volatile("s_waitcnt vmcnt(4)" ::: "memory");     // pieces 0,1 of K-tile 0 landed (this wave's parts)
   VP_BAR();
   if (wr == 1) VP_BAR();                               // stagger: group 1 runs one barrier behind
-  bf16x8 xa[2][4], wb0[2][2], wb1[2][2];
+  bf16x8 xa[2][4], wb0[2][2], wb1[2][2], xn[4];
+  {                                                    // A(m0, ks=0) fragments of K-tile 0 (later ones are prefetched in phase 4)
+    const bf16_t* As = smem;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = wr * 128 + i * 16 + fr;
+      xn[i] = *(const bf16x8*)(As + r * 64 + ((g ^ ((r >> 1) & 7)) << 3));
+    }
+  }
   for (int t = 0; t < nt; ++t) {
     const int cur = t & 1;
     const bf16_t* As = smem + cur * 32768;
     const bf16_t* Bs = As + 16384;
-    // ---- phase 1: quadrant (m0, n0)
+    // ---- phase 1: quadrant (m0, n0).  reads: B(n0) x4, A(m0, ks=1) x4  (A(m0, ks=0) came from the previous phase 4)
     ISSUE_PIECE(0, t + 1, cur ^ 1);
     RD_B(wb0, 0);
-    RD_A(xa, 0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = wr * 128 + i * 16 + fr;
+      xa[0][i] = xn[i];
+      xa[1][i] = *(const bf16x8*)(As + r * 64 + (((4 + g) ^ ((r >> 1) & 7)) << 3));
+    }
     END_R();
     MM(xa, wb0, 0, 0);
     VP_BAR();
-    // ---- phase 2: quadrant (m0, n1)
+    // ---- phase 2: quadrant (m0, n1).  reads: B(n1) x4
     ISSUE_PIECE(1, t + 1, cur ^ 1);
     RD_B(wb1, 1);
     END_R();
     MM(xa, wb1, 0, 1);
     VP_BAR();
-    // ---- phase 3: quadrant (m1, n1)
+    // ---- phase 3: quadrant (m1, n1).  reads: A(m1) x8
     ISSUE_PIECE(2, t + 1, cur ^ 1);
     RD_A(xa, 1);
     END_R();
     MM(xa, wb1, 1, 1);
     VP_BAR();
-    // ---- phase 4: quadrant (m1, n0)   (B(n0) fragments are still in registers)
+    // ---- phase 4: quadrant (m1, n0) (B(n0) still in registers).  reads: NEXT K-tile's A(m0, ks=0) x4 — its piece was
+    // issued in phase 1 and retired for every wave by the vmcnt(4) at the end of phase 3's R section.
     ISSUE_PIECE(3, t + 1, cur ^ 1);
+    {
+      const bf16_t* Asn = smem + (cur ^ 1) * 32768;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int r = wr * 128 + i * 16 + fr;
+        xn[i] = *(const bf16x8*)(Asn + r * 64 + ((g ^ ((r >> 1) & 7)) << 3));
+      }
+    }
     END_R();
     MM(xa, wb0, 1, 0);
     VP_BAR();
