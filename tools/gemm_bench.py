@@ -30,11 +30,16 @@ for (M, N, K) in SHAPES:
     out = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
     ref = (a[:256].float() @ w.float().t())
     res = {}
-    for name, fg in (("k256", 3), ("k256pp", 4), ("k256p8", 7)):
+    variants = (("k256", 3), ("k256pp", 4), ("k256p8", 7))
+    only = os.environ.get("BENCH_ONLY")
+    if only:
+        variants = tuple(v for v in variants if v[0] in only.split(","))
+    for name, fg in variants:
         ops.gemm(a, w, out=out, force_generic=fg)
         err = float((out[:256].float() - ref).abs().max() / ref.abs().max())
         ms = timeit(lambda: ops.gemm(a, w, out=out, force_generic=fg))
         res[name] = (round(2.0 * M * N * K / ms / 1e9, 1), round(err, 5))
-    ms = timeit(lambda: torch.matmul(a, w.t(), out=out))
-    res["hipblaslt"] = round(2.0 * M * N * K / ms / 1e9, 1)
+    if not only:
+        ms = timeit(lambda: torch.matmul(a, w.t(), out=out))
+        res["hipblaslt"] = round(2.0 * M * N * K / ms / 1e9, 1)
     print(f"{M}x{N}x{K}: " + json.dumps(res), flush=True)

@@ -1,0 +1,28 @@
+import os, sys, ctypes as C
+sys.path.insert(0, "/root/repo")
+os.environ["VP_GEMM_DBG"] = str(0x10000 + int(sys.argv[1]) if len(sys.argv) > 1 else 0x10000)
+import torch, numpy as np
+from visper_lm_amd import ops, _lib
+lib = _lib.load()
+for (M, N, K) in [(16384, 4096, 4096), (16384, 28672, 4096)]:
+    a = torch.randn(M, K, device="cuda", dtype=torch.bfloat16); w = torch.randn(N, K, device="cuda", dtype=torch.bfloat16) * 0.05
+    out = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+    for _ in range(3):
+        ops.gemm(a, w, out=out, force_generic=7)
+    torch.cuda.synchronize()
+    buf = (C.c_long * 2048)()
+    lib.vp_debug_stamps.argtypes = [C.c_void_p]
+    rc = lib.vp_debug_stamps(buf)
+    st = np.array(buf[:], dtype=np.int64).reshape(256, 8)
+    t0 = st[:, 0].min()
+    d = (st[:, :8] - t0) / 100.0   # us
+    print(M, N, K, "rc", rc)
+    print(" start  us: min %.1f max %.1f" % (d[:, 0].min(), d[:, 0].max()))
+    print(" loop0 start: mean %.1f" % d[:, 1].mean())
+    print(" first-tile K loop: mean %.1f min %.1f max %.1f" % ((d[:, 2] - d[:, 1]).mean(), (d[:, 2] - d[:, 1]).min(), (d[:, 2] - d[:, 1]).max()))
+    print(" epilogue issue: mean %.2f min %.2f max %.2f" % ((d[:, 3] - d[:, 2]).mean(), (d[:, 3] - d[:, 2]).min(), (d[:, 3] - d[:, 2]).max()))
+    print(" store drain: mean %.2f min %.2f max %.2f" % ((d[:, 4] - d[:, 3]).mean(), (d[:, 4] - d[:, 3]).min(), (d[:, 4] - d[:, 3]).max()))
+    ep = d[:, 3] - d[:, 2]
+    print(" epilogue by xcd:", [round(float(ep[x::8].mean()), 1) for x in range(8)])
+    print(" (last tile) epi start -> half0 lds written: %.2f ; half0 stores issued: %.2f" % ((d[:, 6] - d[:, 2]).mean(), (d[:, 7] - d[:, 6]).mean()))
+    print(" end: mean %.1f max %.1f ; loopend spread %.1f..%.1f" % (d[:, 5].mean(), d[:, 5].max(), d[:, 2].min(), d[:, 2].max()))

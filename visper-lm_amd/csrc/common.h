@@ -30,6 +30,15 @@ int vp_check_launch(const char* what);
 __device__ __forceinline__ float bf2f(bf16_t h) { return __builtin_bit_cast(float, ((uint32_t)h) << 16); }
 __device__ __forceinline__ bf16_t f2bf(float f) { return __builtin_bit_cast(bf16_t, (__bf16)f); }   // RNE (v_cvt_pk_bf16_f32)
 __device__ __forceinline__ float bfround(float f) { return bf2f(f2bf(f)); }
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+// two floats -> packed bf16 pair (lo | hi << 16), RNE: one v_cvt_pk_bf16_f32
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+  typedef float f32x2_t __attribute__((ext_vector_type(2)));
+  typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+  const f32x2_t v = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
+}
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -10,6 +10,7 @@
 // token row -> 8-byte bf16 stores.  Block ids are remapped XCD-aware + grouped so tiles sharing an
 // operand panel sit in one XCD's L2.
 #include "common.h"
+#include <cstdlib>
 
 enum { EPI_NONE = 0, EPI_GELU = 1, EPI_QUICK_GELU = 2, EPI_RELU = 3 };
 
@@ -22,6 +23,7 @@ struct GemmArgs {
   int M, N, K;
   long lda, ldb, ldc, ldr;
   int epi;
+  int dbg;                                             // experiments only (VP_GEMM_DBG), 0 in production
 };
 
 __device__ __forceinline__ float apply_epi(float v, int epi) {
@@ -252,11 +254,75 @@ __device__ __forceinline__ TileCoord tile_coord_256(int v, int tiles_m, int tile
   return TileCoord{(first_m + (id % width) % gsz) << 8, ((id % width) / gsz) << 8};
 }
 
+// Persistent 256-block grids: step s = v / 256 walks super-blocks of SBM x SBN tiles (SBM * SBN = 256, all concurrently
+// resident), XCD x = v & 7 owns an 8 x 4 sub-block of it, so one K-step touches SBM + SBN operand panels chip-wide (32 for
+// 16 x 16) instead of 64 + 4 with the row-group walk above, and 12 per XCD L2.
+__device__ __forceinline__ TileCoord tile_coord_sb(int v, int tiles_m, int tiles_n, int sbm, int sbn) {
+  const int s = v >> 8, b = v & 255, x = b & 7, slot = b >> 3;
+  const int sb_per_row = tiles_n / sbn;                // super-blocks along N
+  const int sbr = s / sb_per_row, sbc = s - sbr * sb_per_row;
+  const int subs_n = sbn >> 2;                         // 8x4 sub-blocks along N inside a super-block
+  const int xr = x / subs_n, xc = x - xr * subs_n;
+  return TileCoord{(sbr * sbm + xr * 8 + (slot & 7)) << 8, (sbc * sbn + xc * 4 + (slot >> 3)) << 8};
+}
+
 // swizzled C staging: per wave a [64 rows][64 cols] bf16 slice (8 KB), 16-byte chunk index ^= row & 7
+__device__ long vp_dbg_stamps[256 * 8];
 __device__ __forceinline__ void epilogue_256_swz(const GemmArgs& p, bf16_t* wave_lds, const f32x4 (&acc)[8][4], int mrow0, int ncol0,
                                                  int lane) {
   const int fr = lane & 15, g = lane >> 4;
   const int epi = p.epi & 0xff;
+  // Fast path (every decoder GEMM): interior tile, 16-byte aligned rows, no bias / activation.  Kept lean on purpose: the
+  // general path below is ~10x the instructions, and the epilogue runs with the matrix pipe idle.
+  const bool fast = __builtin_amdgcn_readfirstlane(
+      (int)(!p.bias && epi == EPI_NONE && mrow0 + 128 <= p.M && ncol0 + 64 <= p.N && (p.ldc & 7) == 0 &&
+            (((uintptr_t)p.C) & 15) == 0 && (!p.res || ((p.ldr & 7) == 0 && (((uintptr_t)p.res) & 15) == 0))));
+  if (fast) {
+    int woff[4];                                        // this lane's write offset per column block j (row term added per ii)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) woff[j] = fr * 64 + (((j * 2 + (g >> 1)) ^ (fr & 7)) << 3) + (g & 1) * 4;
+    const int rl0 = lane >> 3, ch = lane & 7;
+    const int roff = rl0 * 64 + ((ch ^ (rl0 & 7)) << 3); // read offset for it = 0; it adds 8 rows (same swizzle phase)
+    bf16_t* cptr = (bf16_t*)p.C + (long)(mrow0 + rl0) * p.ldc + ncol0 + ch * 8;
+    const bf16_t* rptr = p.res ? p.res + (long)(mrow0 + rl0) * p.ldr + ncol0 + ch * 8 : nullptr;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+#pragma unroll
+      for (int ii = 0; ii < 4; ++ii)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const f32x4 a = acc[half * 4 + ii][j];
+          u32x2 o;
+          o[0] = pack_bf16x2(a[0], a[1]);
+          o[1] = pack_bf16x2(a[2], a[3]);
+          *(u32x2*)(wave_lds + ii * 16 * 64 + woff[j]) = o;
+        }
+      __builtin_amdgcn_sched_barrier(0);                // residual loads only after this half's accumulators are dead
+      u32x4 rv[8];
+      if (rptr) {
+#pragma unroll
+        for (int it = 0; it < 8; ++it) rv[it] = *(const u32x4*)(rptr + (long)(half * 64 + it * 8) * p.ldr);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if ((p.dbg & 0x10000) && threadIdx.x == 0 && half == 0) vp_dbg_stamps[blockIdx.x * 8 + 6] = wall_clock64();
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        u32x4 v = *(const u32x4*)(wave_lds + it * 8 * 64 + roff);
+        if (rptr) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float lo = __builtin_bit_cast(float, v[e] << 16) + __builtin_bit_cast(float, rv[it][e] << 16);
+            const float hi = __builtin_bit_cast(float, v[e] & 0xffff0000u) + __builtin_bit_cast(float, rv[it][e] & 0xffff0000u);
+            v[e] = pack_bf16x2(lo, hi);
+          }
+        }
+        *(u32x4*)(cptr + (long)(half * 64 + it * 8) * p.ldc) = v;
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if ((p.dbg & 0x10000) && threadIdx.x == 0 && half == 0) vp_dbg_stamps[blockIdx.x * 8 + 7] = wall_clock64();
+    }
+    return;
+  }
   float bias4[4][4];
 #pragma unroll
   for (int j = 0; j < 4; ++j)
@@ -440,60 +506,51 @@ __global__ __launch_bounds__(512) void gemm_nt_256(GemmArgs p) {
 
 template <bool OUT_F32>
 __global__ __launch_bounds__(512) void gemm_nt_256pp(GemmArgs p) {
+  // 4-phase variant with K-HALF pieces: LDS buffer = [A kh0 | B kh0 | A kh1 | B kh1], each [256 rows][32 k] (64-byte rows,
+  // chunk ^= (row>>2)&3).  Phase A(t) = R: DMA {A,B} kh0 of K-tile t+1 (4 global_load_lds) + 12 ds_reads of kh0(t) | M: 32 MFMAs;
+  // phase B(t) the same on kh1.  Half the barriers of the 8-phase kernel, R (~4 DMA issues + 12 reads) balanced against
+  // M (32 MFMAs), every piece has 2 phases to land, vmcnt(4) never drains the queue.
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   bf16_t* smem = (bf16_t*)smem_raw;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-
   const int tiles_m = (p.M + 255) >> 8, tiles_n = (p.N + 255) >> 8;
-  const int nwg = tiles_m * tiles_n;
-  const int id = xcd_remap(blockIdx.x, nwg);
-  const int GROUP_M = 8;
-  const int width = GROUP_M * tiles_n;
-  const int group = id / width;
-  const int first_m = group * GROUP_M;
-  const int gsz = min(tiles_m - first_m, GROUP_M);
-  const int tm = first_m + (id % width) % gsz;
-  const int tn = (id % width) / gsz;
-  const int m0 = tm << 8, n0 = tn << 8;
-
-  const bf16_t* srcA[4];
-  const bf16_t* srcB[4];
+  const TileCoord tc = tile_coord_256(blockIdx.x, tiles_m, tiles_n);
+  const int m0 = tc.m0, n0 = tc.n0;
+  const int wr = __builtin_amdgcn_readfirstlane(wave >> 2), wc = wave & 3;
+  const int fr = lane & 15, g = lane >> 4;
+  const int nt = p.K >> 6;
+  // staging: a piece = one operand, one k-half: 256 rows x 4 chunks = 1024 chunks -> 2 per thread
+  const bf16_t* srcA[2];
+  const bf16_t* srcB[2];
 #pragma unroll
-  for (int it = 0; it < 4; ++it) {
+  for (int it = 0; it < 2; ++it) {
     const int q = it * 512 + tid;
-    const int row = q >> 3;
-    const int gc = (q & 7) ^ ((row >> 1) & 7);
+    const int row = q >> 2;
+    const int gc = (q & 3) ^ ((row >> 2) & 3);
     srcA[it] = p.A + (long)min(m0 + row, p.M - 1) * p.lda + gc * 8;
     srcB[it] = p.B + (long)min(n0 + row, p.N - 1) * p.ldb + gc * 8;
   }
-  const int wr = __builtin_amdgcn_readfirstlane(wave >> 2), wc = wave & 3;
-  const int fr = lane & 15, g = lane >> 4;
-  f32x4 acc[8][4];
-#pragma unroll
-  for (int i = 0; i < 8; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  const int nt = p.K >> 6;
-#define ISSUE_TILE(T, BUF)                                                         \
+  // element offsets inside a buffer: A kh0 @0, B kh0 @8192, A kh1 @16384, B kh1 @24576
+#define ISSUE_KH(KH, T, BUF)                                                       \
   {                                                                                \
-    bf16_t* As_ = smem + (BUF) * 32768;                                            \
-    bf16_t* Bs_ = As_ + 16384;                                                     \
-    _Pragma("unroll") for (int it = 0; it < 4; ++it) {                             \
-      GLDS16(srcA[it] + (long)(T) * 64, As_ + (it * 512 + wave * 64) * 8);         \
-      GLDS16(srcB[it] + (long)(T) * 64, Bs_ + (it * 512 + wave * 64) * 8);         \
+    const long ko_ = (long)min((T), nt - 1) * 64 + (KH) * 32;                      \
+    bf16_t* base_ = smem + (BUF) * 32768 + (KH) * 16384;                           \
+    _Pragma("unroll") for (int it = 0; it < 2; ++it) {                             \
+      GLDS16(srcA[it] + ko_, base_ + (it * 512 + wave * 64) * 8);                  \
+      GLDS16(srcB[it] + ko_, base_ + 8192 + (it * 512 + wave * 64) * 8);           \
     }                                                                              \
   }
-#define READ_FRAGS(KS)                                                             \
+#define READ_KH(KH)                                                                \
   {                                                                                \
-    const int cg = (KS) * 4 + g;                                                   \
+    const bf16_t* Ak = buf + (KH) * 16384;                                         \
+    const bf16_t* Bk = Ak + 8192;                                                  \
     _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                \
       const int r = wc * 64 + j * 16 + fr;                                         \
-      wf[j] = *(const bf16x8*)(Bs + r * 64 + ((cg ^ ((r >> 1) & 7)) << 3));        \
+      wf[j] = *(const bf16x8*)(Bk + r * 32 + ((g ^ ((r >> 2) & 3)) << 3));         \
     }                                                                              \
     _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                \
       const int r = wr * 128 + i * 16 + fr;                                        \
-      xf[i] = *(const bf16x8*)(As + r * 64 + ((cg ^ ((r >> 1) & 7)) << 3));        \
+      xf[i] = *(const bf16x8*)(Ak + r * 32 + ((g ^ ((r >> 2) & 3)) << 3));         \
     }                                                                              \
   }
 #define MFMA_PHASE()                                                               \
@@ -504,47 +561,50 @@ __global__ __launch_bounds__(512) void gemm_nt_256pp(GemmArgs p) {
         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], xf[i], acc[i][j], 0, 0, 0); \
     __builtin_amdgcn_s_setprio(0);                                                 \
   }
-  const int dbg = p.epi >> 8;             // dev-only ablation switches (tools/gemm_bench.py): 1 no glds, 2 no ds_read, 4 no mfma
-  ISSUE_TILE(0, 0);
-  if (nt > 1) ISSUE_TILE(1, 1);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  VP_BAR();
-  if (wr == 1) VP_BAR();                 // stagger: the second wave group runs one phase behind
-  bf16x8 xf[8], wf[4];
-#pragma unroll
-  for (int i = 0; i < 8; ++i) xf[i] = bf16x8{1, 2, 3, 4, 5, 6, 7, 8};
-#pragma unroll
-  for (int j = 0; j < 4; ++j) wf[j] = bf16x8{1, 2, 3, 4, 5, 6, 7, 8};
-  for (int t = 0; t < nt; ++t) {
-    const int cur = t & 1;
-    const bf16_t* As = smem + cur * 32768;
-    const bf16_t* Bs = As + 16384;
-    // ---- R0
-    if (t >= 1 && t + 1 < nt && !(dbg & 1)) ISSUE_TILE(t + 1, cur ^ 1);
-    if (!(dbg & 2)) READ_FRAGS(0);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    VP_BAR();
-    // ---- M0
-    if (!(dbg & 4)) MFMA_PHASE();
-    VP_BAR();
-    // ---- R1
-    if (!(dbg & 2)) READ_FRAGS(1);
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    VP_BAR();
-    // ---- M1
-    if (!(dbg & 4)) MFMA_PHASE();
-    VP_BAR();
-  }
-  if (wr == 0) VP_BAR();
-#undef ISSUE_TILE
-#undef READ_FRAGS
-#undef MFMA_PHASE
-  if ((dbg & 8) && acc[0][0][0] != 12345.f) return;     // dev-only: skip the epilogue
+  f32x4 acc[8][4];
 #pragma unroll
   for (int i = 0; i < 8; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
-      store4<OUT_F32>(p, m0 + wr * 128 + i * 16 + fr, n0 + wc * 64 + j * 16 + g * 4, acc[i][j]);
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  ISSUE_KH(0, 0, 0);
+  ISSUE_KH(1, 0, 0);
+  asm volatile("s_waitcnt vmcnt(4)" ::: "memory");     // kh0 of K-tile 0 landed (this wave's part)
+  VP_BAR();
+  if (wr == 1) VP_BAR();                               // stagger: the second wave group runs one barrier behind
+  bf16x8 xf[8], wf[4];
+  for (int t = 0; t < nt; ++t) {
+    const int cur = t & 1;
+    const bf16_t* buf = smem + cur * 32768;
+    // ---- phase A: k-half 0
+    ISSUE_KH(0, t + 1, cur ^ 1);
+    READ_KH(0);
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    VP_BAR();
+    MFMA_PHASE();
+    VP_BAR();
+    // ---- phase B: k-half 1
+    ISSUE_KH(1, t + 1, cur ^ 1);
+    READ_KH(1);
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    VP_BAR();
+    MFMA_PHASE();
+    VP_BAR();
+  }
+  if (wr == 0) VP_BAR();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  VP_BAR();
+#undef ISSUE_KH
+#undef READ_KH
+#undef MFMA_PHASE
+  if (!OUT_F32) {
+    epilogue_256_swz(p, smem + wave * 4096, acc, m0 + wr * 128, n0 + wc * 64, lane);
+  } else {
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        store4<OUT_F32>(p, m0 + wr * 128 + i * 16 + fr, n0 + wc * 64 + j * 16 + g * 4, acc[i][j]);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -849,52 +909,61 @@ __global__ __launch_bounds__(256) void gemm_nt_256w4(GemmArgs p) {
 //     has >= 3 phases to land and the queue is never drained: s_waitcnt vmcnt(4) keeps two pieces in flight across
 //     every barrier (the wait at the end of phase k's R retires exactly the piece phase k+1 reads first).
 // ------------------------------------------------------------------------------------------------
+#define STAMP(I) if ((p.dbg & 0x10000) && threadIdx.x == 0 && first_tile) vp_dbg_stamps[blockIdx.x * 8 + (I)] = wall_clock64();
 template <bool OUT_F32>
 __global__ __launch_bounds__(512) void gemm_nt_256p8(GemmArgs p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   bf16_t* smem = (bf16_t*)smem_raw;                    // [buf][A 256x64 | B 256x64]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int tiles_m = (p.M + 255) >> 8, tiles_n = (p.N + 255) >> 8;
-  const TileCoord tc = tile_coord_256(blockIdx.x, tiles_m, tiles_n);
-  const int m0 = tc.m0, n0 = tc.n0;
+  const int ntiles = tiles_m * tiles_n;
   const int wr = __builtin_amdgcn_readfirstlane(wave >> 2), wc = wave & 3;
   const int fr = lane & 15, g = lane >> 4;
-  const int nt = p.K >> 6;
+  const int nt = p.K >> 6;                             // even when the grid is persistent (checked by the launcher)
 
   // staging pieces (128 rows x 64 k = 16 KB = 2 chunks per thread each):
   //   piece 0: A rows wr'*128 + [0,64)      piece 1: B rows wc'*64 + [0,32)
   //   piece 2: B rows wc'*64 + [32,64)      piece 3: A rows wr'*128 + [64,128)
-  const bf16_t* src[4][2];
-  int ldsoff[4][2];                                    // element offset inside a buffer of this wave's 1 KB DMA destination
+  int ldsoff[4][2];                                    // wave-uniform LDS offsets (SGPRs)
 #pragma unroll
   for (int pc = 0; pc < 4; ++pc)
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
-      const int q = it * 512 + tid;                    // chunk inside the piece: 128 rows x 8 chunks
-      const int pr = q >> 3;                           // piece row 0..127
-      int row;                                         // row inside the operand tile
-      if (pc == 0) row = (pr >> 6) * 128 + (pr & 63);
-      else if (pc == 3) row = (pr >> 6) * 128 + 64 + (pr & 63);
-      else if (pc == 1) row = (pr >> 5) * 64 + (pr & 31);
-      else row = (pr >> 5) * 64 + 32 + (pr & 31);
-      const int gc = (q & 7) ^ ((row >> 1) & 7);
-      const bool isA = (pc == 0 || pc == 3);
-      src[pc][it] = isA ? p.A + (long)min(m0 + row, p.M - 1) * p.lda + gc * 8 : p.B + (long)min(n0 + row, p.N - 1) * p.ldb + gc * 8;
-      // wave-uniform destination: the 8 rows this wave-instruction covers start at piece row (it*512 + wave*64)/8
-      const int pr0 = (it * 512 + wave * 64) >> 3;
+      const int pr0 = (it * 512 + wave * 64) >> 3;     // first of the 8 rows this instruction covers
       int row0;
       if (pc == 0) row0 = (pr0 >> 6) * 128 + (pr0 & 63);
       else if (pc == 3) row0 = (pr0 >> 6) * 128 + 64 + (pr0 & 63);
       else if (pc == 1) row0 = (pr0 >> 5) * 64 + (pr0 & 31);
       else row0 = (pr0 >> 5) * 64 + 32 + (pr0 & 31);
-      ldsoff[pc][it] = (isA ? 0 : 16384) + row0 * 64;
+      ldsoff[pc][it] = ((pc == 0 || pc == 3) ? 0 : 16384) + row0 * 64;
     }
-#define ISSUE_PIECE(PC, T, BUF)                                                    \
+  const bf16_t* src[4][2];                             // source of the NEXT K-tile in the stream (per piece); += 64 per K-tile
+  // (re)computed from the thread id at every output-tile switch; the asm keeps the index math from being hoisted and held
+  // in registers across the K loop
+#define SET_SRC(TC)                                                                \
   {                                                                                \
-    const long ko_ = (long)min((T), nt - 1) * 64;                                  \
+    int tid_ = tid;                                                                \
+    asm volatile("" : "+v"(tid_));                                                 \
+    _Pragma("unroll") for (int pc = 0; pc < 4; ++pc)                               \
+      _Pragma("unroll") for (int it = 0; it < 2; ++it) {                           \
+        const int q = it * 512 + tid_;                                             \
+        const int pr = q >> 3;                                                     \
+        int row;                                                                   \
+        if (pc == 0) row = (pr >> 6) * 128 + (pr & 63);                            \
+        else if (pc == 3) row = (pr >> 6) * 128 + 64 + (pr & 63);                  \
+        else if (pc == 1) row = (pr >> 5) * 64 + (pr & 31);                        \
+        else row = (pr >> 5) * 64 + 32 + (pr & 31);                                \
+        const int gc = ((q & 7) ^ ((row >> 1) & 7)) * 8;                           \
+        src[pc][it] = (pc == 0 || pc == 3)                                         \
+            ? p.A + (long)min((TC).m0 + row, p.M - 1) * p.lda + gc                 \
+            : p.B + (long)min((TC).n0 + row, p.N - 1) * p.ldb + gc;                \
+      }                                                                            \
+  }
+#define ISSUE_PIECE(PC, BUF)                                                       \
+  {                                                                                \
     bf16_t* base_ = smem + (BUF) * 32768;                                          \
-    GLDS16(src[PC][0] + ko_, base_ + ldsoff[PC][0]);                               \
-    GLDS16(src[PC][1] + ko_, base_ + ldsoff[PC][1]);                               \
+    GLDS16(src[PC][0], base_ + ldsoff[PC][0]);                                     \
+    GLDS16(src[PC][1], base_ + ldsoff[PC][1]);                                     \
   }
 #define RD_A(DST, MH)                                                              \
   _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                 \
@@ -920,19 +989,23 @@ __global__ __launch_bounds__(512) void gemm_nt_256p8(GemmArgs p) {
   }
 #define END_R() asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); VP_BAR();     /* ds_reads keep flying across the barrier; the MFMAs wait for them */
 
-  f32x4 acc[8][4];
-#pragma unroll
-  for (int i = 0; i < 8; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  ISSUE_PIECE(0, 0, 0);
-  ISSUE_PIECE(1, 0, 0);
-  ISSUE_PIECE(2, 0, 0);
-  ISSUE_PIECE(3, 0, 0);
+  int v = blockIdx.x;
+  bool first_tile = true;
+  STAMP(0);
+  int sbm = 0, sbn = 0;                                // super-block walk when the (persistent) grid and the tile grid allow it
+  if (gridDim.x == 256 && !(p.dbg & 0x40000)) {
+    if (tiles_m % 16 == 0 && tiles_n % 16 == 0) { sbm = 16; sbn = 16; }
+    else if (tiles_m % 32 == 0 && tiles_n % 8 == 0) { sbm = 32; sbn = 8; }
+  }
+#define TILE_OF(V) (sbm ? tile_coord_sb((V), tiles_m, tiles_n, sbm, sbn) : tile_coord_256((V), tiles_m, tiles_n))
+  TileCoord tc = TILE_OF(v);
+  SET_SRC(tc);
+  ISSUE_PIECE(0, 0);
+  ISSUE_PIECE(1, 0);
+  ISSUE_PIECE(2, 0);
+  ISSUE_PIECE(3, 0);
   asm volatile("s_waitcnt vmcnt(4)" ::: "memory");     // pieces 0,1 of K-tile 0 landed (this wave's parts)
   VP_BAR();
-  if (wr == 1) VP_BAR();                               // stagger: group 1 runs one barrier behind
   bf16x8 xa[2][4], wb0[2][2], wb1[2][2], xn[4];
   {                                                    // A(m0, ks=0) fragments of K-tile 0 (later ones are prefetched in phase 4)
     const bf16_t* As = smem;
@@ -942,66 +1015,97 @@ __global__ __launch_bounds__(512) void gemm_nt_256p8(GemmArgs p) {
       xn[i] = *(const bf16x8*)(As + r * 64 + ((g ^ ((r >> 1) & 7)) << 3));
     }
   }
-  for (int t = 0; t < nt; ++t) {
-    const int cur = t & 1;
-    const bf16_t* As = smem + cur * 32768;
-    const bf16_t* Bs = As + 16384;
-    // ---- phase 1: quadrant (m0, n0).  reads: B(n0) x4, A(m0, ks=1) x4  (A(m0, ks=0) came from the previous phase 4)
-    ISSUE_PIECE(0, t + 1, cur ^ 1);
-    RD_B(wb0, 0);
+  while (true) {
+    STAMP(1);
+    if (wr == 1) VP_BAR();                             // stagger: group 1 runs one barrier behind
+    f32x4 acc[8][4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int r = wr * 128 + i * 16 + fr;
-      xa[0][i] = xn[i];
-      xa[1][i] = *(const bf16x8*)(As + r * 64 + (((4 + g) ^ ((r >> 1) & 7)) << 3));
-    }
-    END_R();
-    MM(xa, wb0, 0, 0);
-    VP_BAR();
-    // ---- phase 2: quadrant (m0, n1).  reads: B(n1) x4
-    ISSUE_PIECE(1, t + 1, cur ^ 1);
-    RD_B(wb1, 1);
-    END_R();
-    MM(xa, wb1, 0, 1);
-    VP_BAR();
-    // ---- phase 3: quadrant (m1, n1).  reads: A(m1) x8
-    ISSUE_PIECE(2, t + 1, cur ^ 1);
-    RD_A(xa, 1);
-    END_R();
-    MM(xa, wb1, 1, 1);
-    VP_BAR();
-    // ---- phase 4: quadrant (m1, n0) (B(n0) still in registers).  reads: NEXT K-tile's A(m0, ks=0) x4 — its piece was
-    // issued in phase 1 and retired for every wave by the vmcnt(4) at the end of phase 3's R section.
-    ISSUE_PIECE(3, t + 1, cur ^ 1);
-    {
-      const bf16_t* Asn = smem + (cur ^ 1) * 32768;
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const TileCoord tcur = tc;
+    const int vnext = v + gridDim.x;
+    for (int t = 0; t < nt; ++t) {
+      const int cur = t & 1;
+      const bf16_t* As = smem + cur * 32768;
+      const bf16_t* Bs = As + 16384;
+      // the K-tile stream continues into this block's NEXT output tile (or a harmless re-fetch at the very end)
+      if (t + 1 < nt) {
+#pragma unroll
+        for (int pc = 0; pc < 4; ++pc) { src[pc][0] += 64; src[pc][1] += 64; }
+      } else {
+        if (vnext < ntiles) tc = TILE_OF(vnext);
+        SET_SRC(tc);
+      }
+      // ---- phase 1: quadrant (m0, n0).  reads: B(n0) x4, A(m0, ks=1) x4  (A(m0, ks=0) came from the previous phase 4)
+      ISSUE_PIECE(0, cur ^ 1);
+      RD_B(wb0, 0);
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int r = wr * 128 + i * 16 + fr;
-        xn[i] = *(const bf16x8*)(Asn + r * 64 + ((g ^ ((r >> 1) & 7)) << 3));
+        xa[0][i] = xn[i];
+        xa[1][i] = *(const bf16x8*)(As + r * 64 + (((4 + g) ^ ((r >> 1) & 7)) << 3));
       }
+      END_R();
+      MM(xa, wb0, 0, 0);
+      VP_BAR();
+      // ---- phase 2: quadrant (m0, n1).  reads: B(n1) x4
+      ISSUE_PIECE(1, cur ^ 1);
+      RD_B(wb1, 1);
+      END_R();
+      MM(xa, wb1, 0, 1);
+      VP_BAR();
+      // ---- phase 3: quadrant (m1, n1).  reads: A(m1) x8
+      ISSUE_PIECE(2, cur ^ 1);
+      RD_A(xa, 1);
+      END_R();
+      MM(xa, wb1, 1, 1);
+      VP_BAR();
+      // ---- phase 4: quadrant (m1, n0) (B(n0) still in registers).  reads: NEXT K-tile's A(m0, ks=0) x4 — its piece was
+      // issued in phase 1 and retired for every wave by the vmcnt(4) at the end of phase 3's R section.
+      ISSUE_PIECE(3, cur ^ 1);
+      {
+        const bf16_t* Asn = smem + (cur ^ 1) * 32768;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int r = wr * 128 + i * 16 + fr;
+          xn[i] = *(const bf16x8*)(Asn + r * 64 + ((g ^ ((r >> 1) & 7)) << 3));
+        }
+      }
+      END_R();
+      MM(xa, wb0, 1, 0);
+      VP_BAR();
     }
-    END_R();
-    MM(xa, wb0, 1, 0);
-    VP_BAR();
+    if (wr == 0) VP_BAR();                             // re-align the two groups at the output-tile boundary
+    STAMP(2);
+    // buffer 1 (the last K-tile's, nt is even) is free for C staging; buffer 0 is receiving the next tile's first K-tile
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (!OUT_F32) {
+      epilogue_256_swz(p, smem + ((nt - 1) & 1) * 32768 + wave * 4096, acc, tcur.m0 + wr * 128, tcur.n0 + wc * 64, lane);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          store4<OUT_F32>(p, tcur.m0 + wr * 128 + i * 16 + fr, tcur.n0 + wc * 64 + j * 16 + g * 4, acc[i][j]);
+    }
+    STAMP(3);
+    if (p.dbg & 0x10000) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); STAMP(4); }
+    first_tile = false;
+    if (vnext >= ntiles) break;
+    v = vnext;
+    VP_BAR();                                          // every wave is done with the staging slices before the next DMA lands there
   }
-  if (wr == 0) VP_BAR();
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // drain the dummy tail DMAs before LDS is reused
-  VP_BAR();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the final dummy DMAs must not outlive the workgroup's LDS
+  first_tile = true;
+  STAMP(5);
+#undef SET_SRC
+#undef TILE_OF
 #undef ISSUE_PIECE
 #undef RD_A
 #undef RD_B
 #undef MM
 #undef END_R
-  if (!OUT_F32) {
-    epilogue_256_swz(p, smem + wave * 4096, acc, m0 + wr * 128, n0 + wc * 64, lane);
-  } else {
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        store4<OUT_F32>(p, m0 + wr * 128 + i * 16 + fr, n0 + wc * 64 + j * 16 + g * 4, acc[i][j]);
-  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1075,6 +1179,10 @@ __global__ __launch_bounds__(256) void transpose_bf16_kernel(const bf16_t* in, b
 
 extern "C" {
 
+int vp_debug_stamps(long* host) {
+  return hipMemcpyFromSymbol(host, HIP_SYMBOL(vp_dbg_stamps), sizeof(long) * 256 * 8) == hipSuccess ? 0 : 1;
+}
+
 int vp_gemm_bf16(int M, int N, int K, const void* A, long lda, const void* B, long ldb, void* C, long ldc,
                  const void* bias, const void* residual, long ldr, int epilogue, int out_f32, int force_generic,
                  hipStream_t stream) {
@@ -1083,7 +1191,12 @@ int vp_gemm_bf16(int M, int N, int K, const void* A, long lda, const void* B, lo
   VP_REQUIRE(lda >= K && ldb >= K && ldc >= N, VP_ERR_BAD_ARG, "vp_gemm_bf16: leading dims too small");
   VP_REQUIRE((epilogue & 0xff) >= 0 && (epilogue & 0xff) <= 3, VP_ERR_BAD_ARG, "vp_gemm_bf16: bad epilogue %d", epilogue);
   GemmArgs p{(const bf16_t*)A, (const bf16_t*)B, C, (const bf16_t*)bias, (const bf16_t*)residual, M, N, K,
-             lda, ldb, ldc, ldr, epilogue};
+             lda, ldb, ldc, ldr, epilogue, 0};
+  {
+    static int dbg_env = -1;
+    if (dbg_env < 0) { const char* e = getenv("VP_GEMM_DBG"); dbg_env = e ? atoi(e) : 0; }
+    p.dbg = dbg_env;
+  }
   const bool fast = (force_generic != 1) && (K % 64 == 0) && (lda % 8 == 0) && (ldb % 8 == 0) &&
                     ((((uintptr_t)A) | ((uintptr_t)B)) & 15) == 0;
   const long big_tiles = (long)((M + 255) / 256) * ((N + 255) / 256);
@@ -1094,8 +1207,11 @@ int vp_gemm_bf16(int M, int N, int K, const void* A, long lda, const void* B, lo
       (void)hipFuncSetAttribute((const void*)gemm_nt_256p8<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
       attr_p8 = true;
     }
-    if (out_f32) hipLaunchKernelGGL(gemm_nt_256p8<true>, dim3((unsigned)big_tiles), dim3(512), 131072, stream, p);
-    else hipLaunchKernelGGL(gemm_nt_256p8<false>, dim3((unsigned)big_tiles), dim3(512), 131072, stream, p);
+    // persistent (one block per CU streaming its output tiles) when the K-tile count is even (buffer parity is then the same
+    // for every output tile); otherwise one block per output tile
+    const unsigned g8 = (unsigned)(((K / 64) % 2 == 0 && big_tiles > 256 && !(p.dbg & 0x20000)) ? 256 : big_tiles);
+    if (out_f32) hipLaunchKernelGGL(gemm_nt_256p8<true>, dim3(g8), dim3(512), 131072, stream, p);
+    else hipLaunchKernelGGL(gemm_nt_256p8<false>, dim3(g8), dim3(512), 131072, stream, p);
   } else if (fast && force_generic == 6) {
     static bool attr_w4 = false;
     if (!attr_w4) {
