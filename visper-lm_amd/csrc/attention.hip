@@ -97,8 +97,11 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(AttnParams p) {
   bf16_t* const Vbuf = Kbuf + 2 * TILE;                // [2][64*LD]   V tiles
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, fr = lane & 15, g = lane >> 4;
   const int nqb = (p.Sq + 127) >> 7;
-  const int qb = nqb - 1 - (int)blockIdx.x;            // heavy (late) causal blocks first
-  const int h = blockIdx.y, b = blockIdx.z, hk = h / (p.Hq / p.Hkv);
+  const int qb = nqb - 1 - (int)blockIdx.z;            // z is the slowest dispatch index: heavy (late) causal blocks first
+  // blocks are dealt round-robin to the 8 XCDs (x & 7): give each XCD whole GQA groups so K/V tiles are shared in its L2
+  const int hx = blockIdx.x;
+  const int h = (p.Hq & 7) == 0 ? (hx & 7) * (p.Hq >> 3) + (hx >> 3) : hx;
+  const int b = blockIdx.y, hk = h / (p.Hq / p.Hkv);
   const int q0 = qb * 128, qw0 = q0 + wave * 16;
   const int qrow = qw0 + fr;
   const int kvlen = p.kv_len ? min(p.kv_len[b], p.Skv) : p.Skv;
@@ -236,7 +239,10 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(AttnParams p) {
     float a = 0.f;
     for (int e = lane * 2; e < D; e += 128) a += bf2f(o[e]) * bf2f(d[e]) + bf2f(o[e + 1]) * bf2f(d[e + 1]);
     a = wave_sum(a);
-    if (lane == 0) p.delta[i] = a;
+    if (lane == 0) {
+      p.delta[i] = a;
+      *(float2*)(p.delta + rows + 2 * i) = float2{p.lse[i], a};      // (lse, delta) pairs for the DMA-fed dK/dV kernel
+    }
   }
 }
 
@@ -250,8 +256,8 @@ __global__ __launch_bounds__(512) void attn_bwd_dkdv_kernel(AttnParams p) {
   __shared__ __attribute__((aligned(16))) bf16_t dObuf[2 * 32 * LD];
   __shared__ float lse_buf[2 * 32], delta_buf[2 * 32];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, fr = lane & 15, g = lane >> 4;
-  const int hk = blockIdx.y, b = blockIdx.z;
-  const int k0 = blockIdx.x * 128, kw0 = k0 + wave * 16, key = kw0 + fr;
+  const int hk = blockIdx.x, b = blockIdx.y;           // z (slowest dispatch index) = key block: early keys (most queries) first
+  const int k0 = blockIdx.z * 128, kw0 = k0 + wave * 16, key = kw0 + fr;
   const int kvlen = p.kv_len ? min(p.kv_len[b], p.Skv) : p.Skv;
   const int off = p.Skv - p.Sq;
   const int rep = p.Hq / p.Hkv;
@@ -365,6 +371,206 @@ __global__ __launch_bounds__(512) void attn_bwd_dkdv_kernel(AttnParams p) {
 }
 
 // ================================================================================================
+// backward: dK, dV for D = 128 (the decoder's shape).  Block = 4 waves x 32 keys of one kv head; loops the GQA group's
+// q heads and 32-query tiles.  The 16-keys-per-wave kernel above is HBM-*latency* bound (one 16 KB tile in flight per CU,
+// ~3.7 us per iteration) and reads every Q/dO tile from LDS once per 16 keys.  Here:
+//   * Q / dO / (lse, delta) tiles stream HBM -> LDS with global_load_lds into a 4-stage ring (3 tiles in flight, no staging
+//     registers, one raw s_barrier per tile, counted vmcnt so the queue never drains);
+//   * LDS tiles are dense [32][128] (DMA writes are lane-linear, no padding possible): the 16-byte chunk index is XOR-ed
+//     with (row & 15) on the SOURCE side, which keeps both the row-wise ds_read_b128 and the transposing
+//     ds_read_b64_tr_b16 fragment reads conflict-free;
+//   * each wave owns 32 keys (two 16-key MFMA column tiles), so every LDS fragment feeds two MFMAs;
+//   * 256 threads at <= 256 VGPRs -> two blocks per CU run out of phase.
+// ================================================================================================
+#define ATTN_GLDS(gptr, ldsptr, BYTES)                                                              \
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr),           \
+                                   (__attribute__((address_space(3))) void*)(ldsptr), BYTES, 0, 0)
+static __device__ __forceinline__ bf16x8 rowfrag_sw(const bf16_t* t, int row, int chunk) {
+  return *(const bf16x8*)(t + row * 128 + ((chunk ^ (row & 15)) << 3));
+}
+static __device__ __forceinline__ bf16x8 trfrag_sw(const bf16_t* t, int f0, int lane) {
+  const int g = lane >> 4, a = (lane & 15) >> 2, b = lane & 3;
+  const int row = 4 * g + a, chunk = (f0 >> 3) + (b >> 1);
+  const bf16_t* p0 = t + row * 128 + ((chunk ^ row) << 3) + (b & 1) * 4;     // rows +16 share the swizzle phase
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p0);
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p0 + 16 * 128));
+  return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+static __device__ __forceinline__ bf16x8 trfrag_at(const bf16_t* p0) {   // p0: this lane's 8-byte piece of token rows 0..15; +16 rows
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p0);
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p0 + 16 * 128));
+  return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+constexpr int DKDV128_STAGE = 2 * 32 * 128 + 128;     // bf16 units: Q tile | dO tile | 32 (lse, delta) fp32 pairs
+constexpr int DKDV128_LDS = 4 * DKDV128_STAGE * 2;    // bytes
+
+template <bool CAUSAL>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_bwd_dkdv128_kernel(AttnParams p) {
+  constexpr int D = 128, NKS = 4, NDB = 8;
+  extern __shared__ __attribute__((aligned(16))) unsigned char attn_smem[];
+  bf16_t* const ring = (bf16_t*)attn_smem;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), fr = lane & 15, g = lane >> 4;
+  const int hk = blockIdx.x, b = blockIdx.y;           // z (slowest dispatch index) = key block: early keys (most queries) first
+  const int k0 = blockIdx.z * 128, kw0 = k0 + wave * 32;
+  const int kvlen = p.kv_len ? min(p.kv_len[b], p.Skv) : p.Skv;
+  const int off = p.Skv - p.Sq;
+  const int rep = p.Hq / p.Hkv;
+  const float c = p.scale * LOG2E;
+  const float* pairs = p.delta + (long)p.B * p.Hq * p.Sq;            // (lse, delta) interleaved, written by the pre-pass
+
+  bf16x8 kf[2][NKS], vf[2][NKS];
+#pragma unroll
+  for (int kt = 0; kt < 2; ++kt) {
+    const int keyc = min(kw0 + kt * 16 + fr, p.Skv - 1);    // clamped; keys >= kv_len are masked (p = 0) and not stored
+    const bf16_t* kp = p.k + (long)b * p.k_bs + (long)keyc * p.k_ts + (long)hk * D;
+    const bf16_t* vp = p.v + (long)b * p.v_bs + (long)keyc * p.v_ts + (long)hk * D;
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+      kf[kt][ks] = *(const bf16x8*)(kp + ks * 32 + g * 8);
+      vf[kt][ks] = *(const bf16x8*)(vp + ks * 32 + g * 8);
+    }
+  }
+  f32x4 dk[2][NDB], dv[2][NDB];
+#pragma unroll
+  for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+    for (int d = 0; d < NDB; ++d) { dk[kt][d] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[kt][d] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+
+  int qstart = 0, qend = p.Sq;
+  if (CAUSAL) qstart = max(0, k0 - off) & ~31;
+  if (p.window > 0) qend = min(p.Sq, k0 + 128 - off + p.window);
+  if (k0 >= kvlen) qend = qstart;                      // whole key tile is padding: gradients are zero
+  const int ntq = qend > qstart ? (qend - qstart + 31) / 32 : 0;
+  const int nit = ntq * rep;                           // flattened (head, q tile) iteration space
+
+  // DMA geometry: instruction i of this wave fills rows (i*4 + wave)*4 .. +3 of a tile; lane -> (row, 16-byte slot).
+  // Rows r and r+16 share the swizzle phase, so both instructions use the same source chunk.
+  // Everything derived from the lane id is RE-derived inside the loop behind an opaque asm: the register budget is full
+  // (dk/dv 128 + K/V fragments 64), and hipcc would otherwise spill these loop invariants to scratch and reload them with
+  // s_waitcnt vmcnt(0) -- which drains the DMA queue every iteration.
+  auto issue = [&](int t, int st, int ln) {
+    const int drow = wave * 4 + (ln >> 4);
+    const int dch = ((ln & 15) ^ (drow & 15)) * 8;
+    const int tc = min(t, nit - 1);                    // past the end: harmless re-fetch keeps the vmcnt bookkeeping uniform
+    const int hh = tc / ntq;
+    const int h = hk * rep + hh, q0 = qstart + (tc - hh * ntq) * 32;
+    bf16_t* sb = ring + st * DKDV128_STAGE;
+    const char* qb = (const char*)(p.q + (long)b * p.q_bs + (long)h * D);      // wave-uniform bases + 32-bit lane offsets
+    const char* gb = (const char*)(p.dout + (long)b * p.do_bs + (long)h * D);
+    const unsigned r0 = (unsigned)min(q0 + drow, p.Sq - 1), r1 = (unsigned)min(q0 + drow + 16, p.Sq - 1);
+    const unsigned qts = (unsigned)p.q_ts, gts = (unsigned)p.do_ts;
+    ATTN_GLDS(qb + (size_t)((r0 * qts + dch) * 2u), sb + wave * 512, 16);
+    ATTN_GLDS(qb + (size_t)((r1 * qts + dch) * 2u), sb + (4 + wave) * 512, 16);
+    ATTN_GLDS(gb + (size_t)((r0 * gts + dch) * 2u), sb + 4096 + wave * 512, 16);
+    ATTN_GLDS(gb + (size_t)((r1 * gts + dch) * 2u), sb + 4096 + (4 + wave) * 512, 16);
+    if (wave == 0) {
+      const long qi = min(q0 + (ln >> 1), p.Sq - 1);
+      ATTN_GLDS(pairs + (((long)b * p.Hq + h) * p.Sq + qi) * 2 + (ln & 1), sb + 8192, 4);
+    }
+  };
+  if (nit > 0) { issue(0, 0, lane); issue(1, 1, lane); issue(2, 2, lane); }
+  for (int it = 0; it < nit; ++it) {
+    // tile `it` landed (this wave's part): at most the two younger stages may still be in flight
+    if (wave == 0) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();                      // every wave's part landed; stage (it-1)&3 is no longer being read
+    __builtin_amdgcn_sched_barrier(0);
+    int ln = threadIdx.x & 63;
+    asm volatile("" : "+v"(ln));                       // opaque: see the note above `issue`
+    issue(it + 3, (it + 3) & 3, ln);
+    const int fr = ln & 15, g = ln >> 4;
+    // LDS fragment addressing: the swizzle is an XOR on the chunk bits, so one base per read kind + compile-time XOR masks
+    const int rbase = fr * 128 + ((g ^ fr) << 3);                         // row-wise: (row fr, chunk g) ^ (ks*4 chunks), + qt*16 rows
+    const int trow = 4 * g + (fr >> 2);
+    const int tbase = trow * 128 + ((((ln & 3) >> 1) ^ trow) << 3) + (ln & 1) * 4;
+    const bf16_t* Qs = ring + (it & 3) * DKDV128_STAGE;
+    const bf16_t* dOs = Qs + 4096;
+    const float* ld = (const float*)(Qs + 8192);
+    const int hh = it / ntq;
+    const int q0 = qstart + (it - hh * ntq) * 32;
+    // wave-uniform skip: every query of this tile is below this wave's first key (causal) -> all p = 0
+    const bool active = !CAUSAL || (q0 + 31 + off >= kw0);
+    if (active) {
+      // s[kt][r]: query = q0 + 16qt + 4g + r, key = kw0 + 16kt + fr.  One 16-query half at a time: only the packed bf16
+      // P / dS halves stay live across the two halves (register budget: dk/dv 128 + K/V fragments 64).
+      const bool need_mask = (q0 + 32 > p.Sq) || (kw0 + 32 > kvlen) || (CAUSAL && (kw0 + 31 > q0 + off)) || (p.window > 0);
+      u32x2 pk[2][2], dsk[2][2];
+#pragma unroll
+      for (int qt = 0; qt < 2; ++qt) {
+        f32x4 s[2], dp[2];
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) { s[kt] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[kt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+          const bf16x8 qa = *(const bf16x8*)(Qs + (rbase ^ (ks * 32)) + qt * 2048);
+          const bf16x8 da = *(const bf16x8*)(dOs + (rbase ^ (ks * 32)) + qt * 2048);
+#pragma unroll
+          for (int kt = 0; kt < 2; ++kt) {
+            s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa, kf[kt][ks], s[kt], 0, 0, 0);
+            dp[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(da, vf[kt][ks], dp[kt], 0, 0, 0);
+          }
+          if (ks & 1) __builtin_amdgcn_sched_barrier(0);     // bound the scheduler's look-ahead: fragments for <= 2 k-steps live
+        }
+        const f32x4 l0 = *(const f32x4*)(ld + (qt * 16 + 4 * g) * 2), l1 = *(const f32x4*)(ld + (qt * 16 + 4 * g) * 2 + 4);
+        const float lse_r[4] = {l0[0], l0[2], l1[0], l1[2]}, del_r[4] = {l0[1], l0[3], l1[1], l1[3]};
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float pv = fast_exp2(fmaf(s[kt][r], c, -lse_r[r]));
+            if (need_mask) {
+              const int qg = q0 + qt * 16 + 4 * g + r, key = kw0 + kt * 16 + fr;
+              const bool ok = qg < p.Sq && key < kvlen && (!CAUSAL || key <= qg + off) && (p.window <= 0 || key > qg + off - p.window);
+              pv = ok ? pv : 0.f;
+            }
+            s[kt][r] = pv;
+            dp[kt][r] = pv * (dp[kt][r] - del_r[r]);
+          }
+          pk[kt][qt] = u32x2{pack_bf16x2(s[kt][0], s[kt][1]), pack_bf16x2(s[kt][2], s[kt][3])};
+          dsk[kt][qt] = u32x2{pack_bf16x2(dp[kt][0], dp[kt][1]), pack_bf16x2(dp[kt][2], dp[kt][3])};
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      bf16x8 pf[2], dsf[2];
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt) {
+        pf[kt] = __builtin_bit_cast(bf16x8, u32x4{pk[kt][0][0], pk[kt][0][1], pk[kt][1][0], pk[kt][1][1]});
+        dsf[kt] = __builtin_bit_cast(bf16x8, u32x4{dsk[kt][0][0], dsk[kt][0][1], dsk[kt][1][0], dsk[kt][1][1]});
+      }
+#pragma unroll
+      for (int d = 0; d < NDB; ++d) {
+        const bf16x8 ta = trfrag_at(dOs + (tbase ^ (d * 16)));
+        const bf16x8 tq = trfrag_at(Qs + (tbase ^ (d * 16)));
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+          dv[kt][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ta, pf[kt], dv[kt][d], 0, 0, 0);
+          dk[kt][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tq, dsf[kt], dk[kt][d], 0, 0, 0);
+        }
+        if (d & 1) __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // trailing (dummy) DMAs must not outlive the block's LDS
+#pragma unroll
+  for (int kt = 0; kt < 2; ++kt) {
+    const int key = kw0 + kt * 16 + fr;
+    if (key < p.Skv) {
+      bf16_t* dkp = p.dk + (long)b * p.dk_bs + (long)key * p.dk_ts + (long)hk * D;
+      bf16_t* dvp = p.dv + (long)b * p.dv_bs + (long)key * p.dv_ts + (long)hk * D;
+#pragma unroll
+      for (int d = 0; d < NDB; ++d) {
+        bf16x4 a, bb;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { a[r] = (short)f2bf(dk[kt][d][r] * p.scale); bb[r] = (short)f2bf(dv[kt][d][r]); }
+        *(bf16x4*)(dkp + d * 16 + 4 * g) = a;
+        *(bf16x4*)(dvp + d * 16 + 4 * g) = bb;
+      }
+    }
+  }
+}
+
+// ================================================================================================
 // backward: dQ  (block = 128 queries of one q head, 16 per wave; loops 64-key tiles)
 // ================================================================================================
 template <int D, bool CAUSAL>
@@ -375,8 +581,11 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(AttnParams p) {
   bf16_t* const Vbuf = Kbuf + 2 * TILE;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, fr = lane & 15, g = lane >> 4;
   const int nqb = (p.Sq + 127) >> 7;
-  const int qb = nqb - 1 - (int)blockIdx.x;
-  const int h = blockIdx.y, b = blockIdx.z, hk = h / (p.Hq / p.Hkv);
+  const int qb = nqb - 1 - (int)blockIdx.z;
+  // blocks are dealt round-robin to the 8 XCDs (x & 7): give each XCD whole GQA groups so K/V tiles are shared in its L2
+  const int hx = blockIdx.x;
+  const int h = (p.Hq & 7) == 0 ? (hx & 7) * (p.Hq >> 3) + (hx >> 3) : hx;
+  const int b = blockIdx.y, hk = h / (p.Hq / p.Hkv);
   const int q0 = qb * 128, qw0 = q0 + wave * 16, qrow = qw0 + fr;
   const int kvlen = p.kv_len ? min(p.kv_len[b], p.Skv) : p.Skv;
   const int off = p.Skv - p.Sq;
@@ -494,7 +703,7 @@ static int launch_fwd(const AttnParams& p, int causal, hipStream_t s) {
     (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<D, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kv_lds_bytes<D>());
     attr = true;
   }
-  dim3 grid((p.Sq + 127) / 128, p.Hq, p.B);
+  dim3 grid(p.Hq, p.B, (p.Sq + 127) / 128);
   if (causal) hipLaunchKernelGGL((attn_fwd_kernel<D, true>), grid, dim3(512), kv_lds_bytes<D>(), s, p);
   else hipLaunchKernelGGL((attn_fwd_kernel<D, false>), grid, dim3(512), kv_lds_bytes<D>(), s, p);
   return vp_check_launch("vp_attn_fwd");
@@ -509,8 +718,22 @@ static int launch_bwd(const AttnParams& p, int causal, hipStream_t s) {
     (void)hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<D, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kv_lds_bytes<D>());
     attr = true;
   }
-  dim3 g1((p.Skv + 127) / 128, p.Hkv, p.B), g2((p.Sq + 127) / 128, p.Hq, p.B);
-  if (causal) {
+  dim3 g1(p.Hkv, p.B, (p.Skv + 127) / 128), g2(p.Hq, p.B, (p.Sq + 127) / 128);
+  if (D == 128) {
+    static bool attr2 = false;
+    if (!attr2) {
+      (void)hipFuncSetAttribute((const void*)attn_bwd_dkdv128_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, DKDV128_LDS);
+      (void)hipFuncSetAttribute((const void*)attn_bwd_dkdv128_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, DKDV128_LDS);
+      attr2 = true;
+    }
+    if (causal) {
+      hipLaunchKernelGGL((attn_bwd_dkdv128_kernel<true>), g1, dim3(256), DKDV128_LDS, s, p);
+      hipLaunchKernelGGL((attn_bwd_dq_kernel<D, true>), g2, dim3(512), kv_lds_bytes<D>(), s, p);
+    } else {
+      hipLaunchKernelGGL((attn_bwd_dkdv128_kernel<false>), g1, dim3(256), DKDV128_LDS, s, p);
+      hipLaunchKernelGGL((attn_bwd_dq_kernel<D, false>), g2, dim3(512), kv_lds_bytes<D>(), s, p);
+    }
+  } else if (causal) {
     hipLaunchKernelGGL((attn_bwd_dkdv_kernel<D, true>), g1, dim3(512), 0, s, p);
     hipLaunchKernelGGL((attn_bwd_dq_kernel<D, true>), g2, dim3(512), kv_lds_bytes<D>(), s, p);
   } else {
@@ -549,7 +772,7 @@ int vp_attn_fwd(int B, int Hq, int Hkv, int Sq, int Skv, int D, const void* q, l
   }
 }
 
-// delta: fp32 workspace [B, Hq, Sq].  dq/dk/dv use the same [B,S,H,D] addressing with their own strides.
+// delta: fp32 workspace of 3 * B * Hq * Sq floats (delta, then interleaved (lse, delta) pairs).  dq/dk/dv use the same [B,S,H,D] addressing with their own strides.
 int vp_attn_bwd(int B, int Hq, int Hkv, int Sq, int Skv, int D, const void* q, long q_bs, long q_ts, const void* k, long k_bs,
                 long k_ts, const void* v, long v_bs, long v_ts, const void* o, long o_bs, long o_ts, const float* lse,
                 const void* dout, long do_bs, long do_ts, void* dq, long dq_bs, long dq_ts, void* dk, long dk_bs, long dk_ts,

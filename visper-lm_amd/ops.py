@@ -281,7 +281,7 @@ def attn_bwd(q, k, v, o, lse, dout, causal, scale=None, window=0, kv_len=None, d
         dk = torch.empty(B, Skv, Hkv, D, device=q.device, dtype=BF16)
     if dv is None:
         dv = torch.empty(B, Skv, Hkv, D, device=q.device, dtype=BF16)
-    delta = torch.empty(B, Hq, Sq, device=q.device, dtype=torch.float32)
+    delta = torch.empty(3, B, Hq, Sq, device=q.device, dtype=torch.float32)   # delta + (lse, delta) pairs
     qb, qt = _bshd(q); kb, kt = _bshd(k); vb, vt = _bshd(v); ob, ot = _bshd(o); gb, gt = _bshd(dout)
     dqb, dqt = _bshd(dq); dkb, dkt = _bshd(dk); dvb, dvt = _bshd(dv)
     _lib.call("vp_attn_bwd", B, Hq, Hkv, Sq, Skv, D, _p(q), qb, qt, _p(k), kb, kt, _p(v), vb, vt, _p(o), ob, ot, _p(lse),
