@@ -95,7 +95,9 @@ int vp_sum_f32(long n, const float* x, float* out, float scale, vp_stream_t stre
 
 /* ---- attention.  HF LlamaAttention eager path (modeling_llama.py:191-214: QK^T/sqrt(d) + causal mask,
  * fp32 softmax, PV), HF CLIPAttention (non-causal), PerceiverAttention (resampler.py:46-75; scale d^-1/4
- * on q and k == d^-1/2 on the product).  Tensors are [B,S,H,D] views (strides in elements). */
+ * on q and k == d^-1/2 on the product).  Tensors are [B,S,H,D] views (strides in elements, multiples of 8; 16-byte
+ * aligned bases).  lse: fp32 [B,Hq,Sq] (log2 domain).  vp_attn_bwd's `delta` is a caller-owned fp32 workspace of
+ * 3*B*Hq*Sq floats (row dots dO.O, then interleaved (lse, delta) pairs for the DMA-fed dK/dV kernel). */
 int vp_attn_fwd(int B, int Hq, int Hkv, int Sq, int Skv, int D, const void* q, long q_bs, long q_ts, const void* k,
                 long k_bs, long k_ts, const void* v, long v_bs, long v_ts, void* o, long o_bs, long o_ts, float* lse,
                 const int* kv_len, int causal, int window, float scale, vp_stream_t stream);
