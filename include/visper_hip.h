@@ -48,6 +48,14 @@ int vp_device_info(int* cu_count, int* wave_size, long* lds_bytes_per_cu);
 int vp_gemm_bf16(int M, int N, int K, const void* A, long lda, const void* B, long ldb, void* C, long ldc,
                  const void* bias, const void* residual, long ldr, int epilogue, int out_f32, int force_generic,
                  vp_stream_t stream);
+
+/* Fused SwiGLU GEMMs for the decoder MLP (HF LlamaMLP.forward: down_proj(act_fn(gate_proj(x)) * up_proj(x))).  The fused
+ * gate/up tensor keeps gate and up interleaved in 8-column chunks (g0..7 | u0..7 | g8..15 | ...), which is also the layout
+ * vp_swiglu_fwd / vp_swiglu_bwd use.  mode 1: C[M,N] = A B^T (gate_up) and C2[M,N/2] = silu(gate)*up.  mode 2: d_act = A B^T
+ * stays on chip, aux = gate_up[M,2N], C[M,2N] = d_gate_up.  M, N multiples of 256, K of 64; else VP_ERR_UNSUPPORTED_SHAPE. */
+int vp_gemm_bf16_swiglu(int mode, int M, int N, int K, const void* A, long lda, const void* B, long ldb, void* C, long ldc,
+                        void* C2, long ldc2, const void* aux, long ldaux, vp_stream_t stream);
+
 int vp_transpose_bf16(int rows, int cols, const void* in, long ld_in, void* out, long ld_out, vp_stream_t stream);
 
 /* ---- norms.  HF LlamaRMSNorm (modeling_llama.py:53-68); nn.LayerNorm in CLIP and the resampler

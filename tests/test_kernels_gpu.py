@@ -165,14 +165,48 @@ def test_rope_fwd_and_inverse(ops):
     close(gd.reshape(B, S, nh, hd), qq.grad.transpose(1, 2), what="rope inverse")
 
 
+def _ileave(t, Fd):
+    """[gate | up] column halves -> the library's 8-wide chunk interleave (g0..7 | u0..7 | g8..15 | ...)."""
+    g, u = t[..., :Fd], t[..., Fd:]
+    return torch.stack([g.reshape(*g.shape[:-1], Fd // 8, 8), u.reshape(*u.shape[:-1], Fd // 8, 8)], -2).reshape(*t.shape)
+
+
 def test_swiglu(ops):
     M, Fd = 33, 136
     gu, d = rnd(M, 2 * Fd, seed=20), rnd(M, Fd, seed=21)
     gr = gu.float().requires_grad_(True)
     ref = F.silu(gr[:, :Fd]) * gr[:, Fd:]
     ref.backward(d.float())
-    close(ops.swiglu_fwd(dev(gu)), ref, what="swiglu fwd")
-    close(ops.swiglu_bwd(dev(d), dev(gu)), gr.grad, what="swiglu bwd")
+    gu_i = dev(_ileave(gu, Fd))
+    close(ops.swiglu_fwd(gu_i), ref, what="swiglu fwd")
+    close(ops.swiglu_bwd(dev(d), gu_i), _ileave(gr.grad, Fd), what="swiglu bwd")
+    w = rnd(2 * Fd, 24, seed=24)
+    assert torch.equal(ops.interleave_gate_up(dev(w)).cpu().t(), _ileave(w.t().contiguous(), Fd))
+
+
+def test_gemm_swiglu_fused(ops):
+    """Fused epilogues == GEMM followed by the standalone SwiGLU kernels, bit for bit (same rounding points)."""
+    M, Fd, H = 512, 768, 256
+    x, wgu, wd = rnd(M, H, seed=25), rnd(2 * Fd, H, seed=26) * 0.1, rnd(H, Fd, seed=27) * 0.1
+    dy = rnd(M, H, seed=28)
+    xg, dyg = dev(x), dev(dy)
+    wgu_i = ops.interleave_gate_up(dev(wgu))
+    wd_T = ops.transpose(dev(wd))                     # [Fd, H]
+    gu_ref = ops.gemm(xg, wgu_i)
+    act_ref = ops.swiglu_fwd(gu_ref)
+    gu, act = ops.gemm_swiglu_fwd(xg, wgu_i)
+    assert torch.equal(gu, gu_ref) and torch.equal(act, act_ref)
+    dgu_ref = ops.swiglu_bwd(ops.gemm(dyg, wd_T), gu_ref)
+    dgu = ops.gemm_swiglu_bwd(dyg, wd_T, gu_ref)
+    # same formula, but hipcc may contract the fp32 multiply-adds differently in the two kernels: allow isolated 1-ulp flips
+    diff = (dgu.float() - dgu_ref.float()).abs()
+    assert float((diff > 0).float().mean()) < 1e-4 and float((diff / dgu_ref.float().abs().clamp_min(1e-3)).max()) < 1e-2
+    # and against fp32 torch
+    gr = (x.float() @ wgu.float().t()).requires_grad_(True)
+    ref = F.silu(gr[:, :Fd]) * gr[:, Fd:]
+    close(act, ref, what="fused swiglu fwd")
+    ref.backward(dy.float() @ wd.float())
+    close(dgu, _ileave(gr.grad, Fd), what="fused swiglu bwd")
 
 
 @pytest.mark.parametrize("kind", [1, 3])

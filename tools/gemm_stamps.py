@@ -24,5 +24,6 @@ for (M, N, K) in [(16384, 4096, 4096), (16384, 28672, 4096)]:
     print(" store drain: mean %.2f min %.2f max %.2f" % ((d[:, 4] - d[:, 3]).mean(), (d[:, 4] - d[:, 3]).min(), (d[:, 4] - d[:, 3]).max()))
     ep = d[:, 3] - d[:, 2]
     print(" epilogue by xcd:", [round(float(ep[x::8].mean()), 1) for x in range(8)])
-    print(" (last tile) epi start -> half0 lds written: %.2f ; half0 stores issued: %.2f" % ((d[:, 6] - d[:, 2]).mean(), (d[:, 7] - d[:, 6]).mean()))
+    cyc = (st[:, 7] - st[:, 6]).astype(float); us = (st[:, 2] - st[:, 1]) / 100.0
+    print(" shader clock during first K loop: %.0f MHz (cycles %.0f / %.1f us)" % ((cyc / us).mean(), cyc.mean(), us.mean()))
     print(" end: mean %.1f max %.1f ; loopend spread %.1f..%.1f" % (d[:, 5].mean(), d[:, 5].max(), d[:, 2].min(), d[:, 2].max()))

@@ -228,18 +228,26 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(AttnParams p) {
 // ================================================================================================
 template <int D>
 __global__ __launch_bounds__(256) void attn_delta_kernel(AttnParams p) {
+  // D/8 lanes per row (16-byte loads), 64/(D/8)-ish rows per wave pass; rows = (b, h, q) flattened with q fastest
+  constexpr int LPR = D / 8 <= 4 ? 4 : (D / 8 <= 8 ? 8 : 16);          // lanes per row (power of two >= D/8)
+  constexpr int RPW = 64 / LPR;
   const long rows = (long)p.B * p.Hq * p.Sq;
-  const int lane = threadIdx.x & 63;
-  for (long i = blockIdx.x * 4L + (threadIdx.x >> 6); i < rows; i += gridDim.x * 4L) {
+  const int lane = threadIdx.x & 63, sub = lane % LPR, rsel = lane / LPR;
+  for (long i0 = (blockIdx.x * 4L + (threadIdx.x >> 6)) * RPW; i0 < rows; i0 += gridDim.x * 4L * RPW) {
+    const long i = min(i0 + rsel, rows - 1);
     const int q = (int)(i % p.Sq);
     const int h = (int)((i / p.Sq) % p.Hq);
     const int b = (int)(i / ((long)p.Sq * p.Hq));
-    const bf16_t* o = p.o + (long)b * p.o_bs + (long)q * p.o_ts + (long)h * D;
-    const bf16_t* d = p.dout + (long)b * p.do_bs + (long)q * p.do_ts + (long)h * D;
     float a = 0.f;
-    for (int e = lane * 2; e < D; e += 128) a += bf2f(o[e]) * bf2f(d[e]) + bf2f(o[e + 1]) * bf2f(d[e + 1]);
-    a = wave_sum(a);
-    if (lane == 0) {
+    if (sub * 8 < D) {
+      const bf16x8 o = *(const bf16x8*)(p.o + (long)b * p.o_bs + (long)q * p.o_ts + (long)h * D + sub * 8);
+      const bf16x8 d = *(const bf16x8*)(p.dout + (long)b * p.do_bs + (long)q * p.do_ts + (long)h * D + sub * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) a += bf2f((bf16_t)o[e]) * bf2f((bf16_t)d[e]);
+    }
+#pragma unroll
+    for (int o = LPR / 2; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
+    if (sub == 0 && i0 + rsel < rows) {
       p.delta[i] = a;
       *(float2*)(p.delta + rows + 2 * i) = float2{p.lse[i], a};      // (lse, delta) pairs for the DMA-fed dK/dV kernel
     }
@@ -690,6 +698,154 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(AttnParams p) {
 }
 
 // ================================================================================================
+// backward: dQ for D = 128.  Same structure as the DMA-fed dK/dV kernel: block = 4 waves x 32 queries of one q head,
+// K / V stream through a 4-stage LDS ring in 32-key tiles (global_load_lds, swizzled source chunks, counted vmcnt).
+// ================================================================================================
+constexpr int DQ128_STAGE = 2 * 32 * 128;             // bf16 units: K tile | V tile
+constexpr int DQ128_LDS = 4 * DQ128_STAGE * 2;        // bytes
+
+template <bool CAUSAL>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_bwd_dq128_kernel(AttnParams p) {
+  constexpr int D = 128, NKS = 4, NDB = 8;
+  extern __shared__ __attribute__((aligned(16))) unsigned char attn_smem[];
+  bf16_t* const ring = (bf16_t*)attn_smem;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int nqb = (p.Sq + 127) >> 7;
+  const int qb = nqb - 1 - (int)blockIdx.z;            // z is the slowest dispatch index: heavy (late) causal blocks first
+  const int hx = blockIdx.x;
+  const int h = (p.Hq & 7) == 0 ? (hx & 7) * (p.Hq >> 3) + (hx >> 3) : hx;     // whole GQA groups per XCD
+  const int b = blockIdx.y, hk = h / (p.Hq / p.Hkv);
+  const int q0 = qb * 128, qw0 = q0 + wave * 32;
+  const int kvlen = p.kv_len ? min(p.kv_len[b], p.Skv) : p.Skv;
+  const int off = p.Skv - p.Sq;
+  const float c = p.scale * LOG2E;
+
+  bf16x8 qf[2][NKS], dof[2][NKS];
+  float lse[2], dlt[2];
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt) {
+    const int qrc = min(qw0 + qt * 16 + (lane & 15), p.Sq - 1);          // clamped (unconditional loads)
+    const bf16_t* qp = p.q + (long)b * p.q_bs + (long)qrc * p.q_ts + (long)h * D;
+    const bf16_t* dp_ = p.dout + (long)b * p.do_bs + (long)qrc * p.do_ts + (long)h * D;
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+      qf[qt][ks] = *(const bf16x8*)(qp + ks * 32 + (lane >> 4) * 8);
+      dof[qt][ks] = *(const bf16x8*)(dp_ + ks * 32 + (lane >> 4) * 8);
+    }
+    const long sidx = ((long)b * p.Hq + h) * p.Sq + qrc;
+    lse[qt] = p.lse[sidx];
+    dlt[qt] = p.delta[sidx];
+  }
+  f32x4 dq[2][NDB];
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+    for (int d = 0; d < NDB; ++d) dq[qt][d] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  int kend = kvlen;
+  if (CAUSAL) kend = min(kend, q0 + 128 + off);
+  int kstart = 0;
+  if (p.window > 0) kstart = max(0, (q0 + off - p.window + 1)) & ~31;
+  const int nit = kend > kstart ? (kend - kstart + 31) / 32 : 0;
+  const char* kb = (const char*)(p.k + (long)b * p.k_bs + (long)hk * D);
+  const char* vb = (const char*)(p.v + (long)b * p.v_bs + (long)hk * D);
+
+  auto issue = [&](int t, int st, int ln) {            // lane-derived values are re-derived per call (see the dK/dV kernel)
+    const int k0 = kstart + min(t, nit - 1) * 32;
+    const int drow = wave * 4 + (ln >> 4);
+    const int dch = ((ln & 15) ^ (drow & 15)) * 8;
+    bf16_t* sb = ring + st * DQ128_STAGE;
+    const unsigned r0 = (unsigned)min(k0 + drow, p.Skv - 1), r1 = (unsigned)min(k0 + drow + 16, p.Skv - 1);
+    const unsigned kts = (unsigned)p.k_ts, vts = (unsigned)p.v_ts;
+    ATTN_GLDS(kb + (size_t)((r0 * kts + dch) * 2u), sb + wave * 512, 16);
+    ATTN_GLDS(kb + (size_t)((r1 * kts + dch) * 2u), sb + (4 + wave) * 512, 16);
+    ATTN_GLDS(vb + (size_t)((r0 * vts + dch) * 2u), sb + 4096 + wave * 512, 16);
+    ATTN_GLDS(vb + (size_t)((r1 * vts + dch) * 2u), sb + 4096 + (4 + wave) * 512, 16);
+  };
+  if (nit > 0) { issue(0, 0, lane); issue(1, 1, lane); issue(2, 2, lane); }
+  for (int it = 0; it < nit; ++it) {
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // tile `it` landed (this wave's part); two younger stages in flight
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    int ln = threadIdx.x & 63;
+    asm volatile("" : "+v"(ln));
+    issue(it + 3, (it + 3) & 3, ln);
+    const int fr = ln & 15, g = ln >> 4;
+    const int rbase = fr * 128 + ((g ^ fr) << 3);
+    const int trow = 4 * g + (fr >> 2);
+    const int tbase = trow * 128 + ((((ln & 3) >> 1) ^ trow) << 3) + (ln & 1) * 4;
+    const bf16_t* Ks = ring + (it & 3) * DQ128_STAGE;
+    const bf16_t* Vs = Ks + 4096;
+    const int k0 = kstart + it * 32;
+    const bool active = !CAUSAL || (k0 <= qw0 + 31 + off);
+    if (active) {
+      const bool need_mask = (qw0 + 32 > p.Sq) || (k0 + 32 > kvlen) || (CAUSAL && (k0 + 31 > qw0 + off)) || (p.window > 0);
+      u32x2 dsk[2][2];                                 // [qt][kt] packed dS halves
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt) {
+        f32x4 st[2], dpt[2];
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) { st[qt] = f32x4{0.f, 0.f, 0.f, 0.f}; dpt[qt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+          const bf16x8 ka = *(const bf16x8*)(Ks + (rbase ^ (ks * 32)) + kt * 2048);
+          const bf16x8 va = *(const bf16x8*)(Vs + (rbase ^ (ks * 32)) + kt * 2048);
+#pragma unroll
+          for (int qt = 0; qt < 2; ++qt) {
+            st[qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka, qf[qt][ks], st[qt], 0, 0, 0);
+            dpt[qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va, dof[qt][ks], dpt[qt], 0, 0, 0);
+          }
+          if (ks & 1) __builtin_amdgcn_sched_barrier(0);
+        }
+        // st[qt][r]: key = k0 + 16kt + 4g + r, query = qw0 + 16qt + fr
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float pv = fast_exp2(fmaf(st[qt][r], c, -lse[qt]));
+            if (need_mask) {
+              const int key = k0 + kt * 16 + 4 * g + r, qrow = qw0 + qt * 16 + fr;
+              const bool ok = qrow < p.Sq && key < kvlen && (!CAUSAL || key <= qrow + off) && (p.window <= 0 || key > qrow + off - p.window);
+              pv = ok ? pv : 0.f;
+            }
+            dpt[qt][r] = pv * (dpt[qt][r] - dlt[qt]);
+          }
+          dsk[qt][kt] = u32x2{pack_bf16x2(dpt[qt][0], dpt[qt][1]), pack_bf16x2(dpt[qt][2], dpt[qt][3])};
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      bf16x8 dsf[2];
+#pragma unroll
+      for (int qt = 0; qt < 2; ++qt)
+        dsf[qt] = __builtin_bit_cast(bf16x8, u32x4{dsk[qt][0][0], dsk[qt][0][1], dsk[qt][1][0], dsk[qt][1][1]});
+#pragma unroll
+      for (int d = 0; d < NDB; ++d) {
+        const bf16x8 ktf = trfrag_at(Ks + (tbase ^ (d * 16)));
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) dq[qt][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ktf, dsf[qt], dq[qt][d], 0, 0, 0);
+        if (d & 1) __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // trailing (dummy) DMAs must not outlive the block's LDS
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt) {
+    const int qrow = qw0 + qt * 16 + (lane & 15);
+    if (qrow < p.Sq) {
+      bf16_t* dqp = p.dq + (long)b * p.dq_bs + (long)qrow * p.dq_ts + (long)h * D;
+#pragma unroll
+      for (int d = 0; d < NDB; ++d) {
+        bf16x4 a;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) a[r] = (short)f2bf(dq[qt][d][r] * p.scale);
+        *(bf16x4*)(dqp + d * 16 + 4 * (lane >> 4)) = a;
+      }
+    }
+  }
+}
+
+// ================================================================================================
 // C ABI
 // ================================================================================================
 template <int D>
@@ -711,7 +867,7 @@ static int launch_fwd(const AttnParams& p, int causal, hipStream_t s) {
 template <int D>
 static int launch_bwd(const AttnParams& p, int causal, hipStream_t s) {
   const long rows = (long)p.B * p.Hq * p.Sq;
-  hipLaunchKernelGGL((attn_delta_kernel<D>), dim3((unsigned)min(8192L, (rows + 3) / 4)), dim3(256), 0, s, p);
+  hipLaunchKernelGGL((attn_delta_kernel<D>), dim3((unsigned)min(8192L, (rows + 15) / 16)), dim3(256), 0, s, p);
   static bool attr = false;
   if (!attr) {
     (void)hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<D, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kv_lds_bytes<D>());
@@ -724,14 +880,16 @@ static int launch_bwd(const AttnParams& p, int causal, hipStream_t s) {
     if (!attr2) {
       (void)hipFuncSetAttribute((const void*)attn_bwd_dkdv128_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, DKDV128_LDS);
       (void)hipFuncSetAttribute((const void*)attn_bwd_dkdv128_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, DKDV128_LDS);
+      (void)hipFuncSetAttribute((const void*)attn_bwd_dq128_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, DQ128_LDS);
+      (void)hipFuncSetAttribute((const void*)attn_bwd_dq128_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, DQ128_LDS);
       attr2 = true;
     }
     if (causal) {
       hipLaunchKernelGGL((attn_bwd_dkdv128_kernel<true>), g1, dim3(256), DKDV128_LDS, s, p);
-      hipLaunchKernelGGL((attn_bwd_dq_kernel<D, true>), g2, dim3(512), kv_lds_bytes<D>(), s, p);
+      hipLaunchKernelGGL((attn_bwd_dq128_kernel<true>), g2, dim3(256), DQ128_LDS, s, p);
     } else {
       hipLaunchKernelGGL((attn_bwd_dkdv128_kernel<false>), g1, dim3(256), DKDV128_LDS, s, p);
-      hipLaunchKernelGGL((attn_bwd_dq_kernel<D, false>), g2, dim3(512), kv_lds_bytes<D>(), s, p);
+      hipLaunchKernelGGL((attn_bwd_dq128_kernel<false>), g2, dim3(256), DQ128_LDS, s, p);
     }
   } else if (causal) {
     hipLaunchKernelGGL((attn_bwd_dkdv_kernel<D, true>), g1, dim3(512), 0, s, p);

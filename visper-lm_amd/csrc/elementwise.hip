@@ -38,14 +38,15 @@ __global__ void rope_kernel(bf16_t* __restrict__ x, const float* __restrict__ cs
 }
 
 // ---------------------------------------------------------------- SwiGLU -----------------------
-// gu: [M, 2F] = [gate | up];  out[M,F] = silu(gate) * up
+// gu: [M, 2F] with gate / up interleaved in 8-wide chunks (g0..7 | u0..7 | g8..15 | ...; the layout the fused GEMM
+// epilogues produce and consume);  out[M,F] = silu(gate) * up
 __global__ void swiglu_fwd_kernel(const bf16_t* __restrict__ gu, bf16_t* __restrict__ out, long M, int F, long ldg, long ldo) {
   const int vpr = F >> 3;
   const long total = M * vpr;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const long r = i / vpr;
     const int c = (int)(i % vpr) * 8;
-    const bf16x8 g = *(const bf16x8*)(gu + r * ldg + c), u = *(const bf16x8*)(gu + r * ldg + F + c);
+    const bf16x8 g = *(const bf16x8*)(gu + r * ldg + 2 * c), u = *(const bf16x8*)(gu + r * ldg + 2 * c + 8);
     bf16x8 o;
 #pragma unroll
     for (int j = 0; j < 8; ++j) o[j] = (short)f2bf(bfround(silu(bf2f((bf16_t)g[j]))) * bf2f((bf16_t)u[j]));
@@ -61,7 +62,7 @@ __global__ void swiglu_bwd_kernel(const bf16_t* __restrict__ dact, const bf16_t*
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const long r = i / vpr;
     const int c = (int)(i % vpr) * 8;
-    const bf16x8 g = *(const bf16x8*)(gu + r * ldg + c), u = *(const bf16x8*)(gu + r * ldg + F + c);
+    const bf16x8 g = *(const bf16x8*)(gu + r * ldg + 2 * c), u = *(const bf16x8*)(gu + r * ldg + 2 * c + 8);
     const bf16x8 d = *(const bf16x8*)(dact + r * ldd + c);
     bf16x8 og, ou;
 #pragma unroll
@@ -71,8 +72,8 @@ __global__ void swiglu_bwd_kernel(const bf16_t* __restrict__ dact, const bf16_t*
       og[j] = (short)f2bf(dd * uu * sg * (1.f + gg * (1.f - sg)));
       ou[j] = (short)f2bf(dd * gg * sg);
     }
-    *(bf16x8*)(dgu + r * ldg + c) = og;
-    *(bf16x8*)(dgu + r * ldg + F + c) = ou;
+    *(bf16x8*)(dgu + r * ldg + 2 * c) = og;
+    *(bf16x8*)(dgu + r * ldg + 2 * c + 8) = ou;
   }
 }
 

@@ -24,6 +24,14 @@ struct GemmArgs {
   long lda, ldb, ldc, ldr;
   int epi;
   int dbg;                                             // experiments only (VP_GEMM_DBG), 0 in production
+  // fused SwiGLU epilogues (8-phase kernel, interior tiles only; gate/up columns interleaved in 8-wide chunks: g8 | u8 | ...):
+  //   mode 1: C[M,N] = gate_up (as usual) and C2[M,N/2] = silu(gate) * up
+  //   mode 2: the accumulator is d_act[M,N]; aux = gate_up[M,2N]; C[M,2N] = d_gate_up
+  int mode;
+  void* C2;
+  long ldc2;
+  const bf16_t* aux;
+  long ldaux;
 };
 
 __device__ __forceinline__ float apply_epi(float v, int epi) {
@@ -77,68 +85,6 @@ __device__ __forceinline__ void store4(const GemmArgs& p, int m, int n, f32x4 ac
   }
 }
 
-
-// Coalesced epilogue for the 256-tile kernels (bf16 output): every wave stages its 128x64 accumulator block
-// through its own LDS slice (two 64-row passes, 144-byte padded rows) and writes/reads global memory as 16-byte
-// pieces with 8 lanes covering one full 128-byte row segment — the MFMA register layout alone only yields 8-byte
-// pieces scattered over 16 rows per instruction, which measured ~30 % of the whole kernel at K = 4096.
-// Same rounding points as store4: (acc + bias) -> bf16 -> act -> bf16 (in registers), + residual -> bf16 (on the way out).
-__device__ __forceinline__ void epilogue_256_bf16(const GemmArgs& p, bf16_t* wave_lds, const f32x4 (&acc)[8][4], int mrow0, int ncol0,
-                                                  int lane) {
-  constexpr int RS = 72;                      // row stride (elements): 64 + 8 pad
-  const int fr = lane & 15, g = lane >> 4;
-  const int epi = p.epi & 0xff;
-  float bias4[4][4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int n = ncol0 + j * 16 + g * 4 + r;
-      bias4[j][r] = (p.bias && n < p.N) ? bf2f(p.bias[n]) : 0.f;
-    }
-#pragma unroll
-  for (int half = 0; half < 2; ++half) {
-#pragma unroll
-    for (int ii = 0; ii < 4; ++ii) {
-      const int i = half * 4 + ii;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        bf16x4 o;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float x = bfround(acc[i][j][r] + bias4[j][r]);
-          if (epi != EPI_NONE) x = bfround(apply_epi(x, epi));
-          o[r] = (short)f2bf(x);
-        }
-        *(bf16x4*)(wave_lds + (ii * 16 + fr) * RS + j * 16 + g * 4) = o;
-      }
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // wave-private slice: our own writes are visible to our own reads
-#pragma unroll
-    for (int it = 0; it < 8; ++it) {
-      const int rl = it * 8 + (lane >> 3), c8 = (lane & 7) * 8;
-      const int m = mrow0 + half * 64 + rl, n = ncol0 + c8;
-      bf16x8 v = *(const bf16x8*)(wave_lds + rl * RS + c8);
-      if (m < p.M && n < p.N) {
-        bf16_t* cptr = (bf16_t*)p.C + (long)m * p.ldc + n;
-        const bool full = (n + 8 <= p.N) && ((((uintptr_t)cptr) & 15) == 0);
-        if (p.res) {
-          const bf16_t* rptr = p.res + (long)m * p.ldr + n;
-          if (full && ((((uintptr_t)rptr) & 15) == 0)) {
-            const bf16x8 rv = *(const bf16x8*)rptr;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = (short)f2bf(bf2f((bf16_t)v[e]) + bf2f((bf16_t)rv[e]));
-          } else {
-            for (int e = 0; e < 8 && n + e < p.N; ++e) v[e] = (short)f2bf(bf2f((bf16_t)v[e]) + bf2f(rptr[e]));
-          }
-        }
-        if (full) *(bf16x8*)cptr = v;
-        else for (int e = 0; e < 8 && n + e < p.N; ++e) cptr[e] = (bf16_t)v[e];
-      }
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // reads done before the slice is overwritten by the next pass
-  }
-}
 
 #define GLDS16(gptr, ldsptr)                                                                          \
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr),             \
@@ -298,13 +244,44 @@ __device__ __forceinline__ void epilogue_256_swz(const GemmArgs& p, bf16_t* wave
           *(u32x2*)(wave_lds + ii * 16 * 64 + woff[j]) = o;
         }
       __builtin_amdgcn_sched_barrier(0);                // residual loads only after this half's accumulators are dead
+      if (p.mode == 2) {
+        // d_act tile is staged (bf16-rounded, as the unfused path stores it); lane (row rl0 + 8 it, chunk ch) owns 8 d_act
+        // columns == one (g8 | u8) chunk pair of gate_up / d_gate_up
+        const bf16_t* gptr = p.aux + (long)(mrow0 + half * 64 + rl0) * p.ldaux + 2 * (ncol0 + ch * 8);
+        bf16_t* dptr = (bf16_t*)p.C + (long)(mrow0 + half * 64 + rl0) * p.ldc + 2 * (ncol0 + ch * 8);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int grp = 0; grp < 2; ++grp) {
+          bf16x8 gv[4], uv[4];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            gv[k] = *(const bf16x8*)(gptr + (long)((grp * 4 + k) * 8) * p.ldaux);
+            uv[k] = *(const bf16x8*)(gptr + (long)((grp * 4 + k) * 8) * p.ldaux + 8);
+          }
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const bf16x8 dv = *(const bf16x8*)(wave_lds + (grp * 4 + k) * 8 * 64 + roff);
+            bf16x8 og, ou;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              const float gg = bf2f((bf16_t)gv[k][e]), uu = bf2f((bf16_t)uv[k][e]), dd = bf2f((bf16_t)dv[e]);
+              const float sg = 1.f / (1.f + __expf(-gg));
+              og[e] = (short)f2bf(dd * uu * sg * (1.f + gg * (1.f - sg)));
+              ou[e] = (short)f2bf(dd * gg * sg);
+            }
+            *(bf16x8*)(dptr + (long)((grp * 4 + k) * 8) * p.ldc) = og;
+            *(bf16x8*)(dptr + (long)((grp * 4 + k) * 8) * p.ldc + 8) = ou;
+          }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        continue;
+      }
       u32x4 rv[8];
       if (rptr) {
 #pragma unroll
         for (int it = 0; it < 8; ++it) rv[it] = *(const u32x4*)(rptr + (long)(half * 64 + it * 8) * p.ldr);
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      if ((p.dbg & 0x10000) && threadIdx.x == 0 && half == 0) vp_dbg_stamps[blockIdx.x * 8 + 6] = wall_clock64();
 #pragma unroll
       for (int it = 0; it < 8; ++it) {
         u32x4 v = *(const u32x4*)(wave_lds + it * 8 * 64 + roff);
@@ -318,8 +295,22 @@ __device__ __forceinline__ void epilogue_256_swz(const GemmArgs& p, bf16_t* wave
         }
         *(u32x4*)(cptr + (long)(half * 64 + it * 8) * p.ldc) = v;
       }
+      if (p.mode == 1) {
+        // act = silu(gate) * up from the staged gate_up tile: lane (row rl + 16 it, chunk pair pr) -> 8 act columns
+        const int rl = lane >> 2, pr = lane & 3;
+        bf16_t* aptr = (bf16_t*)p.C2 + (long)(mrow0 + half * 64 + rl) * p.ldc2 + (ncol0 >> 1) + pr * 8;
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+          const int row = it * 16 + rl;
+          const bf16x8 gv = *(const bf16x8*)(wave_lds + row * 64 + (((2 * pr) ^ (row & 7)) << 3));
+          const bf16x8 uv = *(const bf16x8*)(wave_lds + row * 64 + (((2 * pr + 1) ^ (row & 7)) << 3));
+          bf16x8 o;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o[e] = (short)f2bf(bfround(silu(bf2f((bf16_t)gv[e]))) * bf2f((bf16_t)uv[e]));
+          *(bf16x8*)(aptr + (long)(it * 16) * p.ldc2) = o;
+        }
+      }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      if ((p.dbg & 0x10000) && threadIdx.x == 0 && half == 0) vp_dbg_stamps[blockIdx.x * 8 + 7] = wall_clock64();
     }
     return;
   }
@@ -608,297 +599,6 @@ __global__ __launch_bounds__(512) void gemm_nt_256pp(GemmArgs p) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// "skewed" 256x256x64 kernel (default for large problems).  Ablation of the ping-pong kernel above showed what a
-// K-tile costs when nothing overlaps: MFMA ~265 us, L2->LDS DMA ~135 us (at the 34 TB/s L2 roof), ds_reads
-// ~110 us (at the LDS roof), and ~240 cycles per workgroup barrier.  So: ONE barrier per K-tile (it only
-// guards LDS buffer reuse), and the two wave groups run the same R0 M0 R1 M1 phase string skewed by half a
-// K-tile *in program order*: group 0 does [R0 M0 R1 M1] between barriers, group 1 does [M1' R0 M0 R1]
-// (M1' = the MFMAs of the previous tile's second half, whose fragments it carried across the barrier in
-// registers).  Right after every barrier one group starts with MFMAs and the other with ds_reads, so the
-// matrix pipe, the LDS and the L2 DMA stream stay busy together without any extra synchronisation.
-// ------------------------------------------------------------------------------------------------
-template <bool OUT_F32>
-__global__ __launch_bounds__(512) void gemm_nt_256sk(GemmArgs p) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  bf16_t* smem = (bf16_t*)smem_raw;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-
-  const int tiles_m = (p.M + 255) >> 8, tiles_n = (p.N + 255) >> 8;
-  const int nwg = tiles_m * tiles_n;
-  const int id = xcd_remap(blockIdx.x, nwg);
-  const int GROUP_M = 8;
-  const int width = GROUP_M * tiles_n;
-  const int group = id / width;
-  const int first_m = group * GROUP_M;
-  const int gsz = min(tiles_m - first_m, GROUP_M);
-  const int tm = first_m + (id % width) % gsz;
-  const int tn = (id % width) / gsz;
-  const int m0 = tm << 8, n0 = tn << 8;
-
-  const bf16_t* srcA[4];
-  const bf16_t* srcB[4];
-#pragma unroll
-  for (int it = 0; it < 4; ++it) {
-    const int q = it * 512 + tid;
-    const int row = q >> 3;
-    const int gc = (q & 7) ^ ((row >> 1) & 7);
-    srcA[it] = p.A + (long)min(m0 + row, p.M - 1) * p.lda + gc * 8;
-    srcB[it] = p.B + (long)min(n0 + row, p.N - 1) * p.ldb + gc * 8;
-  }
-  const int wr = __builtin_amdgcn_readfirstlane(wave >> 2), wc = wave & 3;
-  const int fr = lane & 15, g = lane >> 4;
-  f32x4 acc[8][4];
-#pragma unroll
-  for (int i = 0; i < 8; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  const int nt = p.K >> 6;
-#define ISSUE_TILE(T, BUF)                                                         \
-  {                                                                                \
-    bf16_t* As_ = smem + (BUF) * 32768;                                            \
-    bf16_t* Bs_ = As_ + 16384;                                                     \
-    _Pragma("unroll") for (int it = 0; it < 4; ++it) {                             \
-      GLDS16(srcA[it] + (long)(T) * 64, As_ + (it * 512 + wave * 64) * 8);         \
-      GLDS16(srcB[it] + (long)(T) * 64, Bs_ + (it * 512 + wave * 64) * 8);         \
-    }                                                                              \
-  }
-#define READ_FRAGS(XF, WF, KS)                                                     \
-  {                                                                                \
-    const int cg = (KS) * 4 + g;                                                   \
-    _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                \
-      const int r = wc * 64 + j * 16 + fr;                                         \
-      WF[j] = *(const bf16x8*)(Bs + r * 64 + ((cg ^ ((r >> 1) & 7)) << 3));        \
-    }                                                                              \
-    _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                \
-      const int r = wr * 128 + i * 16 + fr;                                        \
-      XF[i] = *(const bf16x8*)(As + r * 64 + ((cg ^ ((r >> 1) & 7)) << 3));        \
-    }                                                                              \
-  }
-#define MFMA_PHASE(XF, WF)                                                         \
-  {                                                                                \
-    __builtin_amdgcn_s_setprio(1);                                                 \
-    _Pragma("unroll") for (int i = 0; i < 8; ++i)                                  \
-      _Pragma("unroll") for (int j = 0; j < 4; ++j)                                \
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(WF[j], XF[i], acc[i][j], 0, 0, 0); \
-    __builtin_amdgcn_s_setprio(0);                                                 \
-  }
-  ISSUE_TILE(0, 0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  VP_BAR();
-  if (wr == 0) {
-    for (int t = 0; t < nt; ++t) {
-      const int cur = t & 1;
-      const bf16_t* As = smem + cur * 32768;
-      const bf16_t* Bs = As + 16384;
-      bf16x8 xf[8], wf[4];
-      if (t + 1 < nt) ISSUE_TILE(t + 1, cur ^ 1);
-      READ_FRAGS(xf, wf, 0);
-      VP_SB();
-      MFMA_PHASE(xf, wf);
-      VP_SB();
-      READ_FRAGS(xf, wf, 1);
-      VP_SB();
-      MFMA_PHASE(xf, wf);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      VP_BAR();
-    }
-  } else {
-    bf16x8 xh[8], wh[4];                 // second-half fragments carried across the barrier
-#pragma unroll
-    for (int i = 0; i < 8; ++i) xh[i] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-    for (int j = 0; j < 4; ++j) wh[j] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
-    for (int t = 0; t < nt; ++t) {
-      const int cur = t & 1;
-      const bf16_t* As = smem + cur * 32768;
-      const bf16_t* Bs = As + 16384;
-      bf16x8 xf[8], wf[4];
-      if (t + 1 < nt) ISSUE_TILE(t + 1, cur ^ 1);
-      MFMA_PHASE(xh, wh);                // M1 of tile t-1 (zeros at t = 0)
-      VP_SB();
-      READ_FRAGS(xf, wf, 0);
-      VP_SB();
-      MFMA_PHASE(xf, wf);
-      VP_SB();
-      READ_FRAGS(xh, wh, 1);
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // our LDS reads are done before anyone may overwrite the buffer
-      VP_BAR();
-    }
-    MFMA_PHASE(xh, wh);
-  }
-#undef ISSUE_TILE
-#undef READ_FRAGS
-#undef MFMA_PHASE
-  if (!OUT_F32) {
-    epilogue_256_bf16(p, smem + wave * (64 * 72), acc, m0 + wr * 128, n0 + wc * 64, lane);
-  } else {
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        store4<OUT_F32>(p, m0 + wr * 128 + i * 16 + fr, n0 + wc * 64 + j * 16 + g * 4, acc[i][j]);
-  }
-}
-
-// ------------------------------------------------------------------------------------------------
-// 4-wave variant: 256x256 block tile, each wave owns 128x128 (8x8 MFMA tiles, 256 accumulator registers -> one wave
-// per SIMD with the whole 512-register file).  Per K step of 32 a wave reads 16 fragments for 64 MFMAs, i.e. 1/3 fewer
-// LDS bytes per flop than the 8-wave kernel (the ablation showed LDS/L2 data movement, not scheduling, is the limiter).
-// LDS is a 4-deep ring of 32-K stages (4 x 32 KB); stage s+3 is DMA'd while stage s is computed, fragments of stage
-// s+1 are prefetched into a second register set under the MFMAs of stage s, and the DMA queue is never drained
-// (counted s_waitcnt vmcnt(8): the newest stage stays in flight across every barrier).  One raw s_barrier per stage.
-// ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void epilogue_w4_swz(const GemmArgs& p, bf16_t* wave_lds, const f32x4 (&acc)[8][8], int mrow0, int ncol0,
-                                                int lane) {
-  const int fr = lane & 15, g = lane >> 4;
-  const int epi = p.epi & 0xff;
-#pragma unroll
-  for (int pass = 0; pass < 4; ++pass) {            // 32 rows (two m-tiles) x 128 cols per pass: [32][128] bf16 = 8 KB per wave
-#pragma unroll
-    for (int ii = 0; ii < 2; ++ii) {
-      const int i = pass * 2 + ii;
-      const int row = ii * 16 + fr;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        bf16x4 o;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int n = ncol0 + j * 16 + g * 4 + r;
-          float x = acc[i][j][r] + ((p.bias && n < p.N) ? bf2f(p.bias[n]) : 0.f);
-          x = bfround(x);
-          if (epi != EPI_NONE) x = bfround(apply_epi(x, epi));
-          o[r] = (short)f2bf(x);
-        }
-        const int chunk = (j * 2 + (g >> 1)) ^ (row & 15);
-        *(bf16x4*)(wave_lds + row * 128 + chunk * 8 + (g & 1) * 4) = o;
-      }
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-    for (int it = 0; it < 8; ++it) {
-      const int rl = it * 4 + (lane >> 4), ch = lane & 15;
-      const int m = mrow0 + pass * 32 + rl, n = ncol0 + ch * 8;
-      bf16x8 v = *(const bf16x8*)(wave_lds + rl * 128 + ((ch ^ (rl & 15)) << 3));
-      if (m < p.M && n < p.N) {
-        bf16_t* cptr = (bf16_t*)p.C + (long)m * p.ldc + n;
-        const bool full = (n + 8 <= p.N) && ((((uintptr_t)cptr) & 15) == 0);
-        if (p.res) {
-          const bf16_t* rptr = p.res + (long)m * p.ldr + n;
-          if (full && ((((uintptr_t)rptr) & 15) == 0)) {
-            const bf16x8 rv = *(const bf16x8*)rptr;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = (short)f2bf(bf2f((bf16_t)v[e]) + bf2f((bf16_t)rv[e]));
-          } else {
-            for (int e = 0; e < 8 && n + e < p.N; ++e) v[e] = (short)f2bf(bf2f((bf16_t)v[e]) + bf2f(rptr[e]));
-          }
-        }
-        if (full) *(bf16x8*)cptr = v;
-        else for (int e = 0; e < 8 && n + e < p.N; ++e) cptr[e] = (bf16_t)v[e];
-      }
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  }
-}
-
-template <bool OUT_F32>
-__global__ __launch_bounds__(256) void gemm_nt_256w4(GemmArgs p) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  bf16_t* smem = (bf16_t*)smem_raw;                    // 4 stages x [A 256x32 | B 256x32]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int tiles_m = (p.M + 255) >> 8, tiles_n = (p.N + 255) >> 8;
-  const TileCoord tc = tile_coord_256(blockIdx.x, tiles_m, tiles_n);
-  const int m0 = tc.m0, n0 = tc.n0;
-  const int wr = wave >> 1, wc = wave & 1;
-  const int fr = lane & 15, g = lane >> 4;
-  const int ns = p.K >> 5;
-
-  const bf16_t* srcA[4];
-  const bf16_t* srcB[4];
-#pragma unroll
-  for (int it = 0; it < 4; ++it) {
-    const int q = it * 256 + tid;
-    const int row = q >> 2;
-    const int gc = (q & 3) ^ ((row >> 2) & 3);
-    srcA[it] = p.A + (long)min(m0 + row, p.M - 1) * p.lda + gc * 8;
-    srcB[it] = p.B + (long)min(n0 + row, p.N - 1) * p.ldb + gc * 8;
-  }
-#define ISSUE_STAGE(S, SLOT)                                                       \
-  {                                                                                \
-    const long ko_ = (long)min((S), ns - 1) * 32;                                  \
-    bf16_t* As_ = smem + (SLOT) * 16384;                                           \
-    bf16_t* Bs_ = As_ + 8192;                                                      \
-    _Pragma("unroll") for (int it = 0; it < 4; ++it) {                             \
-      GLDS16(srcA[it] + ko_, As_ + (it * 256 + wave * 64) * 8);                    \
-      GLDS16(srcB[it] + ko_, Bs_ + (it * 256 + wave * 64) * 8);                    \
-    }                                                                              \
-  }
-#define READ_STAGE(SLOT, XF, WF)                                                   \
-  {                                                                                \
-    const bf16_t* As_ = smem + (SLOT) * 16384;                                     \
-    const bf16_t* Bs_ = As_ + 8192;                                                \
-    _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                \
-      const int r = wc * 128 + j * 16 + fr;                                        \
-      WF[j] = *(const bf16x8*)(Bs_ + r * 32 + ((g ^ ((r >> 2) & 3)) << 3));        \
-    }                                                                              \
-    _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                \
-      const int r = wr * 128 + i * 16 + fr;                                        \
-      XF[i] = *(const bf16x8*)(As_ + r * 32 + ((g ^ ((r >> 2) & 3)) << 3));        \
-    }                                                                              \
-  }
-#define MFMA_STAGE(XF, WF)                                                         \
-  _Pragma("unroll") for (int i = 0; i < 8; ++i)                                    \
-    _Pragma("unroll") for (int j = 0; j < 8; ++j)                                  \
-      acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(WF[j], XF[i], acc[i][j], 0, 0, 0);
-
-  f32x4 acc[8][8];
-#pragma unroll
-  for (int i = 0; i < 8; ++i)
-#pragma unroll
-    for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  ISSUE_STAGE(0, 0);
-  ISSUE_STAGE(1, 1);
-  ISSUE_STAGE(2, 2);
-  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                // stages 0 and 1 landed (this wave's parts)
-  VP_BAR();
-  bf16x8 xa[8], wa[8], xb[8], wb[8];
-  READ_STAGE(0, xa, wa);
-  // stage s:  barrier | DMA stage s+3 | prefetch fragments of stage s+1 | 64 MFMAs on stage s | wait until only the
-  // newest stage is still in flight (=> this wave's part of stage s+2 has landed before the next barrier)
-  for (int s = 0; s < ns; s += 2) {
-    VP_BAR();
-    ISSUE_STAGE(s + 3, (s + 3) & 3);
-    READ_STAGE((s + 1) & 3, xb, wb);
-    VP_SB();
-    MFMA_STAGE(xa, wa);
-    VP_SB();
-    asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
-    VP_BAR();
-    ISSUE_STAGE(s + 4, (s + 4) & 3);
-    if (s + 2 < ns) READ_STAGE((s + 2) & 3, xa, wa);
-    VP_SB();
-    MFMA_STAGE(xb, wb);
-    VP_SB();
-    asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
-  }
-  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");     // drain the (dummy) tail DMAs before LDS is reused
-  VP_BAR();
-#undef ISSUE_STAGE
-#undef READ_STAGE
-#undef MFMA_STAGE
-  if (!OUT_F32) {
-    epilogue_w4_swz(p, smem + wave * 4096, acc, m0 + wr * 128, n0 + wc * 128, lane);
-  } else {
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-      for (int j = 0; j < 8; ++j)
-        store4<OUT_F32>(p, m0 + wr * 128 + i * 16 + fr, n0 + wc * 128 + j * 16 + g * 4, acc[i][j]);
-  }
-}
-
-// ------------------------------------------------------------------------------------------------
 // 8-phase ping-pong kernel (two K-tiles = 8 phases per loop trip).  Same 256x256x64 tile / 8 waves / 2 LDS buffers as
 // above; what changes is the *granularity and balance* of the pipeline:
 //   * a phase = [R: <= 12 ds_read_b128 + 2 global_load_lds] barrier [M: 16 MFMAs on one 64x32 quadrant] barrier, and
@@ -1017,6 +717,7 @@ __global__ __launch_bounds__(512) void gemm_nt_256p8(GemmArgs p) {
   }
   while (true) {
     STAMP(1);
+    if ((p.dbg & 0x10000) && threadIdx.x == 0 && first_tile) vp_dbg_stamps[blockIdx.x * 8 + 6] = clock64();   // shader cycles
     if (wr == 1) VP_BAR();                             // stagger: group 1 runs one barrier behind
     f32x4 acc[8][4];
 #pragma unroll
@@ -1078,6 +779,7 @@ __global__ __launch_bounds__(512) void gemm_nt_256p8(GemmArgs p) {
     }
     if (wr == 0) VP_BAR();                             // re-align the two groups at the output-tile boundary
     STAMP(2);
+    if ((p.dbg & 0x10000) && threadIdx.x == 0 && first_tile) vp_dbg_stamps[blockIdx.x * 8 + 7] = clock64();
     // buffer 1 (the last K-tile's, nt is even) is free for C staging; buffer 0 is receiving the next tile's first K-tile
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     if (!OUT_F32) {
@@ -1191,7 +893,7 @@ int vp_gemm_bf16(int M, int N, int K, const void* A, long lda, const void* B, lo
   VP_REQUIRE(lda >= K && ldb >= K && ldc >= N, VP_ERR_BAD_ARG, "vp_gemm_bf16: leading dims too small");
   VP_REQUIRE((epilogue & 0xff) >= 0 && (epilogue & 0xff) <= 3, VP_ERR_BAD_ARG, "vp_gemm_bf16: bad epilogue %d", epilogue);
   GemmArgs p{(const bf16_t*)A, (const bf16_t*)B, C, (const bf16_t*)bias, (const bf16_t*)residual, M, N, K,
-             lda, ldb, ldc, ldr, epilogue, 0};
+             lda, ldb, ldc, ldr, epilogue, 0, 0, nullptr, 0, nullptr, 0};
   {
     static int dbg_env = -1;
     if (dbg_env < 0) { const char* e = getenv("VP_GEMM_DBG"); dbg_env = e ? atoi(e) : 0; }
@@ -1212,24 +914,6 @@ int vp_gemm_bf16(int M, int N, int K, const void* A, long lda, const void* B, lo
     const unsigned g8 = (unsigned)(((K / 64) % 2 == 0 && big_tiles > 256 && !(p.dbg & 0x20000)) ? 256 : big_tiles);
     if (out_f32) hipLaunchKernelGGL(gemm_nt_256p8<true>, dim3(g8), dim3(512), 131072, stream, p);
     else hipLaunchKernelGGL(gemm_nt_256p8<false>, dim3(g8), dim3(512), 131072, stream, p);
-  } else if (fast && force_generic == 6) {
-    static bool attr_w4 = false;
-    if (!attr_w4) {
-      (void)hipFuncSetAttribute((const void*)gemm_nt_256w4<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
-      (void)hipFuncSetAttribute((const void*)gemm_nt_256w4<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
-      attr_w4 = true;
-    }
-    if (out_f32) hipLaunchKernelGGL(gemm_nt_256w4<true>, dim3((unsigned)big_tiles), dim3(256), 131072, stream, p);
-    else hipLaunchKernelGGL(gemm_nt_256w4<false>, dim3((unsigned)big_tiles), dim3(256), 131072, stream, p);
-  } else if (fast && force_generic == 5) {
-    static bool attr_sk = false;
-    if (!attr_sk) {
-      (void)hipFuncSetAttribute((const void*)gemm_nt_256sk<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
-      (void)hipFuncSetAttribute((const void*)gemm_nt_256sk<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
-      attr_sk = true;
-    }
-    if (out_f32) hipLaunchKernelGGL(gemm_nt_256sk<true>, dim3((unsigned)big_tiles), dim3(512), 131072, stream, p);
-    else hipLaunchKernelGGL(gemm_nt_256sk<false>, dim3((unsigned)big_tiles), dim3(512), 131072, stream, p);
   } else if (fast && force_generic == 4) {
     static bool attr_pp = false;
     if (!attr_pp) {
@@ -1260,6 +944,40 @@ int vp_gemm_bf16(int M, int N, int K, const void* A, long lda, const void* B, lo
   }
   return vp_check_launch("vp_gemm_bf16");
 }
+
+// Fused SwiGLU GEMMs for the decoder MLP (reference: HF LlamaMLP.forward, modeling_llama.py — down(act(gate(x)) * up(x)); the
+// fused gate/up weight keeps its columns interleaved in 8-wide chunks: g0..7 | u0..7 | g8..15 | ...).
+//   mode 1 (forward):  C[M,N] = A[M,K] B[N,K]^T (gate_up), C2[M,N/2] = silu(gate) * up         (aux unused)
+//   mode 2 (backward): d_act[M,N] = A B^T stays on chip; aux = gate_up[M,2N]; C[M,2N] = d_gate_up  (C2 unused)
+// Only the 8-phase kernel implements these epilogues: M, N multiples of 256, K a multiple of 64, 16-byte aligned rows.
+int vp_gemm_bf16_swiglu(int mode, int M, int N, int K, const void* A, long lda, const void* B, long ldb, void* C, long ldc,
+                        void* C2, long ldc2, const void* aux, long ldaux, hipStream_t stream) {
+  VP_REQUIRE(mode == 1 || mode == 2, VP_ERR_BAD_ARG, "vp_gemm_bf16_swiglu: mode %d", mode);
+  VP_REQUIRE(M > 0 && N > 0 && K > 0 && A && B && C, VP_ERR_BAD_ARG, "vp_gemm_bf16_swiglu: bad operands");
+  VP_REQUIRE(M % 256 == 0 && N % 256 == 0 && K % 64 == 0, VP_ERR_UNSUPPORTED_SHAPE,
+             "vp_gemm_bf16_swiglu: needs M, N multiples of 256 and K a multiple of 64 (got %d %d %d)", M, N, K);
+  VP_REQUIRE(lda >= K && ldb >= K && lda % 8 == 0 && ldb % 8 == 0 && ldc % 8 == 0 &&
+                 ((((uintptr_t)A) | ((uintptr_t)B) | ((uintptr_t)C)) & 15) == 0,
+             VP_ERR_BAD_ARG, "vp_gemm_bf16_swiglu: leading dims / alignment");
+  if (mode == 1)
+    VP_REQUIRE(C2 && ldc >= N && ldc2 >= N / 2 && ldc2 % 8 == 0 && (((uintptr_t)C2) & 15) == 0, VP_ERR_BAD_ARG,
+               "vp_gemm_bf16_swiglu: forward outputs");
+  if (mode == 2)
+    VP_REQUIRE(aux && ldc >= 2 * N && ldaux >= 2 * N && ldaux % 8 == 0 && (((uintptr_t)aux) & 15) == 0, VP_ERR_BAD_ARG,
+               "vp_gemm_bf16_swiglu: backward operands");
+  GemmArgs p{(const bf16_t*)A, (const bf16_t*)B, C, nullptr, nullptr, M, N, K, lda, ldb, ldc, 0, EPI_NONE, 0,
+             mode, C2, ldc2, (const bf16_t*)aux, ldaux};
+  static bool attr_p8 = false;
+  if (!attr_p8) {
+    (void)hipFuncSetAttribute((const void*)gemm_nt_256p8<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+    attr_p8 = true;
+  }
+  const long big_tiles = (long)(M / 256) * (N / 256);
+  const unsigned g8 = (unsigned)(((K / 64) % 2 == 0 && big_tiles > 256) ? 256 : big_tiles);
+  hipLaunchKernelGGL(gemm_nt_256p8<false>, dim3(g8), dim3(512), 131072, stream, p);
+  return vp_check_launch("vp_gemm_bf16_swiglu");
+}
+
 
 int vp_transpose_bf16(int rows, int cols, const void* in, long ld_in, void* out, long ld_out, hipStream_t stream) {
   VP_REQUIRE(rows > 0 && cols > 0 && in && out, VP_ERR_BAD_ARG, "vp_transpose_bf16: bad args");

@@ -208,7 +208,7 @@ class Engine:
                 wqkv = torch.cat([W[p + f"self_attn.{x}_proj.weight"] for x in "qkv"], 0)
                 wgu = torch.cat([W[p + "mlp.gate_proj.weight"], W[p + "mlp.up_proj.weight"]], 0)
             fz[o + "wqkv"] = d(wqkv)
-            fz[o + "wgu"] = d(wgu)
+            fz[o + "wgu"] = ops.interleave_gate_up(d(wgu))      # gate / up rows interleaved in 8-row chunks (fused SwiGLU epilogues)
             fz[o + "wo"] = d(W[p + "self_attn.o_proj.weight"])
             fz[o + "wd"] = d(W[p + "mlp.down_proj.weight"])
             for k in ("wqkv", "wgu", "wo", "wd"):
@@ -553,8 +553,13 @@ class Engine:
             att, lse = ops.attn_fwd(q4, k4, v4, causal=True, window=window, kv_len=kv_len)
             h1 = ops.gemm(att.view(M, nh * hd), fz[o + "wo"], residual=x)
             hn, rstd2 = ops.rmsnorm_fwd(h1, fz[o + "ln2"], cfg.rms_norm_eps)
-            gu = ops.gemm(hn, fz[o + "wgu"])
-            act = ops.swiglu_fwd(gu)
+            fuse = ops.swiglu_fusable(M, 2 * cfg.intermediate_size, cfg.hidden_size) and \
+                ops.swiglu_fusable(M, cfg.intermediate_size, cfg.hidden_size)
+            if fuse:
+                gu, act = ops.gemm_swiglu_fwd(hn, fz[o + "wgu"])
+            else:
+                gu = ops.gemm(hn, fz[o + "wgu"])
+                act = ops.swiglu_fwd(gu)
             xo = ops.gemm(act, fz[o + "wd"], residual=h1)
             if compute_grads:
                 saved.append((x, rstd1, qkv, att, lse, h1, rstd2, gu))
@@ -649,9 +654,12 @@ class Engine:
             x_in, rstd1, qkv, att, lse, h1, rstd2, gu = saved[l]
             if l in d_state and l != L - 1:
                 ops.add(dx, d_state[l], out=dx)
-            d_act = ops.gemm(dx, fz[o + "wd_T"])
-            d_gu = ops.swiglu_bwd(d_act, gu)
-            del d_act
+            if ops.swiglu_fusable(M, cfg.intermediate_size, cfg.hidden_size) and gu.is_contiguous():
+                d_gu = ops.gemm_swiglu_bwd(dx, fz[o + "wd_T"], gu)
+            else:
+                d_act = ops.gemm(dx, fz[o + "wd_T"])
+                d_gu = ops.swiglu_bwd(d_act, gu)
+                del d_act
             d_hn = ops.gemm(d_gu, fz[o + "wgu_T"])
             del d_gu
             d_h1 = ops.rmsnorm_bwd(d_hn, h1, fz[o + "ln2"], rstd2, dres=dx)

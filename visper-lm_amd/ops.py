@@ -63,6 +63,56 @@ def gemm(a, w, bias=None, residual=None, epi=EPI_NONE, out=None, out_f32=False, 
     return out
 
 
+def swiglu_fusable(M, N, K):
+    """Shapes the fused SwiGLU GEMM epilogues accept (vp_gemm_bf16_swiglu: 8-phase kernel, interior tiles only)."""
+    return M % 256 == 0 and N % 256 == 0 and K % 64 == 0
+
+
+def interleave_gate_up(w_gate_up):
+    """[gate; up] row halves (HF gate_proj / up_proj, or Phi-3's fused gate_up_proj) -> rows interleaved in 8-wide chunks
+    (g0..7, u0..7, g8..15, ...): the layout of every gate_up / d_gate_up activation in this library."""
+    F2 = w_gate_up.shape[0]
+    F = F2 // 2
+    assert F % 8 == 0
+    g, u = w_gate_up[:F], w_gate_up[F:]
+    rest = w_gate_up.shape[1:]
+    return torch.stack([g.reshape(F // 8, 8, *rest), u.reshape(F // 8, 8, *rest)], 1).reshape(F2, *rest).contiguous()
+
+
+def gemm_swiglu_fwd(a, w_gu):
+    """gate_up = a @ w_gu^T (chunk-interleaved), act = silu(gate) * up, in one kernel.  Returns (gate_up, act)."""
+    M, K, lda = _rows2d(a)
+    N, K2, ldb = _rows2d(w_gu)
+    assert K == K2 and swiglu_fusable(M, N, K)
+    gu = torch.empty(*a.shape[:-1], N, device=a.device, dtype=BF16)
+    act = torch.empty(*a.shape[:-1], N // 2, device=a.device, dtype=BF16)
+    if GEMM_PROF is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    _lib.call("vp_gemm_bf16_swiglu", 1, M, N, K, _p(a), lda, _p(w_gu), ldb, _p(gu), N, _p(act), N // 2, None, 0, _stream())
+    if GEMM_PROF is not None:
+        e1.record()
+        GEMM_PROF.append((e0, e1, 2.0 * M * N * K, (M, N, K)))
+    return gu, act
+
+
+def gemm_swiglu_bwd(dy, w_down_T, gate_up):
+    """d_gate_up = swiglu_bwd(dy @ w_down_T^T, gate_up) in one kernel (d_act never leaves the chip)."""
+    M, K, lda = _rows2d(dy)
+    N, K2, ldb = _rows2d(w_down_T)
+    assert K == K2 and swiglu_fusable(M, N, K) and gate_up.shape[-1] == 2 * N and gate_up.is_contiguous()
+    dgu = torch.empty_like(gate_up)
+    if GEMM_PROF is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    _lib.call("vp_gemm_bf16_swiglu", 2, M, N, K, _p(dy), lda, _p(w_down_T), ldb, _p(dgu), 2 * N, None, 0, _p(gate_up), 2 * N,
+              _stream())
+    if GEMM_PROF is not None:
+        e1.record()
+        GEMM_PROF.append((e0, e1, 2.0 * M * N * K, (M, N, K)))
+    return dgu
+
+
 def transpose(x, out=None):
     """2-D transpose (bf16)."""
     R, Cc, ldi = _rows2d(x)
@@ -141,6 +191,7 @@ def dwconv7x7_nhwc(x, w_tap_major, bias):
 
 
 def swiglu_fwd(gate_up):
+    """gate_up: [..., 2F] chunk-interleaved (see interleave_gate_up) -> silu(gate) * up [..., F]."""
     M, F2, ldg = _rows2d(gate_up)
     F = F2 // 2
     out = torch.empty(*gate_up.shape[:-1], F, device=gate_up.device, dtype=BF16)
