@@ -56,6 +56,9 @@ int vp_gemm_bf16(int M, int N, int K, const void* A, long lda, const void* B, lo
 int vp_gemm_bf16_swiglu(int mode, int M, int N, int K, const void* A, long lda, const void* B, long ldb, void* C, long ldc,
                         void* C2, long ldc2, const void* aux, long ldaux, vp_stream_t stream);
 
+/* dev aid (tools/gemm_stamps.py): per-block timestamps written by gemm_nt_256p8 when VP_GEMM_DBG=65536; 256*8 longs. */
+int vp_debug_stamps(long* host);
+
 int vp_transpose_bf16(int rows, int cols, const void* in, long ld_in, void* out, long ld_out, vp_stream_t stream);
 
 /* ---- norms.  HF LlamaRMSNorm (modeling_llama.py:53-68); nn.LayerNorm in CLIP and the resampler
