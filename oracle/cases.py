@@ -48,7 +48,7 @@ def tiny_llama_case(arch="llama"):
                         vit_heads=t["vit_heads"], aux_mode=t["aux_mode"], image_gen=t["image_gen"],
                         image_seg=t["image_seg"], image_depth=t["image_depth"])
     manifest = json.loads(str(g["manifest"]))
-    W = {k: WT.param(k, s) for k, s in manifest.items() if not k.startswith("da_v2_head.")}
+    W = {k: WT.param(k, s) for k, s in manifest.items()}
     B, T, col = json.loads(str(g["batch"])) if "batch" in g else (2, 59, 38)
     batch = make_batch(B, T, col)
     assert np.array_equal(batch["input_ids"].numpy(), g["input_ids"])

@@ -186,9 +186,8 @@ def _fresh_tiny_llama(B, tiny=None, arch="llama"):
     model, cfg = build_llama(tiny or TINY_LLAMA, arch)
     # PT-stage trainability (ola_vlm_train.py:1127-1131,1147): LLM + tower frozen.
     shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
-    sd = {k: WT.param(k, s) for k, s in shapes.items() if not k.startswith("da_v2_head.")}
-    missing = model.load_state_dict(sd, strict=False)
-    assert all(k.startswith("da_v2_head.") for k in missing.missing_keys), missing
+    sd = {k: WT.param(k, s) for k, s in shapes.items()}
+    model.load_state_dict(sd, strict=True)                 # including the frozen DPT decoder (da_v2_head.*)
     model.requires_grad_(False)
     for n, p in model.named_parameters():
         if ("mm_projector" in n or "_heads." in n or "special_" in n or "logit_scale" in n):
@@ -237,6 +236,8 @@ def run_tiny_llama(arch="llama"):
                 res[f"hidden{li}_sub"] = hs[li][:, ::13, ::3].detach().numpy().copy()
             res["depth_embs_len"] = np.array(len(out.depth_embs[0]))
             res["depth_preds_shape"] = np.array(out.depth_preds[0].shape)
+            res["depth_pred_sub"] = out.depth_preds[0][:, ::5, ::5].detach().float().numpy().copy()   # a11: DPT decoder output
+            res["depth_pred_mean"] = np.float64(out.depth_preds[0].double().mean().item())
             res["seg_emb_sub"] = sub(out.seg_embs[0], 2048)
             res["gen_emb_sub"] = sub(out.image_embs[0], 1024)
         grads = {}

@@ -442,6 +442,96 @@ def head_forward(state, task, i, W, cfg):
 
 
 # ----------------------------------------------------------------------------------------------
+# a11: frozen DPT depth decoder  (aux_heads/da_v2_head.py:182-321; called under no_grad at
+# base_ola_vlm.py:462-470 on the depth head's 4 feature maps; output only -> `depth_preds`)
+# ----------------------------------------------------------------------------------------------
+DPT_OUT_CHANNELS = (256, 512, 1024, 1024)             # da_v2_head.py:300 (vitl)
+DPT_FEATURES = 256
+
+
+def _rcu(x, W, p):
+    """ResidualConvUnit.forward (da_v2_head.py:63-88), bn=False: conv2(relu(conv1(relu(x)))) + x."""
+    out = F.conv2d(F.relu(x), W[p + "conv1.weight"], W[p + "conv1.bias"], padding=1)
+    out = F.conv2d(F.relu(out), W[p + "conv2.weight"], W[p + "conv2.bias"], padding=1)
+    return out + x
+
+
+def _fusion(W, p, x0, x1=None, size=None):
+    """FeatureFusionBlock.forward (da_v2_head.py:127-153): align_corners=True bilinear, then the 1x1 out_conv."""
+    out = x0
+    if x1 is not None:
+        out = out + _rcu(x1, W, p + "resConfUnit1.")
+    out = _rcu(out, W, p + "resConfUnit2.")
+    if size is None:
+        out = F.interpolate(out, scale_factor=2, mode="bilinear", align_corners=True)
+    else:
+        out = F.interpolate(out, size=tuple(size), mode="bilinear", align_corners=True)
+    return F.conv2d(out, W[p + "out_conv.weight"], W[p + "out_conv.bias"])
+
+
+def dpt_depth_pred(feats, W, prefix="da_v2_head.depth_head.", patch=24):
+    """DAv2_Head.forward (da_v2_head.py:316-321) + DPTHead.forward (:260-293) + the min-max normalisation of
+    base_ola_vlm.py:466-468.  feats: 4 tensors (B, patch*patch, 1024) -> (B, 14*patch, 14*patch)."""
+    outs = []
+    for i, x in enumerate(feats):
+        x = x.permute(0, 2, 1).reshape(x.shape[0], x.shape[-1], patch, patch)
+        x = F.conv2d(x, W[prefix + f"projects.{i}.weight"], W[prefix + f"projects.{i}.bias"])
+        if i == 0:
+            x = F.conv_transpose2d(x, W[prefix + "resize_layers.0.weight"], W[prefix + "resize_layers.0.bias"], stride=4)
+        elif i == 1:
+            x = F.conv_transpose2d(x, W[prefix + "resize_layers.1.weight"], W[prefix + "resize_layers.1.bias"], stride=2)
+        elif i == 3:
+            x = F.conv2d(x, W[prefix + "resize_layers.3.weight"], W[prefix + "resize_layers.3.bias"], stride=2, padding=1)
+        outs.append(x)
+    sc = prefix + "scratch."
+    rn = [F.conv2d(outs[i], W[sc + f"layer{i + 1}_rn.weight"], None, padding=1) for i in range(4)]
+    path4 = _fusion(W, sc + "refinenet4.", rn[3], size=rn[2].shape[2:])
+    path3 = _fusion(W, sc + "refinenet3.", path4, rn[2], size=rn[1].shape[2:])
+    path2 = _fusion(W, sc + "refinenet2.", path3, rn[1], size=rn[0].shape[2:])
+    path1 = _fusion(W, sc + "refinenet1.", path2, rn[0])
+    out = F.conv2d(path1, W[sc + "output_conv1.weight"], W[sc + "output_conv1.bias"], padding=1)
+    out = F.interpolate(out, (14 * patch, 14 * patch), mode="bilinear", align_corners=True)
+    out = F.relu(F.conv2d(out, W[sc + "output_conv2.0.weight"], W[sc + "output_conv2.0.bias"], padding=1))
+    out = F.relu(F.conv2d(out, W[sc + "output_conv2.2.weight"], W[sc + "output_conv2.2.bias"]))
+    depth = F.relu(out).squeeze(1)
+    mn, mx = depth.amin(dim=(1, 2), keepdim=True), depth.amax(dim=(1, 2), keepdim=True)
+    return (depth - mn) / (mx - mn)
+
+
+def dpt_param_shapes(prefix="da_v2_head.depth_head."):
+    """State-dict names/shapes of DAv2_Head('vitl') (da_v2_head.py:182-258, 296-314)."""
+    oc, f = DPT_OUT_CHANNELS, DPT_FEATURES
+    sh = {}
+    for i, c in enumerate(oc):
+        sh[prefix + f"projects.{i}.weight"] = (c, 1024, 1, 1)
+        sh[prefix + f"projects.{i}.bias"] = (c,)
+    sh[prefix + "resize_layers.0.weight"] = (oc[0], oc[0], 4, 4)
+    sh[prefix + "resize_layers.0.bias"] = (oc[0],)
+    sh[prefix + "resize_layers.1.weight"] = (oc[1], oc[1], 2, 2)
+    sh[prefix + "resize_layers.1.bias"] = (oc[1],)
+    sh[prefix + "resize_layers.3.weight"] = (oc[3], oc[3], 3, 3)
+    sh[prefix + "resize_layers.3.bias"] = (oc[3],)
+    sc = prefix + "scratch."
+    for i, c in enumerate(oc):
+        sh[sc + f"layer{i + 1}_rn.weight"] = (f, c, 3, 3)
+    for r in (1, 2, 3, 4):
+        p = sc + f"refinenet{r}."
+        sh[p + "out_conv.weight"] = (f, f, 1, 1)
+        sh[p + "out_conv.bias"] = (f,)
+        for u in (1, 2):
+            for cv in (1, 2):
+                sh[p + f"resConfUnit{u}.conv{cv}.weight"] = (f, f, 3, 3)
+                sh[p + f"resConfUnit{u}.conv{cv}.bias"] = (f,)
+    sh[sc + "output_conv1.weight"] = (f // 2, f, 3, 3)
+    sh[sc + "output_conv1.bias"] = (f // 2,)
+    sh[sc + "output_conv2.0.weight"] = (32, f // 2, 3, 3)
+    sh[sc + "output_conv2.0.bias"] = (32,)
+    sh[sc + "output_conv2.2.weight"] = (1, 32, 1, 1)
+    sh[sc + "output_conv2.2.bias"] = (1,)
+    return sh
+
+
+# ----------------------------------------------------------------------------------------------
 # embedding losses  (base_ola_vlm.py:289-320 ; ola_utils.py:96-125)
 # ----------------------------------------------------------------------------------------------
 def contrastive_loss(preds, targets, logit_scale, rank=0, gathered_targets=None):
@@ -498,6 +588,9 @@ def forward(W, batch, cfg, rank=0, gathered=None, need_logits=True):
         for i, idx in enumerate(layer_indices(hcfg[ikey])):
             pred, extra = head_forward(states[idx], task, i, W, cfg)
             embs.append(extra if extra is not None else pred)
+            if task == "depth" and "da_v2_head.depth_head.projects.0.weight" in W:
+                with torch.no_grad():                          # base_ola_vlm.py:462-470
+                    out.setdefault("depth_preds", []).append(dpt_depth_pred([f.detach() for f in extra], W))
             tgt = batch.get(f"{task}_target")
             if tgt is None:
                 continue

@@ -58,6 +58,12 @@ def param(name: str, shape) -> torch.Tensor:
     if "embed_tokens" in name or "position_embedding" in name:
         return tensor(name, shape, 0.05)
     fan_in = int(np.prod(shape[1:]))
+    if name.startswith("da_v2_head."):
+        # ~25 ReLU convs deep: He-style gain keeps the signal alive; ConvTranspose2d weights are [in, out, k, k] and
+        # each output pixel sees exactly `in` taps
+        if "resize_layers.0." in name or "resize_layers.1." in name:
+            fan_in = shape[0]
+        return tensor(name, shape, 1.4 / np.sqrt(fan_in))
     return tensor(name, shape, 0.8 / np.sqrt(fan_in))
 
 

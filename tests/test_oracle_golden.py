@@ -95,6 +95,16 @@ def test_e2e_forward_matches_reference(tiny):
     assert int(g["depth_embs_len"]) == len(out["depth_embs"][0]) == 4
 
 
+def test_e2e_dpt_depth_pred_matches_reference(tiny, tiny_phi3):
+    """a11: the frozen DPT decoder (da_v2_head.py:260-321) + min-max normalisation (base_ola_vlm.py:462-470)."""
+    for cfg, W, batch, g, out, tr in (tiny, tiny_phi3):
+        dp = out["depth_preds"][0]
+        assert tuple(dp.shape) == tuple(g["depth_preds_shape"]) == (2, 336, 336)
+        assert float(dp.min()) == 0.0 and abs(float(dp.max()) - 1.0) < 1e-6
+        _close(dp[:, ::5, ::5].numpy(), g["depth_pred_sub"], 2e-3, 2e-4)
+        _close(float(dp.double().mean()), g["depth_pred_mean"], 1e-3, 1e-5)
+
+
 def test_e2e_gradients_match_reference(tiny):
     cfg, W, batch, g, out, tr = tiny
     none_ref = set(json.loads(str(g["keep_grad_none"])))
