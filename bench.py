@@ -143,6 +143,10 @@ def main():
     ap.add_argument("--text-len", type=int, default=1449)          # -> post-splice S = 2048 with 3 tasks
     ap.add_argument("--layers", type=int, default=None, help="debug only: fewer decoder layers (result marked invalid)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-depth-decoder", action="store_true",
+                    help="skip the frozen DPT depth decoder (depth_preds: a logging-only output the reference computes under no_grad in "
+                         "every training step, base_ola_vlm.py:462-470; ~6 ms/step here); on by default so the timed step does all the "
+                         "reference's work")
     ap.add_argument("--workload", default="llama3_8b", choices=["llama3_8b", "convnext", "phi3"],
                     help="llama3_8b = BASELINE configs[1] (the headline metric); convnext = configs[3]; phi3 = configs[4] (secondary)")
     ap.add_argument("--lr", type=float, default=1e-3)
@@ -176,6 +180,7 @@ def main():
             args.text_len, args.batch = 3497, min(args.batch, 4)      # post-splice S = 4096
     else:
         cfg = llama3_8b()
+    cfg.depth_decoder = not args.no_depth_decoder
     if args.layers:
         cfg.num_hidden_layers = args.layers
         cfg.image_gen["img_layer_indices"] = str(min(20, args.layers))
@@ -248,6 +253,7 @@ def main():
                                        "phi3": "configs[4]: CLIP-ViT-L/14-336 + Phi-3-mini PT step, 3 distill heads, seq 4096"}[args.workload],
                           "global_batch": args.batch * world, "per_gpu_batch": args.batch, "seq_len": S, "text_len": args.text_len,
                           "parallelism": f"dp{world}", "decoder_layers": cfg.num_hidden_layers, "loss": round(loss, 4),
+                          "depth_decoder": not args.no_depth_decoder,
                           "valid": args.layers is None},
                "roofline": roof}
         if world == 1 and not args.no_cpu_baseline and args.workload == "llama3_8b":

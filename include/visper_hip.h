@@ -104,6 +104,15 @@ int vp_cast_f32_to_bf16(long n, const float* x, void* y, vp_stream_t stream);
 int vp_cast_bf16_to_f32(long n, const void* x, float* y, int accumulate, vp_stream_t stream);
 int vp_sum_f32(long n, const float* x, float* out, float scale, vp_stream_t stream);
 
+/* ---- frozen DPT depth decoder (da_v2_head.py:182-321, run under no_grad at base_ola_vlm.py:462-470; output `depth_preds`).
+ * NHWC bf16.  3x3 convs = vp_im2col3x3_nhwc (pad 1, stride 1|2, optional input ReLU of ResidualConvUnit; column order
+ * (ky, kx, c)) + vp_gemm_bf16; ConvTranspose2d(k = stride) = vp_gemm_bf16 to [pixels, k*k*C] + vp_pixel_shuffle_nhwc;
+ * F.interpolate(mode="bilinear", align_corners=True) = vp_bilinear_nhwc; (x - min) / (max - min) per image = vp_minmax_norm. */
+int vp_im2col3x3_nhwc(int B, int H, int W, int C, int stride, int relu_in, const void* x, void* col, vp_stream_t stream);
+int vp_bilinear_nhwc(int B, int H, int W, int C, int Ho, int Wo, const void* x, void* y, vp_stream_t stream);
+int vp_pixel_shuffle_nhwc(int B, int H, int W, int k, int C, const void* x, void* y, vp_stream_t stream);
+int vp_minmax_norm(int B, long n, const void* x, void* y, vp_stream_t stream);
+
 /* ---- attention.  HF LlamaAttention eager path (modeling_llama.py:191-214: QK^T/sqrt(d) + causal mask,
  * fp32 softmax, PV), HF CLIPAttention (non-causal), PerceiverAttention (resampler.py:46-75; scale d^-1/4
  * on q and k == d^-1/2 on the product).  Tensors are [B,S,H,D] views (strides in elements, multiples of 8; 16-byte

@@ -23,7 +23,7 @@ def tiny():
     from visper_lm_amd.config import VisperConfig
     from visper_lm_amd.engine import Engine
     ocfg, W, batch, g = cases.tiny_llama_case()
-    cfg = VisperConfig(**vars(ocfg))
+    cfg = VisperConfig(**vars(ocfg), depth_decoder=True)      # a11: also run the frozen DPT decoder (depth_preds)
     eng = Engine(cfg)
     eng.load_weights(W)
     eng.keep_logits = True
@@ -43,6 +43,23 @@ def tiny():
 
 def rel(a, b):
     return abs(float(a) - float(b)) / max(abs(float(b)), 1e-12)
+
+
+def test_dpt_depth_pred_matches_oracle_and_reference_golden(tiny):
+    """a11 (da_v2_head.py:260-321 + base_ola_vlm.py:462-470): ~25 bf16 convolutions deep and min-max normalised to [0, 1], so
+    the tolerance is stated on the map itself: mean |err| < 1e-2, max |err| < 8e-2 against the fp32 oracle on the SAME bf16
+    features, and mean |err| < 2e-2 against the reference's own fp32 output (which also differs in the upstream features)."""
+    from oracle import visper_oracle as O
+    eng, out, g, Wq = tiny["eng"], tiny["out"], tiny["g"], tiny["Wq"]
+    dp = out["depth_preds"][0].float().cpu()
+    assert tuple(dp.shape) == (2, 336, 336) and float(dp.min()) == 0.0 and abs(float(dp.max()) - 1.0) < 1e-2
+    feats = [f.float().cpu() for f in out["depth_feats"][0]]
+    with torch.no_grad():
+        ref = O.dpt_depth_pred(feats, {k: v.detach() for k, v in Wq.items()})
+    err = (dp - ref).abs()
+    assert float(err.mean()) < 1e-2 and float(err.max()) < 8e-2, (float(err.mean()), float(err.max()))
+    gerr = (dp[:, ::5, ::5].numpy() - g["depth_pred_sub"])
+    assert float(np.abs(gerr).mean()) < 2e-2, float(np.abs(gerr).mean())
 
 
 def test_losses_match_oracle_and_reference_golden(tiny):

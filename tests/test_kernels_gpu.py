@@ -371,3 +371,30 @@ def test_emb_loss(ops, B, world, rank, shape, mask):
     dp = ops.emb_loss_bwd(dev(pred).reshape(B, D), dev(tg_all), coef, 0.5, rank=rank)
     close(dp.reshape(shape), pr.grad, rtol=3e-2, atol=2e-2 * float(pr.grad.abs().max()), what="emb loss dpred")
     close(coef[-1:] * 0.5, ls.grad[None], rtol=5e-3, atol=1e-6, what="dlogit_scale")
+
+
+def test_dpt_conv_helpers(ops):
+    """conv.hip (frozen DPT decoder, da_v2_head.py:182-321): im2col3x3 + GEMM == F.conv2d, GEMM + pixel shuffle ==
+    F.conv_transpose2d(k = stride), bilinear align_corners=True, per-image min-max normalisation."""
+    B, H, W, C, Co = 2, 12, 10, 16, 24
+    x = rnd(B, H, W, C, seed=40)
+    xn = x.float().permute(0, 3, 1, 2)
+    for stride, relu_in in ((1, False), (2, False), (1, True)):
+        w = rnd(Co, C, 3, 3, seed=41) * 0.2
+        b = rnd(Co, seed=42)
+        ref = F.conv2d(F.relu(xn) if relu_in else xn, w.float(), b.float(), stride=stride, padding=1).permute(0, 2, 3, 1)
+        wm = dev(w.permute(0, 2, 3, 1).reshape(Co, -1).contiguous())
+        got = ops.conv3x3_nhwc(dev(x), wm, bias=dev(b), stride=stride, relu_in=relu_in)
+        close(got, ref, what=f"conv3x3 s{stride} relu{relu_in}")
+    for k in (2, 4):
+        wt = rnd(C, Co, k, k, seed=43) * 0.2
+        bt = rnd(Co, seed=44)
+        ref = F.conv_transpose2d(xn, wt.float(), bt.float(), stride=k).permute(0, 2, 3, 1)
+        wm = dev(wt.permute(2, 3, 1, 0).reshape(k * k * Co, C).contiguous())
+        close(ops.conv_transpose_nhwc(dev(x), wm, dev(bt.repeat(k * k)), k), ref, what=f"conv_transpose k{k}")
+    for (Ho, Wo) in ((24, 20), (17, 31), (12, 10)):
+        ref = F.interpolate(xn, size=(Ho, Wo), mode="bilinear", align_corners=True).permute(0, 2, 3, 1)
+        close(ops.bilinear_nhwc(dev(x), Ho, Wo), ref, rtol=1e-2, what=f"bilinear {Ho}x{Wo}")
+    d = rnd(3, 1000, seed=45).abs()
+    mn, mx = d.float().amin(1, keepdim=True), d.float().amax(1, keepdim=True)
+    close(ops.minmax_norm(dev(d)), (d.float() - mn) / (mx - mn), what="minmax")

@@ -10,7 +10,7 @@ from visper_lm_amd.engine import is_trainable
 
 def test_manifest_matches_reference_state_dict():
     ocfg, W, batch, g = cases.tiny_llama_case()
-    ref = {k: tuple(v) for k, v in json.loads(str(g["manifest"])).items() if not k.startswith("da_v2_head.")}
+    ref = {k: tuple(v) for k, v in json.loads(str(g["manifest"])).items()}
     mine = param_shapes(VisperConfig(**vars(ocfg)), vit_nested=False)
     assert set(mine) == set(ref), (sorted(set(mine) ^ set(ref))[:10])
     for k in ref:
@@ -34,7 +34,7 @@ def test_api_mirror_state_dict_keys_cpu():
     from visper_lm_amd.model import OlaLlavaLlamaForCausalLM, OlaLlavaLlamaConfig
     ocfg, W, batch, g = cases.tiny_llama_case()
     model = OlaLlavaLlamaForCausalLM(OlaLlavaLlamaConfig(**vars(ocfg)), device="cpu", init="empty")
-    ref = {k: tuple(v) for k, v in json.loads(str(g["manifest"])).items() if not k.startswith("da_v2_head.")}
+    ref = {k: tuple(v) for k, v in json.loads(str(g["manifest"])).items()}
     ref = {(k.replace("model.vision_tower.vision_tower.", "model.vision_tower.vision_tower.vision_model.")
             if k.startswith("model.vision_tower.vision_tower.") else k): v for k, v in ref.items()}
     sd = model.state_dict()

@@ -38,6 +38,7 @@ class VisperConfig:
                            seg_layer_indices="18", seg_loss_weight=0.5),
             tokenizer_model_max_length=4096, tokenizer_padding_side="right",
             zero_masks=False,      # True reproduces the as-released `mask.zero_()` (base_ola_vlm.py:472-473,...)
+            depth_decoder=False,   # True also runs the frozen DPT decoder on every depth head (base_ola_vlm.py:462-470 -> depth_preds)
         )
         d.update(kw)
         if "mm_hidden_size" not in kw:

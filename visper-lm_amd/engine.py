@@ -215,6 +215,35 @@ class Engine:
                 fz[o + k + "_T"] = _tp(fz[o + k])
             fz[o + "ln1"] = d(W[p + "input_layernorm.weight"])
             fz[o + "ln2"] = d(W[p + "post_attention_layernorm.weight"])
+        # ---- frozen DPT depth decoder (a11; da_v2_head.py:182-314): conv weights as GEMM matrices over NHWC activations
+        dp = "da_v2_head.depth_head."
+        if dp + "projects.0.weight" in W:
+            c3 = lambda k: d(W[k].permute(0, 2, 3, 1).reshape(W[k].shape[0], -1))            # [Co,Ci,3,3] -> [Co, (ky,kx,ci)]
+            c1 = lambda k: d(W[k].reshape(W[k].shape[0], -1))                                # [Co,Ci,1,1] -> [Co, Ci]
+            for i in range(4):
+                fz[f"dpt.proj{i}.w"], fz[f"dpt.proj{i}.b"] = c1(dp + f"projects.{i}.weight"), d(W[dp + f"projects.{i}.bias"])
+                fz[f"dpt.rn{i}.w"] = c3(dp + f"scratch.layer{i + 1}_rn.weight")
+            for i, k in ((0, 4), (1, 2)):                                                    # ConvTranspose2d(k = stride): [Ci,Co,k,k]
+                w = W[dp + f"resize_layers.{i}.weight"]
+                fz[f"dpt.up{i}.w"] = d(w.permute(2, 3, 1, 0).reshape(k * k * w.shape[1], w.shape[0]))     # rows (ky, kx, co)
+                fz[f"dpt.up{i}.b"] = d(W[dp + f"resize_layers.{i}.bias"].repeat(k * k))
+            fz["dpt.down3.w"], fz["dpt.down3.b"] = c3(dp + "resize_layers.3.weight"), d(W[dp + "resize_layers.3.bias"])
+            for r in (1, 2, 3, 4):
+                q = dp + f"scratch.refinenet{r}."
+                fz[f"dpt.ref{r}.out.w"], fz[f"dpt.ref{r}.out.b"] = c1(q + "out_conv.weight"), d(W[q + "out_conv.bias"])
+                for u in (1, 2):
+                    for cv in (1, 2):
+                        fz[f"dpt.ref{r}.rcu{u}.c{cv}.w"] = c3(q + f"resConfUnit{u}.conv{cv}.weight")
+                        fz[f"dpt.ref{r}.rcu{u}.c{cv}.b"] = d(W[q + f"resConfUnit{u}.conv{cv}.bias"])
+            sc = dp + "scratch."
+            fz["dpt.oc1.w"], fz["dpt.oc1.b"] = c3(sc + "output_conv1.weight"), d(W[sc + "output_conv1.bias"])
+            fz["dpt.oc2a.w"], fz["dpt.oc2a.b"] = c3(sc + "output_conv2.0.weight"), d(W[sc + "output_conv2.0.bias"])
+            # the last 1x1 conv has one output channel: pad to 8 rows so the GEMM output rows stay 16-byte aligned
+            w1 = torch.zeros(8, 32, dtype=torch.float32, device=W[sc + "output_conv2.2.weight"].device)
+            w1[0] = W[sc + "output_conv2.2.weight"].reshape(-1).float()
+            b1 = torch.zeros(8, dtype=torch.float32, device=w1.device)
+            b1[0] = W[sc + "output_conv2.2.bias"].reshape(-1).float()[0]
+            fz["dpt.oc2b.w"], fz["dpt.oc2b.b"] = d(w1), d(b1)
         # ---- trainable.  Flat-buffer order: [heads + logit scales | projector + task tokens] so the first block's
         # gradients (final as soon as the heads' backward is done) can be all-reduced under the decoder backward.
         allshapes = getattr(W, "shapes", None) or OrderedDict((k, tuple(v.shape)) for k, v in W.items())
@@ -347,6 +376,50 @@ class Engine:
         if cfg.mm_vision_select_feature == "patch":
             x = x[:, 1:]
         return x.contiguous().view(-1, C)
+
+    # ------------------------------------------------------------------------------------------ a11: DPT depth decoder
+    def dpt_forward(self, feats):
+        """DAv2_Head.forward + DPTHead.forward (da_v2_head.py:260-293, 316-321) and the min-max normalisation of
+        base_ola_vlm.py:466-468, frozen / no grad.  feats: 4 x [B, 576, 1024] bf16 -> depth_pred [B, 336, 336] bf16."""
+        fz = self.fz
+        if "dpt.proj0.w" not in fz:
+            raise RuntimeError("the DPT depth decoder weights (da_v2_head.*) were not loaded")
+        B, P = feats[0].shape[0], int(round(feats[0].shape[1] ** 0.5))
+        outs = []
+        for i, x in enumerate(feats):
+            x = ops.gemm(x.reshape(B * P * P, -1), fz[f"dpt.proj{i}.w"], bias=fz[f"dpt.proj{i}.b"]).view(B, P, P, -1)
+            if i == 0:
+                x = ops.conv_transpose_nhwc(x, fz["dpt.up0.w"], fz["dpt.up0.b"], 4)
+            elif i == 1:
+                x = ops.conv_transpose_nhwc(x, fz["dpt.up1.w"], fz["dpt.up1.b"], 2)
+            elif i == 3:
+                x = ops.conv3x3_nhwc(x, fz["dpt.down3.w"], bias=fz["dpt.down3.b"], stride=2)
+            outs.append(x)
+        rn = [ops.conv3x3_nhwc(outs[i], fz[f"dpt.rn{i}.w"]) for i in range(4)]
+
+        def rcu(x, p):                                   # ResidualConvUnit: conv2(relu(conv1(relu(x)))) + x
+            t = ops.conv3x3_nhwc(x, fz[p + "c1.w"], bias=fz[p + "c1.b"], relu_in=True, epi=ops.EPI_RELU)
+            return ops.conv3x3_nhwc(t, fz[p + "c2.w"], bias=fz[p + "c2.b"], residual=x)
+
+        def fusion(r, x0, x1=None, size=None):           # FeatureFusionBlock
+            out = x0
+            if x1 is not None:
+                out = ops.add(out, rcu(x1, f"dpt.ref{r}.rcu1."))
+            out = rcu(out, f"dpt.ref{r}.rcu2.")
+            Ho, Wo = size if size is not None else (2 * out.shape[1], 2 * out.shape[2])
+            out = ops.bilinear_nhwc(out, Ho, Wo)
+            return ops.gemm(out.view(-1, out.shape[-1]), fz[f"dpt.ref{r}.out.w"], bias=fz[f"dpt.ref{r}.out.b"]).view(B, Ho, Wo, -1)
+
+        path4 = fusion(4, rn[3], size=rn[2].shape[1:3])
+        path3 = fusion(3, path4, rn[2], size=rn[1].shape[1:3])
+        path2 = fusion(2, path3, rn[1], size=rn[0].shape[1:3])
+        path1 = fusion(1, path2, rn[0])
+        out = ops.conv3x3_nhwc(path1, fz["dpt.oc1.w"], bias=fz["dpt.oc1.b"])
+        out = ops.bilinear_nhwc(out, 14 * P, 14 * P)
+        out = ops.conv3x3_nhwc(out, fz["dpt.oc2a.w"], bias=fz["dpt.oc2a.b"], epi=ops.EPI_RELU)
+        out = ops.gemm(out.view(-1, out.shape[-1]), fz["dpt.oc2b.w"], bias=fz["dpt.oc2b.b"], epi=ops.EPI_RELU)   # [pixels, 8]; col 0
+        depth = out[:, 0].contiguous().view(B, 14 * P * 14 * P)       # relu(relu(x)) == relu(x): DAv2_Head's extra F.relu is a no-op
+        return ops.minmax_norm(depth).view(B, 14 * P, 14 * P)
 
     # ------------------------------------------------------------------------------------------ linear helpers
     def _wgrad(self, x2d, dy2d, gview, accumulate=False):
@@ -608,6 +681,9 @@ class Engine:
                     w_t = getattr(cfg, TASK_SPEC[task][0])[TASK_SPEC[task][2]]
                     task_loss[task] = res["loss3"][0:1] * w_t if task not in task_loss else task_loss[task] + res["loss3"][0:1] * w_t
                 out["embs"].setdefault(task, []).append(res["emb"])
+                if "depth_pred" in res:
+                    out.setdefault("depth_preds", []).append(res["depth_pred"])
+                    out.setdefault("depth_feats", []).append(res["depth_feats"])
                 if compute_grads and res["dx"] is not None:
                     dx_parts[idx].append((task, res["dx"]))
         if compute_grads and self.world > 1:
@@ -803,6 +879,16 @@ class Engine:
             ad = ops.act_fwd(zd, ops.EPI_RELU)
             pred = ops.gemm(ad, ps.w(l1 + "2.weight"), bias=ps.w(l1 + "2.bias"))
         res = dict(emb=emb if task != "depth" else pred.view(B, nq, -1), loss3=None, dx=None)
+        if task == "depth" and getattr(cfg, "depth_decoder", False):
+            # depth_embs entry = [lin1(v), lin2(v), lin3(v), v] (da_v2_head.py:444-457); depth_pred = DPT(feats) (base_ola_vlm.py:462-470)
+            fe = [pred]
+            for j in (2, 3):
+                lj = f"{hname}.{i}.linear_{j}."
+                zz = ops.gemm(vout, ps.w(lj + "0.weight"), bias=ps.w(lj + "0.bias"), epi=ops.EPI_RELU)
+                fe.append(ops.gemm(zz, ps.w(lj + "2.weight"), bias=ps.w(lj + "2.bias")))
+            fe.append(vout)
+            res["depth_feats"] = [t.view(B, nq, -1) for t in fe]
+            res["depth_pred"] = self.dpt_forward(res["depth_feats"])
         tg = targets.get(task)
         if tg is None:
             return res

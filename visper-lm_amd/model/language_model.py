@@ -213,7 +213,8 @@ class _OlaCausalLMBase(OlaLlavaMetaForCausalLM, BaseOLA_VLM, nn.Module):
         embs = out.get("embs", {})
         return OlaCausalLLMOutputWithPast(loss=loss, logits=out.get("logits"), hidden_states=(out["hidden"],),
                                           image_embs=embs.get("gen", []), seg_embs=embs.get("seg", []),
-                                          depth_embs=embs.get("depth", []), depth_preds=[])
+                                          depth_embs=out.get("depth_feats") or embs.get("depth", []),
+                                          depth_preds=out.get("depth_preds", []))     # filled when config.depth_decoder
 
     _forward = forward
 

@@ -190,6 +190,43 @@ def dwconv7x7_nhwc(x, w_tap_major, bias):
     return y
 
 
+# ---- NHWC helpers for the frozen DPT depth decoder (conv.hip)
+def conv3x3_nhwc(x, w_mat, bias=None, stride=1, relu_in=False, epi=EPI_NONE, residual=None):
+    """x: [B,H,W,C] bf16; w_mat: [Cout, 9*C] with column order (ky, kx, c); pad 1.  -> [B,Ho,Wo,Cout]."""
+    B, H, W, C = x.shape
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    col = torch.empty(B * Ho * Wo, 9 * C, device=x.device, dtype=BF16)
+    _lib.call("vp_im2col3x3_nhwc", B, H, W, C, stride, 1 if relu_in else 0, _p(x), _p(col), _stream())
+    res2 = None if residual is None else residual.reshape(B * Ho * Wo, -1)
+    return gemm(col, w_mat, bias=bias, epi=epi, residual=res2).view(B, Ho, Wo, -1)
+
+
+def bilinear_nhwc(x, Ho, Wo):
+    """F.interpolate(mode="bilinear", align_corners=True) on [B,H,W,C] bf16."""
+    B, H, W, C = x.shape
+    y = torch.empty(B, Ho, Wo, C, device=x.device, dtype=BF16)
+    _lib.call("vp_bilinear_nhwc", B, H, W, C, Ho, Wo, _p(x), _p(y), _stream())
+    return y
+
+
+def conv_transpose_nhwc(x, w_mat, bias_rep, k):
+    """ConvTranspose2d(kernel = stride = k): w_mat [k*k*Cout, Cin] (rows (ky, kx, co)), bias_rep = bias tiled k*k times."""
+    B, H, W, C = x.shape
+    t = gemm(x.reshape(B * H * W, C), w_mat, bias=bias_rep)
+    Co = w_mat.shape[0] // (k * k)
+    y = torch.empty(B, H * k, W * k, Co, device=x.device, dtype=BF16)
+    _lib.call("vp_pixel_shuffle_nhwc", B, H, W, k, Co, _p(t), _p(y), _stream())
+    return y
+
+
+def minmax_norm(x):
+    """Per leading-index (x - min) / (max - min), bf16 rounding after each op."""
+    B = x.shape[0]
+    y = torch.empty_like(x)
+    _lib.call("vp_minmax_norm", B, x[0].numel(), _p(x), _p(y), _stream())
+    return y
+
+
 def swiglu_fwd(gate_up):
     """gate_up: [..., 2F] chunk-interleaved (see interleave_gate_up) -> silu(gate) * up [..., F]."""
     M, F2, ldg = _rows2d(gate_up)

@@ -3,8 +3,8 @@ create them — SURVEY §5.4 — so reference checkpoints round-trip) and an on-
 
 Names follow OlaLlavaLlamaForCausalLM / OlaLlavaPhi3ForCausalLM (ola_llama.py / ola_phi3.py), OlaLlavaMetaModel
 (ola_arch.py:45,67-94,127), init_heads (base_ola_vlm.py:104-168), TaskTokenResampler (resampler.py:167-200),
-TaskToken{Gen,Depth}Head / OneFormerTaskTokenSegHead, HF CLIPVisionModel.  The frozen DPT decoder
-(`da_v2_head.*`, base_ola_vlm.py:139) is visualisation-only and out of scope."""
+TaskToken{Gen,Depth}Head / OneFormerTaskTokenSegHead, HF CLIPVisionModel, and the frozen DPT decoder
+(`da_v2_head.*`, base_ola_vlm.py:139-148; DAv2_Head('vitl'), da_v2_head.py:182-314) whenever "depth" is in aux_mode."""
 from __future__ import annotations
 
 from collections import OrderedDict
@@ -120,6 +120,37 @@ def param_shapes(cfg, vit_nested=True, with_vit=True) -> "OrderedDict[str, tuple
     sh["model.mm_projector.0.weight"] = (H, cfg.mm_hidden_size); sh["model.mm_projector.0.bias"] = (H,)
     sh["model.mm_projector.2.weight"] = (H, H); sh["model.mm_projector.2.bias"] = (H,)
     sh["lm_head.weight"] = (V, H)
+    if "depth" in order and hasattr(cfg, "image_depth"):
+        sh.update(dpt_param_shapes())
+    return sh
+
+
+DPT_OUT_CHANNELS = (256, 512, 1024, 1024)             # da_v2_head.py:300 (vitl)
+DPT_FEATURES = 256
+
+
+def dpt_param_shapes(prefix="da_v2_head.depth_head.") -> "OrderedDict[str, tuple]":
+    """DAv2_Head('vitl').state_dict() (da_v2_head.py:182-258 DPTHead.__init__, :8-30 _make_scratch, :33-88 ResidualConvUnit,
+    :91-125 FeatureFusionBlock), in module-registration order."""
+    oc, f = DPT_OUT_CHANNELS, DPT_FEATURES
+    sh = OrderedDict()
+    for i, c in enumerate(oc):
+        sh[prefix + f"projects.{i}.weight"] = (c, 1024, 1, 1); sh[prefix + f"projects.{i}.bias"] = (c,)
+    sh[prefix + "resize_layers.0.weight"] = (oc[0], oc[0], 4, 4); sh[prefix + "resize_layers.0.bias"] = (oc[0],)
+    sh[prefix + "resize_layers.1.weight"] = (oc[1], oc[1], 2, 2); sh[prefix + "resize_layers.1.bias"] = (oc[1],)
+    sh[prefix + "resize_layers.3.weight"] = (oc[3], oc[3], 3, 3); sh[prefix + "resize_layers.3.bias"] = (oc[3],)
+    sc = prefix + "scratch."
+    for i, c in enumerate(oc):
+        sh[sc + f"layer{i + 1}_rn.weight"] = (f, c, 3, 3)
+    for r in (1, 2, 3, 4):
+        q = sc + f"refinenet{r}."
+        sh[q + "out_conv.weight"] = (f, f, 1, 1); sh[q + "out_conv.bias"] = (f,)
+        for u in (1, 2):
+            for cv in (1, 2):
+                sh[q + f"resConfUnit{u}.conv{cv}.weight"] = (f, f, 3, 3); sh[q + f"resConfUnit{u}.conv{cv}.bias"] = (f,)
+    sh[sc + "output_conv1.weight"] = (f // 2, f, 3, 3); sh[sc + "output_conv1.bias"] = (f // 2,)
+    sh[sc + "output_conv2.0.weight"] = (32, f // 2, 3, 3); sh[sc + "output_conv2.0.bias"] = (32,)
+    sh[sc + "output_conv2.2.weight"] = (1, 32, 1, 1); sh[sc + "output_conv2.2.bias"] = (1,)
     return sh
 
 
@@ -132,6 +163,9 @@ def init_value(name, shape, gen, device, dtype):
         return torch.full((), 2.0, device=device, dtype=dtype)
     if "special_" in name:
         return torch.randn(shape, device=device, dtype=dtype, generator=gen)
+    if name.startswith("da_v2_head.") and len(shape) == 4:
+        fan = shape[0] if ("resize_layers.0." in name or "resize_layers.1." in name) else shape[1] * shape[2] * shape[3]
+        return torch.randn(shape, device=device, dtype=dtype, generator=gen) * (1.4 / fan ** 0.5)
     if len(shape) == 1:
         if name.endswith("bias"):
             return torch.zeros(shape, device=device, dtype=dtype)
