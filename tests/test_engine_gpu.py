@@ -192,3 +192,80 @@ def test_convnext_tower_matches_oracle():
     got = eng.vit_forward(images.cuda()).float().cpu().view(1, 576, 192)
     err = (got - ref).abs().max() / ref.abs().max()
     assert err < 3e-2, float(err)
+
+
+def _edge_case(ocfg_kw, mutate, min_cos=0.97):
+    """Engine vs the fp32 oracle (same bf16-rounded weights / inputs) on a mutated copy of the tiny Llama case."""
+    from oracle import cases, visper_oracle as O
+    from visper_lm_amd.config import VisperConfig
+    from visper_lm_amd.engine import Engine
+    ocfg, W, batch, g = cases.tiny_llama_case()
+    ocfg = O.make_config(**{**vars(ocfg), **ocfg_kw})
+    batch = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in batch.items()}
+    mutate(batch)
+    eng = Engine(VisperConfig(**vars(ocfg)))
+    eng.load_weights(W)
+    out = eng.train_step(_to_gpu_batch(batch))
+    tr = json.loads(str(g["trainable"]))
+    Wq = {k: v.to(BF).float() for k, v in W.items()}
+    for k in tr:
+        Wq[k] = Wq[k].clone().requires_grad_(True)
+    bq = {k: (v.to(BF).float() if (torch.is_tensor(v) and v.is_floating_point() and not k.endswith("_mask")) else v) for k, v in batch.items()}
+    ref = O.forward(Wq, bq, ocfg)
+    ref["loss"].backward()
+    assert rel(out["text_loss"], ref["text_loss"]) < 5e-3, (float(out["text_loss"]), float(ref["text_loss"]))
+    assert rel(out["loss"], ref["loss"]) < 5e-3, (float(out["loss"]), float(ref["loss"]))
+    for key, trip in ref["layer_losses"].items():
+        mine = out["layer_losses"][key].float().cpu().numpy()
+        assert np.allclose(mine, [float(x) for x in trip], rtol=2e-2, atol=2e-3), (key, mine, trip)
+    for k in eng.ps.index:
+        got = eng.ps.g(k).detach().float().cpu()
+        want = Wq[k].grad
+        if want is None:
+            assert float(got.abs().max()) == 0.0, k
+            continue
+        mine, theirs = got.reshape(-1), want.reshape(-1)          # same bar as test_gradients_match_oracle (bf16 vs fp32)
+        if mine.numel() == 1:                                      # logit scales: a sum of a few signed terms, so absolute slack too
+            assert abs(float(mine) - float(theirs)) <= 0.25 * abs(float(theirs)) + 2e-3, (k, float(mine), float(theirs))
+            continue
+        if float(theirs.norm()) == 0.0:
+            assert float(mine.norm()) < 1e-6, k
+            continue
+        cos = float(torch.dot(mine, theirs) / (mine.norm() * theirs.norm() + 1e-30))
+        nr = float(mine.norm() / (theirs.norm() + 1e-30))
+        assert cos > min_cos and 0.9 < nr < 1.1, (k, cos, nr)
+    return out, ref
+
+
+def test_edge_ragged_right_padded_batch():
+    """ola_arch.py:337-338 strips padding by attention_mask, :408-427 right-pads the spliced sequences: sample 1 is 17 tokens
+    shorter than sample 0, so its tail rows are padding (labels -100, keys masked by kv_len)."""
+    def mutate(b):
+        b["attention_mask"][1, 42:] = False
+    out, ref = _edge_case({}, mutate)
+    assert out["plan"]["S"] == ref["labels"].shape[1]
+
+
+def test_edge_sample_without_image():
+    """ola_arch.py:344-355: a sample with no <image> token consumes an empty feature slot and carries no image / task rows."""
+    def mutate(b):
+        b["input_ids"][1, 38] = 7
+    # the text-only sample feeds ~600 rows of padding-position states into every head's cross-attention: the softmax gradients
+    # (to_q / to_kv) are the noisiest in bf16, hence the slightly wider bar
+    _edge_case({}, mutate, min_cos=0.95)
+
+
+def test_edge_truncation():
+    """ola_arch.py:394-397 truncates the spliced sequence (658 rows here) to tokenizer_model_max_length."""
+    out, ref = _edge_case({"tokenizer_model_max_length": 652}, lambda b: None)      # keeps 8 supervised tokens per sample
+    assert out["plan"]["S"] == 652 == ref["labels"].shape[1]
+
+
+def test_edge_short_sequence_head_path():
+    """S < 600 (text-only batch): forward_emb_predictor hands the WHOLE layer state to the heads (base_ola_vlm.py:419-421).
+    (With "gen" in aux_mode the reference then slices an empty latent block and returns NaN, so this case uses depth-seg.)"""
+    def mutate(b):
+        b["input_ids"][:, 38] = 7
+        b.pop("gen_target", None); b.pop("gen_mask", None)
+    out, ref = _edge_case({"aux_mode": "depth-seg"}, mutate)
+    assert out["plan"]["S"] == 59

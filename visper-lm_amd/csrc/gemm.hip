@@ -218,11 +218,12 @@ __device__ __forceinline__ void epilogue_256_swz(const GemmArgs& p, bf16_t* wave
                                                  int lane) {
   const int fr = lane & 15, g = lane >> 4;
   const int epi = p.epi & 0xff;
-  // Fast path (every decoder GEMM): interior tile, 16-byte aligned rows, no bias / activation.  Kept lean on purpose: the
+  // Fast path: interior tile, 16-byte aligned rows (every decoder GEMM; with bias / activation: ViT, heads, DPT).  Kept lean: the
   // general path below is ~10x the instructions, and the epilogue runs with the matrix pipe idle.
   const bool fast = __builtin_amdgcn_readfirstlane(
-      (int)(!p.bias && epi == EPI_NONE && mrow0 + 128 <= p.M && ncol0 + 64 <= p.N && (p.ldc & 7) == 0 &&
-            (((uintptr_t)p.C) & 15) == 0 && (!p.res || ((p.ldr & 7) == 0 && (((uintptr_t)p.res) & 15) == 0))));
+      (int)(mrow0 + 128 <= p.M && ncol0 + 64 <= p.N && (p.ldc & 7) == 0 && (((uintptr_t)p.C) & 15) == 0 &&
+            (!p.bias || (((uintptr_t)p.bias) & 7) == 0) &&
+            (!p.res || ((p.ldr & 7) == 0 && (((uintptr_t)p.res) & 15) == 0))));
   if (fast) {
     int woff[4];                                        // this lane's write offset per column block j (row term added per ii)
 #pragma unroll
@@ -233,16 +234,43 @@ __device__ __forceinline__ void epilogue_256_swz(const GemmArgs& p, bf16_t* wave
     const bf16_t* rptr = p.res ? p.res + (long)(mrow0 + rl0) * p.ldr + ncol0 + ch * 8 : nullptr;
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
+      if (!p.bias && epi == EPI_NONE) {
 #pragma unroll
-      for (int ii = 0; ii < 4; ++ii)
+        for (int ii = 0; ii < 4; ++ii)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const f32x4 a = acc[half * 4 + ii][j];
+            u32x2 o;
+            o[0] = pack_bf16x2(a[0], a[1]);
+            o[1] = pack_bf16x2(a[2], a[3]);
+            *(u32x2*)(wave_lds + ii * 16 * 64 + woff[j]) = o;
+          }
+      } else {                                          // bias and/or activation (ViT, heads, DPT decoder): same rounding points
+        float bias4[4][4];                              // as the general path: linear(+bias) -> bf16, activation -> bf16
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          const f32x4 a = acc[half * 4 + ii][j];
-          u32x2 o;
-          o[0] = pack_bf16x2(a[0], a[1]);
-          o[1] = pack_bf16x2(a[2], a[3]);
-          *(u32x2*)(wave_lds + ii * 16 * 64 + woff[j]) = o;
+          bf16x4 bv = {0, 0, 0, 0};
+          if (p.bias) bv = *(const bf16x4*)(p.bias + ncol0 + j * 16 + g * 4);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) bias4[j][r] = bf2f((bf16_t)bv[r]);
         }
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const f32x4 a = acc[half * 4 + ii][j];
+            float x[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              x[r] = a[r] + bias4[j][r];
+              if (epi != EPI_NONE) x[r] = apply_epi(bfround(x[r]), epi);
+            }
+            u32x2 o;
+            o[0] = pack_bf16x2(x[0], x[1]);
+            o[1] = pack_bf16x2(x[2], x[3]);
+            *(u32x2*)(wave_lds + ii * 16 * 64 + woff[j]) = o;
+          }
+      }
       __builtin_amdgcn_sched_barrier(0);                // residual loads only after this half's accumulators are dead
       if (p.mode == 2) {
         // d_act tile is staged (bf16-rounded, as the unfused path stores it); lane (row rl0 + 8 it, chunk ch) owns 8 d_act
