@@ -76,70 +76,98 @@ constexpr int EL_STATS = EL_B * EL_B + 3 * EL_B;
 // grid (nblk, njc): block handles feature slab and gathered-target chunk jc (targets jc*8 .. jc*8+7).
 // part: [njc][nblk][EL_STATS].
 __global__ __launch_bounds__(256) void emb_loss_stats_kernel(const bf16_t* __restrict__ pred, const bf16_t* __restrict__ tgt_all,
-                                                             float* __restrict__ part, int B, int Bw, long D, int rank) {
-  __shared__ float red[16];
+                                                             float* __restrict__ part, int B, int Bw, long D, int rank, int nslot) {
+  // lane = (k-vector slot, gathered target j): every thread owns ONE target column j of this chunk and all 8 local
+  // predictions, i.e. 8 + 3 accumulators (pt[.][j], tt_j, pp_j, and the smooth-L1 sum of the local pair whose target is j).
+  // The 8 lanes of a slot read the same pred vectors (one coalesced broadcast request), so pred and targets are each
+  // streamed exactly once per chunk.
+  __shared__ float wred[4][EL_STATS];
   const int jc = blockIdx.y;
   const int nj = min(EL_B, Bw - jc * EL_B);
-  float pt[EL_B][EL_B], pp[EL_B], tt[EL_B], sl[EL_B];
+  const int j = threadIdx.x & 7, slot = threadIdx.x >> 3;          // 32 k-vector slots per block
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const bool has_t = j < nj;
+  const int bl = jc * EL_B + j - rank * B;                          // local sample whose own target is column j (or out of range)
+  const bool has_pair = has_t && bl >= 0 && bl < B;
+  const bf16_t* trow = tgt_all + (long)(jc * EL_B + (has_t ? j : 0)) * D;
+  float pt[EL_B], tt = 0.f, pp = 0.f, sl = 0.f;
 #pragma unroll
-  for (int b = 0; b < EL_B; ++b) {
-    pp[b] = tt[b] = sl[b] = 0.f;
-#pragma unroll
-    for (int j = 0; j < EL_B; ++j) pt[b][j] = 0.f;
-  }
+  for (int b = 0; b < EL_B; ++b) pt[b] = 0.f;
   const long nvec = D >> 3;
-  for (long i = blockIdx.x * 256L + threadIdx.x; i < nvec; i += gridDim.x * 256L) {
-    bf16x8 pv[EL_B], tv[EL_B];
+  for (long i = blockIdx.x * 32L + slot; i < nvec; i += gridDim.x * 32L) {
+    bf16x8 tv = {0, 0, 0, 0, 0, 0, 0, 0}, pv[EL_B];
+    if (has_t) tv = *(const bf16x8*)(trow + i * 8);
 #pragma unroll
-    for (int b = 0; b < EL_B; ++b)
+    for (int b = 0; b < EL_B; ++b) {
+      pv[b] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
       if (b < B) pv[b] = *(const bf16x8*)(pred + (long)b * D + i * 8);
-#pragma unroll
-    for (int j = 0; j < EL_B; ++j)
-      if (j < nj) tv[j] = *(const bf16x8*)(tgt_all + (long)(jc * EL_B + j) * D + i * 8);
+    }
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      float pf[EL_B], tf[EL_B];
-#pragma unroll
-      for (int b = 0; b < EL_B; ++b) pf[b] = b < B ? bf2f((bf16_t)pv[b][e]) : 0.f;
-#pragma unroll
-      for (int j = 0; j < EL_B; ++j) tf[j] = j < nj ? bf2f((bf16_t)tv[j][e]) : 0.f;
+      const float tf = bf2f((bf16_t)tv[e]);
+      tt += tf * tf;
+      float pj = 0.f, pl = 0.f;                                     // pred of sample j (for pp_j) and of the paired sample bl
 #pragma unroll
       for (int b = 0; b < EL_B; ++b) {
-        pp[b] += pf[b] * pf[b];
-#pragma unroll
-        for (int j = 0; j < EL_B; ++j) pt[b][j] += pf[b] * tf[j];
+        const float pf = bf2f((bf16_t)pv[b][e]);
+        pt[b] += pf * tf;
+        pj = (b == j) ? pf : pj;
+        pl = (b == bl) ? pf : pl;
       }
-#pragma unroll
-      for (int j = 0; j < EL_B; ++j) tt[j] += tf[j] * tf[j];
-      // smooth-L1 (beta = 1) between local pairs: target of local sample b is gathered index rank*B + b
-#pragma unroll
-      for (int b = 0; b < EL_B; ++b) {
-        const int jj = rank * B + b - jc * EL_B;
-        if (b < B && jj >= 0 && jj < nj) {
-          float tsel = 0.f;
-#pragma unroll
-          for (int j = 0; j < EL_B; ++j) tsel = (j == jj) ? tf[j] : tsel;
-          const float d = fabsf(pf[b] - tsel);
-          sl[b] += d < 1.f ? 0.5f * d * d : d - 0.5f;
-        }
-      }
+      pp += pj * pj;
+      const float d = fabsf(pl - tf);                               // smooth-L1, beta = 1
+      sl += d < 1.f ? 0.5f * d * d : d - 0.5f;
     }
   }
-  float* out = part + ((long)jc * gridDim.x + blockIdx.x) * EL_STATS;
+  if (!has_pair) sl = 0.f;
+  // reduce over the 8 slots of the wave that share j (lane bits 3..5), then over the 4 waves through LDS
 #pragma unroll
-  for (int b = 0; b < EL_B; ++b) {
+  for (int o = 8; o < 64; o <<= 1) {
 #pragma unroll
-    for (int j = 0; j < EL_B; ++j) {
-      const float v = block_sum(pt[b][j], red);
-      if (threadIdx.x == 0) out[b * EL_B + j] = v;
-    }
-    const float a = block_sum(pp[b], red), t2 = block_sum(tt[b], red), s1 = block_sum(sl[b], red);
-    if (threadIdx.x == 0) {
-      out[EL_B * EL_B + b] = a;
-      out[EL_B * EL_B + EL_B + b] = t2;
-      out[EL_B * EL_B + 2 * EL_B + b] = s1;
-    }
+    for (int b = 0; b < EL_B; ++b) pt[b] += __shfl_xor(pt[b], o, 64);
+    tt += __shfl_xor(tt, o, 64);
+    pp += __shfl_xor(pp, o, 64);
+    sl += __shfl_xor(sl, o, 64);
   }
+  if (threadIdx.x < EL_STATS) wred[0][threadIdx.x] = wred[1][threadIdx.x] = wred[2][threadIdx.x] = wred[3][threadIdx.x] = 0.f;
+  __syncthreads();
+  if (lane < 8) {
+#pragma unroll
+    for (int b = 0; b < EL_B; ++b) wred[wv][b * EL_B + j] = pt[b];
+    if (j < B) wred[wv][EL_B * EL_B + j] = pp;
+    wred[wv][EL_B * EL_B + EL_B + j] = tt;
+    if (has_pair) wred[wv][EL_B * EL_B + 2 * EL_B + bl] = sl;
+  }
+  __syncthreads();
+  if (threadIdx.x < EL_STATS)
+    part[((long)jc * nslot + blockIdx.x) * EL_STATS + threadIdx.x] =
+        (wred[0][threadIdx.x] + wred[1][threadIdx.x]) + (wred[2][threadIdx.x] + wred[3][threadIdx.x]);
+}
+
+// Second level: block jc sums the nblk per-block partial rows of its chunk (fixed order -> deterministic) into the chunk's LAST
+// slot part[jc][nslot-1][.].  Rows are pulled into LDS with wide independent loads (a serial walk over L2 latencies made the old
+// single-block finalize the slowest kernel of the three), then 88 x 2 threads each add one padded LDS column half.
+__global__ __launch_bounds__(256) void emb_loss_reduce_kernel(float* __restrict__ part, int nblk, int nslot) {
+  __shared__ float rows[128][EL_STATS + 1];
+  __shared__ float halves[2][EL_STATS];
+  const int jc = blockIdx.x, t = threadIdx.x;
+  const float* src = part + (long)jc * nslot * EL_STATS;
+  const int st = t % EL_STATS, hf = t / EL_STATS;      // threads 0..175 do the column sums
+  float acc = 0.f;
+  for (int base = 0; base < nblk; base += 128) {
+    const int n = min(128, nblk - base);
+    for (int q = t; q < n * EL_STATS; q += 256) rows[q / EL_STATS][q % EL_STATS] = src[(long)base * EL_STATS + q];
+    __syncthreads();
+    if (hf < 2) {
+      float a0 = 0.f, a1 = 0.f;
+      for (int k = hf; k < n; k += 4) { a0 += rows[k][st]; if (k + 2 < n) a1 += rows[k + 2][st]; }
+      acc += a0 + a1;
+    }
+    __syncthreads();
+  }
+  if (hf < 2) halves[hf][st] = acc;
+  __syncthreads();
+  if (t < EL_STATS) part[((long)jc * nslot + nslot - 1) * EL_STATS + t] = halves[0][t] + halves[1][t];
 }
 
 // Single block. Produces out3 = {emb_loss, sl1_loss, contrastive_loss} (already masked/weighted as the
@@ -149,32 +177,28 @@ __global__ __launch_bounds__(256) void emb_loss_stats_kernel(const bf16_t* __res
 //   coef[2B..2B+B*Bw)     c_bj  : dL/dZ_bj * scale / (|p_b| |t_j|)
 //   coef[2B+B*Bw]         dlogit_scale (d loss / d log-scale parameter)
 // mask semantics: sl1 = mean_all(sl1_elem * mask_b); con = w * mean_b(CE_b) * mean_b(mask_b)  (outer-product quirk).
-__global__ __launch_bounds__(64) void emb_loss_finalize_kernel(const float* __restrict__ part, int nblk, int njc, int B, int Bw,
+__global__ __launch_bounds__(256) void emb_loss_finalize_kernel(const float* __restrict__ part, int nblk, int njc, int B, int Bw,
                                                                long D, int rank, const float* __restrict__ mask,
                                                                const float* __restrict__ logit_scale, float w_con,
                                                                float* __restrict__ out3, float* __restrict__ coef) {
+  __shared__ float S[8][EL_STATS];                     // per j-chunk statistics (reduced by emb_loss_reduce_kernel into the last slot)
   __shared__ float pt[EL_B][64], pp[EL_B], tt[64], sl[EL_B], Z[EL_B][64], ce[EL_B], dce[EL_B];
   const int t = threadIdx.x;
-  // reduce partials (deterministic order)
-  for (int idx = t; idx < B * Bw; idx += 64) {
+  for (int q = t; q < njc * EL_STATS; q += 256) S[q / EL_STATS][q % EL_STATS] = part[((long)(q / EL_STATS) * nblk + nblk - 1) * EL_STATS + q % EL_STATS];
+  __syncthreads();
+  for (int idx = t; idx < B * Bw; idx += 256) {
     const int b = idx / Bw, j = idx % Bw, jc = j / EL_B, jj = j % EL_B;
-    float a = 0.f;
-    for (int k = 0; k < nblk; ++k) a += part[((long)jc * nblk + k) * EL_STATS + b * EL_B + jj];
-    pt[b][j] = a;
+    pt[b][j] = S[jc][b * EL_B + jj];
   }
-  for (int j = t; j < Bw; j += 64) {
+  for (int j = t; j < Bw; j += 256) {
     const int jc = j / EL_B, jj = j % EL_B;
-    float a = 0.f;
-    for (int k = 0; k < nblk; ++k) a += part[((long)jc * nblk + k) * EL_STATS + EL_B * EL_B + EL_B + jj];
-    tt[j] = a;
+    tt[j] = S[jc][EL_B * EL_B + EL_B + jj];
   }
   if (t < B) {
-    float a = 0.f, s = 0.f;
-    for (int k = 0; k < nblk; ++k) a += part[((long)0 * nblk + k) * EL_STATS + EL_B * EL_B + t];
-    for (int jc = 0; jc < njc; ++jc)
-      for (int k = 0; k < nblk; ++k) s += part[((long)jc * nblk + k) * EL_STATS + EL_B * EL_B + 2 * EL_B + t];
-    pp[t] = a;
-    sl[t] = s;
+    float s1 = 0.f;
+    for (int jc = 0; jc < njc; ++jc) s1 += S[jc][EL_B * EL_B + 2 * EL_B + t];
+    pp[t] = S[0][EL_B * EL_B + t];
+    sl[t] = s1;
   }
   __syncthreads();
   float scale = 0.f, dscale_dls = 0.f;
@@ -295,7 +319,9 @@ int vp_ce_fwd_bwd(long rows, int V, void* logits, long ld, const long* labels, f
 
 // workspace (fp32): part = njc * nblk * 88 floats with njc = ceil(Bw/8), nblk = vp_emb_loss_nblk(D);
 // coef = 2B + B*Bw + 1 floats (kept for the backward).
-int vp_emb_loss_nblk(long D) { return (int)max(1L, min(512L, (D / 8 + 255) / 256)); }
+// slots per j-chunk in the workspace: up to 256 streaming blocks (32 k-vectors per block pass, >= 4 passes each) + 1 slot for
+// the chunk's reduced statistics
+int vp_emb_loss_nblk(long D) { return 1 + (int)max(1L, min(256L, (D / 8 + 127) / 128)); }
 
 int vp_emb_loss_fwd(int B, int Bw, long D, int rank, const void* pred, const void* tgt_all, const float* mask,
                     const float* logit_scale, float w_contrastive, float* out3, float* coef, float* part, hipStream_t s) {
@@ -303,9 +329,10 @@ int vp_emb_loss_fwd(int B, int Bw, long D, int rank, const void* pred, const voi
              "vp_emb_loss_fwd: need 0<B<=8, B<=Bw<=64, D%%8==0 (got B=%d Bw=%d D=%ld)", B, Bw, D);
   VP_REQUIRE(rank >= 0 && (rank + 1) * B <= Bw, VP_ERR_BAD_ARG, "vp_emb_loss_fwd: rank/B/Bw mismatch");
   const int nblk = vp_emb_loss_nblk(D), njc = (Bw + EL_B - 1) / EL_B;
-  hipLaunchKernelGGL(emb_loss_stats_kernel, dim3(nblk, njc), dim3(256), 0, s, (const bf16_t*)pred, (const bf16_t*)tgt_all, part, B, Bw,
-                     D, rank);
-  hipLaunchKernelGGL(emb_loss_finalize_kernel, dim3(1), dim3(64), 0, s, part, nblk, njc, B, Bw, D, rank, mask, logit_scale,
+  hipLaunchKernelGGL(emb_loss_stats_kernel, dim3(nblk - 1, njc), dim3(256), 0, s, (const bf16_t*)pred, (const bf16_t*)tgt_all, part, B, Bw,
+                     D, rank, nblk);
+  hipLaunchKernelGGL(emb_loss_reduce_kernel, dim3(njc), dim3(256), 0, s, part, nblk - 1, nblk);
+  hipLaunchKernelGGL(emb_loss_finalize_kernel, dim3(1), dim3(256), 0, s, part, nblk, njc, B, Bw, D, rank, mask, logit_scale,
                      w_contrastive, out3, coef);
   return vp_check_launch("vp_emb_loss_fwd");
 }
