@@ -191,9 +191,15 @@ def main():
     eng.init_random(seed=0)                       # identical weights on every rank
     batch = make_batch(cfg, args.batch, args.text_len, rank, dev)
 
+    from visper_lm_amd import optim
+    total_steps = 2181                                  # LLaVA-558K / global batch 256 (scripts/train/pretrain.sh), 3 % warm-up, cosine
+    n_warm = optim.warmup_steps(total_steps, 0.03)
+    it = [0]
+
     def step():
         out = eng.train_step(batch)
-        eng.optimizer_step(lr=args.lr)
+        eng.optimizer_step(lr=args.lr, lr_mult=optim.cosine_with_warmup(it[0], total_steps, n_warm))   # wd 0, no clipping: pretrain.sh
+        it[0] += 1
         return out
 
     def fence():

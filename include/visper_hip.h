@@ -103,6 +103,9 @@ int vp_gather_sum_rows(long n_out, int cnt, int H, const void* src, long lds, in
 int vp_cast_f32_to_bf16(long n, const float* x, void* y, vp_stream_t stream);
 int vp_cast_bf16_to_f32(long n, const void* x, float* y, int accumulate, vp_stream_t stream);
 int vp_sum_f32(long n, const float* x, float* out, float scale, vp_stream_t stream);
+/* out[0] = sum x[i]^2 (global gradient norm for clip_grad_norm_ semantics); part = workspace of vp_sumsq_nblk(n) floats */
+int vp_sumsq_nblk(long n);
+int vp_sumsq_f32(long n, const float* x, float* part, float* out, vp_stream_t stream);
 
 /* ---- frozen DPT depth decoder (da_v2_head.py:182-321, run under no_grad at base_ola_vlm.py:462-470; output `depth_preds`).
  * NHWC bf16.  3x3 convs = vp_im2col3x3_nhwc (pad 1, stride 1|2, optional input ReLU of ResidualConvUnit; column order

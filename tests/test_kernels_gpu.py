@@ -398,3 +398,37 @@ def test_dpt_conv_helpers(ops):
     d = rnd(3, 1000, seed=45).abs()
     mn, mx = d.float().amin(1, keepdim=True), d.float().amax(1, keepdim=True)
     close(ops.minmax_norm(dev(d)), (d.float() - mn) / (mx - mn), what="minmax")
+
+
+def test_param_store_adamw_groups_schedule_clipping():
+    """ParamStore.adamw_step (grouped fused launches + schedule multiplier + global-norm clipping) == torch.optim.AdamW with the
+    reference trainer's parameter groups, transformers' cosine schedule and clip_grad_norm_."""
+    from collections import OrderedDict
+    from transformers import get_cosine_schedule_with_warmup
+    from visper_lm_amd import optim
+    from visper_lm_amd.engine import ParamStore
+    shapes = OrderedDict([("image_gen_heads.0.projector.proj_in.weight", (24, 40)), ("image_gen_heads.0.projector.proj_in.bias", (24,)),
+                          ("image_gen_heads.0.projector.norm_out.weight", (24,)), ("gen_logit_scale", ()),
+                          ("model.mm_projector.0.weight", (40, 16)), ("model.mm_projector.0.bias", (40,)), ("model.special_gen_tokens", (8, 40))])
+    ps = ParamStore(shapes, "cuda")
+    ref = OrderedDict((k, torch.nn.Parameter(rnd(*s, seed=60 + i).float() if len(s) else torch.tensor(2.0))) for i, (k, s) in enumerate(shapes.items()))
+    for k, v in ref.items():
+        ps.p(k).copy_(v.detach().reshape(ps.p(k).shape))
+    base_lr, wd, plr, total, mx = 1e-2, 0.1, 3e-3, 12, 0.7
+    gr = optim.param_groups(shapes.keys(), wd, plr)
+    opt = torch.optim.AdamW([dict(params=[ref[k]], weight_decay=gr[k][1], lr=(base_lr if gr[k][0] is None else gr[k][0])) for k in shapes],
+                            lr=base_lr, betas=(0.9, 0.999), eps=1e-8)
+    nw = optim.warmup_steps(total, 0.25)
+    sch = get_cosine_schedule_with_warmup(opt, nw, total)
+    for step in range(6):
+        for i, (k, v) in enumerate(ref.items()):
+            g = (rnd(*shapes[k], seed=100 + 10 * step + i).float() if len(shapes[k]) else torch.tensor(0.3 * (step + 1))) * (2.0 if step % 2 else 0.2)
+            v.grad = g.clone()
+            ps.g(k).copy_(g.reshape(ps.g(k).shape))
+        torch.nn.utils.clip_grad_norm_(list(ref.values()), mx)
+        opt.step(); 
+        ps.adamw_step(base_lr, weight_decay=wd, mm_projector_lr=plr, lr_mult=optim.cosine_with_warmup(step, total, nw), max_grad_norm=mx)
+        sch.step()
+    for k, v in ref.items():
+        close(ps.p(k).view(v.shape), v.detach(), rtol=2e-5, atol=2e-6, what=f"adamw {k}")
+        close(ps.w(k).view(v.shape), v.detach(), rtol=1e-2, what=f"bf16 shadow {k}")

@@ -47,11 +47,13 @@ _SIGS = {
     "vp_cast_f32_to_bf16": [l, p, p, p],
     "vp_cast_bf16_to_f32": [l, p, p, i, p],
     "vp_sum_f32": [l, p, p, f, p],
+    "vp_sumsq_f32": [l, p, p, p, p],
     "vp_attn_fwd": [i, i, i, i, i, i, p, l, l, p, l, l, p, l, l, p, l, l, p, p, i, i, f, p],
     "vp_attn_bwd": [i, i, i, i, i, i, p, l, l, p, l, l, p, l, l, p, l, l, p, p, l, l, p, l, l, p, l, l, p, l, l, p, p,
                     i, i, f, p],
     "vp_ce_fwd_bwd": [l, i, p, l, p, p, f, i, p],
     "vp_emb_loss_nblk": [l],
+    "vp_sumsq_nblk": [l],
     "vp_emb_loss_fwd": [i, i, l, i, p, p, p, p, f, p, p, p, p],
     "vp_emb_loss_bwd": [i, i, l, i, p, p, p, f, p, p],
     "vp_adamw": [l, p, p, p, p, p, f, f, f, f, f, i, f, p],

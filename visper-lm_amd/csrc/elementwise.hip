@@ -225,6 +225,15 @@ __global__ __launch_bounds__(1024) void sum_f32_kernel(const float* __restrict__
   if (threadIdx.x == 0) out[0] = a * scale;
 }
 
+// sum of squares of n floats (gradient-clipping norm): per-block partials, then sum_f32_kernel over them (deterministic)
+__global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* __restrict__ x, float* __restrict__ part, long n) {
+  __shared__ float red[16];
+  float a = 0.f;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += gridDim.x * 256L) a += x[i] * x[i];
+  a = block_sum(a, red);
+  if (threadIdx.x == 0) part[blockIdx.x] = a;
+}
+
 // ---------------------------------------------------------------- fused AdamW ------------------
 // fp32 master params/grads/moments (flat), optional bf16 shadow written in the same pass.
 // torch.optim.AdamW semantics: p *= 1 - lr*wd ; m,v EMA ; p -= lr/bc1 * m / (sqrt(v)/sqrt(bc2) + eps)
@@ -396,6 +405,16 @@ int vp_sum_f32(long n, const float* x, float* out, float scale, hipStream_t s) {
   VP_REQUIRE(n > 0, VP_ERR_BAD_ARG, "vp_sum_f32: bad n");
   hipLaunchKernelGGL(sum_f32_kernel, dim3(1), dim3(1024), 0, s, x, out, n, scale);
   return vp_check_launch("vp_sum_f32");
+}
+
+// out[0] = sum x^2; `part` = caller-owned workspace of vp_sumsq_nblk(n) floats
+int vp_sumsq_nblk(long n) { return (int)max(1L, min(1024L, (n + 4095) / 4096)); }
+int vp_sumsq_f32(long n, const float* x, float* part, float* out, hipStream_t s) {
+  VP_REQUIRE(n > 0 && x && part && out, VP_ERR_BAD_ARG, "vp_sumsq_f32: bad args");
+  const int nb = vp_sumsq_nblk(n);
+  hipLaunchKernelGGL(sumsq_partial_kernel, dim3(nb), dim3(256), 0, s, x, part, n);
+  hipLaunchKernelGGL(sum_f32_kernel, dim3(1), dim3(1024), 0, s, part, out, (long)nb, 1.f);
+  return vp_check_launch("vp_sumsq_f32");
 }
 
 int vp_adamw(long n, float* p, const float* g, float* m, float* v, void* bf16_shadow, float lr, float beta1, float beta2, float eps,

@@ -85,14 +85,31 @@ class ParamStore:
     def zero_grad(self):
         self.grad.zero_()
 
-    def adamw_step(self, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, grad_scale=1.0):
-        """HF `adamw_torch` (ola_vlm_train.py:124) on the whole flat buffer; refreshes the bf16 shadow in-kernel."""
+    def grad_norm(self, grad_scale=1.0):
+        """Global L2 norm of grad_scale * grad (host float; one small reduction kernel + a sync)."""
+        return abs(grad_scale) * float(ops.sumsq(self.grad)) ** 0.5
+
+    def adamw_step(self, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, grad_scale=1.0, mm_projector_lr=None,
+                   lr_mult=1.0, max_grad_norm=None):
+        """HF `adamw_torch` (ola_vlm_train.py:124) with the reference trainer's parameter groups (llava_trainer.py:890-995: no
+        weight decay on biases / LayerNorm parameters, optional projector learning rate), `lr_mult` = the scheduler's multiplier
+        for this step (optim.cosine_with_warmup) and optional global-norm clipping.  One fused launch per contiguous run of the
+        flat buffer with equal (lr, weight decay) — a single launch in the reference configuration (weight_decay 0, one lr);
+        refreshes the bf16 shadow in-kernel."""
+        from . import optim
         if self.exp_avg is None:
             self.exp_avg = torch.zeros_like(self.master)
             self.exp_avg_sq = torch.zeros_like(self.master)
         self.step += 1
-        ops.adamw_(self.master, self.grad, self.exp_avg, self.exp_avg_sq, self.shadow, lr, betas[0], betas[1], eps,
-                   weight_decay, self.step, grad_scale)
+        if max_grad_norm is not None:
+            grad_scale = grad_scale * optim.clip_coefficient(self.grad_norm(grad_scale), max_grad_norm)
+        key = (float(weight_decay), mm_projector_lr)
+        if getattr(self, "_runs_key", None) != key:
+            self._runs = optim.runs(self.index, optim.param_groups(self.index.keys(), weight_decay, mm_projector_lr))
+            self._runs_key = key
+        for a, b, glr, wd in self._runs:
+            ops.adamw_(self.master[a:b], self.grad[a:b], self.exp_avg[a:b], self.exp_avg_sq[a:b], self.shadow[a:b],
+                       (lr if glr is None else glr) * lr_mult, betas[0], betas[1], eps, wd, self.step, grad_scale)
 
 
 def _tp(w):
@@ -276,10 +293,13 @@ class Engine:
         if self.world > 1:
             self._reducer().finish()
 
-    def optimizer_step(self, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
-        """Mean-reduce over DP ranks is folded into AdamW's grad_scale (ZeRO-2 / DDP averaging semantics)."""
+    def optimizer_step(self, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, mm_projector_lr=None, lr_mult=1.0,
+                       max_grad_norm=None):
+        """Mean-reduce over DP ranks is folded into AdamW's grad_scale (ZeRO-2 / DDP averaging semantics); groups, schedule
+        multiplier and clipping as in ParamStore.adamw_step."""
         self.finish_grads()
-        self.ps.adamw_step(lr, betas, eps, weight_decay, grad_scale=1.0 / self.world)
+        self.ps.adamw_step(lr, betas, eps, weight_decay, grad_scale=1.0 / self.world, mm_projector_lr=mm_projector_lr,
+                           lr_mult=lr_mult, max_grad_norm=max_grad_norm)
 
     def vit_layers_run(self):
         sel = self.cfg.mm_vision_select_layer

@@ -328,6 +328,15 @@ def cast_to_f32(x, out=None, accumulate=False):
     return out
 
 
+def sumsq(x):
+    """sum(x^2) of an fp32 tensor -> fp32 [1] (deterministic two-stage reduction)."""
+    n = x.numel()
+    part = torch.empty(_lib.raw("vp_sumsq_nblk", n), device=x.device, dtype=torch.float32)
+    out = torch.empty(1, device=x.device, dtype=torch.float32)
+    _lib.call("vp_sumsq_f32", n, _p(x), _p(part), _p(out), _stream())
+    return out
+
+
 def sum_f32(x, scale=1.0, out=None):
     if out is None:
         out = torch.empty(1, device=x.device, dtype=torch.float32)
