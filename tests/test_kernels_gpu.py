@@ -79,9 +79,8 @@ def test_gemm_256_tile_kernel(ops, M, N, K):
     close(out, ref, what=f"gemm256 {M}x{N}x{K}")
     out2 = ops.gemm(dev(a), dev(w), bias=dev(b), residual=dev(r), force_generic=2)
     close(out2, ref, what=f"gemm128 {M}x{N}x{K}")
-    for code in (4, 5, 6, 7):                       # ping-pong / skewed / 4-wave / 8-phase variants
-        o = ops.gemm(dev(a), dev(w), bias=dev(b), residual=dev(r), force_generic=code)
-        close(o, ref, what=f"gemm variant {code} {M}x{N}x{K}")
+    o = ops.gemm(dev(a), dev(w), bias=dev(b), residual=dev(r), force_generic=7)      # 8-phase kernel forced on a small problem
+    close(o, ref, what=f"gemm 8-phase {M}x{N}x{K}")
 
 
 def test_gemm_8phase_large_k_and_edges(ops):

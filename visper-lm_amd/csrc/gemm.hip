@@ -2,13 +2,17 @@
 // Both operands are K-contiguous ("NT"): activations [tokens, features] x nn.Linear weights [out, in].
 // (dgrad uses the pre-transposed frozen weight, wgrad uses explicitly transposed operands — DESIGN.md.)
 //
-// Fast kernel: 128x128x64 block tile, 4 waves (2x2, each 64x64 = 4x4 MFMA 16x16x32 tiles), operands staged
-// HBM -> LDS with 16-byte global_load_lds (no VGPR round trip).  LDS image is lane-linear (a glds
-// constraint), so bank conflicts are removed by XOR-swizzling the 16-B chunk index on the *source*
-// address and again on the ds_read_b128 (chunk ^= (row>>1)&7).  MFMA roles are swapped (A-operand =
-// weight rows, B-operand = token rows) so each lane ends up with 4 consecutive output columns of one
-// token row -> 8-byte bf16 stores.  Block ids are remapped XCD-aware + grouped so tiles sharing an
-// operand panel sit in one XCD's L2.
+// Kernels (dispatch in vp_gemm_bf16):
+//   gemm_nt_256p8   the production kernel for every large problem: persistent 256x256x64 tiles, 8 waves, 8-phase ping-pong
+//                   (see the comment on the kernel), fused bias / activation / residual / SwiGLU epilogues
+//   gemm_nt_256     the plain persistent 256-tile kernel it grew out of (one barrier per K-tile); kept as the A/B reference
+//   gemm_nt_128     128x128x64, 4 waves (2x2, each 64x64): small problems (heads, ViT N=1024, DPT convs)
+//   gemm_nt_generic bounds-checked fallback for K % 64 != 0 or unaligned rows
+// Common ground: operands go HBM -> LDS with 16-byte global_load_lds (no VGPR round trip).  The LDS image is lane-linear (a
+// glds constraint), so bank conflicts are removed by XOR-swizzling the 16-B chunk index on the *source* address and again on the
+// ds_read_b128 (chunk ^= (row>>1)&7).  MFMA roles are swapped (A-operand = weight rows, B-operand = token rows) so each lane
+// ends up with 4 consecutive output columns of one token row.  Block ids are remapped XCD-aware so tiles sharing an operand
+// panel sit in one XCD's L2.
 #include "common.h"
 #include <cstdlib>
 
@@ -505,16 +509,7 @@ __global__ __launch_bounds__(512) void gemm_nt_256(GemmArgs p) {
 #undef SET_TILE
 }
 
-// ------------------------------------------------------------------------------------------------
-// ping-pong variant of the 256x256x64 kernel.  The plain kernel above re-synchronises all 8 waves once per
-// K-tile, so both waves of a SIMD read LDS at the same time and then both issue MFMAs at the same time: the
-// matrix pipe idles during every read phase (PMC: MFMA busy ~49 %).  Here the two wave groups (wr = 0 / 1,
-// one wave of each per SIMD) run one phase apart: a K-tile is 4 phases per wave — R0 (ds_read the ks=0
-// fragments), M0 (32 MFMAs), R1, M1 — separated by raw s_barriers, and group 1 starts one barrier late, so
-// in every barrier interval one group is in an M phase while the other is in an R phase.  global_load_lds
-// of tile t+1 is issued in R0(t) (its buffer was last read in R1(t-1), one full interval earlier even for
-// the late group) and waited for (vmcnt(0)) at the end of R1(t) — two intervals before anyone reads it.
-// ------------------------------------------------------------------------------------------------
+// raw workgroup barrier fenced against the instruction scheduler (used by the 8-phase kernel below)
 #define VP_SB() __builtin_amdgcn_sched_barrier(0)
 #define VP_BAR()                      \
   do {                                \
@@ -522,109 +517,6 @@ __global__ __launch_bounds__(512) void gemm_nt_256(GemmArgs p) {
     __builtin_amdgcn_s_barrier();     \
     VP_SB();                          \
   } while (0)
-
-template <bool OUT_F32>
-__global__ __launch_bounds__(512) void gemm_nt_256pp(GemmArgs p) {
-  // 4-phase variant with K-HALF pieces: LDS buffer = [A kh0 | B kh0 | A kh1 | B kh1], each [256 rows][32 k] (64-byte rows,
-  // chunk ^= (row>>2)&3).  Phase A(t) = R: DMA {A,B} kh0 of K-tile t+1 (4 global_load_lds) + 12 ds_reads of kh0(t) | M: 32 MFMAs;
-  // phase B(t) the same on kh1.  Half the barriers of the 8-phase kernel, R (~4 DMA issues + 12 reads) balanced against
-  // M (32 MFMAs), every piece has 2 phases to land, vmcnt(4) never drains the queue.
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  bf16_t* smem = (bf16_t*)smem_raw;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int tiles_m = (p.M + 255) >> 8, tiles_n = (p.N + 255) >> 8;
-  const TileCoord tc = tile_coord_256(blockIdx.x, tiles_m, tiles_n);
-  const int m0 = tc.m0, n0 = tc.n0;
-  const int wr = __builtin_amdgcn_readfirstlane(wave >> 2), wc = wave & 3;
-  const int fr = lane & 15, g = lane >> 4;
-  const int nt = p.K >> 6;
-  // staging: a piece = one operand, one k-half: 256 rows x 4 chunks = 1024 chunks -> 2 per thread
-  const bf16_t* srcA[2];
-  const bf16_t* srcB[2];
-#pragma unroll
-  for (int it = 0; it < 2; ++it) {
-    const int q = it * 512 + tid;
-    const int row = q >> 2;
-    const int gc = (q & 3) ^ ((row >> 2) & 3);
-    srcA[it] = p.A + (long)min(m0 + row, p.M - 1) * p.lda + gc * 8;
-    srcB[it] = p.B + (long)min(n0 + row, p.N - 1) * p.ldb + gc * 8;
-  }
-  // element offsets inside a buffer: A kh0 @0, B kh0 @8192, A kh1 @16384, B kh1 @24576
-#define ISSUE_KH(KH, T, BUF)                                                       \
-  {                                                                                \
-    const long ko_ = (long)min((T), nt - 1) * 64 + (KH) * 32;                      \
-    bf16_t* base_ = smem + (BUF) * 32768 + (KH) * 16384;                           \
-    _Pragma("unroll") for (int it = 0; it < 2; ++it) {                             \
-      GLDS16(srcA[it] + ko_, base_ + (it * 512 + wave * 64) * 8);                  \
-      GLDS16(srcB[it] + ko_, base_ + 8192 + (it * 512 + wave * 64) * 8);           \
-    }                                                                              \
-  }
-#define READ_KH(KH)                                                                \
-  {                                                                                \
-    const bf16_t* Ak = buf + (KH) * 16384;                                         \
-    const bf16_t* Bk = Ak + 8192;                                                  \
-    _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                \
-      const int r = wc * 64 + j * 16 + fr;                                         \
-      wf[j] = *(const bf16x8*)(Bk + r * 32 + ((g ^ ((r >> 2) & 3)) << 3));         \
-    }                                                                              \
-    _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                \
-      const int r = wr * 128 + i * 16 + fr;                                        \
-      xf[i] = *(const bf16x8*)(Ak + r * 32 + ((g ^ ((r >> 2) & 3)) << 3));         \
-    }                                                                              \
-  }
-#define MFMA_PHASE()                                                               \
-  {                                                                                \
-    __builtin_amdgcn_s_setprio(1);                                                 \
-    _Pragma("unroll") for (int i = 0; i < 8; ++i)                                  \
-      _Pragma("unroll") for (int j = 0; j < 4; ++j)                                \
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], xf[i], acc[i][j], 0, 0, 0); \
-    __builtin_amdgcn_s_setprio(0);                                                 \
-  }
-  f32x4 acc[8][4];
-#pragma unroll
-  for (int i = 0; i < 8; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  ISSUE_KH(0, 0, 0);
-  ISSUE_KH(1, 0, 0);
-  asm volatile("s_waitcnt vmcnt(4)" ::: "memory");     // kh0 of K-tile 0 landed (this wave's part)
-  VP_BAR();
-  if (wr == 1) VP_BAR();                               // stagger: the second wave group runs one barrier behind
-  bf16x8 xf[8], wf[4];
-  for (int t = 0; t < nt; ++t) {
-    const int cur = t & 1;
-    const bf16_t* buf = smem + cur * 32768;
-    // ---- phase A: k-half 0
-    ISSUE_KH(0, t + 1, cur ^ 1);
-    READ_KH(0);
-    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    VP_BAR();
-    MFMA_PHASE();
-    VP_BAR();
-    // ---- phase B: k-half 1
-    ISSUE_KH(1, t + 1, cur ^ 1);
-    READ_KH(1);
-    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    VP_BAR();
-    MFMA_PHASE();
-    VP_BAR();
-  }
-  if (wr == 0) VP_BAR();
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  VP_BAR();
-#undef ISSUE_KH
-#undef READ_KH
-#undef MFMA_PHASE
-  if (!OUT_F32) {
-    epilogue_256_swz(p, smem + wave * 4096, acc, m0 + wr * 128, n0 + wc * 64, lane);
-  } else {
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        store4<OUT_F32>(p, m0 + wr * 128 + i * 16 + fr, n0 + wc * 64 + j * 16 + g * 4, acc[i][j]);
-  }
-}
 
 // ------------------------------------------------------------------------------------------------
 // 8-phase ping-pong kernel (two K-tiles = 8 phases per loop trip).  Same 256x256x64 tile / 8 waves / 2 LDS buffers as
@@ -942,15 +834,6 @@ int vp_gemm_bf16(int M, int N, int K, const void* A, long lda, const void* B, lo
     const unsigned g8 = (unsigned)(((K / 64) % 2 == 0 && big_tiles > 256 && !(p.dbg & 0x20000)) ? 256 : big_tiles);
     if (out_f32) hipLaunchKernelGGL(gemm_nt_256p8<true>, dim3(g8), dim3(512), 131072, stream, p);
     else hipLaunchKernelGGL(gemm_nt_256p8<false>, dim3(g8), dim3(512), 131072, stream, p);
-  } else if (fast && force_generic == 4) {
-    static bool attr_pp = false;
-    if (!attr_pp) {
-      (void)hipFuncSetAttribute((const void*)gemm_nt_256pp<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
-      (void)hipFuncSetAttribute((const void*)gemm_nt_256pp<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
-      attr_pp = true;
-    }
-    if (out_f32) hipLaunchKernelGGL(gemm_nt_256pp<true>, dim3((unsigned)big_tiles), dim3(512), 131072, stream, p);
-    else hipLaunchKernelGGL(gemm_nt_256pp<false>, dim3((unsigned)big_tiles), dim3(512), 131072, stream, p);
   } else if (fast && force_generic != 2 && (force_generic == 3 || (big_tiles >= 192 && M >= 256 && N >= 256))) {
     static bool attr_done = false;
     if (!attr_done) {

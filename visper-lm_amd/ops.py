@@ -41,7 +41,8 @@ def _rows2d(t):
 # ------------------------------------------------------------------------------------------------
 def gemm(a, w, bias=None, residual=None, epi=EPI_NONE, out=None, out_f32=False, force_generic=False):
     """out[M,N] = epi(a[M,K] @ w[N,K]^T + bias) + residual.
-    force_generic: 0 auto | 1 bounds-checked generic kernel | 2 force the 128-tile kernel | 3 force the 256-tile kernel."""
+    force_generic: 0 auto | 1 bounds-checked generic kernel | 2 the 128-tile kernel | 3 the simple persistent 256-tile kernel |
+    7 the 8-phase kernel (the auto choice for large problems)."""
     M, K, lda = _rows2d(a)
     N, K2, ldb = _rows2d(w)
     assert K == K2, (a.shape, w.shape)
