@@ -147,7 +147,7 @@ def main():
                     help="skip the frozen DPT depth decoder (depth_preds: a logging-only output the reference computes under no_grad in "
                          "every training step, base_ola_vlm.py:462-470; ~6 ms/step here); on by default so the timed step does all the "
                          "reference's work")
-    ap.add_argument("--workload", default="llama3_8b", choices=["llama3_8b", "convnext", "phi3"],
+    ap.add_argument("--workload", default="llama3_8b", choices=["llama3_8b", "convnext", "phi3", "ift"],
                     help="llama3_8b = BASELINE configs[1] (the headline metric); convnext = configs[3]; phi3 = configs[4] (secondary)")
     ap.add_argument("--lr", type=float, default=1e-3)
     ap.add_argument("--force-dist", action="store_true", help="initialise the RCCL process group even with one rank (test hook)")
@@ -178,9 +178,15 @@ def main():
         cfg.image_depth = dict(cfg.image_depth); cfg.image_gen = dict(cfg.image_gen); cfg.image_seg = dict(cfg.image_seg)
         if args.text_len == 1449:
             args.text_len, args.batch = 3497, min(args.batch, 4)      # post-splice S = 4096
+    elif args.workload == "ift":
+        # IFT-stage step on the same shapes (NTP only, whole Llama-3-8B trainable: + 238 TFLOP of weight gradients,
+        # 8 B-parameter AdamW, per-layer gradient buckets); not the headline metric
+        cfg, step_tf = llama3_8b(aux_mode="", num_task_tokens=0, train_llm=True), 95.5
+        if args.text_len == 1449:
+            args.text_len = 1473                                          # post-splice S = T - 1 + 576 = 2048 without task tokens
     else:
         cfg = llama3_8b()
-    cfg.depth_decoder = not args.no_depth_decoder
+    cfg.depth_decoder = not args.no_depth_decoder and args.workload != "ift"
     if args.layers:
         cfg.num_hidden_layers = args.layers
         cfg.image_gen["img_layer_indices"] = str(min(20, args.layers))
@@ -251,15 +257,18 @@ def main():
             "all_gemm_tflop_per_step": round(g_fl / args.steps / 1e12, 2),
             "step_frac_of_peak": round(value / world * step_tf / PEAK_BF16_TF, 4)}
     if rank == 0:
-        res = {"metric": "train-step images/sec (NTP+distill), ViT-L+Llama3-8B seq2048" if args.workload == "llama3_8b" else f"train-step images/sec (NTP+distill), {args.workload}", "value": round(value, 4), "unit": "images/s",
+        res = {"metric": "train-step images/sec (NTP+distill), ViT-L+Llama3-8B seq2048" if args.workload == "llama3_8b" else
+               ("train-step images/sec (NTP only, IFT stage: whole LLM trainable), ViT-L+Llama3-8B seq2048" if args.workload == "ift"
+                else f"train-step images/sec (NTP+distill), {args.workload}"), "value": round(value, 4), "unit": "images/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 2), "higher_is_better": True,
                "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic (random-init weights, random images/tokens/targets)",
                "config": {"workload": {"llama3_8b": "configs[1]: CLIP-ViT-L/14-336 + Llama-3-8B PT step, 3 distill heads (d18,s18,g20), 336px",
                                        "convnext": "configs[3]: CLIP-ConvNeXt-XXL (768px) + Llama-3-8B PT step, 3 distill heads",
-                                       "phi3": "configs[4]: CLIP-ViT-L/14-336 + Phi-3-mini PT step, 3 distill heads, seq 4096"}[args.workload],
+                                       "phi3": "configs[4]: CLIP-ViT-L/14-336 + Phi-3-mini PT step, 3 distill heads, seq 4096",
+                                       "ift": "SURVEY f-2: CLIP-ViT-L/14-336 + Llama-3-8B IFT step (NTP only, whole LLM trainable)"}[args.workload],
                           "global_batch": args.batch * world, "per_gpu_batch": args.batch, "seq_len": S, "text_len": args.text_len,
                           "parallelism": f"dp{world}", "decoder_layers": cfg.num_hidden_layers, "loss": round(loss, 4),
-                          "depth_decoder": not args.no_depth_decoder,
+                          "depth_decoder": bool(cfg.depth_decoder),
                           "valid": args.layers is None},
                "roofline": roof}
         if world == 1 and not args.no_cpu_baseline and args.workload == "llama3_8b":

@@ -78,9 +78,13 @@ int vp_layernorm_bwd_wb_partial(int M, int H, const void* dy, const void* x, con
  * GELU / ReLU fwd+bwd for the trainable projector/heads, residual adds. */
 int vp_rope(long T, int S, int nheads, int head_dim, void* x, long ld, const float* cos_t, const float* sin_t,
             const int* pos, int inverse, vp_stream_t stream);
-int vp_swiglu_fwd(long M, int F, const void* gate_up, long ldg, void* out, long ldo, vp_stream_t stream);
-int vp_swiglu_bwd(long M, int F, const void* dact, long ldd, const void* gate_up, void* dgate_up, long ldg,
+/* interleaved = 1: gate / up in 8-column chunks (the frozen-LLM layout of the fused GEMM epilogues); 0: [gate | up] halves
+ * (trainable LLM, where gate_proj / up_proj stay contiguous views of the flat parameter buffer) */
+int vp_swiglu_fwd(long M, int F, const void* gate_up, long ldg, void* out, long ldo, int interleaved, vp_stream_t stream);
+int vp_swiglu_bwd(long M, int F, const void* dact, long ldd, const void* gate_up, void* dgate_up, long ldg, int interleaved,
                   vp_stream_t stream);
+/* dst[idx[r], :] += src[r, :] (fp32 atomics, idx < 0 skips): embed_tokens gradient when the LLM is trainable (IFT stage) */
+int vp_scatter_add_rows(long n, int H, const void* src, long lds, const int* idx, float* dst, vp_stream_t stream);
 int vp_act_fwd(int kind, long n, const void* x, void* y, vp_stream_t stream);
 int vp_act_bwd(int kind, long n, const void* dy, const void* x, void* dx, vp_stream_t stream);
 int vp_add_bf16(long n, const void* a, const void* b, void* out, vp_stream_t stream);

@@ -59,3 +59,16 @@ def sub(t, n=4096):
     f = t.detach().float().flatten()
     step = max(1, f.numel() // n)
     return f[::step][:n].numpy().copy()
+
+
+def tiny_ift_case():
+    """(cfg, W, batch, golden) for tests/golden/tiny_llama_ift.npz: the reference's LlavaLlamaForCausalLM (IFT stage: no aux tasks,
+    no task tokens; everything but the vision tower trainable)."""
+    g = load_golden("tiny_llama_ift.npz")
+    base, _, _, _ = tiny_llama_case()
+    cfg = O.make_config(**{**vars(base), "aux_mode": "", "num_task_tokens": 0})
+    W = {k: WT.param(k, s) for k, s in json.loads(str(g["manifest"])).items()}
+    B, T, col = json.loads(str(g["batch"]))
+    batch = {k: v for k, v in make_batch(B, T, col).items() if k in ("input_ids", "labels", "attention_mask", "images")}
+    assert np.array_equal(batch["input_ids"].numpy(), g["input_ids"])
+    return cfg, W, batch, g

@@ -262,6 +262,58 @@ def run_tiny_llama(arch="llama"):
     return model
 
 
+def run_tiny_ift():
+    """IFT-stage golden: the reference's LlavaLlamaForCausalLM (llava_llama.py:50-119 + llava_arch.py:300-486, no
+    task tokens, NTP loss only) with everything but the vision tower trainable (scripts/train/finetune.sh) -> loss + the norm and
+    a subsample of EVERY parameter gradient."""
+    from ola_vlm.model.multimodal_encoder.clip_encoder import CLIPVisionTower
+    from ola_vlm.model.multimodal_projector.builder import build_vision_projector
+    from ola_vlm.model.language_model.llava_llama import LlavaLlamaForCausalLM, LlavaConfig
+    tiny = TINY_LLAMA
+    cfg = LlavaConfig(vocab_size=tiny["vocab_size"], hidden_size=tiny["hidden_size"], intermediate_size=tiny["intermediate_size"],
+                      num_hidden_layers=tiny["num_hidden_layers"], num_attention_heads=tiny["num_attention_heads"],
+                      num_key_value_heads=tiny["num_key_value_heads"], rms_norm_eps=1e-5, max_position_embeddings=4096)
+    try:
+        cfg.rope_parameters = {"rope_type": "default", "rope_theta": 500000.0}
+    except Exception:
+        pass
+    cfg.rope_theta = 500000.0
+    cfg._attn_implementation = "eager"
+    cfg.tokenizer_model_max_length, cfg.tokenizer_padding_side = 4096, "right"
+    if not hasattr(cfg, "pretraining_tp"):
+        cfg.pretraining_tp = 1
+    model = LlavaLlamaForCausalLM(cfg)
+    tower = CLIPVisionTower.__new__(CLIPVisionTower)
+    torch.nn.Module.__init__(tower)
+    tower.is_loaded, tower.select_layer, tower.select_feature = True, -2, "patch"
+    vcfg = CLIPVisionConfig(hidden_size=tiny["vit_hidden"], intermediate_size=tiny["vit_inter"], num_hidden_layers=tiny["vit_layers"],
+                            num_attention_heads=tiny["vit_heads"], image_size=336, patch_size=14)
+    vcfg._attn_implementation = "eager"
+    tower.vision_tower = CLIPVisionModel(vcfg).requires_grad_(False)
+    model.model.vision_tower = tower
+    cfg.mm_projector_type, cfg.mm_hidden_size = "mlp2x_gelu", tiny["vit_hidden"]
+    model.model.mm_projector = build_vision_projector(cfg)
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    model.load_state_dict({k: WT.param(k, s) for k, s in shapes.items()}, strict=True)
+    model.requires_grad_(True)
+    model.model.vision_tower.requires_grad_(False)
+    B, T, col = 2, 59, 38
+    ids, labels, images, *_ = make_batch(B, T, col)
+    out = model(input_ids=ids, attention_mask=torch.ones_like(ids, dtype=torch.bool), labels=labels, images=images)
+    out.loss.backward()
+    res = {"loss": np.float64(out.loss.item()), "logits_shape": np.array(out.logits.shape),
+           "logits_sub": out.logits[:, ::41, ::997].detach().numpy().copy(),
+           "manifest": json.dumps({k: list(s) for k, s in shapes.items()}),
+           "trainable": json.dumps(sorted(n for n, p in model.named_parameters() if p.requires_grad)),
+           "input_ids": ids.numpy(), "labels": labels.numpy(), "batch": json.dumps([B, T, col])}
+    for n, p in model.named_parameters():
+        if p.requires_grad:
+            res[f"gradnorm::{n}"] = np.float64(p.grad.double().norm().item())
+            res[f"gradsub::{n}"] = sub(p.grad, 128)
+    np.savez_compressed(os.path.join(OUT, "tiny_llama_ift.npz"), **res)
+    print("tiny_llama_ift: loss", res["loss"], "params with grad", len(json.loads(res["trainable"])))
+
+
 def run_units():
     """Unit fixtures straight from the reference functions."""
     from ola_vlm.ola_utils import calculate_contrastive_loss
@@ -306,10 +358,12 @@ if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
     setup_reference()
-    which = sys.argv[1:] or ["units", "llama", "phi3"]
+    which = sys.argv[1:] or ["units", "llama", "phi3", "ift"]
     if "units" in which:
         run_units()
     if "llama" in which:
         run_tiny_llama("llama")
     if "phi3" in which:
         run_tiny_llama("phi3")
+    if "ift" in which:
+        run_tiny_ift()

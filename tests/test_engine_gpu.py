@@ -269,3 +269,69 @@ def test_edge_short_sequence_head_path():
         b.pop("gen_target", None); b.pop("gen_mask", None)
     out, ref = _edge_case({"aux_mode": "depth-seg"}, mutate)
     assert out["plan"]["S"] == 59
+
+
+@pytest.mark.parametrize("arch", ["llama", "phi3"])
+def test_ift_stage_llm_weight_gradients_match_oracle(arch):
+    """SURVEY §8f f-2 (IFT / visual-instruction-tuning step: NTP only, the whole LLM + projector trainable, tower frozen;
+    scripts/train/finetune.sh, llava_llama.py:73-119): every parameter gradient of the fused forward+backward against autograd
+    through the fp32 oracle on the same bf16-rounded weights, then one AdamW step must lower the loss."""
+    from oracle import cases, visper_oracle as O
+    from visper_lm_amd.config import VisperConfig
+    from visper_lm_amd.engine import Engine, is_trainable
+    ocfg, W, batch, g = cases.tiny_llama_case(arch)
+    ocfg = O.make_config(**{**vars(ocfg), "aux_mode": "", "num_task_tokens": 0})
+    batch = {k: v for k, v in batch.items() if not (k.endswith("_target") or k.endswith("_mask")) or k == "attention_mask"}
+    eng = Engine(VisperConfig(**vars(ocfg), train_llm=True))
+    eng.load_weights(W)
+    out = eng.train_step(_to_gpu_batch(batch))
+    tr = [k for k in eng.ps.index]
+    assert all(is_trainable(k, True) for k in tr) and "lm_head.weight" in tr and "model.embed_tokens.weight" in tr
+    Wq = {k: v.to(BF).float() for k, v in W.items()}
+    for k in tr:
+        Wq[k] = Wq[k].clone().requires_grad_(True)
+    bq = {k: (v.to(BF).float() if (torch.is_tensor(v) and v.is_floating_point()) else v) for k, v in batch.items()}
+    ref = O.forward(Wq, bq, ocfg)
+    ref["loss"].backward()
+    assert rel(out["loss"], ref["loss"]) < 5e-3, (float(out["loss"]), float(ref["loss"]))
+    worst = []
+    for k in tr:
+        mine = eng.ps.g(k).detach().float().cpu().reshape(-1)
+        if Wq[k].grad is None:                                       # heads / task tokens of the fixture: unused without aux tasks
+            assert float(mine.abs().max()) == 0.0, k
+            continue
+        theirs = Wq[k].grad.reshape(-1)
+        cos = float(torch.dot(mine, theirs) / (mine.norm() * theirs.norm() + 1e-30))
+        nr = float(mine.norm() / (theirs.norm() + 1e-30))
+        worst.append((cos, nr, k))
+        assert cos > 0.97 and 0.9 < nr < 1.1, (k, cos, nr)
+    l0 = float(out["loss"])
+    for _ in range(3):
+        eng.optimizer_step(lr=2e-4)
+        l1 = float(eng.train_step(_to_gpu_batch(batch))["loss"])
+    assert l1 < l0, (l0, l1)
+    # the re-transposed dgrad copies follow the updated weights
+    assert torch.equal(eng.fz["dec.0.wo_T"], eng.fz["dec.0.wo"].t().contiguous())
+
+
+def test_ift_stage_matches_reference_golden():
+    """Same step against the fixture produced by the reference's own LlavaLlamaForCausalLM (tests/golden/tiny_llama_ift.npz):
+    loss within 1e-2 (bf16 vs the reference's fp32), every parameter-gradient norm within 10 %, subsampled gradients aligned."""
+    from oracle import cases
+    from visper_lm_amd.config import VisperConfig
+    from visper_lm_amd.engine import Engine
+    ocfg, W, batch, g = cases.tiny_ift_case()
+    eng = Engine(VisperConfig(**vars(ocfg), train_llm=True))
+    eng.load_weights(W)
+    out = eng.train_step(_to_gpu_batch(batch))
+    assert rel(out["loss"], g["loss"]) < 1e-2, (float(out["loss"]), float(g["loss"]))
+    tr = json.loads(str(g["trainable"]))
+    assert sorted(eng.ps.index) == tr
+    for k in tr:
+        got = eng.ps.g(k).detach().float().cpu()
+        ref_norm = float(g[f"gradnorm::{k}"])
+        assert abs(float(got.norm()) - ref_norm) <= 0.1 * ref_norm + 1e-7, (k, float(got.norm()), ref_norm)
+        mine, theirs = torch.from_numpy(cases.sub(got, 128)), torch.from_numpy(g[f"gradsub::{k}"])
+        if float(theirs.norm()) > 0:
+            cos = float(torch.dot(mine, theirs) / (mine.norm() * theirs.norm() + 1e-30))
+            assert cos > 0.95, (k, cos)

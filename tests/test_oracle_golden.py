@@ -163,3 +163,21 @@ def test_phi3_e2e_forward_and_grads_match_reference(tiny_phi3):
             continue
         ref_norm = float(g[f"keep_gradnorm::{k}"])
         assert abs(float(W[k].grad.double().norm()) - ref_norm) <= 2e-4 * ref_norm + 1e-9, k
+
+
+def test_ift_stage_matches_reference_llava_llama():
+    """NTP-only step of the reference's LlavaLlamaForCausalLM (llava_llama.py, llava_arch.py) with the whole LLM
+    trainable — loss, logits and EVERY parameter gradient of the oracle against the reference's own autograd."""
+    cfg, W, batch, g = cases.tiny_ift_case()
+    tr = json.loads(str(g["trainable"]))
+    W = {k: (v.clone().requires_grad_(True) if k in tr else v) for k, v in W.items()}
+    out = O.forward(W, batch, cfg)
+    out["loss"].backward()
+    _close(out["loss"].item(), g["loss"], 1e-5, 1e-6)
+    assert tuple(out["logits"].shape) == tuple(g["logits_shape"])
+    _close(out["logits"][:, ::41, ::997].detach().numpy(), g["logits_sub"], 1e-3, 2e-5)
+    assert len(tr) == 43 and "lm_head.weight" in tr and "model.embed_tokens.weight" in tr
+    for k in tr:
+        ref_norm = float(g[f"gradnorm::{k}"])
+        assert abs(float(W[k].grad.double().norm()) - ref_norm) <= 2e-4 * ref_norm + 1e-9, k
+        _close(cases.sub(W[k].grad, 128), g[f"gradsub::{k}"], 2e-3, 1e-7 + 1e-4 * float(np.abs(g[f"gradsub::{k}"]).max()))

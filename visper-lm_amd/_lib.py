@@ -33,8 +33,9 @@ _SIGS = {
     "vp_bilinear_nhwc": [i, i, i, i, i, i, p, p, p],
     "vp_pixel_shuffle_nhwc": [i, i, i, i, i, p, p, p],
     "vp_minmax_norm": [i, l, p, p, p],
-    "vp_swiglu_fwd": [l, i, p, l, p, l, p],
-    "vp_swiglu_bwd": [l, i, p, l, p, p, l, p],
+    "vp_swiglu_fwd": [l, i, p, l, p, l, i, p],
+    "vp_scatter_add_rows": [l, i, p, l, p, p, p],
+    "vp_swiglu_bwd": [l, i, p, l, p, p, l, i, p],
     "vp_act_fwd": [i, l, p, p, p],
     "vp_act_bwd": [i, l, p, p, p, p],
     "vp_add_bf16": [l, p, p, p, p],

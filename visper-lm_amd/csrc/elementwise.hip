@@ -40,13 +40,14 @@ __global__ void rope_kernel(bf16_t* __restrict__ x, const float* __restrict__ cs
 // ---------------------------------------------------------------- SwiGLU -----------------------
 // gu: [M, 2F] with gate / up interleaved in 8-wide chunks (g0..7 | u0..7 | g8..15 | ...; the layout the fused GEMM
 // epilogues produce and consume);  out[M,F] = silu(gate) * up
-__global__ void swiglu_fwd_kernel(const bf16_t* __restrict__ gu, bf16_t* __restrict__ out, long M, int F, long ldg, long ldo) {
+__global__ void swiglu_fwd_kernel(const bf16_t* __restrict__ gu, bf16_t* __restrict__ out, long M, int F, long ldg, long ldo, int il) {
   const int vpr = F >> 3;
   const long total = M * vpr;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const long r = i / vpr;
     const int c = (int)(i % vpr) * 8;
-    const bf16x8 g = *(const bf16x8*)(gu + r * ldg + 2 * c), u = *(const bf16x8*)(gu + r * ldg + 2 * c + 8);
+    const long go = il ? 2L * c : c, uo = il ? 2L * c + 8 : (long)F + c;      // interleaved 8-chunks | [gate | up] halves
+    const bf16x8 g = *(const bf16x8*)(gu + r * ldg + go), u = *(const bf16x8*)(gu + r * ldg + uo);
     bf16x8 o;
 #pragma unroll
     for (int j = 0; j < 8; ++j) o[j] = (short)f2bf(bfround(silu(bf2f((bf16_t)g[j]))) * bf2f((bf16_t)u[j]));
@@ -56,13 +57,14 @@ __global__ void swiglu_fwd_kernel(const bf16_t* __restrict__ gu, bf16_t* __restr
 
 // dgu[M,2F]: dgate = dact * up * silu'(gate), dup = dact * silu(gate)
 __global__ void swiglu_bwd_kernel(const bf16_t* __restrict__ dact, const bf16_t* __restrict__ gu, bf16_t* __restrict__ dgu,
-                                  long M, int F, long ldd, long ldg) {
+                                  long M, int F, long ldd, long ldg, int il) {
   const int vpr = F >> 3;
   const long total = M * vpr;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const long r = i / vpr;
     const int c = (int)(i % vpr) * 8;
-    const bf16x8 g = *(const bf16x8*)(gu + r * ldg + 2 * c), u = *(const bf16x8*)(gu + r * ldg + 2 * c + 8);
+    const long go = il ? 2L * c : c, uo = il ? 2L * c + 8 : (long)F + c;      // interleaved 8-chunks | [gate | up] halves
+    const bf16x8 g = *(const bf16x8*)(gu + r * ldg + go), u = *(const bf16x8*)(gu + r * ldg + uo);
     const bf16x8 d = *(const bf16x8*)(dact + r * ldd + c);
     bf16x8 og, ou;
 #pragma unroll
@@ -72,8 +74,8 @@ __global__ void swiglu_bwd_kernel(const bf16_t* __restrict__ dact, const bf16_t*
       og[j] = (short)f2bf(dd * uu * sg * (1.f + gg * (1.f - sg)));
       ou[j] = (short)f2bf(dd * gg * sg);
     }
-    *(bf16x8*)(dgu + r * ldg + 2 * c) = og;
-    *(bf16x8*)(dgu + r * ldg + 2 * c + 8) = ou;
+    *(bf16x8*)(dgu + r * ldg + go) = og;
+    *(bf16x8*)(dgu + r * ldg + uo) = ou;
   }
 }
 
@@ -225,6 +227,23 @@ __global__ __launch_bounds__(1024) void sum_f32_kernel(const float* __restrict__
   if (threadIdx.x == 0) out[0] = a * scale;
 }
 
+// dst[idx[r], :] += src[r, :] (fp32 atomics; idx < 0 skips the row): embedding-table gradient of a trainable LLM (IFT stage).
+// Like torch's index_add_ / embedding backward on GPUs the accumulation order is not deterministic.
+__global__ void scatter_add_rows_kernel(const bf16_t* __restrict__ src, const int* __restrict__ idx, float* __restrict__ dst, long n,
+                                        int H, long lds) {
+  const int cv = H >> 3;
+  const long total = n * cv;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long r = i / cv;
+    const int c = (int)(i % cv) * 8;
+    const int t = idx[r];
+    if (t < 0) continue;
+    const bf16x8 v = *(const bf16x8*)(src + r * lds + c);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) atomicAdd(dst + (long)t * H + c + e, bf2f((bf16_t)v[e]));
+  }
+}
+
 // sum of squares of n floats (gradient-clipping norm): per-block partials, then sum_f32_kernel over them (deterministic)
 __global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* __restrict__ x, float* __restrict__ part, long n) {
   __shared__ float red[16];
@@ -309,16 +328,17 @@ int vp_rope(long T, int S, int nheads, int hd, void* x, long ld, const float* co
   return vp_check_launch("vp_rope");
 }
 
-int vp_swiglu_fwd(long M, int F, const void* gate_up, long ldg, void* out, long ldo, hipStream_t s) {
+int vp_swiglu_fwd(long M, int F, const void* gate_up, long ldg, void* out, long ldo, int interleaved, hipStream_t s) {
   VP_REQUIRE(M > 0 && F > 0 && F % 8 == 0 && ldg % 8 == 0 && ldo % 8 == 0, VP_ERR_BAD_ARG, "vp_swiglu_fwd: bad args");
-  hipLaunchKernelGGL(swiglu_fwd_kernel, GRID_FOR(M * (F / 8)), dim3(256), 0, s, (const bf16_t*)gate_up, (bf16_t*)out, M, F, ldg, ldo);
+  hipLaunchKernelGGL(swiglu_fwd_kernel, GRID_FOR(M * (F / 8)), dim3(256), 0, s, (const bf16_t*)gate_up, (bf16_t*)out, M, F, ldg, ldo, interleaved);
   return vp_check_launch("vp_swiglu_fwd");
 }
 
-int vp_swiglu_bwd(long M, int F, const void* dact, long ldd, const void* gate_up, void* dgate_up, long ldg, hipStream_t s) {
+int vp_swiglu_bwd(long M, int F, const void* dact, long ldd, const void* gate_up, void* dgate_up, long ldg, int interleaved,
+                  hipStream_t s) {
   VP_REQUIRE(M > 0 && F > 0 && F % 8 == 0 && ldg % 8 == 0 && ldd % 8 == 0, VP_ERR_BAD_ARG, "vp_swiglu_bwd: bad args");
   hipLaunchKernelGGL(swiglu_bwd_kernel, GRID_FOR(M * (F / 8)), dim3(256), 0, s, (const bf16_t*)dact, (const bf16_t*)gate_up,
-                     (bf16_t*)dgate_up, M, F, ldd, ldg);
+                     (bf16_t*)dgate_up, M, F, ldd, ldg, interleaved);
   return vp_check_launch("vp_swiglu_bwd");
 }
 
@@ -405,6 +425,12 @@ int vp_sum_f32(long n, const float* x, float* out, float scale, hipStream_t s) {
   VP_REQUIRE(n > 0, VP_ERR_BAD_ARG, "vp_sum_f32: bad n");
   hipLaunchKernelGGL(sum_f32_kernel, dim3(1), dim3(1024), 0, s, x, out, n, scale);
   return vp_check_launch("vp_sum_f32");
+}
+
+int vp_scatter_add_rows(long n, int H, const void* src, long lds, const int* idx, float* dst, hipStream_t s) {
+  VP_REQUIRE(n > 0 && H > 0 && H % 8 == 0 && lds % 8 == 0 && src && idx && dst, VP_ERR_BAD_ARG, "vp_scatter_add_rows: bad args");
+  hipLaunchKernelGGL(scatter_add_rows_kernel, GRID_FOR(n * (H / 8)), dim3(256), 0, s, (const bf16_t*)src, idx, dst, n, H, lds);
+  return vp_check_launch("vp_scatter_add_rows");
 }
 
 // out[0] = sum x^2; `part` = caller-owned workspace of vp_sumsq_nblk(n) floats

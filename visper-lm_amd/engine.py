@@ -40,9 +40,16 @@ TASK_SPEC = {   # task -> (config attr, layer key, weight key, logit-scale name,
 }
 
 
-def is_trainable(name: str) -> bool:
-    """PT-stage trainable set: projector, heads, task tokens, logit scales (ola_vlm_train.py:1127-1131, 1239-1242)."""
-    return ("mm_projector" in name or "_heads." in name or "special_" in name or name.endswith("logit_scale"))
+def is_trainable(name: str, train_llm: bool = False) -> bool:
+    """PT-stage trainable set: projector, heads, task tokens, logit scales (ola_vlm_train.py:1127-1131, 1239-1242).
+    IFT stage (`train_llm`, scripts/train/finetune.sh: full fine-tune, tower frozen): additionally every LLM parameter."""
+    if "mm_projector" in name or "_heads." in name or "special_" in name or name.endswith("logit_scale"):
+        return True
+    return train_llm and not ("vision_tower" in name or name.startswith("da_v2_head."))
+
+
+def _is_llm(name: str) -> bool:
+    return name.startswith("model.layers.") or name in ("model.embed_tokens.weight", "model.norm.weight", "lm_head.weight")
 
 
 class ParamStore:
@@ -151,6 +158,30 @@ class Engine:
         self._red = None
         self.keep_logits = False
 
+    def _load_frozen_decoder(self, W, d):
+        """PT stage: the LLM is frozen -> bf16 kernel-ready copies, q/k/v and gate/up fused, plus pre-transposed dgrad copies."""
+        cfg, fz = self.cfg, self.fz
+        fz["embed"] = d(W["model.embed_tokens.weight"])
+        fz["norm"] = d(W["model.norm.weight"])
+        fz["lm_head"] = d(W["lm_head.weight"])
+        fz["lm_head_T"] = _tp(fz["lm_head"])
+        for l in range(cfg.num_hidden_layers):
+            p = f"model.layers.{l}."
+            o = f"dec.{l}."
+            if cfg.arch == "phi3":
+                wqkv, wgu = W[p + "self_attn.qkv_proj.weight"], W[p + "mlp.gate_up_proj.weight"]
+            else:
+                wqkv = torch.cat([W[p + f"self_attn.{x}_proj.weight"] for x in "qkv"], 0)
+                wgu = torch.cat([W[p + "mlp.gate_proj.weight"], W[p + "mlp.up_proj.weight"]], 0)
+            fz[o + "wqkv"] = d(wqkv)
+            fz[o + "wgu"] = ops.interleave_gate_up(d(wgu))      # gate / up rows interleaved in 8-row chunks (fused SwiGLU epilogues)
+            fz[o + "wo"] = d(W[p + "self_attn.o_proj.weight"])
+            fz[o + "wd"] = d(W[p + "mlp.down_proj.weight"])
+            for k in ("wqkv", "wgu", "wo", "wd"):
+                fz[o + k + "_T"] = _tp(fz[o + k])
+            fz[o + "ln1"] = d(W[p + "input_layernorm.weight"])
+            fz[o + "ln2"] = d(W[p + "post_attention_layernorm.weight"])
+
     # ------------------------------------------------------------------------------------------ weights
     def load_weights(self, W):
         """W: {reference state-dict name: tensor}. Frozen weights -> bf16 device buffers (fused / pre-transposed);
@@ -211,27 +242,11 @@ class Engine:
                     gam = W[b_ + "gamma"].float()
                     fz[o + "w2"] = d(W[b_ + "mlp.fc2.weight"].float() * gam[:, None])      # layer scale folded (frozen tower)
                     fz[o + "b2"] = d(W[b_ + "mlp.fc2.bias"].float() * gam)
-        # ---- decoder
-        fz["embed"] = d(W["model.embed_tokens.weight"])
-        fz["norm"] = d(W["model.norm.weight"])
-        fz["lm_head"] = d(W["lm_head.weight"])
-        fz["lm_head_T"] = _tp(fz["lm_head"])
-        for l in range(cfg.num_hidden_layers):
-            p = f"model.layers.{l}."
-            o = f"dec.{l}."
-            if cfg.arch == "phi3":
-                wqkv, wgu = W[p + "self_attn.qkv_proj.weight"], W[p + "mlp.gate_up_proj.weight"]
-            else:
-                wqkv = torch.cat([W[p + f"self_attn.{x}_proj.weight"] for x in "qkv"], 0)
-                wgu = torch.cat([W[p + "mlp.gate_proj.weight"], W[p + "mlp.up_proj.weight"]], 0)
-            fz[o + "wqkv"] = d(wqkv)
-            fz[o + "wgu"] = ops.interleave_gate_up(d(wgu))      # gate / up rows interleaved in 8-row chunks (fused SwiGLU epilogues)
-            fz[o + "wo"] = d(W[p + "self_attn.o_proj.weight"])
-            fz[o + "wd"] = d(W[p + "mlp.down_proj.weight"])
-            for k in ("wqkv", "wgu", "wo", "wd"):
-                fz[o + k + "_T"] = _tp(fz[o + k])
-            fz[o + "ln1"] = d(W[p + "input_layernorm.weight"])
-            fz[o + "ln2"] = d(W[p + "post_attention_layernorm.weight"])
+        # ---- decoder (frozen copies; with a trainable LLM the kernel-side weights alias the parameter store instead, see below)
+        train_llm = bool(getattr(cfg, "train_llm", False))
+        self.gu_interleaved = not train_llm
+        if not train_llm:
+            self._load_frozen_decoder(W, d)
         # ---- frozen DPT depth decoder (a11; da_v2_head.py:182-314): conv weights as GEMM matrices over NHWC activations
         dp = "da_v2_head.depth_head."
         if dp + "projects.0.weight" in W:
@@ -264,16 +279,87 @@ class Engine:
         # ---- trainable.  Flat-buffer order: [heads + logit scales | projector + task tokens] so the first block's
         # gradients (final as soon as the heads' backward is done) can be all-reduced under the decoder backward.
         allshapes = getattr(W, "shapes", None) or OrderedDict((k, tuple(v.shape)) for k, v in W.items())
-        tr = [k for k in allshapes if is_trainable(k)]
+        tr = [k for k in allshapes if is_trainable(k, train_llm)]
         early = [k for k in tr if ("_heads." in k or k.endswith("logit_scale"))]
-        late = [k for k in tr if k not in set(early)]
-        shapes = OrderedDict((k, tuple(allshapes[k])) for k in early + late)
+        late = [k for k in tr if k not in set(early) and not _is_llm(k)]
+        # IFT: LLM parameters follow in BACKWARD order (lm_head, final norm, layers L-1..0, embeddings) so that each gradient
+        # bucket that becomes final during the backward pass is one contiguous range of the flat buffer
+        llm = [k for k in tr if _is_llm(k)]
+        lay = lambda k: int(k.split(".")[2]) if k.startswith("model.layers.") else -1
+        llm_order = ([k for k in llm if k == "lm_head.weight"] + [k for k in llm if k == "model.norm.weight"] +
+                     [k for l in range(cfg.num_hidden_layers - 1, -1, -1) for k in llm if lay(k) == l] +
+                     [k for k in llm if k == "model.embed_tokens.weight"])
+        shapes = OrderedDict((k, tuple(allshapes[k])) for k in early + late + llm_order)
         self.ps = ParamStore(shapes, dev)
         self.ps.split = self.ps.index[late[0]][0] if late else self.ps.total
         for k in shapes:
             self.ps.p(k).copy_(W[k].detach().to(device=dev, dtype=F32).reshape(self.ps.p(k).shape))
         self.ps.refresh_shadow()
+        self.train_llm = train_llm
+        if train_llm:
+            self._alias_llm_weights()
         self._build_static()
+
+    # ------------------------------------------------------------------------------------------ IFT: trainable LLM
+    def _fused_range(self, names):
+        """(offset, numel) of parameters that sit back to back in the flat buffer (q,k,v / gate,up)."""
+        ps = self.ps
+        off0 = ps.index[names[0]][0]
+        off = off0
+        for n in names:
+            o, cnt, _ = ps.index[n]
+            assert o == off and cnt % 64 == 0, f"{n} is not contiguous with its fusion partners"
+            off += cnt
+        return off0, off - off0
+
+    def _alias_llm_weights(self):
+        """Kernel-side decoder weights = views of the parameter store's bf16 shadow (updated in place by the fused AdamW); q/k/v and
+        gate/up are adjacent in the flat buffer, so their fused matrices are plain views ([gate | up] halves, not interleaved: the
+        names must stay contiguous views for state-dict I/O).  The [in,out] dgrad copies are re-transposed after every step."""
+        cfg, fz, ps = self.cfg, self.fz, self.ps
+        H = cfg.hidden_size
+        self._llm_ranges = {}
+        fz["embed"], fz["norm"], fz["lm_head"] = ps.w("model.embed_tokens.weight"), ps.w("model.norm.weight"), ps.w("lm_head.weight")
+        fz["lm_head_T"] = torch.empty(H, cfg.vocab_size, device=self.dev, dtype=BF16)
+        for l in range(cfg.num_hidden_layers):
+            p, o = f"model.layers.{l}.", f"dec.{l}."
+            if cfg.arch == "phi3":
+                qn, gn = [p + "self_attn.qkv_proj.weight"], [p + "mlp.gate_up_proj.weight"]
+            else:
+                qn = [p + f"self_attn.{x}_proj.weight" for x in "qkv"]
+                gn = [p + "mlp.gate_proj.weight", p + "mlp.up_proj.weight"]
+            (oq, nq), (og, ng) = self._fused_range(qn), self._fused_range(gn)
+            fz[o + "wqkv"] = ps.shadow[oq:oq + nq].view(-1, H)
+            fz[o + "wgu"] = ps.shadow[og:og + ng].view(-1, H)
+            self._llm_ranges[o + "wqkv"], self._llm_ranges[o + "wgu"] = (oq, nq), (og, ng)
+            fz[o + "wo"], fz[o + "wd"] = ps.w(p + "self_attn.o_proj.weight"), ps.w(p + "mlp.down_proj.weight")
+            fz[o + "ln1"], fz[o + "ln2"] = ps.w(p + "input_layernorm.weight"), ps.w(p + "post_attention_layernorm.weight")
+            for k in ("wqkv", "wgu", "wo", "wd"):
+                w = fz[o + k]
+                fz[o + k + "_T"] = torch.empty(w.shape[1], w.shape[0], device=self.dev, dtype=BF16)
+            names = [n for n in ps.index if n.startswith(p)]
+            lo = min(ps.index[n][0] for n in names)
+            hi = max(ps.index[n][0] + (ps.index[n][1] + 63) // 64 * 64 for n in names)
+            self._llm_ranges[o] = (lo, hi - lo)
+        self.refresh_transposes()
+
+    def refresh_transposes(self):
+        """[in,out] copies of the (just updated) trainable decoder weights for the dgrad GEMMs."""
+        fz = self.fz
+        ops.transpose(fz["lm_head"], out=fz["lm_head_T"])
+        for l in range(self.cfg.num_hidden_layers):
+            o = f"dec.{l}."
+            for k in ("wqkv", "wgu", "wo", "wd"):
+                ops.transpose(fz[o + k], out=fz[o + k + "_T"])
+
+    def _gfused(self, key):
+        """fp32 gradient view of a fused weight (same layout as the fused bf16 view)."""
+        off, n = self._llm_ranges[key]
+        return self.ps.grad[off:off + n].view(-1, self.cfg.hidden_size)
+
+    def _reduce_range(self, off, n):
+        if self.world > 1:
+            self._reducer().reduce_range(off, off + n)
 
     def init_random(self, seed=0):
         """Random-init weights of the configured architecture, generated on the device (bench / smoke runs)."""
@@ -300,6 +386,8 @@ class Engine:
         self.finish_grads()
         self.ps.adamw_step(lr, betas, eps, weight_decay, grad_scale=1.0 / self.world, mm_projector_lr=mm_projector_lr,
                            lr_mult=lr_mult, max_grad_norm=max_grad_norm)
+        if getattr(self, "train_llm", False):
+            self.refresh_transposes()
 
     def vit_layers_run(self):
         sel = self.cfg.mm_vision_select_layer
@@ -646,13 +734,14 @@ class Engine:
             att, lse = ops.attn_fwd(q4, k4, v4, causal=True, window=window, kv_len=kv_len)
             h1 = ops.gemm(att.view(M, nh * hd), fz[o + "wo"], residual=x)
             hn, rstd2 = ops.rmsnorm_fwd(h1, fz[o + "ln2"], cfg.rms_norm_eps)
-            fuse = ops.swiglu_fusable(M, 2 * cfg.intermediate_size, cfg.hidden_size) and \
+            il = self.gu_interleaved
+            fuse = il and ops.swiglu_fusable(M, 2 * cfg.intermediate_size, cfg.hidden_size) and \
                 ops.swiglu_fusable(M, cfg.intermediate_size, cfg.hidden_size)
             if fuse:
                 gu, act = ops.gemm_swiglu_fwd(hn, fz[o + "wgu"])
             else:
                 gu = ops.gemm(hn, fz[o + "wgu"])
-                act = ops.swiglu_fwd(gu)
+                act = ops.swiglu_fwd(gu, interleaved=il)
             xo = ops.gemm(act, fz[o + "wd"], residual=h1)
             if compute_grads:
                 saved.append((x, rstd1, qkv, att, lse, h1, rstd2, gu))
@@ -679,6 +768,8 @@ class Engine:
             row_loss[r0:r1] = ops.ce_fwd_bwd(lg, plan["shift_labels"][r0:r1], gscale, write_grad=compute_grads)
             if compute_grads:
                 ops.gemm(lg, fz["lm_head_T"], out=d_hidden[r0:r1])
+                if self.train_llm:                             # lm_head.weight.grad (+)= dlogits^T h, chunk by chunk
+                    self._wgrad(hidden[r0:r1], lg, ps.g("lm_head.weight"), accumulate=r0 > 0)
         text_loss = ops.sum_f32(row_loss, gscale)
         out["text_loss"] = text_loss
         if logits_keep is not None:
@@ -743,6 +834,12 @@ class Engine:
         # ---- decoder backward (dgrad only: LLM frozen)
         if (L - 1) in d_state:
             ops.add(d_hidden, d_state[L - 1], out=d_hidden)
+        train_llm = self.train_llm
+        if train_llm:
+            ps.g("model.norm.weight").copy_(ops.rmsnorm_bwd_w(d_hidden, x, rstd_f))
+            i0 = ps.index["lm_head.weight"][0]
+            i1 = ps.index["model.norm.weight"][0] + 64 * ((ps.index["model.norm.weight"][1] + 63) // 64)
+            self._reduce_range(i0, i1 - i0)                   # lm_head + final norm gradients are final: reduce under the backward
         dx = ops.rmsnorm_bwd(d_hidden, x, fz["norm"], rstd_f)
         del d_hidden
         for l in range(L - 1, -1, -1):
@@ -750,15 +847,25 @@ class Engine:
             x_in, rstd1, qkv, att, lse, h1, rstd2, gu = saved[l]
             if l in d_state and l != L - 1:
                 ops.add(dx, d_state[l], out=dx)
-            if ops.swiglu_fusable(M, cfg.intermediate_size, cfg.hidden_size) and gu.is_contiguous():
+            pl = f"model.layers.{l}."
+            if self.gu_interleaved and ops.swiglu_fusable(M, cfg.intermediate_size, cfg.hidden_size) and gu.is_contiguous():
                 d_gu = ops.gemm_swiglu_bwd(dx, fz[o + "wd_T"], gu)
             else:
                 d_act = ops.gemm(dx, fz[o + "wd_T"])
-                d_gu = ops.swiglu_bwd(d_act, gu)
+                d_gu = ops.swiglu_bwd(d_act, gu, interleaved=self.gu_interleaved)
                 del d_act
+            if train_llm:                                       # weight gradients; cheap activations (act, hn) are recomputed
+                self._wgrad(ops.swiglu_fwd(gu, interleaved=False), dx, ps.g(pl + "mlp.down_proj.weight"))
+                hn, _ = ops.rmsnorm_fwd(h1, fz[o + "ln2"], cfg.rms_norm_eps, save_rstd=False)
+                self._wgrad(hn, d_gu, self._gfused(o + "wgu"))
+                del hn
             d_hn = ops.gemm(d_gu, fz[o + "wgu_T"])
             del d_gu
+            if train_llm:
+                ps.g(pl + "post_attention_layernorm.weight").copy_(ops.rmsnorm_bwd_w(d_hn, h1, rstd2))
             d_h1 = ops.rmsnorm_bwd(d_hn, h1, fz[o + "ln2"], rstd2, dres=dx)
+            if train_llm:
+                self._wgrad(att.view(M, nh * hd), d_h1, ps.g(pl + "self_attn.o_proj.weight"))
             d_att = ops.gemm(d_h1, fz[o + "wo_T"])
             dqkv = torch.empty_like(qkv)
             q4 = qkv.view(B, S, -1)[..., :nh * hd].view(B, S, nh, hd)
@@ -771,9 +878,19 @@ class Engine:
                          dq=dq4, dk=dk4, dv=dv4)
             ops.rope_(dqkv, M, S, nh + nkv, hd, cos_t, sin_t, inverse=True)
             d_xn = ops.gemm(dqkv, fz[o + "wqkv_T"])
+            if train_llm:
+                xn, _ = ops.rmsnorm_fwd(x_in, fz[o + "ln1"], cfg.rms_norm_eps, save_rstd=False)
+                self._wgrad(xn, dqkv, self._gfused(o + "wqkv"))
+                del xn
+                ps.g(pl + "input_layernorm.weight").copy_(ops.rmsnorm_bwd_w(d_xn, x_in, rstd1))
+                self._reduce_range(*self._llm_ranges[o])        # this layer's gradients are final
             dx = ops.rmsnorm_bwd(d_xn, x_in, fz[o + "ln1"], rstd1, dres=d_h1)
             saved[l] = None
         out["d_inputs_embeds"] = dx.view(B, S, H)
+        if train_llm:                                           # embed_tokens.weight.grad: scatter-add of the text rows
+            if "embed_idx" not in plan:
+                plan["embed_idx"] = torch.where(plan["kind"] == 0, plan["row"], torch.full_like(plan["row"], -1)).to(torch.int32)
+            ops.scatter_add_rows_(ps.g("model.embed_tokens.weight"), dx, plan["embed_idx"])
 
         # ---- splice backward: image rows -> projector, task-token rows -> special-token parameters
         d_img = torch.empty(plan["n_img"] * N_IMG_TOK, H, device=dev, dtype=BF16)

@@ -168,6 +168,29 @@ def layernorm_bwd(dy, x, w, mean, rstd, dres=None, want_wb=True):
     return dx, dw, db
 
 
+def rmsnorm_bwd_w(dy, x, rstd):
+    """RMSNorm weight gradient sum_rows dy * x * rstd -> f32 [H] (the LayerNorm partial kernel with mean = 0)."""
+    M, H, ld = _rows2d(x)
+    assert dy.is_contiguous() and x.is_contiguous()
+    rpb = max(1, (M + 255) // 256)
+    nslab = (M + rpb - 1) // rpb
+    pw = torch.empty(nslab, H, device=x.device, dtype=torch.float32)
+    pb = torch.empty(nslab, H, device=x.device, dtype=torch.float32)
+    zero = torch.zeros(M, device=x.device, dtype=torch.float32)
+    _lib.call("vp_layernorm_bwd_wb_partial", M, H, _p(dy), _p(x), _p(zero), _p(rstd), _p(pw), _p(pb), ld, rpb, _stream())
+    dw = torch.empty(H, device=x.device, dtype=torch.float32)
+    _lib.call("vp_colsum_finish", nslab, H, _p(pw), _p(dw), 1.0, 0, _stream())
+    return dw
+
+
+def scatter_add_rows_(dst_f32, src, idx):
+    """dst[idx[r]] += src[r] (fp32 atomics; idx < 0 skips)."""
+    n, H, lds = _rows2d(src)
+    assert dst_f32.dtype == torch.float32 and dst_f32.is_contiguous() and idx.dtype == torch.int32
+    _lib.call("vp_scatter_add_rows", n, H, _p(src), lds, _p(idx), _p(dst_f32), _stream())
+    return dst_f32
+
+
 def rope_tables(S, head_dim, theta, device):
     """cos/sin [S, head_dim/2] fp32, rounded to bf16 first (HF casts the tables to the activation dtype)."""
     inv = 1.0 / (theta ** (torch.arange(0, head_dim, 2, dtype=torch.float32) / head_dim))
@@ -228,21 +251,21 @@ def minmax_norm(x):
     return y
 
 
-def swiglu_fwd(gate_up):
-    """gate_up: [..., 2F] chunk-interleaved (see interleave_gate_up) -> silu(gate) * up [..., F]."""
+def swiglu_fwd(gate_up, interleaved=True):
+    """gate_up: [..., 2F], chunk-interleaved (see interleave_gate_up) or [gate | up] halves -> silu(gate) * up [..., F]."""
     M, F2, ldg = _rows2d(gate_up)
     F = F2 // 2
     out = torch.empty(*gate_up.shape[:-1], F, device=gate_up.device, dtype=BF16)
-    _lib.call("vp_swiglu_fwd", M, F, _p(gate_up), ldg, _p(out), F, _stream())
+    _lib.call("vp_swiglu_fwd", M, F, _p(gate_up), ldg, _p(out), F, 1 if interleaved else 0, _stream())
     return out
 
 
-def swiglu_bwd(dact, gate_up):
+def swiglu_bwd(dact, gate_up, interleaved=True):
     M, F2, ldg = _rows2d(gate_up)
     F = F2 // 2
     _, _, ldd = _rows2d(dact)
     dgu = torch.empty_like(gate_up)
-    _lib.call("vp_swiglu_bwd", M, F, _p(dact), ldd, _p(gate_up), _p(dgu), ldg, _stream())
+    _lib.call("vp_swiglu_bwd", M, F, _p(dact), ldd, _p(gate_up), _p(dgu), ldg, 1 if interleaved else 0, _stream())
     return dgu
 
 

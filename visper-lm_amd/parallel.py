@@ -33,19 +33,32 @@ def all_gather_rows(flat: torch.Tensor) -> torch.Tensor:
 class GradReducer:
     def __init__(self, flat_grad: torch.Tensor, split: int):
         self.g, self.split, self.pending = flat_grad, split, []
+        self.done = []                                  # [lo, hi) ranges already launched this step
 
     def _launch(self, lo, hi):
         _, world = world_info()
-        if world > 1 and hi > lo:
-            self.pending.append(dist.all_reduce(self.g[lo:hi], op=dist.ReduceOp.SUM, async_op=True))
+        if hi > lo:
+            self.done.append((lo, hi))
+            if world > 1:
+                self.pending.append(dist.all_reduce(self.g[lo:hi], op=dist.ReduceOp.SUM, async_op=True))
 
     def start_early(self):
         """heads + logit-scale gradients are final: reduce them while the decoder backward runs."""
         self._launch(0, self.split)
 
+    def reduce_range(self, lo, hi):
+        """IFT stage: one bucket (lm_head + final norm, then one decoder layer at a time, in backward order) whose gradients are
+        final; its all-reduce overlaps the rest of the backward pass."""
+        self._launch(lo, hi)
+
     def finish(self):
-        """reduce the late block (projector + task tokens) and join everything (stream-side wait on GPU)."""
-        self._launch(self.split, self.g.numel())
+        """reduce everything not launched yet (PT: projector + task tokens; IFT: also the embeddings) and join (stream-side
+        wait on the GPU)."""
+        pos = 0
+        for lo, hi in sorted(self.done) + [(self.g.numel(), self.g.numel())]:
+            if lo > pos:
+                self._launch(pos, lo)
+            pos = max(pos, hi)
         for w in self.pending:
             w.wait()
-        self.pending = []
+        self.pending, self.done = [], []
