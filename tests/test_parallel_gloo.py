@@ -35,6 +35,16 @@ def _worker(rank, world, port, ret):
         red.start_early()
         red.finish()
         assert torch.allclose(g, torch.arange(10, dtype=torch.float32) * sum(r + 1 for r in range(world)))
+        # IFT stage: buckets launched in backward order as they become final; finish() reduces exactly the complement, once
+        g2 = torch.arange(20, dtype=torch.float32) * (rank + 1)
+        red2 = GradReducer(g2, split=0)
+        red2.start_early()                                       # empty early block
+        red2.reduce_range(12, 20)                                # lm_head + final norm
+        red2.reduce_range(8, 12)                                 # last layer
+        red2.reduce_range(4, 8)                                  # first layer
+        red2.finish()                                            # remaining [0, 4): projector / embeddings
+        assert torch.allclose(g2, torch.arange(20, dtype=torch.float32) * sum(r + 1 for r in range(world)))
+        assert red2.pending == [] and red2.done == []
         ret[rank] = True
     finally:
         dist.destroy_process_group()
