@@ -705,11 +705,22 @@ __global__ __launch_bounds__(512) void gemm_nt_256p8(GemmArgs p) {
     if (!OUT_F32) {
       epilogue_256_swz(p, smem + ((nt - 1) & 1) * 32768 + wave * 4096, acc, tcur.m0 + wr * 128, tcur.n0 + wc * 64, lane);
     } else {
+      // fp32 output (weight gradients): interior, plain tiles go straight from the accumulators as 16-byte stores
+      const int mr = tcur.m0 + wr * 128, nc = tcur.n0 + wc * 64;
+      const bool lean = __builtin_amdgcn_readfirstlane((int)(!p.bias && !p.res && (p.epi & 0xff) == EPI_NONE && mr + 128 <= p.M &&
+                                                             nc + 64 <= p.N && (p.ldc & 3) == 0 && (((uintptr_t)p.C) & 15) == 0));
+      if (lean) {
+        float* c = (float*)p.C + (long)(mr + fr) * p.ldc + nc + g * 4;
 #pragma unroll
-      for (int i = 0; i < 8; ++i)
+        for (int i = 0; i < 8; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-          store4<OUT_F32>(p, tcur.m0 + wr * 128 + i * 16 + fr, tcur.n0 + wc * 64 + j * 16 + g * 4, acc[i][j]);
+          for (int j = 0; j < 4; ++j) *(f32x4*)(c + (long)(i * 16) * p.ldc + j * 16) = acc[i][j];
+      } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) store4<OUT_F32>(p, mr + i * 16 + fr, nc + j * 16 + g * 4, acc[i][j]);
+      }
     }
     STAMP(3);
     if (p.dbg & 0x10000) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); STAMP(4); }
