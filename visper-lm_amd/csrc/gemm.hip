@@ -792,12 +792,34 @@ __global__ __launch_bounds__(256) void gemm_nt_generic(GemmArgs p) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// 2-D transpose (bf16): out[c][r] = in[r][c]; 64x64 tiles through LDS
+// 2-D transpose (bf16): out[c][r] = in[r][c]; 64x64 tiles through LDS.  Interior tiles of 16-byte-aligned matrices move as
+// 16-byte vectors on both sides (row pitch 66 elements keeps the column gathers conflict-free); edge / unaligned tiles go element-wise.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void transpose_bf16_kernel(const bf16_t* in, bf16_t* out, int rows, int cols, long ldi,
                                                              long ldo) {
   __shared__ bf16_t t[64][66];
   const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  const bool vec = r0 + 64 <= rows && c0 + 64 <= cols && (ldi & 7) == 0 && (ldo & 7) == 0 &&
+                   ((((uintptr_t)in) | ((uintptr_t)out)) & 15) == 0;
+  if (vec) {
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int q = it * 256 + threadIdx.x, r = q >> 3, ch = q & 7;
+      const bf16x8 v = *(const bf16x8*)(in + (long)(r0 + r) * ldi + c0 + ch * 8);
+#pragma unroll
+      for (int e = 0; e < 8; e += 2) *(uint32_t*)&t[r][ch * 8 + e] = (uint32_t)(uint16_t)v[e] | ((uint32_t)(uint16_t)v[e + 1] << 16);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int q = it * 256 + threadIdx.x, c = q >> 3, rc = q & 7;
+      bf16x8 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = (short)t[rc * 8 + e][c];
+      *(bf16x8*)(out + (long)(c0 + c) * ldo + r0 + rc * 8) = o;
+    }
+    return;
+  }
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   for (int i = ty; i < 64; i += 4) {
     const int r = r0 + i, c = c0 + tx;

@@ -705,7 +705,13 @@ class Engine:
         B, S = plan["B"], plan["S"]
         M = B * S
         if compute_grads:
-            ps.zero_grad()
+            if self.train_llm:
+                # every decoder / lm_head / norm gradient is overwritten by its wgrad GEMM below: clear only what accumulates
+                # (heads, projector, task tokens in front of the LLM block, and the scatter-added embedding table at its end)
+                ps.grad[:ps.index["lm_head.weight"][0]].zero_()
+                ps.g("model.embed_tokens.weight").zero_()
+            else:
+                ps.zero_grad()
         out = {"plan": plan}
 
         # ---- vision tower + projector + splice (a1..a5)
