@@ -314,6 +314,33 @@ def run_tiny_ift():
     print("tiny_llama_ift: loss", res["loss"], "params with grad", len(json.loads(res["trainable"])))
 
 
+def run_data_path():
+    """f-4: tokenizer_image_token / expand2square outputs of the reference's own functions (ola_vlm/mm_utils.py) on a toy
+    whitespace tokenizer and synthetic PIL images."""
+    from ola_vlm.mm_utils import tokenizer_image_token, expand2square
+    from PIL import Image
+
+    class Tok:
+        bos_token_id = 1
+
+        def __init__(self, bos):
+            self.bos = bos
+
+        def __call__(self, text):
+            ids = [3 + (sum(map(ord, w)) % 997) for w in text.split()]
+            return types.SimpleNamespace(input_ids=([1] if self.bos else []) + ids)
+    prompts = ["<image>\na photo of a cat", "describe <image> and then <image> briefly", "no image here", "<image>", "", "tail image <image>"]
+    res = {"prompts": prompts, "with_bos": [tokenizer_image_token(p, Tok(True)) for p in prompts],
+           "no_bos": [tokenizer_image_token(p, Tok(False)) for p in prompts], "squares": []}
+    for (w, h) in ((7, 3), (3, 8), (5, 5)):
+        img = Image.fromarray((np.arange(w * h * 3).reshape(h, w, 3) % 251).astype(np.uint8), "RGB")
+        sq = expand2square(img, (122, 116, 104))
+        res["squares"].append({"size": [w, h], "out": np.asarray(sq).tolist()})
+    with open(os.path.join(OUT, "data_path.json"), "w") as fh:
+        json.dump(res, fh)
+    print("data_path: ", res["with_bos"][1])
+
+
 def run_units():
     """Unit fixtures straight from the reference functions."""
     from ola_vlm.ola_utils import calculate_contrastive_loss
@@ -358,7 +385,7 @@ if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
     setup_reference()
-    which = sys.argv[1:] or ["units", "llama", "phi3", "ift"]
+    which = sys.argv[1:] or ["units", "llama", "phi3", "ift", "data"]
     if "units" in which:
         run_units()
     if "llama" in which:
@@ -367,3 +394,5 @@ if __name__ == "__main__":
         run_tiny_llama("phi3")
     if "ift" in which:
         run_tiny_ift()
+    if "data" in which:
+        run_data_path()

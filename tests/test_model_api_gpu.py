@@ -66,3 +66,30 @@ def test_encode_images_and_prepare_inputs(setup):
     ref = g["hidden0_sub"]
     got = r[4].float().cpu()[:, ::13, ::3].numpy()
     assert np.allclose(got, ref, rtol=3e-2, atol=3e-2)
+
+
+def test_mm_projector_checkpoint_round_trip(tmp_path):
+    """f-4: `mm_projector.bin` in the reference's format (llava_trainer.py:1006-1014) written from the engine and loaded back."""
+    import torch
+    from oracle import cases
+    from visper_lm_amd import data
+    from visper_lm_amd.config import VisperConfig
+    from visper_lm_amd.engine import Engine
+    ocfg, W, batch, g = cases.tiny_llama_case()
+    eng = Engine(VisperConfig(**vars(ocfg)))
+    eng.load_weights(W)
+    path = str(tmp_path / "mm_projector.bin")
+    data.save_mm_projector(eng, path)
+    sd = torch.load(path)
+    assert sorted(sd) == sorted(k for k in eng.ps.index if "mm_projector" in k) and all(v.dtype == torch.bfloat16 for v in sd.values())
+    before = {k: eng.ps.p(k).clone() for k in sd}
+    for k in sd:
+        eng.ps.p(k).zero_()
+    loaded = data.load_mm_projector(eng, path)
+    assert sorted(loaded) == sorted(sd)
+    for k in sd:
+        assert torch.equal(eng.ps.p(k), before[k].to(torch.bfloat16).float())
+        assert torch.equal(eng.ps.w(k), before[k].to(torch.bfloat16))
+    # the reference's loader also accepts keys without the leading "model." (builder.py:131-137)
+    torch.save({k[len("model."):]: v for k, v in sd.items()}, path)
+    assert sorted(data.load_mm_projector(eng, path)) == sorted(sd)

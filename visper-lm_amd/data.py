@@ -1,0 +1,112 @@
+"""Host data path feeding the step: the pieces of the reference's input pipeline that define the *format* of a batch.
+
+* `tokenizer_image_token`  — ola_vlm/mm_utils.py:333-352: split the prompt at "<image>", tokenize the chunks, splice IMAGE_TOKEN_INDEX.
+* `expand2square`          — ola_vlm/mm_utils.py:289-306: pad a PIL image to a square with the processor's mean colour
+                             (`image_aspect_ratio == "pad"`, the setting of scripts/train/*.sh).
+* `Collator`               — ola_vlm/train/ola_vlm_train.py:882-925 `DataCollatorForSupervisedDataset`: right-pad ids with the pad token and
+                             labels with IGNORE_INDEX, truncate to `model_max_length`, attention_mask = ids != pad, stack images, pass
+                             `pil_images` and the per-sample {seg,depth,gen}_mask flags through.  Output buffers are pinned so the engine's
+                             H2D copies of `images` overlap the host-side index plan.
+Pinned: the first two against the reference's own functions (oracle/gen_golden.py `data` -> tests/golden/data_path.json); the collator is
+a restatement checked against torch's pad_sequence semantics (the reference module does not import under the installed transformers)."""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Sequence
+
+import torch
+
+from .config import IGNORE_INDEX, IMAGE_TOKEN_INDEX
+
+
+def tokenizer_image_token(prompt: str, tokenizer, image_token_index: int = IMAGE_TOKEN_INDEX, return_tensors: Optional[str] = None):
+    chunks = [tokenizer(chunk).input_ids for chunk in prompt.split("<image>")]
+    ids: List[int] = []
+    offset = 0
+    if len(chunks) > 0 and len(chunks[0]) > 0 and chunks[0][0] == tokenizer.bos_token_id:
+        offset = 1                                               # keep one BOS, drop the BOS every later chunk starts with
+        ids.append(chunks[0][0])
+    for i, chunk in enumerate(chunks):
+        if i > 0:
+            ids.append(image_token_index)
+        ids.extend(chunk[offset:])
+    if return_tensors is not None:
+        if return_tensors == "pt":
+            return torch.tensor(ids, dtype=torch.long)
+        raise ValueError(f"Unsupported tensor type: {return_tensors}")
+    return ids
+
+
+def expand2square(pil_img, background_color):
+    from PIL import Image
+    width, height = pil_img.size
+    if width == height:
+        return pil_img
+    side = max(width, height)
+    result = Image.new(pil_img.mode, (side, side), background_color)
+    result.paste(pil_img, (0, (width - height) // 2) if width > height else ((height - width) // 2, 0))
+    return result
+
+
+class Collator:
+    def __init__(self, pad_token_id: int, model_max_length: int, pin_memory: bool = True):
+        self.pad, self.max_len, self.pin = int(pad_token_id), int(model_max_length), pin_memory
+
+    def _pin(self, t: torch.Tensor) -> torch.Tensor:
+        return t.pin_memory() if (self.pin and torch.cuda.is_available()) else t
+
+    def __call__(self, instances: Sequence[Dict]) -> Dict[str, object]:
+        n = len(instances)
+        T = max(int(x["input_ids"].shape[0]) for x in instances)
+        ids = torch.full((n, T), self.pad, dtype=torch.long)
+        labels = torch.full((n, T), IGNORE_INDEX, dtype=torch.long)
+        for i, x in enumerate(instances):
+            L = int(x["input_ids"].shape[0])
+            ids[i, :L] = x["input_ids"]
+            labels[i, :L] = x["labels"]
+        ids, labels = ids[:, :self.max_len], labels[:, :self.max_len]
+        batch: Dict[str, object] = dict(input_ids=ids, labels=labels, attention_mask=ids.ne(self.pad))
+        if "image" in instances[0]:
+            images = [x["image"] for x in instances]
+            if all(im is not None and im.shape == images[0].shape for im in images):
+                batch["images"] = self._pin(torch.stack(images))
+            else:
+                batch["images"] = images
+        if "pil_image" in instances[0]:
+            batch["pil_images"] = [x["pil_image"] for x in instances]
+            for k in ("seg_mask", "depth_mask", "gen_mask"):
+                batch[k] = torch.tensor([x[k] for x in instances])
+        return batch
+
+
+# ---------------------------------------------------------------------------------------------- checkpoints
+ADAPTER_KEYS = ("mm_projector", "vision_resampler")                     # llava_trainer.py:1006
+
+
+def adapter_state(named_tensors, use_im_start_end: bool = False) -> Dict[str, torch.Tensor]:
+    """`get_mm_adapter_state_maybe_zero_3` (llava_trainer.py:116-119): what the PT stage writes to `mm_projector.bin`."""
+    keys = ADAPTER_KEYS + (("embed_tokens", "embed_in") if use_im_start_end else ())
+    return {k: v.detach().cpu() for k, v in named_tensors if any(m in k for m in keys)}
+
+
+def save_mm_projector(engine, path: str) -> None:
+    """PT-stage checkpoint in the reference's format (torch.save of {state-dict name: tensor}, llava_trainer.py:1014)."""
+    ps = engine.ps
+    torch.save(adapter_state((k, ps.p(k).to(torch.bfloat16)) for k in ps.index), path)
+
+
+def load_mm_projector(engine, path: str) -> List[str]:
+    """Load a reference `mm_projector.bin` (keys may carry the `base_model.model.` / `model.` prefixes of builder.py:131-137)."""
+    sd = torch.load(path, map_location="cpu")
+    loaded = []
+    for k, v in sd.items():
+        name = k
+        for pre in ("base_model.model.", ):
+            if name.startswith(pre):
+                name = name[len(pre):]
+        if name not in engine.ps.index and ("model." + name) in engine.ps.index:
+            name = "model." + name
+        if name in engine.ps.index:
+            engine.ps.p(name).copy_(v.to(torch.float32).reshape(engine.ps.p(name).shape))
+            loaded.append(name)
+    engine.ps.refresh_shadow()
+    return loaded
