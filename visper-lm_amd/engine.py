@@ -642,7 +642,7 @@ class Engine:
         B, S = plan["B"], plan["S"]
         ns, nt, order = cfg.num_sys_tokens, cfg.num_task_tokens, cfg.token_order
         out = {}
-        for task in {t for t, _, _ in self.tasks}:
+        for task in sorted({t for t, _, _ in self.tasks}):        # SORTED: every rank must issue the all-gathers in the same order
             k = order.index(task)
             s0 = ns + N_IMG_TOK + nt * k
             end = ns + N_IMG_TOK + nt * len(order)
@@ -925,7 +925,7 @@ class Engine:
         (seg targets (B,C,24,24) are re-laid out to (B,576,C) once so the loss kernel streams both linearly), then
         all-gather across DP ranks for the contrastive negatives (ola_utils.py:96-106), once per task per step."""
         out = {}
-        for task in {t for t, _, _ in self.tasks}:
+        for task in sorted({t for t, _, _ in self.tasks}):        # SORTED: every rank must issue the all-gathers in the same order
             tg = batch.get(f"{task}_target")
             if tg is None:
                 out[task] = None

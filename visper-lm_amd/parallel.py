@@ -25,6 +25,10 @@ def all_gather_rows(flat: torch.Tensor) -> torch.Tensor:
     rank, world = world_info()
     if world == 1:
         return flat
+    if dist.get_backend() == "gloo":                   # CPU test backend: no bf16 / device all_gather_into_tensor -> stage via fp32 host
+        parts = [torch.empty(flat.shape, dtype=torch.float32) for _ in range(world)]
+        dist.all_gather(parts, flat.detach().float().cpu().contiguous())
+        return torch.cat(parts, 0).to(device=flat.device, dtype=flat.dtype)
     out = torch.empty(world * flat.shape[0], flat.shape[1], device=flat.device, dtype=flat.dtype)
     dist.all_gather_into_tensor(out, flat.contiguous())
     return out
