@@ -158,13 +158,21 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a MI355X: the product path has no CPU fallback")
+    # test hook: VP_TEST_SHARED_GPU=1 puts every rank on GPU 0 with the gloo backend (RCCL refuses two ranks on one device), so the
+    # N>1 control flow of this script can be exercised on a one-GPU box; the real runs are one process per GPU over RCCL
+    shared = os.environ.get("VP_TEST_SHARED_GPU") == "1"
+    if shared:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
     if world > 1 or args.force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if shared:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from visper_lm_amd import ops
     from visper_lm_amd.config import llama3_8b, llama3_8b_convnext, phi3_mini

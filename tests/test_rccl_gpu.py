@@ -49,3 +49,21 @@ def test_bench_under_torchrun_world1():
            "--no-cpu-baseline", "--force-dist"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root)
     assert '"n_gpus": 1' in r.stdout and '"metric"' in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
+
+
+def test_bench_two_ranks_on_one_gpu_control_flow():
+    """The N>1 control flow of bench.py (per-rank data, barriers, MAX-over-ranks timing, one JSON line from rank 0, whole-job value)
+    with two ranks sharing the test GPU over gloo (VP_TEST_SHARED_GPU) and a shallow debug model."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29613", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--layers", "2",
+           "--no-cpu-baseline"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=root, env=dict(os.environ, VP_TEST_SHARED_GPU="1"))
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{") and '"metric"' in l]
+    assert len(lines) == 1, r.stdout[-1500:] + r.stderr[-2500:]
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 2 and res["config"]["global_batch"] == 16 and res["scaling"] == "weak" and res["steps"] == 2
+    assert abs(res["value"] - 16 / (res["ms_per_step"] / 1e3)) < 0.05 * res["value"]
