@@ -388,7 +388,8 @@ __global__ __launch_bounds__(512) void attn_bwd_dkdv_kernel(AttnParams p) {
 //     with (row & 15) on the SOURCE side, which keeps both the row-wise ds_read_b128 and the transposing
 //     ds_read_b64_tr_b16 fragment reads conflict-free;
 //   * each wave owns 32 keys (two 16-key MFMA column tiles), so every LDS fragment feeds two MFMAs;
-//   * 256 threads at <= 256 VGPRs -> two blocks per CU run out of phase.
+//   * 256 threads at <= 256 VGPRs -> two blocks per CU run out of phase.  (KT = 1, i.e. 8 waves x 16 keys at 128 VGPRs / 4 waves per
+//     SIMD, was measured too: 1.46 ms against 0.74 ms -- twice the LDS traffic per MFMA and spills that drain the DMA ring.)
 // ================================================================================================
 #define ATTN_GLDS(gptr, ldsptr, BYTES)                                                              \
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr),           \
@@ -409,26 +410,30 @@ static __device__ __forceinline__ bf16x8 trfrag_at(const bf16_t* p0) {   // p0: 
   const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p0 + 16 * 128));
   return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 }
+#ifndef DKDV_KT
+#define DKDV_KT 2
+#endif
 constexpr int DKDV128_STAGE = 2 * 32 * 128 + 128;     // bf16 units: Q tile | dO tile | 32 (lse, delta) fp32 pairs
 constexpr int DKDV128_LDS = 4 * DKDV128_STAGE * 2;    // bytes
 
-template <bool CAUSAL>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_bwd_dkdv128_kernel(AttnParams p) {
-  constexpr int D = 128, NKS = 4, NDB = 8;
+template <bool CAUSAL, int KT>      // KT = 16-key column tiles per wave: 2 -> 4 waves x 32 keys, 1 -> 8 waves x 16 keys (128 keys per block)
+__global__ __launch_bounds__(64 * (8 / KT)) __attribute__((amdgpu_waves_per_eu(KT == 2 ? 2 : 4, KT == 2 ? 2 : 4)))
+void attn_bwd_dkdv128_kernel(AttnParams p) {
+  constexpr int D = 128, NKS = 4, NDB = 8, NW = 8 / KT, NI = 8 / NW;      // NI = DMA instructions per wave per 32-row tile
   extern __shared__ __attribute__((aligned(16))) unsigned char attn_smem[];
   bf16_t* const ring = (bf16_t*)attn_smem;
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), fr = lane & 15, g = lane >> 4;
   const int hk = blockIdx.x, b = blockIdx.y;           // z (slowest dispatch index) = key block: early keys (most queries) first
-  const int k0 = blockIdx.z * 128, kw0 = k0 + wave * 32;
+  const int k0 = blockIdx.z * 128, kw0 = k0 + wave * 16 * KT;
   const int kvlen = p.kv_len ? min(p.kv_len[b], p.Skv) : p.Skv;
   const int off = p.Skv - p.Sq;
   const int rep = p.Hq / p.Hkv;
   const float c = p.scale * LOG2E;
   const float* pairs = p.delta + (long)p.B * p.Hq * p.Sq;            // (lse, delta) interleaved, written by the pre-pass
 
-  bf16x8 kf[2][NKS], vf[2][NKS];
+  bf16x8 kf[KT][NKS], vf[KT][NKS];
 #pragma unroll
-  for (int kt = 0; kt < 2; ++kt) {
+  for (int kt = 0; kt < KT; ++kt) {
     const int keyc = min(kw0 + kt * 16 + fr, p.Skv - 1);    // clamped; keys >= kv_len are masked (p = 0) and not stored
     const bf16_t* kp = p.k + (long)b * p.k_bs + (long)keyc * p.k_ts + (long)hk * D;
     const bf16_t* vp = p.v + (long)b * p.v_bs + (long)keyc * p.v_ts + (long)hk * D;
@@ -438,9 +443,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       vf[kt][ks] = *(const bf16x8*)(vp + ks * 32 + g * 8);
     }
   }
-  f32x4 dk[2][NDB], dv[2][NDB];
+  f32x4 dk[KT][NDB], dv[KT][NDB];
 #pragma unroll
-  for (int kt = 0; kt < 2; ++kt)
+  for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
     for (int d = 0; d < NDB; ++d) { dk[kt][d] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[kt][d] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 
@@ -457,20 +462,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   // (dk/dv 128 + K/V fragments 64), and hipcc would otherwise spill these loop invariants to scratch and reload them with
   // s_waitcnt vmcnt(0) -- which drains the DMA queue every iteration.
   auto issue = [&](int t, int st, int ln) {
-    const int drow = wave * 4 + (ln >> 4);
-    const int dch = ((ln & 15) ^ (drow & 15)) * 8;
     const int tc = min(t, nit - 1);                    // past the end: harmless re-fetch keeps the vmcnt bookkeeping uniform
     const int hh = tc / ntq;
     const int h = hk * rep + hh, q0 = qstart + (tc - hh * ntq) * 32;
     bf16_t* sb = ring + st * DKDV128_STAGE;
     const char* qb = (const char*)(p.q + (long)b * p.q_bs + (long)h * D);      // wave-uniform bases + 32-bit lane offsets
     const char* gb = (const char*)(p.dout + (long)b * p.do_bs + (long)h * D);
-    const unsigned r0 = (unsigned)min(q0 + drow, p.Sq - 1), r1 = (unsigned)min(q0 + drow + 16, p.Sq - 1);
     const unsigned qts = (unsigned)p.q_ts, gts = (unsigned)p.do_ts;
-    ATTN_GLDS(qb + (size_t)((r0 * qts + dch) * 2u), sb + wave * 512, 16);
-    ATTN_GLDS(qb + (size_t)((r1 * qts + dch) * 2u), sb + (4 + wave) * 512, 16);
-    ATTN_GLDS(gb + (size_t)((r0 * gts + dch) * 2u), sb + 4096 + wave * 512, 16);
-    ATTN_GLDS(gb + (size_t)((r1 * gts + dch) * 2u), sb + 4096 + (4 + wave) * 512, 16);
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int blk = i * NW + wave;                   // 4-row group of the tile this instruction fills
+      const int drow = blk * 4 + (ln >> 4);
+      const int dch = ((ln & 15) ^ (drow & 15)) * 8;
+      const unsigned r = (unsigned)min(q0 + drow, p.Sq - 1);
+      ATTN_GLDS(qb + (size_t)((r * qts + dch) * 2u), sb + blk * 512, 16);
+      ATTN_GLDS(gb + (size_t)((r * gts + dch) * 2u), sb + 4096 + blk * 512, 16);
+    }
     if (wave == 0) {
       const long qi = min(q0 + (ln >> 1), p.Sq - 1);
       ATTN_GLDS(pairs + (((long)b * p.Hq + h) * p.Sq + qi) * 2 + (ln & 1), sb + 8192, 4);
@@ -479,8 +486,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   if (nit > 0) { issue(0, 0, lane); issue(1, 1, lane); issue(2, 2, lane); }
   for (int it = 0; it < nit; ++it) {
     // tile `it` landed (this wave's part): at most the two younger stages may still be in flight
-    if (wave == 0) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    if (wave == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (2 * NI + 1)) : "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * 2 * NI) : "memory");
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();                      // every wave's part landed; stage (it-1)&3 is no longer being read
     __builtin_amdgcn_sched_barrier(0);
@@ -502,19 +509,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     if (active) {
       // s[kt][r]: query = q0 + 16qt + 4g + r, key = kw0 + 16kt + fr.  One 16-query half at a time: only the packed bf16
       // P / dS halves stay live across the two halves (register budget: dk/dv 128 + K/V fragments 64).
-      const bool need_mask = (q0 + 32 > p.Sq) || (kw0 + 32 > kvlen) || (CAUSAL && (kw0 + 31 > q0 + off)) || (p.window > 0);
-      u32x2 pk[2][2], dsk[2][2];
+      const bool need_mask = (q0 + 32 > p.Sq) || (kw0 + 16 * KT > kvlen) || (CAUSAL && (kw0 + 16 * KT - 1 > q0 + off)) || (p.window > 0);
+      u32x2 pk[KT][2], dsk[KT][2];
 #pragma unroll
       for (int qt = 0; qt < 2; ++qt) {
-        f32x4 s[2], dp[2];
+        f32x4 s[KT], dp[KT];
 #pragma unroll
-        for (int kt = 0; kt < 2; ++kt) { s[kt] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[kt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        for (int kt = 0; kt < KT; ++kt) { s[kt] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[kt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks) {
           const bf16x8 qa = *(const bf16x8*)(Qs + (rbase ^ (ks * 32)) + qt * 2048);
           const bf16x8 da = *(const bf16x8*)(dOs + (rbase ^ (ks * 32)) + qt * 2048);
 #pragma unroll
-          for (int kt = 0; kt < 2; ++kt) {
+          for (int kt = 0; kt < KT; ++kt) {
             s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa, kf[kt][ks], s[kt], 0, 0, 0);
             dp[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(da, vf[kt][ks], dp[kt], 0, 0, 0);
           }
@@ -523,7 +530,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         const f32x4 l0 = *(const f32x4*)(ld + (qt * 16 + 4 * g) * 2), l1 = *(const f32x4*)(ld + (qt * 16 + 4 * g) * 2 + 4);
         const float lse_r[4] = {l0[0], l0[2], l1[0], l1[2]}, del_r[4] = {l0[1], l0[3], l1[1], l1[3]};
 #pragma unroll
-        for (int kt = 0; kt < 2; ++kt) {
+        for (int kt = 0; kt < KT; ++kt) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             float pv = fast_exp2(fmaf(s[kt][r], c, -lse_r[r]));
@@ -540,9 +547,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         }
         __builtin_amdgcn_sched_barrier(0);
       }
-      bf16x8 pf[2], dsf[2];
+      bf16x8 pf[KT], dsf[KT];
 #pragma unroll
-      for (int kt = 0; kt < 2; ++kt) {
+      for (int kt = 0; kt < KT; ++kt) {
         pf[kt] = __builtin_bit_cast(bf16x8, u32x4{pk[kt][0][0], pk[kt][0][1], pk[kt][1][0], pk[kt][1][1]});
         dsf[kt] = __builtin_bit_cast(bf16x8, u32x4{dsk[kt][0][0], dsk[kt][0][1], dsk[kt][1][0], dsk[kt][1][1]});
       }
@@ -551,7 +558,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         const bf16x8 ta = trfrag_at(dOs + (tbase ^ (d * 16)));
         const bf16x8 tq = trfrag_at(Qs + (tbase ^ (d * 16)));
 #pragma unroll
-        for (int kt = 0; kt < 2; ++kt) {
+        for (int kt = 0; kt < KT; ++kt) {
           dv[kt][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ta, pf[kt], dv[kt][d], 0, 0, 0);
           dk[kt][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tq, dsf[kt], dk[kt][d], 0, 0, 0);
         }
@@ -561,7 +568,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // trailing (dummy) DMAs must not outlive the block's LDS
 #pragma unroll
-  for (int kt = 0; kt < 2; ++kt) {
+  for (int kt = 0; kt < KT; ++kt) {
     const int key = kw0 + kt * 16 + fr;
     if (key < p.Skv) {
       bf16_t* dkp = p.dk + (long)b * p.dk_bs + (long)key * p.dk_ts + (long)hk * D;
@@ -878,17 +885,17 @@ static int launch_bwd(const AttnParams& p, int causal, hipStream_t s) {
   if (D == 128) {
     static bool attr2 = false;
     if (!attr2) {
-      (void)hipFuncSetAttribute((const void*)attn_bwd_dkdv128_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, DKDV128_LDS);
-      (void)hipFuncSetAttribute((const void*)attn_bwd_dkdv128_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, DKDV128_LDS);
+      (void)hipFuncSetAttribute((const void*)attn_bwd_dkdv128_kernel<true, DKDV_KT>, hipFuncAttributeMaxDynamicSharedMemorySize, DKDV128_LDS);
+      (void)hipFuncSetAttribute((const void*)attn_bwd_dkdv128_kernel<false, DKDV_KT>, hipFuncAttributeMaxDynamicSharedMemorySize, DKDV128_LDS);
       (void)hipFuncSetAttribute((const void*)attn_bwd_dq128_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, DQ128_LDS);
       (void)hipFuncSetAttribute((const void*)attn_bwd_dq128_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, DQ128_LDS);
       attr2 = true;
     }
     if (causal) {
-      hipLaunchKernelGGL((attn_bwd_dkdv128_kernel<true>), g1, dim3(256), DKDV128_LDS, s, p);
+      hipLaunchKernelGGL((attn_bwd_dkdv128_kernel<true, DKDV_KT>), g1, dim3(64 * (8 / DKDV_KT)), DKDV128_LDS, s, p);
       hipLaunchKernelGGL((attn_bwd_dq128_kernel<true>), g2, dim3(256), DQ128_LDS, s, p);
     } else {
-      hipLaunchKernelGGL((attn_bwd_dkdv128_kernel<false>), g1, dim3(256), DKDV128_LDS, s, p);
+      hipLaunchKernelGGL((attn_bwd_dkdv128_kernel<false, DKDV_KT>), g1, dim3(64 * (8 / DKDV_KT)), DKDV128_LDS, s, p);
       hipLaunchKernelGGL((attn_bwd_dq128_kernel<false>), g2, dim3(256), DQ128_LDS, s, p);
     }
   } else if (causal) {
