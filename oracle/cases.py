@@ -72,3 +72,16 @@ def tiny_ift_case():
     batch = {k: v for k, v in make_batch(B, T, col).items() if k in ("input_ids", "labels", "attention_mask", "images")}
     assert np.array_equal(batch["input_ids"].numpy(), g["input_ids"])
     return cfg, W, batch, g
+
+
+def dinov2_weights(manifest):
+    """Closed-form weights of the DINOv2 teacher fixture (same overrides as gen_golden.run_dinov2_teacher)."""
+    W = {}
+    for k, s in manifest.items():
+        if k.endswith(".gamma"):
+            W[k] = WT.tensor(k, s, 0.3, 1.0)
+        elif k.endswith("cls_token") or k.endswith("pos_embed") or k.endswith("mask_token"):
+            W[k] = WT.tensor(k, s, 0.2)
+        else:
+            W[k] = WT.param(k, s)
+    return W

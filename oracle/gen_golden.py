@@ -341,6 +341,36 @@ def run_data_path():
     print("data_path: ", res["with_bos"][1])
 
 
+def run_dinov2_teacher():
+    """f-3: the reference's own DinoVisionTransformer (depth_anything_v2/dinov2.py) at reduced width/depth, pos-embed grid 37x37 (img_size
+    518) evaluated at 336 px -> the depth teacher target of _get_dav2_feats: mean of 4 normed intermediate patch-token maps."""
+    from functools import partial
+    from ola_vlm.model.aux_heads.depth_anything_v2.dinov2 import DinoVisionTransformer
+    from ola_vlm.model.aux_heads.depth_anything_v2.dinov2_layers.block import Block
+    from ola_vlm.model.aux_heads.depth_anything_v2.dinov2_layers.attention import MemEffAttention
+    dims = dict(embed_dim=128, depth=6, num_heads=4)
+    taps = [1, 2, 4, 5]
+    m = DinoVisionTransformer(img_size=518, patch_size=14, init_values=1.0, ffn_layer="mlp", block_chunks=0, num_register_tokens=0,
+                              interpolate_antialias=False, interpolate_offset=0.1, mlp_ratio=4,
+                              block_fn=partial(Block, attn_class=MemEffAttention), **dims).eval()
+    shapes = {"dav2_backbone.pretrained." + k: tuple(v.shape) for k, v in m.state_dict().items()}
+    sd = {k: WT.param(k, s) for k, s in shapes.items()}
+    for k in sd:                                               # layer scale / tokens large enough to matter
+        if k.endswith(".gamma"):
+            sd[k] = WT.tensor(k, shapes[k], 0.3, 1.0)
+        if k.endswith("cls_token") or k.endswith("pos_embed") or k.endswith("mask_token"):
+            sd[k] = WT.tensor(k, shapes[k], 0.2)
+    m.load_state_dict({k[len("dav2_backbone.pretrained."):]: v for k, v in sd.items()}, strict=True)
+    images = WT.tensor("dino_images", (2, 3, 336, 336))
+    with torch.no_grad():
+        feats = m.get_intermediate_layers(images, taps, return_class_token=True)
+        tgt = (feats[0][0] + feats[1][0] + feats[2][0] + feats[3][0]) / 4
+    np.savez_compressed(os.path.join(OUT, "dinov2_teacher.npz"), manifest=json.dumps({k: list(s) for k, s in shapes.items()}),
+                        dims=json.dumps(dims), taps=np.array(taps), target_shape=np.array(tgt.shape), target_sub=tgt[:, ::7, ::3].numpy().copy(),
+                        target_mean=np.float64(tgt.double().mean().item()), target_std=np.float64(tgt.double().std().item()))
+    print("dinov2_teacher:", tuple(tgt.shape), float(tgt.std()))
+
+
 def run_units():
     """Unit fixtures straight from the reference functions."""
     from ola_vlm.ola_utils import calculate_contrastive_loss
@@ -385,7 +415,7 @@ if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
     setup_reference()
-    which = sys.argv[1:] or ["units", "llama", "phi3", "ift", "data"]
+    which = sys.argv[1:] or ["units", "llama", "phi3", "ift", "data", "dino"]
     if "units" in which:
         run_units()
     if "llama" in which:
@@ -396,3 +426,5 @@ if __name__ == "__main__":
         run_tiny_ift()
     if "data" in which:
         run_data_path()
+    if "dino" in which:
+        run_dinov2_teacher()

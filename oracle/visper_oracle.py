@@ -532,6 +532,50 @@ def dpt_param_shapes(prefix="da_v2_head.depth_head."):
 
 
 # ----------------------------------------------------------------------------------------------
+# f-3: frozen depth teacher features (base_ola_vlm.py:347-365 _get_dav2_feats -> DepthAnythingV2.forward, dpt.py:164-169 ->
+# DinoVisionTransformer.get_intermediate_layers, depth_anything_v2/dinov2.py:177-330): mean of the final-normed patch tokens of
+# 4 intermediate blocks of a DINOv2 ViT (LayerScale blocks, GELU(erf) MLP, LayerNorm eps 1e-6, bicubic position interpolation).
+# ----------------------------------------------------------------------------------------------
+def dinov2_pos_embed(pos_embed, grid, patch_offset=0.1):
+    """interpolate_pos_encoding (dinov2.py:177-204): (1, 1 + N, C) -> (1, 1 + grid*grid, C); identity when the grids match."""
+    N = pos_embed.shape[1] - 1
+    if N == grid * grid:
+        return pos_embed
+    C = pos_embed.shape[-1]
+    sq = int(math.sqrt(N))
+    sc = float(grid + patch_offset) / math.sqrt(N)
+    pp = F.interpolate(pos_embed[:, 1:].float().reshape(1, sq, sq, C).permute(0, 3, 1, 2), scale_factor=(sc, sc), mode="bicubic",
+                       antialias=False)
+    assert pp.shape[-1] == grid and pp.shape[-2] == grid
+    return torch.cat([pos_embed[:, :1].float(), pp.permute(0, 2, 3, 1).reshape(1, -1, C)], 1).to(pos_embed.dtype)
+
+
+def dinov2_depth_target(images, W, heads, taps, prefix="dav2_backbone.pretrained.", patch=14):
+    """images (B,3,S,S) normalised -> (B, (S/14)^2, C): (f0 + f1 + f2 + f3) / 4 of the normed patch tokens (base_ola_vlm.py:355)."""
+    B, _, S, _ = images.shape
+    grid = S // patch
+    x = F.conv2d(images, W[prefix + "patch_embed.proj.weight"], W[prefix + "patch_embed.proj.bias"], stride=patch).flatten(2).transpose(1, 2)
+    x = torch.cat([W[prefix + "cls_token"].expand(B, -1, -1).to(x.dtype), x], 1)
+    x = x + dinov2_pos_embed(W[prefix + "pos_embed"], grid).to(x.dtype)
+    C = x.shape[-1]
+    hd = C // heads
+    feats = []
+    for i in range(max(taps) + 1):
+        b = f"{prefix}blocks.{i}."
+        y = F.layer_norm(x, (C,), W[b + "norm1.weight"], W[b + "norm1.bias"], 1e-6)
+        qkv = F.linear(y, W[b + "attn.qkv.weight"], W[b + "attn.qkv.bias"]).reshape(B, -1, 3, heads, hd).permute(2, 0, 3, 1, 4)
+        att = torch.softmax((qkv[0] * hd ** -0.5) @ qkv[1].transpose(-2, -1), -1) @ qkv[2]
+        y = F.linear(att.transpose(1, 2).reshape(B, -1, C), W[b + "attn.proj.weight"], W[b + "attn.proj.bias"])
+        x = x + y * W[b + "ls1.gamma"]
+        y = F.layer_norm(x, (C,), W[b + "norm2.weight"], W[b + "norm2.bias"], 1e-6)
+        y = F.linear(F.gelu(F.linear(y, W[b + "mlp.fc1.weight"], W[b + "mlp.fc1.bias"])), W[b + "mlp.fc2.weight"], W[b + "mlp.fc2.bias"])
+        x = x + y * W[b + "ls2.gamma"]
+        if i in taps:
+            feats.append(F.layer_norm(x, (C,), W[prefix + "norm.weight"], W[prefix + "norm.bias"], 1e-6)[:, 1:])
+    return sum(feats) / len(feats)
+
+
+# ----------------------------------------------------------------------------------------------
 # embedding losses  (base_ola_vlm.py:289-320 ; ola_utils.py:96-125)
 # ----------------------------------------------------------------------------------------------
 def contrastive_loss(preds, targets, logit_scale, rank=0, gathered_targets=None):

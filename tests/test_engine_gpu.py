@@ -335,3 +335,29 @@ def test_ift_stage_matches_reference_golden():
         if float(theirs.norm()) > 0:
             cos = float(torch.dot(mine, theirs) / (mine.norm() * theirs.norm() + 1e-30))
             assert cos > 0.95, (k, cos)
+
+
+def test_dinov2_depth_teacher_matches_oracle_and_reference_golden():
+    """the batched DINOv2 depth teacher on the GPU (teachers.DinoV2DepthTeacher) against the fp32 oracle on the same
+    bf16-rounded weights / images and against the reference's own DinoVisionTransformer output (tests/golden/dinov2_teacher.npz)."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from oracle import cases, visper_oracle as O, weights as WT
+    from visper_lm_amd.teachers import DinoV2DepthTeacher
+    g = cases.load_golden("dinov2_teacher.npz")
+    man = json.loads(str(g["manifest"]))
+    dims = json.loads(str(g["dims"]))
+    taps = [int(t) for t in g["taps"]]
+    W = cases.dinov2_weights(man)
+    assert {k: tuple(v) for k, v in man.items()} == DinoV2DepthTeacher.shapes(dims["embed_dim"], dims["depth"])
+    t = DinoV2DepthTeacher(dims["embed_dim"], dims["depth"], dims["num_heads"], taps)
+    t.load_weights(W)
+    images = WT.tensor("dino_images", (2, 3, 336, 336))
+    got = t.forward(images.cuda()).float().cpu()
+    with torch.no_grad():
+        ref = O.dinov2_depth_target(images.to(BF).float(), {k: v.to(BF).float() for k, v in W.items()}, dims["num_heads"], taps)
+    assert tuple(got.shape) == tuple(g["target_shape"])
+    err = (got - ref).abs().max() / ref.abs().max()
+    assert float(err) < 3e-2, float(err)
+    gerr = np.abs(got[:, ::7, ::3].numpy() - g["target_sub"]).max() / np.abs(g["target_sub"]).max()
+    assert float(gerr) < 4e-2, float(gerr)

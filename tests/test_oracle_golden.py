@@ -181,3 +181,20 @@ def test_ift_stage_matches_reference_llava_llama():
         ref_norm = float(g[f"gradnorm::{k}"])
         assert abs(float(W[k].grad.double().norm()) - ref_norm) <= 2e-4 * ref_norm + 1e-9, k
         _close(cases.sub(W[k].grad, 128), g[f"gradsub::{k}"], 2e-3, 1e-7 + 1e-4 * float(np.abs(g[f"gradsub::{k}"]).max()))
+
+
+def test_dinov2_depth_teacher_matches_reference():
+    """the DINOv2 depth-teacher target (mean of 4 normed intermediate patch-token maps; base_ola_vlm.py:347-365 ->
+    depth_anything_v2/dinov2.py) against the reference's own DinoVisionTransformer, incl. the bicubic 37x37 -> 24x24 position grid."""
+    from oracle import weights as WT
+    g = cases.load_golden("dinov2_teacher.npz")
+    man = json.loads(str(g["manifest"]))
+    W = cases.dinov2_weights(man)
+    dims = json.loads(str(g["dims"]))
+    images = WT.tensor("dino_images", (2, 3, 336, 336))
+    with torch.no_grad():
+        tgt = O.dinov2_depth_target(images, W, dims["num_heads"], [int(t) for t in g["taps"]])
+    assert tuple(tgt.shape) == tuple(g["target_shape"])
+    _close(tgt[:, ::7, ::3].numpy(), g["target_sub"], 1e-3, 2e-5)
+    _close(float(tgt.double().mean()), g["target_mean"], 1e-4, 1e-6)
+    _close(float(tgt.double().std()), g["target_std"], 1e-4, 1e-6)
