@@ -431,3 +431,33 @@ def test_param_store_adamw_groups_schedule_clipping():
     for k, v in ref.items():
         close(ps.p(k).view(v.shape), v.detach(), rtol=2e-5, atol=2e-6, what=f"adamw {k}")
         close(ps.w(k).view(v.shape), v.detach(), rtol=1e-2, what=f"bf16 shadow {k}")
+
+
+def test_ift_support_kernels(ops):
+    """Kernels the IFT stage adds: [gate | up]-halves SwiGLU layout, RMSNorm weight gradient, embedding scatter-add, sum of squares."""
+    M, Fd = 37, 72
+    gu, d = rnd(M, 2 * Fd, seed=70), rnd(M, Fd, seed=71)
+    gr = gu.float().requires_grad_(True)
+    ref = F.silu(gr[:, :Fd]) * gr[:, Fd:]
+    ref.backward(d.float())
+    close(ops.swiglu_fwd(dev(gu), interleaved=False), ref, what="swiglu fwd halves")
+    close(ops.swiglu_bwd(dev(d), dev(gu), interleaved=False), gr.grad, what="swiglu bwd halves")
+    # RMSNorm weight gradient: y = x * rstd * w  ->  dw = sum_rows dy * x * rstd
+    Mr, H = 300, 256
+    x, dy, w = rnd(Mr, H, seed=72), rnd(Mr, H, seed=73), (rnd(H, seed=74) * 0.1 + 1.0)
+    xf = x.float()
+    wf = w.float().requires_grad_(True)
+    rstd = torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + 1e-5)
+    (xf * rstd * wf).backward(dy.float())
+    close(ops.rmsnorm_bwd_w(dev(dy), dev(x), dev(rstd.reshape(-1).contiguous())), wf.grad, rtol=1e-3, what="rmsnorm dw")
+    # embedding gradient: dst[idx[r]] += src[r], idx < 0 skipped
+    V, Hh, n = 50, 64, 400
+    src = rnd(n, Hh, seed=75)
+    idx = torch.randint(-1, V, (n,), generator=torch.Generator().manual_seed(76)).to(torch.int32)
+    want = torch.zeros(V, Hh)
+    keep = idx >= 0
+    want.index_add_(0, idx[keep].long(), src[keep].float())
+    got = ops.scatter_add_rows_(torch.zeros(V, Hh, device="cuda"), dev(src), idx.cuda())
+    close(got, want, rtol=1e-4, atol=1e-4, what="scatter_add_rows")
+    v = torch.randn(100003)
+    assert abs(float(ops.sumsq(v.cuda())) - float((v.double() ** 2).sum())) < 1e-3 * float((v.double() ** 2).sum())
