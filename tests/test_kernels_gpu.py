@@ -3,6 +3,7 @@ reference op, plain torch math otherwise).  Inputs are bf16-rounded on the host 
 same values; tolerances are stated per test (bf16 outputs: ~2^-8 relative)."""
 import math
 
+import numpy as np
 import pytest
 import torch
 import torch.nn.functional as F
@@ -461,3 +462,72 @@ def test_ift_support_kernels(ops):
     close(got, want, rtol=1e-4, atol=1e-4, what="scatter_add_rows")
     v = torch.randn(100003)
     assert abs(float(ops.sumsq(v.cuda())) - float((v.double() ** 2).sum())) < 1e-3 * float((v.double() ** 2).sum())
+
+
+def test_gemm_random_shape_sweep(ops):
+    """Seeded sweep over the dispatcher's corner cases: ragged M/N (partial 256 / 128 tiles), K not a multiple of 64 (generic
+    kernel), strided A / C views, odd bias offsets (unaligned bias pointer -> general epilogue), every epilogue, fp32 output."""
+    rng = np.random.RandomState(1234)
+    for case in range(40):
+        M = int(rng.choice([1, 7, 64, 130, 255, 256, 300, 513, 1024, 2200]))
+        N = int(rng.choice([8, 24, 64, 136, 256, 264, 520, 1032]))
+        K = int(rng.choice([8, 40, 64, 128, 192, 200, 512]))
+        epi = int(rng.choice([0, 0, 1, 2, 3]))
+        use_bias, use_res, f32, strided = rng.rand() < 0.6, rng.rand() < 0.5, rng.rand() < 0.2, rng.rand() < 0.3
+        force = int(rng.choice([0, 0, 0, 2, 3, 7]))
+        if K % 64 != 0 and force in (2, 3, 7):
+            force = 0
+        a_full = rnd(M, K + (16 if strided else 0), seed=1000 + case)
+        a = a_full[:, 8:8 + K] if strided else a_full
+        w = rnd(N, K, scale=0.1, seed=2000 + case)
+        bias_buf = rnd(N + 3, seed=3000 + case)
+        b = bias_buf[3:3 + N] if (use_bias and case % 3 == 0) else (bias_buf[:N] if use_bias else None)   # odd offset: 2-byte aligned only
+        r = rnd(M, N, seed=4000 + case) if (use_res and not f32) else None
+        x = a.float() @ w.float().t() + (b.float() if b is not None else 0.0)
+        if not f32:
+            x = x.to(BF).float()
+            if epi == 1:
+                x = F.gelu(x).to(BF).float()
+            elif epi == 2:
+                x = (x * torch.sigmoid(1.702 * x)).to(BF).float()
+            elif epi == 3:
+                x = F.relu(x)
+            if r is not None:
+                x = (x + r.float()).to(BF).float()
+        elif epi != 0:
+            continue                                            # activations are a bf16-output feature
+        a_dev = dev(a_full)[:, 8:8 + K] if strided else dev(a)
+        b_dev = None if b is None else (dev(bias_buf)[3:3 + N] if (use_bias and case % 3 == 0) else dev(bias_buf)[:N])
+        got = ops.gemm(a_dev, dev(w), bias=b_dev, residual=None if r is None else dev(r), epi=epi, out_f32=f32, force_generic=force)
+        close(got, x, what=f"gemm sweep #{case} M{M} N{N} K{K} epi{epi} bias{use_bias} res{r is not None} f32{f32} strided{strided} force{force}")
+
+
+@pytest.mark.parametrize("B,Hq,Hkv,Sq,Skv,causal,window,kvl", [
+    (2, 4, 2, 77, 77, True, 0, None),            # ragged (not a multiple of the 32-row DMA tiles), GQA
+    (1, 4, 4, 200, 333, False, 0, None),         # cross attention, Skv != Sq
+    (1, 4, 1, 130, 190, True, 0, None),          # causal with offset Skv - Sq, 4 q heads per kv head
+    (2, 2, 2, 161, 161, True, 50, None),         # sliding window
+    (2, 4, 2, 96, 96, True, 0, [96, 41]),        # right-padded batch: keys >= kv_len masked, their dK / dV exactly zero
+    (1, 2, 2, 31, 31, True, 0, None),            # shorter than one tile
+    (1, 2, 1, 257, 257, False, 0, [200]),        # non-causal + padding, one key past two 128-key blocks
+])
+def test_attention_d128_dma_kernels_edges(ops, B, Hq, Hkv, Sq, Skv, causal, window, kvl):
+    """The D = 128 DMA-ring kernels (dK/dV, dQ) and the D = 128 forward on shapes that exercise clamped tile rows, the causal offset,
+    windows and kv_len masking, forward and backward against fp32 attention."""
+    D = 128
+    q, k, v, do = rnd(B, Sq, Hq, D, seed=81), rnd(B, Skv, Hkv, D, seed=82), rnd(B, Skv, Hkv, D, seed=83), rnd(B, Sq, Hq, D, seed=84)
+    qr, kr, vr = (t.float().requires_grad_(True) for t in (q, k, v))
+    ref = attn_ref(qr, kr, vr, causal, kv_len=kvl, window=window)
+    ref.backward(do.float())
+    kv = None if kvl is None else torch.tensor(kvl, dtype=torch.int32).cuda()
+    qd, kd, vd = dev(q), dev(k), dev(v)
+    o, lse = ops.attn_fwd(qd, kd, vd, causal, window=window, kv_len=kv)
+    close(o, ref, what="attn fwd")
+    dq, dk, dv = ops.attn_bwd(qd, kd, vd, o, lse, dev(do), causal, window=window, kv_len=kv)
+    close(dq, qr.grad, rtol=3e-2, what="attn dq")
+    close(dk, kr.grad, rtol=3e-2, what="attn dk")
+    close(dv, vr.grad, rtol=3e-2, what="attn dv")
+    if kvl is not None:
+        for b, n in enumerate(kvl):
+            assert float(dk[b, n:].float().abs().max() if n < Skv else 0.0) == 0.0
+            assert float(dv[b, n:].float().abs().max() if n < Skv else 0.0) == 0.0
