@@ -789,39 +789,49 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     if (active) {
       const bool need_mask = (qw0 + 32 > p.Sq) || (k0 + 32 > kvlen) || (CAUSAL && (k0 + 31 > qw0 + off)) || (p.window > 0);
       u32x2 dsk[2][2];                                 // [qt][kt] packed dS halves
-#pragma unroll
-      for (int kt = 0; kt < 2; ++kt) {
-        f32x4 st[2], dpt[2];
-#pragma unroll
-        for (int qt = 0; qt < 2; ++qt) { st[qt] = f32x4{0.f, 0.f, 0.f, 0.f}; dpt[qt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-#pragma unroll
-        for (int ks = 0; ks < NKS; ++ks) {
-          const bf16x8 ka = *(const bf16x8*)(Ks + (rbase ^ (ks * 32)) + kt * 2048);
-          const bf16x8 va = *(const bf16x8*)(Vs + (rbase ^ (ks * 32)) + kt * 2048);
-#pragma unroll
-          for (int qt = 0; qt < 2; ++qt) {
-            st[qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka, qf[qt][ks], st[qt], 0, 0, 0);
-            dpt[qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va, dof[qt][ks], dpt[qt], 0, 0, 0);
-          }
-          if (ks & 1) __builtin_amdgcn_sched_barrier(0);
-        }
-        // st[qt][r]: key = k0 + 16kt + 4g + r, query = qw0 + 16qt + fr
-#pragma unroll
-        for (int qt = 0; qt < 2; ++qt) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            float pv = fast_exp2(fmaf(st[qt][r], c, -lse[qt]));
-            if (need_mask) {
-              const int key = k0 + kt * 16 + 4 * g + r, qrow = qw0 + qt * 16 + fr;
-              const bool ok = qrow < p.Sq && key < kvlen && (!CAUSAL || key <= qrow + off) && (p.window <= 0 || key > qrow + off - p.window);
-              pv = ok ? pv : 0.f;
-            }
-            dpt[qt][r] = pv * (dpt[qt][r] - dlt[qt]);
-          }
-          dsk[qt][kt] = u32x2{pack_bf16x2(dpt[qt][0], dpt[qt][1]), pack_bf16x2(dpt[qt][2], dpt[qt][3])};
-        }
-        __builtin_amdgcn_sched_barrier(0);
-      }
+      f32x4 st[2][2], dpt[2][2];                       // [kt][qt]
+#define DQ_MF(KT)                                                                                             \
+  _Pragma("unroll") for (int qt = 0; qt < 2; ++qt) { st[KT][qt] = f32x4{0.f, 0.f, 0.f, 0.f}; dpt[KT][qt] = f32x4{0.f, 0.f, 0.f, 0.f}; } \
+  _Pragma("unroll") for (int ks = 0; ks < NKS; ++ks) {                                                        \
+    const bf16x8 ka = *(const bf16x8*)(Ks + (rbase ^ (ks * 32)) + (KT) * 2048);                               \
+    const bf16x8 va = *(const bf16x8*)(Vs + (rbase ^ (ks * 32)) + (KT) * 2048);                               \
+    _Pragma("unroll") for (int qt = 0; qt < 2; ++qt) {                                                        \
+      st[KT][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka, qf[qt][ks], st[KT][qt], 0, 0, 0);              \
+      dpt[KT][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va, dof[qt][ks], dpt[KT][qt], 0, 0, 0);           \
+    }                                                                                                         \
+  }
+#define DQ_SM(KT, MASK)                                                                                           \
+  _Pragma("unroll") for (int qt = 0; qt < 2; ++qt) {                                                          \
+    _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                                           \
+      float pv = fast_exp2(fmaf(st[KT][qt][r], c, -lse[qt]));                                                 \
+      if (MASK) {                                                                                             \
+        const int key = k0 + (KT) * 16 + 4 * g + r, qrow = qw0 + qt * 16 + fr;                                \
+        const bool ok = qrow < p.Sq && key < kvlen && (!CAUSAL || key <= qrow + off) && (p.window <= 0 || key > qrow + off - p.window); \
+        pv = ok ? pv : 0.f;                                                                                   \
+      }                                                                                                       \
+      dpt[KT][qt][r] = pv * (dpt[KT][qt][r] - dlt[qt]);                                                       \
+    }                                                                                                         \
+    dsk[qt][KT] = u32x2{pack_bf16x2(dpt[KT][qt][0], dpt[KT][qt][1]), pack_bf16x2(dpt[KT][qt][2], dpt[KT][qt][3])}; \
+  }
+      DQ_MF(0)
+      __builtin_amdgcn_sched_barrier(0);
+      // key half 1's MFMAs interleaved with key half 0's softmax arithmetic (different pipes): 1 MFMA : 5 VALU.  Two copies so that
+      // each is ONE basic block (a branch on need_mask inside would fence the scheduler).
+#define DQ_REGION(MASK)                                                                    \
+  DQ_MF(1)                                                                                 \
+  DQ_SM(0, MASK)                                                                           \
+  _Pragma("unroll") for (int i = 0; i < 16; ++i) {                                         \
+    if (i < 8) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                          \
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                     \
+    __builtin_amdgcn_sched_group_barrier(0x002, (MASK) ? 9 : 5, 0);                        \
+  }                                                                                        \
+  __builtin_amdgcn_sched_barrier(0);                                                       \
+  DQ_SM(1, MASK)                                                                           \
+  __builtin_amdgcn_sched_barrier(0);
+      if (need_mask) { DQ_REGION(true) } else { DQ_REGION(false) }
+#undef DQ_REGION
+#undef DQ_MF
+#undef DQ_SM
       bf16x8 dsf[2];
 #pragma unroll
       for (int qt = 0; qt < 2; ++qt)
