@@ -97,6 +97,10 @@ __device__ __forceinline__ void store4(const GemmArgs& p, int m, int n, f32x4 ac
 // ------------------------------------------------------------------------------------------------
 // fast path: K % 64 == 0, 16-byte aligned rows
 // ------------------------------------------------------------------------------------------------
+template <int HALVES>
+__device__ __forceinline__ void epilogue_swz(const GemmArgs& p, bf16_t* wave_lds, const f32x4 (&acc)[HALVES * 4][4], int mrow0, int ncol0,
+                                            int lane);      // defined below (shared LDS-staged epilogue)
+
 template <bool OUT_F32>
 __global__ __launch_bounds__(256) void gemm_nt_128(GemmArgs p) {
   __shared__ __attribute__((aligned(16))) bf16_t smem[2 * 128 * 64];
@@ -170,6 +174,12 @@ __global__ __launch_bounds__(256) void gemm_nt_128(GemmArgs p) {
   }
 
   // D tile (A-operand = weight rows): row index = output column n (4g + r), col index = token row m (fr)
+  if (!OUT_F32) {
+    // bf16 output: the operand tiles are dead (last barrier above) -> each wave stages its 64 x 64 sub-tile in its own 8 KB slice and
+    // writes 16-byte coalesced rows with the fused bias / activation / residual (same lean path as the 256-tile kernels)
+    epilogue_swz<1>(p, smem + wave * 4096, acc, m0 + wm * 64, n0 + wn * 64, lane);
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -218,14 +228,15 @@ __device__ __forceinline__ TileCoord tile_coord_sb(int v, int tiles_m, int tiles
 
 // swizzled C staging: per wave a [64 rows][64 cols] bf16 slice (8 KB), 16-byte chunk index ^= row & 7
 __device__ long vp_dbg_stamps[256 * 8];
-__device__ __forceinline__ void epilogue_256_swz(const GemmArgs& p, bf16_t* wave_lds, const f32x4 (&acc)[8][4], int mrow0, int ncol0,
-                                                 int lane) {
+template <int HALVES>      // 64-row halves of the wave's sub-tile: 2 for the 256-tile kernels (128 x 64 per wave), 1 for the 128-tile kernel
+__device__ __forceinline__ void epilogue_swz(const GemmArgs& p, bf16_t* wave_lds, const f32x4 (&acc)[HALVES * 4][4], int mrow0, int ncol0,
+                                            int lane) {
   const int fr = lane & 15, g = lane >> 4;
   const int epi = p.epi & 0xff;
   // Fast path: interior tile, 16-byte aligned rows (every decoder GEMM; with bias / activation: ViT, heads, DPT).  Kept lean: the
   // general path below is ~10x the instructions, and the epilogue runs with the matrix pipe idle.
   const bool fast = __builtin_amdgcn_readfirstlane(
-      (int)(mrow0 + 128 <= p.M && ncol0 + 64 <= p.N && (p.ldc & 7) == 0 && (((uintptr_t)p.C) & 15) == 0 &&
+      (int)(mrow0 + 64 * HALVES <= p.M && ncol0 + 64 <= p.N && (p.ldc & 7) == 0 && (((uintptr_t)p.C) & 15) == 0 &&
             (!p.bias || (((uintptr_t)p.bias) & 7) == 0) &&
             (!p.res || ((p.ldr & 7) == 0 && (((uintptr_t)p.res) & 15) == 0))));
   if (fast) {
@@ -237,7 +248,7 @@ __device__ __forceinline__ void epilogue_256_swz(const GemmArgs& p, bf16_t* wave
     bf16_t* cptr = (bf16_t*)p.C + (long)(mrow0 + rl0) * p.ldc + ncol0 + ch * 8;
     const bf16_t* rptr = p.res ? p.res + (long)(mrow0 + rl0) * p.ldr + ncol0 + ch * 8 : nullptr;
 #pragma unroll
-    for (int half = 0; half < 2; ++half) {
+    for (int half = 0; half < HALVES; ++half) {
       if (!p.bias && epi == EPI_NONE) {
 #pragma unroll
         for (int ii = 0; ii < 4; ++ii)
@@ -355,7 +366,7 @@ __device__ __forceinline__ void epilogue_256_swz(const GemmArgs& p, bf16_t* wave
       bias4[j][r] = (p.bias && n < p.N) ? bf2f(p.bias[n]) : 0.f;
     }
 #pragma unroll
-  for (int half = 0; half < 2; ++half) {
+  for (int half = 0; half < HALVES; ++half) {
 #pragma unroll
     for (int ii = 0; ii < 4; ++ii) {
       const int i = half * 4 + ii;
@@ -494,7 +505,7 @@ __global__ __launch_bounds__(512) void gemm_nt_256(GemmArgs p) {
     }
     // buf[cur] now holds (or is receiving) the next tile's first K-tile; buf[cur ^ 1] was just consumed -> C staging
     if (!OUT_F32) {
-      epilogue_256_swz(p, smem + (cur ^ 1) * 32768 + wave * 4096, acc, tcur.m0 + wr * 128, tcur.n0 + wc * 64, lane);
+      epilogue_swz<2>(p, smem + (cur ^ 1) * 32768 + wave * 4096, acc, tcur.m0 + wr * 128, tcur.n0 + wc * 64, lane);
     } else {
 #pragma unroll
       for (int i = 0; i < 8; ++i)
@@ -703,7 +714,7 @@ __global__ __launch_bounds__(512) void gemm_nt_256p8(GemmArgs p) {
     // buffer 1 (the last K-tile's, nt is even) is free for C staging; buffer 0 is receiving the next tile's first K-tile
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     if (!OUT_F32) {
-      epilogue_256_swz(p, smem + ((nt - 1) & 1) * 32768 + wave * 4096, acc, tcur.m0 + wr * 128, tcur.n0 + wc * 64, lane);
+      epilogue_swz<2>(p, smem + ((nt - 1) & 1) * 32768 + wave * 4096, acc, tcur.m0 + wr * 128, tcur.n0 + wc * 64, lane);
     } else {
       // fp32 output (weight gradients): interior, plain tiles go straight from the accumulators as 16-byte stores
       const int mr = tcur.m0 + wr * 128, nc = tcur.n0 + wc * 64;
