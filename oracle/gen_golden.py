@@ -371,6 +371,25 @@ def run_dinov2_teacher():
     print("dinov2_teacher:", tuple(tgt.shape), float(tgt.std()))
 
 
+def run_clip_embed_teacher():
+    """f-3: the generation teacher = `pipe.image_encoder(x).image_embeds` (base_ola_vlm.py:323-332) with HF's own
+    CLIPVisionModelWithProjection (the class diffusers' unCLIP pipeline holds) at reduced width / depth, gelu activation as in ViT-H."""
+    from transformers import CLIPVisionModelWithProjection
+    dims = dict(hidden_size=128, intermediate_size=320, num_hidden_layers=3, num_attention_heads=4, image_size=224, patch_size=14,
+                projection_dim=96, hidden_act="gelu")
+    vc = CLIPVisionConfig(**dims)
+    vc._attn_implementation = "eager"
+    m = CLIPVisionModelWithProjection(vc).eval()
+    shapes = {"pipe.image_encoder." + k: tuple(v.shape) for k, v in m.state_dict().items() if "position_ids" not in k}
+    m.load_state_dict({k[len("pipe.image_encoder."):]: WT.param(k, s) for k, s in shapes.items()}, strict=False)
+    images = WT.tensor("clip_embed_images", (2, 3, 224, 224))
+    with torch.no_grad():
+        emb = m(images).image_embeds.unsqueeze(1)
+    np.savez_compressed(os.path.join(OUT, "clip_embed_teacher.npz"), manifest=json.dumps({k: list(s) for k, s in shapes.items()}),
+                        dims=json.dumps(dims), embeds=emb.numpy().copy())
+    print("clip_embed_teacher:", tuple(emb.shape), float(emb.std()))
+
+
 def run_units():
     """Unit fixtures straight from the reference functions."""
     from ola_vlm.ola_utils import calculate_contrastive_loss
@@ -415,7 +434,7 @@ if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
     setup_reference()
-    which = sys.argv[1:] or ["units", "llama", "phi3", "ift", "data", "dino"]
+    which = sys.argv[1:] or ["units", "llama", "phi3", "ift", "data", "dino", "clipemb"]
     if "units" in which:
         run_units()
     if "llama" in which:
@@ -428,3 +447,5 @@ if __name__ == "__main__":
         run_data_path()
     if "dino" in which:
         run_dinov2_teacher()
+    if "clipemb" in which:
+        run_clip_embed_teacher()

@@ -575,6 +575,33 @@ def dinov2_depth_target(images, W, heads, taps, prefix="dav2_backbone.pretrained
     return sum(feats) / len(feats)
 
 
+def clip_image_embeds(images, W, heads, patch, act="gelu", eps=1e-5, prefix="pipe.image_encoder."):
+    """f-3: the generation teacher target (base_ola_vlm.py:323-332: `pipe.image_encoder(x).image_embeds`, unCLIP's
+    CLIPVisionModelWithProjection = CLIP ViT-H/14): full tower, `post_layernorm` on the CLS token, bias-free `visual_projection`
+    (HF modeling_clip.py CLIPVisionTransformer.forward + CLIPVisionModelWithProjection.forward).  -> (B, 1, proj_dim)."""
+    p = prefix + "vision_model."
+    B = images.shape[0]
+    pe = F.conv2d(images, W[p + "embeddings.patch_embedding.weight"], stride=patch).flatten(2).transpose(1, 2)
+    h = torch.cat([W[p + "embeddings.class_embedding"].expand(B, 1, -1), pe], 1) + W[p + "embeddings.position_embedding.weight"][None]
+    C = h.shape[-1]
+    hd = C // heads
+    h = F.layer_norm(h, (C,), W[p + "pre_layrnorm.weight"], W[p + "pre_layrnorm.bias"], eps)
+    L = 1 + max(int(k.split("encoder.layers.")[1].split(".")[0]) for k in W if k.startswith(p + "encoder.layers."))
+    fn = quick_gelu if act == "quick_gelu" else F.gelu
+    for l in range(L):
+        q = p + f"encoder.layers.{l}."
+        y = F.layer_norm(h, (C,), W[q + "layer_norm1.weight"], W[q + "layer_norm1.bias"], eps)
+        N = y.shape[1]
+        qq, kk, vv = (F.linear(y, W[q + f"self_attn.{n}_proj.weight"], W[q + f"self_attn.{n}_proj.bias"]).view(B, N, heads, hd).transpose(1, 2)
+                      for n in "qkv")
+        att = torch.softmax(qq @ kk.transpose(-1, -2) * hd ** -0.5, -1)
+        h = h + F.linear((att @ vv).transpose(1, 2).reshape(B, N, C), W[q + "self_attn.out_proj.weight"], W[q + "self_attn.out_proj.bias"])
+        y = F.layer_norm(h, (C,), W[q + "layer_norm2.weight"], W[q + "layer_norm2.bias"], eps)
+        h = h + F.linear(fn(F.linear(y, W[q + "mlp.fc1.weight"], W[q + "mlp.fc1.bias"])), W[q + "mlp.fc2.weight"], W[q + "mlp.fc2.bias"])
+    pooled = F.layer_norm(h[:, 0], (C,), W[p + "post_layernorm.weight"], W[p + "post_layernorm.bias"], eps)
+    return F.linear(pooled, W[prefix + "visual_projection.weight"]).unsqueeze(1)
+
+
 # ----------------------------------------------------------------------------------------------
 # embedding losses  (base_ola_vlm.py:289-320 ; ola_utils.py:96-125)
 # ----------------------------------------------------------------------------------------------

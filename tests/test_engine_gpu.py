@@ -361,3 +361,26 @@ def test_dinov2_depth_teacher_matches_oracle_and_reference_golden():
     assert float(err) < 3e-2, float(err)
     gerr = np.abs(got[:, ::7, ::3].numpy() - g["target_sub"]).max() / np.abs(g["target_sub"]).max()
     assert float(gerr) < 4e-2, float(gerr)
+
+
+def test_clip_image_embed_teacher_matches_oracle_and_hf_golden():
+    """the batched generation teacher (teachers.ClipImageEmbedTeacher) against the fp32 oracle on bf16-rounded weights
+    and against HF's CLIPVisionModelWithProjection output (tests/golden/clip_embed_teacher.npz)."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from oracle import cases, visper_oracle as O, weights as WT
+    from visper_lm_amd.teachers import ClipImageEmbedTeacher
+    g = cases.load_golden("clip_embed_teacher.npz")
+    dims = json.loads(str(g["dims"]))
+    W = {k: WT.param(k, s) for k, s in json.loads(str(g["manifest"])).items()}
+    t = ClipImageEmbedTeacher(dims["hidden_size"], dims["num_hidden_layers"], dims["num_attention_heads"], dims["image_size"],
+                              dims["patch_size"], act=dims["hidden_act"])
+    t.load_weights(W)
+    images = WT.tensor("clip_embed_images", (2, 3, 224, 224))
+    got = t.forward(images.cuda()).float().cpu()
+    with torch.no_grad():
+        ref = O.clip_image_embeds(images.to(BF).float(), {k: v.to(BF).float() for k, v in W.items()}, dims["num_attention_heads"],
+                                  dims["patch_size"], act=dims["hidden_act"])
+    assert tuple(got.shape) == (2, 1, dims["projection_dim"])
+    assert float((got - ref).abs().max() / ref.abs().max()) < 3e-2
+    assert float(np.abs(got.numpy() - g["embeds"]).max() / np.abs(g["embeds"]).max()) < 4e-2

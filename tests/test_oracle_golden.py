@@ -198,3 +198,17 @@ def test_dinov2_depth_teacher_matches_reference():
     _close(tgt[:, ::7, ::3].numpy(), g["target_sub"], 1e-3, 2e-5)
     _close(float(tgt.double().mean()), g["target_mean"], 1e-4, 1e-6)
     _close(float(tgt.double().std()), g["target_std"], 1e-4, 1e-6)
+
+
+def test_clip_image_embed_teacher_matches_hf():
+    """the generation teacher target `pipe.image_encoder(x).image_embeds` (base_ola_vlm.py:323-332) against HF's own
+    CLIPVisionModelWithProjection (tests/golden/clip_embed_teacher.npz)."""
+    from oracle import weights as WT
+    g = cases.load_golden("clip_embed_teacher.npz")
+    dims = json.loads(str(g["dims"]))
+    W = {k: WT.param(k, s) for k, s in json.loads(str(g["manifest"])).items()}
+    images = WT.tensor("clip_embed_images", (2, 3, 224, 224))
+    with torch.no_grad():
+        emb = O.clip_image_embeds(images, W, dims["num_attention_heads"], dims["patch_size"], act=dims["hidden_act"])
+    assert tuple(emb.shape) == tuple(g["embeds"].shape)
+    _close(emb.numpy(), g["embeds"], 1e-3, 2e-5)
