@@ -128,6 +128,12 @@ int vp_minmax_norm(int B, long n, const void* x, void* y, vp_stream_t stream);
 int vp_attn_fwd(int B, int Hq, int Hkv, int Sq, int Skv, int D, const void* q, long q_bs, long q_ts, const void* k,
                 long k_bs, long k_ts, const void* v, long v_bs, long v_ts, void* o, long o_bs, long o_ts, float* lse,
                 const int* kv_len, int causal, int window, float scale, vp_stream_t stream);
+/* forward with additive fp32 score biases: Swin window attention of the frozen segmentation teacher (HF modeling_swin.py SwinAttention:
+ * relative position bias per head [Hq,Sq,Skv] + shifted-window mask [bias_nb,Sq,Skv] indexed by batch % bias_nb); either may be NULL */
+int vp_attn_fwd_bias(int B, int Hq, int Hkv, int Sq, int Skv, int D, const void* q, long q_bs, long q_ts, const void* k,
+                     long k_bs, long k_ts, const void* v, long v_bs, long v_ts, void* o, long o_bs, long o_ts, float* lse,
+                     const int* kv_len, int causal, int window, float scale, const float* bias_h, const float* bias_b, int bias_nb,
+                     vp_stream_t stream);
 int vp_attn_bwd(int B, int Hq, int Hkv, int Sq, int Skv, int D, const void* q, long q_bs, long q_ts, const void* k,
                 long k_bs, long k_ts, const void* v, long v_bs, long v_ts, const void* o, long o_bs, long o_ts,
                 const float* lse, const void* dout, long do_bs, long do_ts, void* dq, long dq_bs, long dq_ts, void* dk,

@@ -531,3 +531,23 @@ def test_attention_d128_dma_kernels_edges(ops, B, Hq, Hkv, Sq, Skv, causal, wind
         for b, n in enumerate(kvl):
             assert float(dk[b, n:].float().abs().max() if n < Skv else 0.0) == 0.0
             assert float(dv[b, n:].float().abs().max() if n < Skv else 0.0) == 0.0
+
+
+def test_attention_with_additive_biases(ops):
+    """vp_attn_fwd_bias (Swin window attention): per-head relative-position bias + per-window shift mask (-100 entries, HF
+    modeling_swin.py get_attn_mask), 144-token windows, D = 32, batch = images x windows."""
+    nW, imgs, H, N, D = 4, 2, 3, 144, 32
+    B = nW * imgs
+    q, k, v = rnd(B, N, H, D, seed=91), rnd(B, N, H, D, seed=92), rnd(B, N, H, D, seed=93)
+    bh = rnd(H, N, N, seed=94).float() * 2.0
+    mask = torch.zeros(nW, N, N)
+    mask[1, :, 72:] = -100.0
+    mask[1, 72:, :72] = -100.0
+    mask[1, 72:, 72:] = 0.0
+    mask[3, :60, 60:] = -100.0
+    s = (q.float().transpose(1, 2) @ k.float().transpose(1, 2).transpose(-1, -2)) / math.sqrt(D)          # [B,H,N,N]
+    s = s + bh[None] + mask.repeat(imgs, 1, 1)[:, None]
+    ref = (torch.softmax(s, -1) @ v.float().transpose(1, 2)).transpose(1, 2)
+    got = ops.attn_fwd_bias(dev(q), dev(k), dev(v), bias_h=dev(bh).contiguous(), bias_b=dev(mask).contiguous())
+    close(got, ref, what="attn bias_h + bias_b")
+    close(ops.attn_fwd_bias(dev(q), dev(k), dev(v), bias_h=dev(bh).contiguous()), (torch.softmax(s - mask.repeat(imgs, 1, 1)[:, None], -1) @ v.float().transpose(1, 2)).transpose(1, 2), what="attn bias_h only")

@@ -50,6 +50,7 @@ _SIGS = {
     "vp_sum_f32": [l, p, p, f, p],
     "vp_sumsq_f32": [l, p, p, p, p],
     "vp_attn_fwd": [i, i, i, i, i, i, p, l, l, p, l, l, p, l, l, p, l, l, p, p, i, i, f, p],
+    "vp_attn_fwd_bias": [i, i, i, i, i, i, p, l, l, p, l, l, p, l, l, p, l, l, p, p, i, i, f, p, p, i, p],
     "vp_attn_bwd": [i, i, i, i, i, i, p, l, l, p, l, l, p, l, l, p, l, l, p, p, l, l, p, l, l, p, l, l, p, l, l, p, p,
                     i, i, f, p],
     "vp_ce_fwd_bwd": [l, i, p, l, p, p, f, i, p],

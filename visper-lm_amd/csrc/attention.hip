@@ -31,6 +31,11 @@ struct AttnParams {
   int B, Hq, Hkv, Sq, Skv, window;
   const int* kv_len;
   float scale;
+  // optional additive score biases (forward only; Swin window attention): bias_h [Hq, Sq, Skv] per head (relative position bias),
+  // bias_b [bias_nb, Sq, Skv] indexed by batch % bias_nb (the shifted-window mask); fp32, added to the scaled scores
+  const float* bias_h;
+  const float* bias_b;
+  int bias_nb;
 };
 
 #define LOG2E 1.4426950408889634f
@@ -157,6 +162,22 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(AttnParams p) {
         }
       }
       // st[kt][r]: raw score of key k0 + 16kt + 4g + r against query qrow
+      if (p.bias_h || p.bias_b) {                      // wave-uniform; scores are scaled later by c = scale * log2(e): add bias / scale here
+        const float inv_scale = 1.f / p.scale;
+        const int qc = min(qrow, p.Sq - 1);
+        const float* bh = p.bias_h ? p.bias_h + ((long)h * p.Sq + qc) * p.Skv : nullptr;
+        const float* bb = p.bias_b ? p.bias_b + ((long)(b % p.bias_nb) * p.Sq + qc) * p.Skv : nullptr;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int key = min(k0 + kt * 16 + 4 * g + r, p.Skv - 1);
+            float add = 0.f;
+            if (bh) add += bh[key];
+            if (bb) add += bb[key];
+            st[kt][r] = fmaf(add, inv_scale, st[kt][r]);
+          }
+      }
       const bool need_mask = (k0 + 64 > kvlen) || (CAUSAL && (k0 + 63 > qw0 + off)) || (p.window > 0);
       if (need_mask) {
 #pragma unroll
@@ -939,6 +960,28 @@ int vp_attn_fwd(int B, int Hq, int Hkv, int Sq, int Skv, int D, const void* q, l
   p.q = (const bf16_t*)q; p.k = (const bf16_t*)k; p.v = (const bf16_t*)v; p.o = (bf16_t*)o; p.lse = lse;
   p.q_bs = q_bs; p.q_ts = q_ts; p.k_bs = k_bs; p.k_ts = k_ts; p.v_bs = v_bs; p.v_ts = v_ts; p.o_bs = o_bs; p.o_ts = o_ts;
   p.B = B; p.Hq = Hq; p.Hkv = Hkv; p.Sq = Sq; p.Skv = Skv; p.window = window; p.kv_len = kv_len; p.scale = scale;
+  switch (D) {
+    case 32: return launch_fwd<32>(p, causal, s);
+    case 64: return launch_fwd<64>(p, causal, s);
+    case 96: return launch_fwd<96>(p, causal, s);
+    default: return launch_fwd<128>(p, causal, s);
+  }
+}
+
+// Same, with additive fp32 score biases (Swin window attention, HF modeling_swin.py SwinAttention.forward: relative position bias per
+// head [Hq,Sq,Skv] + shifted-window mask [bias_nb,Sq,Skv] indexed by batch % bias_nb).  Forward only (frozen teacher).
+int vp_attn_fwd_bias(int B, int Hq, int Hkv, int Sq, int Skv, int D, const void* q, long q_bs, long q_ts, const void* k, long k_bs,
+                long k_ts, const void* v, long v_bs, long v_ts, void* o, long o_bs, long o_ts, float* lse, const int* kv_len,
+                int causal, int window, float scale, const float* bias_h, const float* bias_b, int bias_nb,
+                     hipStream_t s) {
+  int e = check_attn("vp_attn_fwd_bias", B, Hq, Hkv, Sq, Skv, D);
+  if (e) return e;
+  AttnParams p{};
+  p.q = (const bf16_t*)q; p.k = (const bf16_t*)k; p.v = (const bf16_t*)v; p.o = (bf16_t*)o; p.lse = lse;
+  p.q_bs = q_bs; p.q_ts = q_ts; p.k_bs = k_bs; p.k_ts = k_ts; p.v_bs = v_bs; p.v_ts = v_ts; p.o_bs = o_bs; p.o_ts = o_ts;
+  p.B = B; p.Hq = Hq; p.Hkv = Hkv; p.Sq = Sq; p.Skv = Skv; p.window = window; p.kv_len = kv_len; p.scale = scale;
+  VP_REQUIRE(!bias_b || bias_nb > 0, VP_ERR_BAD_ARG, "vp_attn_fwd_bias: bias_nb");
+  p.bias_h = bias_h; p.bias_b = bias_b; p.bias_nb = bias_nb;
   switch (D) {
     case 32: return launch_fwd<32>(p, causal, s);
     case 64: return launch_fwd<64>(p, causal, s);

@@ -391,6 +391,23 @@ def attn_fwd(q, k, v, causal, scale=None, window=0, kv_len=None, out=None):
     return out, lse
 
 
+def attn_fwd_bias(q, k, v, bias_h=None, bias_b=None, scale=None):
+    """Non-causal attention with additive fp32 score biases (Swin window attention): bias_h [Hq,Sq,Skv] per head, bias_b [nb,Sq,Skv]
+    indexed by batch % nb.  Forward only.  -> o [B,Sq,Hq,D]."""
+    B, Sq, Hq, D = q.shape
+    _, Skv, Hkv, _ = k.shape
+    if scale is None:
+        scale = 1.0 / math.sqrt(D)
+    out = torch.empty(B, Sq, Hq, D, device=q.device, dtype=BF16)
+    lse = torch.empty(B, Hq, Sq, device=q.device, dtype=torch.float32)
+    for t in (bias_h, bias_b):
+        assert t is None or (t.dtype == torch.float32 and t.is_contiguous() and t.shape[-2:] == (Sq, Skv))
+    qb, qt = _bshd(q); kb, kt = _bshd(k); vb, vt = _bshd(v); ob, ot = _bshd(out)
+    _lib.call("vp_attn_fwd_bias", B, Hq, Hkv, Sq, Skv, D, _p(q), qb, qt, _p(k), kb, kt, _p(v), vb, vt, _p(out), ob, ot, _p(lse),
+              None, 0, 0, scale, _p(bias_h), _p(bias_b), 0 if bias_b is None else bias_b.shape[0], _stream())
+    return out
+
+
 def attn_bwd(q, k, v, o, lse, dout, causal, scale=None, window=0, kv_len=None, dq=None, dk=None, dv=None):
     B, Sq, Hq, D = q.shape
     _, Skv, Hkv, _ = k.shape
