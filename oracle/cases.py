@@ -85,3 +85,8 @@ def dinov2_weights(manifest):
         else:
             W[k] = WT.param(k, s)
     return W
+
+
+def swin_weights(manifest):
+    """Closed-form weights of the Swin teacher fixture (same overrides as gen_golden.run_swin_teacher)."""
+    return {k: (WT.tensor(k, s, 0.5) if k.endswith("relative_position_bias_table") else WT.param(k, s)) for k, s in manifest.items()}

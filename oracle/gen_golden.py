@@ -390,6 +390,31 @@ def run_clip_embed_teacher():
     print("clip_embed_teacher:", tuple(emb.shape), float(emb.std()))
 
 
+def run_swin_teacher():
+    """f-3: the segmentation teacher = Swin backbone feature_maps[-1] resized to 24 x 24 (oneformer_head.py:11-69) with HF's own SwinBackbone
+    (what OneFormer's pixel-level module holds) at reduced width / depth: window 12, head_dim 32, 384-px input (grids 96/48/24/12)."""
+    from transformers import SwinConfig, SwinBackbone
+    dims = dict(image_size=384, patch_size=4, embed_dim=32, depths=[2, 2, 2, 2], num_heads=[1, 2, 4, 8], window_size=12)
+    cfg = SwinConfig(**dims, out_features=["stage1", "stage2", "stage3", "stage4"])
+    cfg._attn_implementation = "eager"
+    m = SwinBackbone(cfg).eval()
+    pre = "oneformer.model.pixel_level_module.encoder."
+    shapes = {pre + k: tuple(v.shape) for k, v in m.state_dict().items()}
+    sd = {k: WT.param(k, s) for k, s in shapes.items()}
+    for k in sd:
+        if k.endswith("relative_position_bias_table"):
+            sd[k] = WT.tensor(k, shapes[k], 0.5)                 # biases large enough to matter
+    m.load_state_dict({k[len(pre):]: v for k, v in sd.items()}, strict=True)
+    images = WT.tensor("swin_images", (2, 3, 384, 384))
+    with torch.no_grad():
+        fm = m(images).feature_maps[-1]
+        tgt = torch.nn.functional.interpolate(fm, size=(24, 24), mode="bilinear", align_corners=False)
+    np.savez_compressed(os.path.join(OUT, "swin_teacher.npz"), manifest=json.dumps({k: list(s) for k, s in shapes.items()}),
+                        dims=json.dumps(dims), target_shape=np.array(tgt.shape), target_sub=tgt[:, ::5, ::3, ::3].numpy().copy(),
+                        target_mean=np.float64(tgt.double().mean().item()), target_std=np.float64(tgt.double().std().item()))
+    print("swin_teacher:", tuple(fm.shape), tuple(tgt.shape), float(tgt.std()))
+
+
 def run_units():
     """Unit fixtures straight from the reference functions."""
     from ola_vlm.ola_utils import calculate_contrastive_loss
@@ -434,7 +459,7 @@ if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
     setup_reference()
-    which = sys.argv[1:] or ["units", "llama", "phi3", "ift", "data", "dino", "clipemb"]
+    which = sys.argv[1:] or ["units", "llama", "phi3", "ift", "data", "dino", "clipemb", "swin"]
     if "units" in which:
         run_units()
     if "llama" in which:
@@ -449,3 +474,5 @@ if __name__ == "__main__":
         run_dinov2_teacher()
     if "clipemb" in which:
         run_clip_embed_teacher()
+    if "swin" in which:
+        run_swin_teacher()

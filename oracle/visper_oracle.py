@@ -602,6 +602,74 @@ def clip_image_embeds(images, W, heads, patch, act="gelu", eps=1e-5, prefix="pip
     return F.linear(pooled, W[prefix + "visual_projection.weight"]).unsqueeze(1)
 
 
+def _swin_rel_index(ws):
+    """SwinRelativePositionBias._create_relative_position_index (HF modeling_swin.py): flat index into the (2ws-1)^2 bias table."""
+    c = torch.stack(torch.meshgrid([torch.arange(ws), torch.arange(ws)], indexing="ij")).flatten(1)
+    rel = (c[:, :, None] - c[:, None, :]).permute(1, 2, 0).contiguous()
+    rel[:, :, 0] += ws - 1
+    rel[:, :, 1] += ws - 1
+    rel[:, :, 0] *= 2 * ws - 1
+    return rel.sum(-1)
+
+
+def _swin_shift_mask(Hh, Ww, ws, shift):
+    """SwinLayer.get_attn_mask: (nW, ws*ws, ws*ws) with -100 between tokens of different cyclic-shift regions."""
+    hr = (torch.arange(Hh) >= Hh - ws).long() + (torch.arange(Hh) >= Hh - shift).long()
+    wr = (torch.arange(Ww) >= Ww - ws).long() + (torch.arange(Ww) >= Ww - shift).long()
+    img = (hr[:, None] * 3 + wr[None, :]).float()
+    mw = img.view(Hh // ws, ws, Ww // ws, ws).transpose(1, 2).reshape(-1, ws * ws)
+    d = mw[:, None, :] - mw[:, :, None]
+    return torch.where(d != 0, torch.full_like(d, -100.0), torch.zeros_like(d))
+
+
+def swin_seg_target(images, W, depths, heads, window=12, patch=4, out_hw=24, prefix="oneformer.model.pixel_level_module.encoder.", eps=1e-5):
+    """f-3: the segmentation teacher target (base_ola_vlm.py:382-397 -> oneformer_head.py:11-69): Swin backbone feature_maps[-1]
+    (last stage, `hidden_states_norms.stage4`), bilinear (align_corners=False) to 24 x 24.  HF modeling_swin.py: SwinEmbeddings,
+    SwinLayer (W-MSA / SW-MSA with relative position bias + cyclic-shift mask, always_partition=True as SwinBackbone.forward sets),
+    SwinPatchMerging.  images (B,3,S,S) -> (B, C_last, 24, 24)."""
+    p = prefix + "swin."
+    x = F.conv2d(images, W[p + "embeddings.patch_embeddings.projection.weight"], W[p + "embeddings.patch_embeddings.projection.bias"], stride=patch)
+    B, C, Hh, Ww = x.shape
+    x = x.flatten(2).transpose(1, 2)
+    x = F.layer_norm(x, (C,), W[p + "embeddings.norm.weight"], W[p + "embeddings.norm.bias"], eps)
+    ridx = _swin_rel_index(window).view(-1)
+    N = window * window
+    for s, (dep, nh) in enumerate(zip(depths, heads)):
+        hd = C // nh
+        for bi in range(dep):
+            q = f"{p}encoder.layers.{s}.blocks.{bi}."
+            shift = 0 if bi % 2 == 0 else window // 2
+            y = F.layer_norm(x, (C,), W[q + "layernorm_before.weight"], W[q + "layernorm_before.bias"], eps).view(B, Hh, Ww, C)
+            if shift:
+                y = torch.roll(y, shifts=(-shift, -shift), dims=(1, 2))
+            win = y.view(B, Hh // window, window, Ww // window, window, C).transpose(2, 3).reshape(-1, N, C)
+            qq, kk, vv = (F.linear(win, W[q + f"attention.{n}_proj.weight"], W[q + f"attention.{n}_proj.bias"]).view(-1, N, nh, hd).transpose(1, 2)
+                          for n in "qkv")
+            bias = W[q + "attention.relative_position_bias.relative_position_bias_table"][ridx].view(N, N, nh).permute(2, 0, 1)[None]
+            sc = qq @ kk.transpose(-1, -2) * hd ** -0.5 + bias
+            if shift:
+                sc = sc + _swin_shift_mask(Hh, Ww, window, shift).repeat(B, 1, 1)[:, None].to(sc.dtype)
+            o = (torch.softmax(sc, -1) @ vv).transpose(1, 2).reshape(-1, N, C)
+            o = F.linear(o, W[q + "attention.o_proj.weight"], W[q + "attention.o_proj.bias"])
+            o = o.view(B, Hh // window, Ww // window, window, window, C).transpose(2, 3).reshape(B, Hh, Ww, C)
+            if shift:
+                o = torch.roll(o, shifts=(shift, shift), dims=(1, 2))
+            x = x + o.reshape(B, Hh * Ww, C)
+            y = F.layer_norm(x, (C,), W[q + "layernorm_after.weight"], W[q + "layernorm_after.bias"], eps)
+            x = x + F.linear(F.gelu(F.linear(y, W[q + "mlp.fc1.weight"], W[q + "mlp.fc1.bias"])), W[q + "mlp.fc2.weight"], W[q + "mlp.fc2.bias"])
+        if s < len(depths) - 1:                                      # SwinPatchMerging
+            d = f"{p}encoder.layers.{s}.downsample."
+            g = x.view(B, Hh, Ww, C)
+            g = torch.cat([g[:, r::2, c::2, :] for c in range(2) for r in range(2)], -1).view(B, -1, 4 * C)
+            g = F.layer_norm(g, (4 * C,), W[d + "norm.weight"], W[d + "norm.bias"], eps)
+            x = F.linear(g, W[d + "reduction.weight"])
+            Hh, Ww, C = Hh // 2, Ww // 2, 2 * C
+    k = len(depths)
+    x = F.layer_norm(x, (C,), W[prefix + f"hidden_states_norms.stage{k}.weight"], W[prefix + f"hidden_states_norms.stage{k}.bias"], eps)
+    fm = x.view(B, Hh, Ww, C).permute(0, 3, 1, 2)
+    return F.interpolate(fm, size=(out_hw, out_hw), mode="bilinear", align_corners=False)
+
+
 # ----------------------------------------------------------------------------------------------
 # embedding losses  (base_ola_vlm.py:289-320 ; ola_utils.py:96-125)
 # ----------------------------------------------------------------------------------------------

@@ -212,3 +212,18 @@ def test_clip_image_embed_teacher_matches_hf():
         emb = O.clip_image_embeds(images, W, dims["num_attention_heads"], dims["patch_size"], act=dims["hidden_act"])
     assert tuple(emb.shape) == tuple(g["embeds"].shape)
     _close(emb.numpy(), g["embeds"], 1e-3, 2e-5)
+
+
+def test_swin_seg_teacher_matches_hf():
+    """the segmentation teacher target (Swin backbone last feature map -> 24 x 24; base_ola_vlm.py:382-397,
+    oneformer_head.py:11-69) against HF's own SwinBackbone: W-MSA / SW-MSA with relative position bias and cyclic-shift masks, patch merging."""
+    from oracle import weights as WT
+    g = cases.load_golden("swin_teacher.npz")
+    dims = json.loads(str(g["dims"]))
+    W = cases.swin_weights(json.loads(str(g["manifest"])))
+    images = WT.tensor("swin_images", (2, 3, 384, 384))
+    with torch.no_grad():
+        tgt = O.swin_seg_target(images, W, dims["depths"], dims["num_heads"], window=dims["window_size"], patch=dims["patch_size"])
+    assert tuple(tgt.shape) == tuple(g["target_shape"])
+    _close(tgt[:, ::5, ::3, ::3].numpy(), g["target_sub"], 1e-3, 5e-5)
+    _close(float(tgt.double().std()), g["target_std"], 1e-4, 1e-6)
