@@ -114,9 +114,9 @@ int vp_sumsq_f32(long n, const float* x, float* part, float* out, vp_stream_t st
 /* ---- frozen DPT depth decoder (da_v2_head.py:182-321, run under no_grad at base_ola_vlm.py:462-470; output `depth_preds`).
  * NHWC bf16.  3x3 convs = vp_im2col3x3_nhwc (pad 1, stride 1|2, optional input ReLU of ResidualConvUnit; column order
  * (ky, kx, c)) + vp_gemm_bf16; ConvTranspose2d(k = stride) = vp_gemm_bf16 to [pixels, k*k*C] + vp_pixel_shuffle_nhwc;
- * F.interpolate(mode="bilinear", align_corners=True) = vp_bilinear_nhwc; (x - min) / (max - min) per image = vp_minmax_norm. */
+ * F.interpolate(mode="bilinear", align_corners=True | False) = vp_bilinear_nhwc; (x - min) / (max - min) per image = vp_minmax_norm. */
 int vp_im2col3x3_nhwc(int B, int H, int W, int C, int stride, int relu_in, const void* x, void* col, vp_stream_t stream);
-int vp_bilinear_nhwc(int B, int H, int W, int C, int Ho, int Wo, const void* x, void* y, vp_stream_t stream);
+int vp_bilinear_nhwc(int B, int H, int W, int C, int Ho, int Wo, int align_corners, const void* x, void* y, vp_stream_t stream);
 int vp_pixel_shuffle_nhwc(int B, int H, int W, int k, int C, const void* x, void* y, vp_stream_t stream);
 int vp_minmax_norm(int B, long n, const void* x, void* y, vp_stream_t stream);
 

@@ -384,3 +384,57 @@ def test_clip_image_embed_teacher_matches_oracle_and_hf_golden():
     assert tuple(got.shape) == (2, 1, dims["projection_dim"])
     assert float((got - ref).abs().max() / ref.abs().max()) < 3e-2
     assert float(np.abs(got.numpy() - g["embeds"]).max() / np.abs(g["embeds"]).max()) < 4e-2
+
+
+def test_swin_seg_teacher_matches_oracle_and_hf_golden():
+    """the batched segmentation teacher (teachers.SwinSegTeacher: window attention with relative-position bias and
+    shift masks through vp_attn_fwd_bias) against the fp32 oracle on bf16-rounded weights and HF's SwinBackbone golden."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from oracle import cases, visper_oracle as O, weights as WT
+    from visper_lm_amd.teachers import SwinSegTeacher
+    g = cases.load_golden("swin_teacher.npz")
+    dims = json.loads(str(g["dims"]))
+    W = cases.swin_weights(json.loads(str(g["manifest"])))
+    t = SwinSegTeacher(dims["embed_dim"], dims["depths"], dims["num_heads"], dims["window_size"], dims["patch_size"], dims["image_size"])
+    t.load_weights(W)
+    images = WT.tensor("swin_images", (2, 3, 384, 384))
+    got = t.forward(images.cuda()).float().cpu()
+    with torch.no_grad():
+        ref = O.swin_seg_target(images.to(BF).float(), {k: v.to(BF).float() for k, v in W.items()}, dims["depths"], dims["num_heads"],
+                                window=dims["window_size"], patch=dims["patch_size"])
+    assert tuple(got.shape) == tuple(g["target_shape"])
+    assert float((got - ref).abs().max() / ref.abs().max()) < 4e-2
+    assert float(np.abs(got[:, ::5, ::3, ::3].numpy() - g["target_sub"]).max() / np.abs(g["target_sub"]).max()) < 5e-2
+
+
+def test_clip_image_embed_teacher_padded_head_dim():
+    """ViT-H has head_dim 80, which is not a kernel head size: the teacher zero-pads every head to 96 inside the frozen weights.
+    Checked against the fp32 oracle at hidden 160 / 2 heads (head_dim 80)."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from oracle import visper_oracle as O, weights as WT
+    from visper_lm_amd.teachers import ClipImageEmbedTeacher
+    C, L, nh, S, P, proj = 160, 2, 2, 112, 14, 64
+    pre = "pipe.image_encoder."
+    sh = {pre + "vision_model.embeddings.class_embedding": (C,), pre + "vision_model.embeddings.patch_embedding.weight": (C, 3, P, P),
+          pre + "vision_model.embeddings.position_embedding.weight": ((S // P) ** 2 + 1, C), pre + "visual_projection.weight": (proj, C)}
+    for n in ("pre_layrnorm", "post_layernorm"):
+        sh[pre + f"vision_model.{n}.weight"] = (C,); sh[pre + f"vision_model.{n}.bias"] = (C,)
+    for l in range(L):
+        q = pre + f"vision_model.encoder.layers.{l}."
+        for x in ("q", "k", "v", "out"):
+            sh[q + f"self_attn.{x}_proj.weight"] = (C, C); sh[q + f"self_attn.{x}_proj.bias"] = (C,)
+        for n in ("layer_norm1", "layer_norm2"):
+            sh[q + n + ".weight"] = (C,); sh[q + n + ".bias"] = (C,)
+        sh[q + "mlp.fc1.weight"] = (4 * C, C); sh[q + "mlp.fc1.bias"] = (4 * C,)
+        sh[q + "mlp.fc2.weight"] = (C, 4 * C); sh[q + "mlp.fc2.bias"] = (C,)
+    W = {k: WT.param(k, s) for k, s in sh.items()}
+    t = ClipImageEmbedTeacher(C, L, nh, S, P)
+    t.load_weights(W)
+    assert t.hp == 96
+    images = WT.tensor("clip_pad_images", (2, 3, S, S))
+    got = t.forward(images.cuda()).float().cpu()
+    with torch.no_grad():
+        ref = O.clip_image_embeds(images.to(BF).float(), {k: v.to(BF).float() for k, v in W.items()}, nh, P)
+    assert float((got - ref).abs().max() / ref.abs().max()) < 3e-2

@@ -30,7 +30,7 @@ _SIGS = {
     "vp_dwconv7x7_nhwc": [i, i, i, i, p, p, p, p, p],
     "vp_rope": [l, i, i, i, p, l, p, p, p, i, p],
     "vp_im2col3x3_nhwc": [i, i, i, i, i, i, p, p, p],
-    "vp_bilinear_nhwc": [i, i, i, i, i, i, p, p, p],
+    "vp_bilinear_nhwc": [i, i, i, i, i, i, i, p, p, p],
     "vp_pixel_shuffle_nhwc": [i, i, i, i, i, p, p, p],
     "vp_minmax_norm": [i, l, p, p, p],
     "vp_swiglu_fwd": [l, i, p, l, p, l, i, p],

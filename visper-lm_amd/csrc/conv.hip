@@ -35,10 +35,12 @@ __global__ void im2col3x3_kernel(const bf16_t* __restrict__ x, bf16_t* __restric
 // torch upsample_bilinear2d, align_corners=True (aten UpSample.h area_pixel_compute_source_index / compute_scales_value):
 // scale = (in - 1) / (out - 1) in fp32, src = scale * dst, i0 = (int)src, i1 = i0 + (i0 < in - 1), lambda1 = src - i0;
 // value = h0*(w0*v00 + w1*v01) + h1*(w0*v10 + w1*v11) in fp32, rounded once to bf16.
+// align_corners=False (aten area_pixel_compute_source_index): scale = in / out, src = max(scale * (dst + 0.5) - 0.5, 0).
 __global__ void bilinear_nhwc_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, int B, int H, int W, int C, int Ho,
-                                     int Wo) {
+                                     int Wo, int align) {
   const int cv = C >> 3;
-  const float sh = Ho > 1 ? (float)(H - 1) / (float)(Ho - 1) : 0.f, sw = Wo > 1 ? (float)(W - 1) / (float)(Wo - 1) : 0.f;
+  const float sh = align ? (Ho > 1 ? (float)(H - 1) / (float)(Ho - 1) : 0.f) : (float)H / (float)Ho;
+  const float sw = align ? (Wo > 1 ? (float)(W - 1) / (float)(Wo - 1) : 0.f) : (float)W / (float)Wo;
   const long total = (long)B * Ho * Wo * cv;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const int c8 = (int)(i % cv);
@@ -46,7 +48,7 @@ __global__ void bilinear_nhwc_kernel(const bf16_t* __restrict__ x, bf16_t* __res
     const int ox = (int)(r % Wo);
     const int oy = (int)((r / Wo) % Ho);
     const int b = (int)(r / ((long)Wo * Ho));
-    const float fy = sh * oy, fx = sw * ox;
+    const float fy = align ? sh * oy : fmaxf(sh * (oy + 0.5f) - 0.5f, 0.f), fx = align ? sw * ox : fmaxf(sw * (ox + 0.5f) - 0.5f, 0.f);
     const int y0 = (int)fy, x0 = (int)fx;
     const int y1 = y0 + (y0 < H - 1), x1 = x0 + (x0 < W - 1);
     const float h1 = fy - y0, h0 = 1.f - h1, w1 = fx - x0, w0 = 1.f - w1;
@@ -113,9 +115,9 @@ int vp_im2col3x3_nhwc(int B, int H, int W, int C, int stride, int relu_in, const
   return vp_check_launch("vp_im2col3x3_nhwc");
 }
 
-int vp_bilinear_nhwc(int B, int H, int W, int C, int Ho, int Wo, const void* x, void* y, hipStream_t s) {
+int vp_bilinear_nhwc(int B, int H, int W, int C, int Ho, int Wo, int align_corners, const void* x, void* y, hipStream_t s) {
   VP_REQUIRE(B > 0 && H > 0 && W > 0 && Ho > 0 && Wo > 0 && C > 0 && C % 8 == 0, VP_ERR_BAD_ARG, "vp_bilinear_nhwc: bad args");
-  hipLaunchKernelGGL(bilinear_nhwc_kernel, GRID_FOR((long)B * Ho * Wo * (C / 8)), dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y, B, H, W, C, Ho, Wo);
+  hipLaunchKernelGGL(bilinear_nhwc_kernel, GRID_FOR((long)B * Ho * Wo * (C / 8)), dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y, B, H, W, C, Ho, Wo, align_corners);
   return vp_check_launch("vp_bilinear_nhwc");
 }
 

@@ -225,11 +225,11 @@ def conv3x3_nhwc(x, w_mat, bias=None, stride=1, relu_in=False, epi=EPI_NONE, res
     return gemm(col, w_mat, bias=bias, epi=epi, residual=res2).view(B, Ho, Wo, -1)
 
 
-def bilinear_nhwc(x, Ho, Wo):
-    """F.interpolate(mode="bilinear", align_corners=True) on [B,H,W,C] bf16."""
+def bilinear_nhwc(x, Ho, Wo, align_corners=True):
+    """F.interpolate(mode="bilinear", align_corners=...) on [B,H,W,C] bf16."""
     B, H, W, C = x.shape
     y = torch.empty(B, Ho, Wo, C, device=x.device, dtype=BF16)
-    _lib.call("vp_bilinear_nhwc", B, H, W, C, Ho, Wo, _p(x), _p(y), _stream())
+    _lib.call("vp_bilinear_nhwc", B, H, W, C, Ho, Wo, 1 if align_corners else 0, _p(x), _p(y), _stream())
     return y
 
 
