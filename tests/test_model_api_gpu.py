@@ -93,3 +93,31 @@ def test_mm_projector_checkpoint_round_trip(tmp_path):
     # the reference's loader also accepts keys without the leading "model." (builder.py:131-137)
     torch.save({k[len("model."):]: v for k, v in sd.items()}, path)
     assert sorted(data.load_mm_projector(eng, path)) == sorted(sd)
+
+
+def test_attached_gpu_teachers_feed_the_step():
+    """f-3 through the drop-in API: with teachers attached, `<task>_pixels` tensors replace precomputed `<task>_target`s and the loss equals
+    the one obtained by passing the teachers' outputs explicitly."""
+    import json
+    import torch
+    from oracle import cases, weights as WT
+    from visper_lm_amd.model import OlaLlavaLlamaForCausalLM
+    from visper_lm_amd.model.language_model import OlaLlavaLlamaConfig
+    from visper_lm_amd.teachers import DinoV2DepthTeacher
+    ocfg, W, batch, g = cases.tiny_llama_case()
+    gd = cases.load_golden("dinov2_teacher.npz")
+    dims = json.loads(str(gd["dims"]))
+    # a 1024-wide DINOv2 of 2 blocks so that its output matches the depth head's target width
+    sh = DinoV2DepthTeacher.shapes(1024, 2)
+    t = DinoV2DepthTeacher(1024, 2, 16, taps=(0, 1))
+    t.load_weights({k: WT.param(k, s) for k, s in sh.items()})
+    model = OlaLlavaLlamaForCausalLM(OlaLlavaLlamaConfig(**vars(ocfg)))
+    model.load_state_dict({k: v for k, v in W.items() if k in model.state_dict()}, strict=False)
+    model.reload_frozen()
+    model.attach_teachers(depth=t)
+    px = WT.tensor("teacher_px", (2, 3, 336, 336)).cuda()
+    common = dict(input_ids=batch["input_ids"], attention_mask=batch["attention_mask"], labels=batch["labels"], images=batch["images"].cuda(),
+                  gen_target=batch["gen_target"].cuda(), seg_target=batch["seg_target"].cuda())
+    out1 = model(**common, depth_pixels=px)
+    out2 = model(**common, depth_target=t.forward(px))
+    assert torch.isfinite(out1.loss) and torch.equal(out1.loss.detach(), out2.loss.detach())

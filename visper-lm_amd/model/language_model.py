@@ -97,9 +97,16 @@ class BaseOLA_VLM:
             self.img_seg_loss_weight = config.image_seg["seg_loss_weight"]
 
     def init_target_models(self, config):              # base_ola_vlm.py:56-95
-        """The frozen teachers (unCLIP image encoder, DINOv2-L, OneFormer Swin-L) are OUT OF SCOPE:
-        their features are inputs.  Override _get_gen_feats/_get_dav2_feats/_get_seg_targets or pass *_target tensors."""
+        """The frozen teachers' features are inputs of the step: pass *_target tensors, override
+        _get_gen_feats/_get_dav2_feats/_get_seg_targets, or attach the batched GPU teachers (attach_teachers) and pass
+        pre-processed pixel tensors (gen_pixels / depth_pixels / seg_pixels)."""
         return None
+
+    def attach_teachers(self, depth=None, gen=None, seg=None):
+        """depth: teachers.DinoV2DepthTeacher, gen: teachers.ClipImageEmbedTeacher, seg: teachers.SwinSegTeacher (weights loaded).  With a
+        teacher attached, forward(..., <task>_pixels=tensor) computes that task's target on the GPU (the reference does it per PIL image
+        inside every step: base_ola_vlm.py:323-397; the PIL / cv2 pre-processing itself stays with the caller)."""
+        self._teachers = dict(depth=depth, gen=gen, seg=seg)
 
     def _get_gen_feats(self, pil_images, device):
         raise NotImplementedError("frozen unCLIP teacher is out of scope: pass gen_target= or override _get_gen_feats")
@@ -178,6 +185,8 @@ class _OlaCausalLMBase(OlaLlavaMetaForCausalLM, BaseOLA_VLM, nn.Module):
                 continue
             if kw.get(f"{task}_target") is not None:
                 t[task] = kw[f"{task}_target"]
+            elif kw.get(f"{task}_pixels") is not None and getattr(self, "_teachers", {}).get(task) is not None:
+                t[task] = self._teachers[task].forward(kw[f"{task}_pixels"])
             elif pil_images is not None:
                 if task == "gen":
                     t[task] = self._get_gen_feats(pil_images, dev)
