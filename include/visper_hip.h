@@ -56,6 +56,13 @@ int vp_gemm_bf16(int M, int N, int K, const void* A, long lda, const void* B, lo
 int vp_gemm_bf16_swiglu(int mode, int M, int N, int K, const void* A, long lda, const void* B, long ldb, void* C, long ldc,
                         void* C2, long ldc2, const void* aux, long ldaux, vp_stream_t stream);
 
+/* Weight gradient without transposes: C[M,N] (+)= A[K,M]^T B[K,N], both operands contraction-major (autograd of nn.Linear,
+ * grad_weight = grad_output.t() @ input: A = dY[tokens,out], B = X[tokens,in]).  Same 8-phase kernel structure with transposing
+ * LDS reads.  M, N multiples of 256, K of 64, 16-byte aligned rows; else VP_ERR_UNSUPPORTED_SHAPE (the caller transposes and
+ * uses vp_gemm_bf16).  out_f32=1 writes fp32; accumulate=1 (fp32 only) adds into C (chunked lm_head gradient). */
+int vp_gemm_tn_bf16(int M, int N, int K, const void* A, long lda, const void* B, long ldb, void* C, long ldc, int out_f32,
+                    int accumulate, vp_stream_t stream);
+
 /* dev aid (tools/gemm_stamps.py): per-block timestamps written by gemm_nt_256p8 when VP_GEMM_DBG=65536; 256*8 longs. */
 int vp_debug_stamps(long* host);
 

@@ -209,6 +209,31 @@ def test_gemm_swiglu_fused(ops):
     close(dgu, _ileave(gr.grad, Fd), what="fused swiglu bwd")
 
 
+@pytest.mark.parametrize("M,N,K", [(256, 256, 64), (512, 768, 192), (256, 1024, 4608), (4352, 4096, 256), (8192, 4096, 1024)])
+def test_gemm_tn_weight_gradient(ops, M, N, K):
+    """dW = dY^T X straight from row-major activations == fp32 matmul of the same bf16 operands (fp32 output, strided operands,
+    accumulate mode, persistent (> 256 tiles) and one-block-per-tile grids, odd and even K-tile counts)."""
+    dy, x = rnd(K, M + 8, seed=61), rnd(K, N, seed=62)
+    dyg = dev(dy)[:, 8:]                                # 16-byte aligned column offset, ld > M
+    xg = dev(x)
+    ref = dy[:, 8:].float().t() @ x.float()
+    out = ops.gemm_tn(dyg, xg)
+    assert out.dtype == torch.float32
+    scale = float(ref.abs().max())
+    assert float((out.cpu() - ref).abs().max()) <= 2e-5 * scale * max(1.0, K / 256) ** 0.5
+    ops.gemm_tn(dyg, xg, out=out, accumulate=True)
+    assert float((out.cpu() - 2 * ref).abs().max()) <= 4e-5 * scale * max(1.0, K / 256) ** 0.5
+    if M * N <= 512 * 1024:
+        ob = ops.gemm_tn(dyg, xg, out_f32=False)
+        close(ob, ref, what="tn bf16 out")
+    # same numbers as the path it replaces (transposes + NT GEMM), up to fp32 summation order inside one MFMA
+    old = ops.gemm(ops.transpose(dyg.contiguous()), ops.transpose(xg), out_f32=True)
+    ops.gemm_tn(dyg, xg, out=out)
+    assert float((out - old).abs().max()) <= 1e-5 * scale * max(1.0, K / 256) ** 0.5
+    with pytest.raises(RuntimeError):
+        ops._lib.call("vp_gemm_tn_bf16", 200, 256, 64, dyg.data_ptr(), dyg.stride(0), xg.data_ptr(), N, out.data_ptr(), N, 1, 0, None)
+
+
 @pytest.mark.parametrize("kind", [1, 3])
 def test_act(ops, kind):
     x, d = rnd(40, 64, seed=22), rnd(40, 64, seed=23)

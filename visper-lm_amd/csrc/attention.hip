@@ -426,11 +426,23 @@ static __device__ __forceinline__ bf16x8 trfrag_sw(const bf16_t* t, int f0, int 
   const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p0 + 16 * 128));
   return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 }
-static __device__ __forceinline__ bf16x8 trfrag_at(const bf16_t* p0) {   // p0: this lane's 8-byte piece of token rows 0..15; +16 rows
-  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p0);
-  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p0 + 16 * 128));
+// Transposing LDS reads of the DMA-ring kernels go through inline asm: via the builtin the compiler assumes the read may alias the
+// in-flight global_load_lds writes and drains the whole ring (`s_waitcnt vmcnt(0)`) in front of every batch.  The kernels order ring
+// stages themselves (counted vmcnt + s_barrier), and wait for these reads with ATTN_LGKM before pinning / using the result.
+template <int OFF>
+static __device__ __forceinline__ s16x4 tr_read_asm(uint32_t addr) {
+  s16x4 v;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+  return v;
+}
+static __device__ __forceinline__ uint32_t attn_lds_addr(const void* p) {
+  return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)p;
+}
+static __device__ __forceinline__ bf16x8 tr_join(s16x4 lo, s16x4 hi) {
   return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 }
+#define ATTN_LGKM(N) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory")
+#define ATTN_PIN(F) asm volatile("" : "+v"(F))
 #ifndef DKDV_KT
 #define DKDV_KT 2
 #endif
@@ -574,15 +586,22 @@ void attn_bwd_dkdv128_kernel(AttnParams p) {
         pf[kt] = __builtin_bit_cast(bf16x8, u32x4{pk[kt][0][0], pk[kt][0][1], pk[kt][1][0], pk[kt][1][1]});
         dsf[kt] = __builtin_bit_cast(bf16x8, u32x4{dsk[kt][0][0], dsk[kt][0][1], dsk[kt][1][0], dsk[kt][1][1]});
       }
+      const uint32_t qs_addr = attn_lds_addr(Qs);      // dO tile = +8192 bytes, rows +16 = +4096 bytes
 #pragma unroll
       for (int d = 0; d < NDB; ++d) {
-        const bf16x8 ta = trfrag_at(dOs + (tbase ^ (d * 16)));
-        const bf16x8 tq = trfrag_at(Qs + (tbase ^ (d * 16)));
+        const uint32_t ta_ = qs_addr + 2u * (uint32_t)(tbase ^ (d * 16));
+        const s16x4 al = tr_read_asm<8192>(ta_), ah = tr_read_asm<12288>(ta_);
+        const s16x4 ql = tr_read_asm<0>(ta_), qh = tr_read_asm<4096>(ta_);
+        ATTN_LGKM(2);
+        bf16x8 ta = tr_join(al, ah);
+        ATTN_PIN(ta);
 #pragma unroll
-        for (int kt = 0; kt < KT; ++kt) {
-          dv[kt][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ta, pf[kt], dv[kt][d], 0, 0, 0);
-          dk[kt][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tq, dsf[kt], dk[kt][d], 0, 0, 0);
-        }
+        for (int kt = 0; kt < KT; ++kt) dv[kt][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ta, pf[kt], dv[kt][d], 0, 0, 0);
+        ATTN_LGKM(0);
+        bf16x8 tq = tr_join(ql, qh);
+        ATTN_PIN(tq);
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) dk[kt][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tq, dsf[kt], dk[kt][d], 0, 0, 0);
         if (d & 1) __builtin_amdgcn_sched_barrier(0);
       }
     }
@@ -857,11 +876,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
       for (int qt = 0; qt < 2; ++qt)
         dsf[qt] = __builtin_bit_cast(bf16x8, u32x4{dsk[qt][0][0], dsk[qt][0][1], dsk[qt][1][0], dsk[qt][1][1]});
+      const uint32_t ks_addr = attn_lds_addr(Ks);      // rows +16 = +4096 bytes
+      s16x4 kl = tr_read_asm<0>(ks_addr + 2u * (uint32_t)tbase), kh = tr_read_asm<4096>(ks_addr + 2u * (uint32_t)tbase);
 #pragma unroll
       for (int d = 0; d < NDB; ++d) {
-        const bf16x8 ktf = trfrag_at(Ks + (tbase ^ (d * 16)));
+        s16x4 nl = kl, nh = kh;
+        if (d + 1 < NDB) {                                // one fragment ahead
+          const uint32_t na = ks_addr + 2u * (uint32_t)(tbase ^ ((d + 1) * 16));
+          nl = tr_read_asm<0>(na);
+          nh = tr_read_asm<4096>(na);
+          ATTN_LGKM(2);
+        } else {
+          ATTN_LGKM(0);
+        }
+        bf16x8 ktf = tr_join(kl, kh);
+        ATTN_PIN(ktf);
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt) dq[qt][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ktf, dsf[qt], dq[qt][d], 0, 0, 0);
+        kl = nl;
+        kh = nh;
         if (d & 1) __builtin_amdgcn_sched_barrier(0);
       }
     }

@@ -752,6 +752,240 @@ __global__ __launch_bounds__(512) void gemm_nt_256p8(GemmArgs p) {
 #undef END_R
 }
 
+// Two ds_read_b64_tr_b16 (byte offsets OFF and OFF + GAP from a per-lane LDS byte address): this lane's 8 contraction slots (slot j <->
+// tile row 16*(j>>2) + 4g + (j&3), the same mapping for both operands) of output feature (lane & 15) of the 16-feature block addressed.
+// Inline asm on purpose: through the builtin the compiler assumes the read may alias the in-flight LDS-DMA writes and puts
+// `s_waitcnt vmcnt(0)` in front of every batch (measured: 480 instead of 1150 TFLOP/s).  The caller waits (TR_WAIT) before use.
+template <int OFF, int GAP>
+static __device__ __forceinline__ bf16x8 trfrag2(uint32_t addr) {
+  typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+  s16x4_t lo, hi;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(lo) : "v"(addr), "n"(OFF));
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi) : "v"(addr), "n"(OFF + GAP));
+  return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+static __device__ __forceinline__ uint32_t lds_addr(const void* p) {
+  return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)p;
+}
+
+// ------------------------------------------------------------------------------------------------
+// TN variant of the 8-phase kernel: C[M,N] = A[K,M]^T B[K,N] with both operands contraction-major (weight gradients dW = dY^T X straight
+// from the activations).  Same persistent / ping-pong / piece-ordered DMA structure; only the LDS image and the fragment reads differ.
+// ------------------------------------------------------------------------------------------------
+template <bool OUT_F32>
+__global__ __launch_bounds__(512) void gemm_tn_256p8(GemmArgs p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  bf16_t* smem = (bf16_t*)smem_raw;                    // [buf][A 256x64 | B 256x64]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tiles_m = (p.M + 255) >> 8, tiles_n = (p.N + 255) >> 8;
+  const int ntiles = tiles_m * tiles_n;
+  const int wr = __builtin_amdgcn_readfirstlane(wave >> 2), wc = wave & 3;
+  const int fr = lane & 15, g = lane >> 4;
+  const int nt = p.K >> 6;                             // even when the grid is persistent (checked by the launcher)
+  const int trow = 4 * g + (fr >> 2), tb4 = (lane & 3) * 4;          // transposing read: this lane's row / 8-byte piece
+  const int swA = ((g & 1) << 1) | (fr >> 3), swB = g & 1;           // swizzle phases of that row (k>>1)&3, (k>>2)&1
+
+  // TN operands: A is [K, M], B is [K, N] (the contraction index runs over ROWS: wgrad = dY^T X without transposing anything).
+  // LDS per buffer: A part [m-half MH][wr'][64 k][64 m] (128-byte rows), B part at +16384: [n-half NH][wc'][64 k][32 n] (64-byte rows);
+  // pieces in consumption order as in the NT kernel: 0 = A(MH 0), 1 = B(NH 0), 2 = B(NH 1), 3 = A(MH 1); 16 KB = 2 chunks per thread each.
+  // Fragments contract over tile ROWS, so they come from the transposing ds_read_b64_tr_b16; the 32-byte unit index of a row is XOR-ed
+  // with (k>>1)&3 (A) / (k>>2)&1 (B) on the SOURCE side so that the 16 rows of one read spread over all banks (2-way = optimal).
+  int ldsoff[4][2];                                    // wave-uniform LDS offsets (SGPRs)
+#pragma unroll
+  for (int pc = 0; pc < 4; ++pc)
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int q0 = it * 512 + wave * 64;
+      if (pc == 0 || pc == 3) ldsoff[pc][it] = (((pc == 3) * 2 + (q0 >> 9)) * 64 + ((q0 >> 3) & 63)) * 64;
+      else ldsoff[pc][it] = 16384 + (((pc == 2) * 4 + (q0 >> 8)) * 64 + ((q0 >> 2) & 63)) * 32;
+    }
+  const bf16_t* src[4][2];                             // source of the NEXT K-tile in the stream (per piece); += 64 rows per K-tile
+  const long stepA = 64 * p.lda, stepB = 64 * p.ldb;
+#define SET_SRC(TC)                                                                \
+  {                                                                                \
+    int tid_ = tid;                                                                \
+    asm volatile("" : "+v"(tid_));                                                 \
+    _Pragma("unroll") for (int pc = 0; pc < 4; ++pc)                               \
+      _Pragma("unroll") for (int it = 0; it < 2; ++it) {                           \
+        const int q = it * 512 + tid_;                                             \
+        if (pc == 0 || pc == 3) {                                                  \
+          const int k = (q >> 3) & 63, cc = q & 7;                                 \
+          const int col = (q >> 9) * 128 + (pc == 3) * 64 + (((cc >> 1) ^ ((k >> 1) & 3)) << 4) + (cc & 1) * 8; \
+          src[pc][it] = p.A + (long)k * p.lda + (TC).m0 + col;                     \
+        } else {                                                                   \
+          const int k = (q >> 2) & 63, cc = q & 3;                                 \
+          const int col = (q >> 8) * 64 + (pc == 2) * 32 + (((cc >> 1) ^ ((k >> 2) & 1)) << 4) + (cc & 1) * 8; \
+          src[pc][it] = p.B + (long)k * p.ldb + (TC).n0 + col;                     \
+        }                                                                          \
+      }                                                                            \
+  }
+#define ISSUE_PIECE(PC, BUF)                                                       \
+  {                                                                                \
+    bf16_t* base_ = smem + (BUF) * 32768;                                          \
+    GLDS16(src[PC][0], base_ + ldsoff[PC][0]);                                     \
+    GLDS16(src[PC][1], base_ + ldsoff[PC][1]);                                     \
+  }
+  // per-lane LDS byte addresses of the fragment reads in buffer 0 (everything else is an instruction immediate, + buffer << 16)
+  uint32_t abase[4], bbase[2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) abase[i] = lds_addr(smem) + 2 * ((wr * 64 + trow) * 64 + ((i ^ swA) << 4) + tb4);
+#pragma unroll
+  for (int j = 0; j < 2; ++j) bbase[j] = lds_addr(smem) + 2 * (16384 + (wc * 64 + trow) * 32 + ((j ^ swB) << 4) + tb4);
+#define RD_A(DST, MH)                                                              \
+  _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                  \
+    DST[0][i] = trfrag2<(MH) * 16384, 2048>(abase[i] + co);                        \
+    DST[1][i] = trfrag2<(MH) * 16384 + 4096, 2048>(abase[i] + co);                 \
+  }
+#define RD_B(DST, NH)                                                              \
+  _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                  \
+    DST[0][j] = trfrag2<(NH) * 16384, 1024>(bbase[j] + co);                        \
+    DST[1][j] = trfrag2<(NH) * 16384 + 2048, 1024>(bbase[j] + co);                 \
+  }
+#define PIN(F) asm volatile("" : "+v"(F))
+#define TR_WAIT() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#define MM(XA, WB, MH, NH)                                                         \
+  {                                                                                \
+    __builtin_amdgcn_s_setprio(1);                                                 \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                               \
+      _Pragma("unroll") for (int i = 0; i < 4; ++i)                                \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j)                              \
+          acc[(MH) * 4 + i][(NH) * 2 + j] =                                        \
+              __builtin_amdgcn_mfma_f32_16x16x32_bf16(WB[ks][j], XA[ks][i], acc[(MH) * 4 + i][(NH) * 2 + j], 0, 0, 0); \
+    __builtin_amdgcn_s_setprio(0);                                                 \
+  }
+#define END_R() asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); VP_BAR();     /* ds_reads keep flying across the barrier; the MFMAs wait for them */
+
+  int v = blockIdx.x;
+  int sbm = 0, sbn = 0;                                // super-block walk when the (persistent) grid and the tile grid allow it
+  if (gridDim.x == 256 && !(p.dbg & 0x40000)) {
+    if (tiles_m % 16 == 0 && tiles_n % 16 == 0) { sbm = 16; sbn = 16; }
+    else if (tiles_m % 32 == 0 && tiles_n % 8 == 0) { sbm = 32; sbn = 8; }
+  }
+#define TILE_OF(V) (sbm ? tile_coord_sb((V), tiles_m, tiles_n, sbm, sbn) : tile_coord_256((V), tiles_m, tiles_n))
+  TileCoord tc = TILE_OF(v);
+  SET_SRC(tc);
+  ISSUE_PIECE(0, 0);
+  ISSUE_PIECE(1, 0);
+  ISSUE_PIECE(2, 0);
+  ISSUE_PIECE(3, 0);
+  asm volatile("s_waitcnt vmcnt(4)" ::: "memory");     // pieces 0,1 of K-tile 0 landed (this wave's parts)
+  VP_BAR();
+  bf16x8 xa[2][4], wb0[2][2], wb1[2][2], xn[4];
+  {                                                    // A(m0, ks=0) fragments of K-tile 0 (later ones are prefetched in phase 4)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) xn[i] = trfrag2<0, 2048>(abase[i]);
+    TR_WAIT();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) PIN(xn[i]);
+  }
+  while (true) {
+    if (wr == 1) VP_BAR();                             // stagger: group 1 runs one barrier behind
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const TileCoord tcur = tc;
+    const int vnext = v + gridDim.x;
+    for (int t = 0; t < nt; ++t) {
+      const int cur = t & 1;
+      const uint32_t co = (uint32_t)cur << 16;        // byte offset of the current buffer
+      // the K-tile stream continues into this block's NEXT output tile (or a harmless re-fetch at the very end)
+      if (t + 1 < nt) {
+#pragma unroll
+        for (int pc = 0; pc < 4; ++pc) { const long st_ = (pc == 0 || pc == 3) ? stepA : stepB; src[pc][0] += st_; src[pc][1] += st_; }
+      } else {
+        if (vnext < ntiles) tc = TILE_OF(vnext);
+        SET_SRC(tc);
+      }
+      // ---- phase 1: quadrant (m0, n0).  reads: B(n0) x4, A(m0, ks=1) x4  (A(m0, ks=0) came from the previous phase 4)
+      ISSUE_PIECE(0, cur ^ 1);
+      RD_B(wb0, 0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        xa[0][i] = xn[i];
+        xa[1][i] = trfrag2<4096, 2048>(abase[i] + co);
+      }
+      END_R();
+      TR_WAIT();
+#pragma unroll
+      for (int q = 0; q < 2; ++q) { PIN(wb0[0][q]); PIN(wb0[1][q]); }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) PIN(xa[1][i]);
+      MM(xa, wb0, 0, 0);
+      VP_BAR();
+      // ---- phase 2: quadrant (m0, n1).  reads: B(n1) x4
+      ISSUE_PIECE(1, cur ^ 1);
+      RD_B(wb1, 1);
+      END_R();
+      TR_WAIT();
+#pragma unroll
+      for (int q = 0; q < 2; ++q) { PIN(wb1[0][q]); PIN(wb1[1][q]); }
+      MM(xa, wb1, 0, 1);
+      VP_BAR();
+      // ---- phase 3: quadrant (m1, n1).  reads: A(m1) x8
+      ISSUE_PIECE(2, cur ^ 1);
+      RD_A(xa, 1);
+      END_R();
+      TR_WAIT();
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { PIN(xa[0][i]); PIN(xa[1][i]); }
+      MM(xa, wb1, 1, 1);
+      VP_BAR();
+      // ---- phase 4: quadrant (m1, n0) (B(n0) still in registers).  reads: NEXT K-tile's A(m0, ks=0) x4 — its piece was
+      // issued in phase 1 and retired for every wave by the vmcnt(4) at the end of phase 3's R section.
+      ISSUE_PIECE(3, cur ^ 1);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) xn[i] = trfrag2<0, 2048>(abase[i] + (co ^ 65536u));
+      END_R();
+      TR_WAIT();
+#pragma unroll
+      for (int i = 0; i < 4; ++i) PIN(xn[i]);
+      MM(xa, wb0, 1, 0);
+      VP_BAR();
+    }
+    if (wr == 0) VP_BAR();                             // re-align the two groups at the output-tile boundary
+    // buffer 1 (the last K-tile's, nt is even) is free for C staging; buffer 0 is receiving the next tile's first K-tile
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (!OUT_F32) {
+      epilogue_swz<2>(p, smem + ((nt - 1) & 1) * 32768 + wave * 4096, acc, tcur.m0 + wr * 128, tcur.n0 + wc * 64, lane);
+    } else {
+      // fp32 output (weight gradients): interior, plain tiles go straight from the accumulators as 16-byte stores
+      const int mr = tcur.m0 + wr * 128, nc = tcur.n0 + wc * 64;
+      const bool lean = __builtin_amdgcn_readfirstlane((int)(!p.bias && !p.res && (p.epi & 0xff) == EPI_NONE && mr + 128 <= p.M &&
+                                                             nc + 64 <= p.N && (p.ldc & 3) == 0 && (((uintptr_t)p.C) & 15) == 0));
+      if (lean) {
+        float* c = (float*)p.C + (long)(mr + fr) * p.ldc + nc + g * 4;
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            f32x4* dst = (f32x4*)(c + (long)(i * 16) * p.ldc + j * 16);
+            *dst = (p.mode == 3) ? acc[i][j] + *dst : acc[i][j];       // mode 3: C += (gradient accumulation over token chunks)
+          }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) store4<OUT_F32>(p, mr + i * 16 + fr, nc + j * 16 + g * 4, acc[i][j]);
+      }
+    }
+    if (vnext >= ntiles) break;
+    v = vnext;
+    VP_BAR();                                          // every wave is done with the staging slices before the next DMA lands there
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the final dummy DMAs must not outlive the workgroup's LDS
+#undef SET_SRC
+#undef TILE_OF
+#undef ISSUE_PIECE
+#undef PIN
+#undef TR_WAIT
+#undef RD_A
+#undef RD_B
+#undef MM
+#undef END_R
+}
+
 // ------------------------------------------------------------------------------------------------
 // generic path: any M, N, K, any alignment (register-staged, zero-filled K tail). 64x64x32 tile.
 // ------------------------------------------------------------------------------------------------
@@ -931,6 +1165,34 @@ int vp_gemm_bf16_swiglu(int mode, int M, int N, int K, const void* A, long lda, 
   const unsigned g8 = (unsigned)(((K / 64) % 2 == 0 && big_tiles > 256) ? 256 : big_tiles);
   hipLaunchKernelGGL(gemm_nt_256p8<false>, dim3(g8), dim3(512), 131072, stream, p);
   return vp_check_launch("vp_gemm_bf16_swiglu");
+}
+
+// C[M,N] (+)= A[K,M]^T B[K,N]: both operands contraction-major, i.e. the weight gradient dW[out,in] = dY[tokens,out]^T X[tokens,in]
+// straight from the activation buffers (reference: autograd of nn.Linear, grad_weight = grad_output.t() @ input).  8-phase TN kernel
+// only: M, N multiples of 256, K a multiple of 64, 16-byte aligned rows; anything else is VP_ERR_UNSUPPORTED_SHAPE (the caller then
+// transposes and uses vp_gemm_bf16).  accumulate != 0 (fp32 output only) adds into C.
+int vp_gemm_tn_bf16(int M, int N, int K, const void* A, long lda, const void* B, long ldb, void* C, long ldc, int out_f32,
+                    int accumulate, hipStream_t stream) {
+  VP_REQUIRE(M > 0 && N > 0 && K > 0 && A && B && C, VP_ERR_BAD_ARG, "vp_gemm_tn_bf16: bad operands");
+  VP_REQUIRE(M % 256 == 0 && N % 256 == 0 && K % 64 == 0, VP_ERR_UNSUPPORTED_SHAPE,
+             "vp_gemm_tn_bf16: needs M, N multiples of 256 and K a multiple of 64 (got %d %d %d)", M, N, K);
+  VP_REQUIRE(lda >= M && ldb >= N && ldc >= N && lda % 8 == 0 && ldb % 8 == 0 && ldc % 8 == 0 &&
+                 ((((uintptr_t)A) | ((uintptr_t)B) | ((uintptr_t)C)) & 15) == 0,
+             VP_ERR_BAD_ARG, "vp_gemm_tn_bf16: leading dims / alignment");
+  VP_REQUIRE(!accumulate || out_f32, VP_ERR_BAD_ARG, "vp_gemm_tn_bf16: accumulate needs fp32 output");
+  GemmArgs p{(const bf16_t*)A, (const bf16_t*)B, C, nullptr, nullptr, M, N, K, lda, ldb, ldc, 0, EPI_NONE, 0,
+             accumulate ? 3 : 0, nullptr, 0, nullptr, 0};
+  static bool attr_tn = false;
+  if (!attr_tn) {
+    (void)hipFuncSetAttribute((const void*)gemm_tn_256p8<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+    (void)hipFuncSetAttribute((const void*)gemm_tn_256p8<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+    attr_tn = true;
+  }
+  const long big_tiles = (long)(M / 256) * (N / 256);
+  const unsigned g8 = (unsigned)(((K / 64) % 2 == 0 && big_tiles > 256) ? 256 : big_tiles);
+  if (out_f32) hipLaunchKernelGGL(gemm_tn_256p8<true>, dim3(g8), dim3(512), 131072, stream, p);
+  else hipLaunchKernelGGL(gemm_tn_256p8<false>, dim3(g8), dim3(512), 131072, stream, p);
+  return vp_check_launch("vp_gemm_tn_bf16");
 }
 
 

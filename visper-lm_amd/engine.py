@@ -531,15 +531,20 @@ class Engine:
 
     # ------------------------------------------------------------------------------------------ linear helpers
     def _wgrad(self, x2d, dy2d, gview, accumulate=False):
-        """gview[N,K] (fp32) (+)= dy^T @ x  via two zero-padded transposes + the NT GEMM."""
+        """gview[N,K] (fp32) (+)= dy^T @ x.  Aligned shapes go straight from the row-major activations through the TN kernel
+        (no transposed copies); the rest via two zero-padded transposes + the NT GEMM."""
         M = x2d.shape[0]
-        Mp = (M + 63) // 64 * 64
         N, K = dy2d.shape[1], x2d.shape[1]
+        g2 = gview.view(N, K)
+        if (ops.gemm_tn_ok(N, K, M) and dy2d.stride(0) % 8 == 0 and x2d.stride(0) % 8 == 0 and dy2d.stride(1) == 1 and x2d.stride(1) == 1
+                and (dy2d.data_ptr() | x2d.data_ptr() | g2.data_ptr()) % 16 == 0):
+            ops.gemm_tn(dy2d, x2d, out=g2, accumulate=accumulate)
+            return
+        Mp = (M + 63) // 64 * 64
         dyT = torch.zeros(N, Mp, device=self.dev, dtype=BF16) if Mp != M else torch.empty(N, Mp, device=self.dev, dtype=BF16)
         xT = torch.zeros(K, Mp, device=self.dev, dtype=BF16) if Mp != M else torch.empty(K, Mp, device=self.dev, dtype=BF16)
         ops.transpose(dy2d, out=dyT)
         ops.transpose(x2d, out=xT)
-        g2 = gview.view(N, K)
         if accumulate:
             tmp = ops.gemm(dyT, xT, out_f32=True)
             ops._lib.call("vp_colsum_finish", 1, N * K, ops._p(tmp), ops._p(g2), 1.0, 1, ops._stream())

@@ -114,6 +114,30 @@ def gemm_swiglu_bwd(dy, w_down_T, gate_up):
     return dgu
 
 
+def gemm_tn_ok(M, N, K):
+    """Shapes the TN (transpose-free weight-gradient) kernel takes."""
+    return M % 256 == 0 and N % 256 == 0 and K % 64 == 0
+
+
+def gemm_tn(a, b, out=None, out_f32=True, accumulate=False):
+    """out[M,N] (+)= a[K,M]^T @ b[K,N]  (dW = dY^T X from row-major activations; no transposed copies)."""
+    K, M, lda = _rows2d(a)
+    K2, N, ldb = _rows2d(b)
+    assert K == K2 and gemm_tn_ok(M, N, K)
+    if out is None:
+        assert not accumulate
+        out = torch.empty(M, N, device=a.device, dtype=torch.float32 if out_f32 else BF16)
+    assert out.stride(-1) == 1 and out.dtype == (torch.float32 if out_f32 else BF16)
+    if GEMM_PROF is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    _lib.call("vp_gemm_tn_bf16", M, N, K, _p(a), lda, _p(b), ldb, _p(out), out.stride(0), int(out_f32), int(accumulate), _stream())
+    if GEMM_PROF is not None:
+        e1.record()
+        GEMM_PROF.append((e0, e1, 2.0 * M * N * K, (M, N, K)))
+    return out
+
+
 def transpose(x, out=None):
     """2-D transpose (bf16)."""
     R, Cc, ldi = _rows2d(x)
