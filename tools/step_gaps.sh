@@ -22,5 +22,12 @@ busy += cur_e - cur_s
 gaps = sorted(((seg[i + 1][0] - seg[i][1]) / 1e3, seg[i][2][:40], seg[i + 1][2][:40]) for i in range(len(seg) - 1))
 print(f"last step: {len(seg)} kernels, span {span / 1e6:.2f} ms, busy {busy / 1e6:.2f} ms, idle {(span - busy) / 1e6:.2f} ms ({100 * (span - busy) / span:.2f} %)")
 print("largest gaps (us):", [(round(g, 1), x, y) for g, x, y in gaps[-6:]])
+tot = {}
+for s_, e_, n in seg:
+    k = n[:60]
+    t = tot.setdefault(k, [0, 0]); t[0] += e_ - s_; t[1] += 1
+print("per-kernel totals inside the step (ms, calls):")
+for k, (t, c) in sorted(tot.items(), key=lambda kv: -kv[1][0])[:45]:
+    print(f"  {t / 1e6:8.3f} {c:5d}  {k}")
 PY
 fi

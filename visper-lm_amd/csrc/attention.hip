@@ -94,7 +94,7 @@ struct TileRegs {
 // ================================================================================================
 // forward: block = 128 queries (8 waves x 16), loops 64-key tiles
 // ================================================================================================
-template <int D, bool CAUSAL>
+template <int D, bool CAUSAL, bool BIAS = false>        // BIAS: separate instantiation (the extra live pointers cost the plain path 40 %)
 __global__ __launch_bounds__(512) void attn_fwd_kernel(AttnParams p) {
   constexpr int LD = D + 16, NKS = D / 32, NDB = D / 16, TILE = 64 * LD;
   extern __shared__ __attribute__((aligned(16))) unsigned char attn_smem[];
@@ -162,7 +162,7 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(AttnParams p) {
         }
       }
       // st[kt][r]: raw score of key k0 + 16kt + 4g + r against query qrow
-      if (p.bias_h || p.bias_b) {                      // wave-uniform; scores are scaled later by c = scale * log2(e): add bias / scale here
+      if (BIAS) {                                      // scores are scaled later by c = scale * log2(e): add bias / scale here
         const float inv_scale = 1.f / p.scale;
         const int qc = min(qrow, p.Sq - 1);
         const float* bh = p.bias_h ? p.bias_h + ((long)h * p.Sq + qc) * p.Skv : nullptr;
@@ -928,11 +928,18 @@ static int launch_fwd(const AttnParams& p, int causal, hipStream_t s) {
   if (!attr) {
     (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<D, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kv_lds_bytes<D>());
     (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<D, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kv_lds_bytes<D>());
+    (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<D, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kv_lds_bytes<D>());
+    (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<D, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kv_lds_bytes<D>());
     attr = true;
   }
   dim3 grid(p.Hq, p.B, (p.Sq + 127) / 128);
-  if (causal) hipLaunchKernelGGL((attn_fwd_kernel<D, true>), grid, dim3(512), kv_lds_bytes<D>(), s, p);
-  else hipLaunchKernelGGL((attn_fwd_kernel<D, false>), grid, dim3(512), kv_lds_bytes<D>(), s, p);
+  if (p.bias_h || p.bias_b) {
+    if (causal) hipLaunchKernelGGL((attn_fwd_kernel<D, true, true>), grid, dim3(512), kv_lds_bytes<D>(), s, p);
+    else hipLaunchKernelGGL((attn_fwd_kernel<D, false, true>), grid, dim3(512), kv_lds_bytes<D>(), s, p);
+  } else {
+    if (causal) hipLaunchKernelGGL((attn_fwd_kernel<D, true>), grid, dim3(512), kv_lds_bytes<D>(), s, p);
+    else hipLaunchKernelGGL((attn_fwd_kernel<D, false>), grid, dim3(512), kv_lds_bytes<D>(), s, p);
+  }
   return vp_check_launch("vp_attn_fwd");
 }
 template <int D>
