@@ -44,7 +44,8 @@ int vp_device_info(int* cu_count, int* wave_size, long* lds_bytes_per_cu);
  * (multimodal_projector/resampler.py:9-16,40-44,186-190), depth MLPs (aux_heads/da_v2_head.py:439-442).
  * out_f32=1 writes fp32 (used for weight gradients). force_generic: 0 = auto (256x256 8-phase ping-pong kernel for
  * large problems, 128x128 otherwise, bounds-checked generic kernel when K%64 != 0 or rows are not 16-B aligned),
- * 1 = generic, 2 = 128-tile, 3 = the simple persistent 256-tile kernel (kept as the A/B reference), 7 = 8-phase. */
+ * 1 = generic, 2 = 128-tile, 3 = the simple persistent 256-tile kernel (kept as the A/B reference), 7 = 8-phase,
+ * 8 = experimental one-wave-per-SIMD 256-tile kernel (aligned shapes only; 9-12 = its timing ablations, wrong results). */
 int vp_gemm_bf16(int M, int N, int K, const void* A, long lda, const void* B, long ldb, void* C, long ldc,
                  const void* bias, const void* residual, long ldr, int epilogue, int out_f32, int force_generic,
                  vp_stream_t stream);

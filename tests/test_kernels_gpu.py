@@ -84,6 +84,23 @@ def test_gemm_256_tile_kernel(ops, M, N, K):
     close(o, ref, what=f"gemm 8-phase {M}x{N}x{K}")
 
 
+@pytest.mark.parametrize("M,N,K", [(512, 512, 128), (256, 768, 384), (4608, 4096, 384), (8192, 4096, 512)])
+def test_gemm_4wave_kernel(ops, M, N, K):
+    """One-wave-per-SIMD 256-tile kernel (force code 8): plain, bias + GELU + residual epilogue, fp32 output; single tiles, a persistent grid with
+    1-2 tiles per block and the super-block walk."""
+    a, w, b, r = rnd(M, K, seed=70), rnd(N, K, scale=0.1, seed=71), rnd(N, seed=72), rnd(M, N, seed=73)
+    ag, wg = dev(a), dev(w)
+    ref = a.float() @ w.float().t()
+    close(ops.gemm(ag, wg, force_generic=8), ref, what=f"w4 {M}x{N}x{K}")
+    assert torch.equal(ops.gemm(ag, wg, force_generic=8), ops.gemm(ag, wg, force_generic=7))       # same k order per MFMA chain as the 8-phase kernel
+    o32 = ops.gemm(ag, wg, out_f32=True, force_generic=8)
+    assert o32.dtype == torch.float32
+    assert float((o32.cpu() - ref).abs().max()) <= 2e-5 * float(ref.abs().max()) * max(1.0, K / 256) ** 0.5
+    if M * N <= 1 << 20:
+        ref2 = F.gelu((ref + b.float()).to(BF).float()).to(BF).float() + r.float()
+        close(ops.gemm(ag, wg, bias=dev(b), residual=dev(r), epi=ops.EPI_GELU, force_generic=8), ref2, what="w4 epilogue")
+
+
 def test_gemm_8phase_large_k_and_edges(ops):
     """default large-problem kernel: many K-tiles (piece pipeline wraps both buffers), ragged M/N edges, auto dispatch."""
     M, N, K = 4100, 3080, 1024

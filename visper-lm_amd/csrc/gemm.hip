@@ -987,6 +987,191 @@ __global__ __launch_bounds__(512) void gemm_tn_256p8(GemmArgs p) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// EXPERIMENTAL (force code 8 / VP_GEMM_W4=1; not the default): 4-wave variant of the persistent 256x256x64 kernel, the structure of
+// hipBLASLt's hand-written MT256x256x64 kernel: ONE wave per SIMD, each owning a 128x128 quarter of the output tile with its 256
+// accumulator registers in AGPRs.  Against the 8-wave kernel every LDS fragment feeds 8 MFMAs instead of 4 (128 KB instead of 192 KB
+// of LDS reads per K-tile and CU) and there is one barrier per K-tile instead of eight; in exchange nothing hides a stall, so the
+// single wave software-pipelines itself and the loop body is hand-ordered inline asm (with 256 accumulators the compiler's own MFMAs
+// come out untied, dst != srcC, and it moves every accumulator through a VGPR once per K-tile: 500 v_accvgpr moves; "+a" ties them.
+// asm ds_reads need explicit waits and a register pin before the first consumer).
+//   step (kt,0): 64 MFMAs on f0 | the 16 reads of f1 = fragments(kt, ks 1), one per MFMA
+//   step (kt,1): 8 MFMAs on f1, vmcnt(0) + barrier (K-tile kt+1 landed everywhere, nobody reads buffer kt&1 any more), 56 MFMAs |
+//                the 16 reads of f0 = fragments(kt+1, ks 0) from the other buffer | the 16 DMA pieces of K-tile kt+2, one per 3.5 MFMAs
+// Measured (tools/gemm_stamps.py, force codes 9-12 = ablations): 64 K-tiles take 168 k shader cycles (8-phase kernel: 170 k; 131 k =
+// MFMA issue only); without the DMA instructions 137 k -- an LDS-DMA instruction costs the lone wave ~30 cycles of MFMA issue even when
+// they are spaced out (2 MFMAs apart: 50 cycles each, 190 k in total; buffer_load...lds and global_load_lds cost the same), which a
+// second wave per SIMD hides for free.  A k-half-major LDS image that spreads the 16 pieces over both steps (two barriers per K-tile,
+// 64-byte rows) was slower (184 k).  End to end it ties the 8-phase kernel (+9 % at N = 28672, -8 % at K = 14336), so the default stays.
+// The K-tile stream runs on into the block's next output tile; C staging has its own 32 KB of LDS behind the two buffers.
+// Interior tiles only: M, N multiples of 256, K a multiple of 128 (the launcher checks).
+// ------------------------------------------------------------------------------------------------
+template <bool OUT_F32, int VAR = 0>     // VAR != 0: timing ablations (wrong results): 1 no DMA, 2 no fragment reads, 3 no barrier, 4 no DMA + no reads
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void gemm_nt_256w4(GemmArgs p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  bf16_t* smem = (bf16_t*)smem_raw;                    // [buf 0: A 256x64 | B 256x64][buf 1][C staging 4 x 8 KB]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 1, wc = wave & 1;
+  const int fr = lane & 15, g = lane >> 4;
+  const int tiles_m = p.M >> 8, tiles_n = p.N >> 8;
+  const int ntiles = tiles_m * tiles_n;
+  const int nt = p.K >> 6;                             // even, >= 2
+
+  // LDS-DMA geometry: 16-byte chunk q = it * 256 + tid (it 0..7) of an operand lands at LDS chunk q (lane-linear) = row q >> 3, slot q & 7;
+  // it is chunk (q & 7) ^ ((row >> 1) & 7) of that row on the source side, so the 128-byte LDS rows read conflict-free with ds_read_b128
+  const int drow = tid >> 3, dsw = ((tid & 7) ^ ((drow >> 1) & 7)) << 3;
+  const uint32_t laneA = (uint32_t)(drow * p.lda + dsw) * 2u, laneB = (uint32_t)(drow * p.ldb + dsw) * 2u;     // byte offsets
+  const uint32_t stepA = (uint32_t)(32 * p.lda * 2), stepB = (uint32_t)(32 * p.ldb * 2);                       // 32 rows per `it`
+  // fragment read addresses (bytes, within a buffer): + i * 2048 per 16-row block
+  const int fsw0 = (g ^ ((fr >> 1) & 7)) << 3, fsw1 = ((4 + g) ^ ((fr >> 1) & 7)) << 3;
+  const uint32_t ldsb = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)smem;
+  const uint32_t aad0 = ldsb + 2u * (uint32_t)((wr * 128 + fr) * 64 + fsw0), aad1 = ldsb + 2u * (uint32_t)((wr * 128 + fr) * 64 + fsw1);
+  const uint32_t bad0 = ldsb + 32768u + 2u * (uint32_t)((wc * 128 + fr) * 64 + fsw0), bad1 = ldsb + 32768u + 2u * (uint32_t)((wc * 128 + fr) * 64 + fsw1);
+
+  int sbm = 0, sbn = 0;
+  if (gridDim.x == 256 && !(p.dbg & 0x40000)) {
+    if (tiles_m % 16 == 0 && tiles_n % 16 == 0) { sbm = 16; sbn = 16; }
+    else if (tiles_m % 32 == 0 && tiles_n % 8 == 0) { sbm = 32; sbn = 8; }
+  }
+#define TILE_OF(V) (sbm ? tile_coord_sb((V), tiles_m, tiles_n, sbm, sbn) : tile_coord_256((V), tiles_m, tiles_n))
+  int v = blockIdx.x;
+  TileCoord tc = TILE_OF(v);
+  // DMA stream state (wave-uniform): next K-tile to fetch = K-tile `kn` of tile `vn`.  buffer_load ... lds: one 32-bit lane offset per
+  // operand, everything else (panel base, K-tile, 32-row step) in the SGPR descriptor / soffset
+  int vn = v, kn = 0;
+  __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)(p.A + (long)tc.m0 * p.lda), 0, (int)(256u * (uint32_t)p.lda * 2u), 0x00020000);
+  __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)(p.B + (long)tc.n0 * p.ldb), 0, (int)(256u * (uint32_t)p.ldb * 2u), 0x00020000);
+#define W4_DMA_A(IT, DST) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)(DST), 16, (int)laneA, kn * 128 + (IT) * (int)stepA, 0, 0)
+#define W4_DMA_B(IT, DST) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (__attribute__((address_space(3))) void*)(DST), 16, (int)laneB, kn * 128 + (IT) * (int)stepB, 0, 0)
+  // piece d (0..15) of the K-tile going to buffer BP (element pointer): even A, odd B
+#define W4_PIECE(D, BP)                                                                                \
+  {                                                                                                    \
+    if ((D) & 1) W4_DMA_B((D) >> 1, (BP) + 16384 + ((D) >> 1) * 2048 + wave * 512);                    \
+    else W4_DMA_A((D) >> 1, (BP) + ((D) >> 1) * 2048 + wave * 512);                                    \
+  }
+#define ADVANCE_STREAM()                                                                               \
+  {                                                                                                    \
+    if (++kn == nt) {                                                                                  \
+      kn = 0;                                                                                          \
+      if (vn + (int)gridDim.x < ntiles) vn += gridDim.x;      /* else: harmless in-bounds re-fetch of the last tile */ \
+      const TileCoord tn_ = TILE_OF(vn);                                                               \
+      rsA = __builtin_amdgcn_make_buffer_rsrc((void*)(p.A + (long)tn_.m0 * p.lda), 0, (int)(256u * (uint32_t)p.lda * 2u), 0x00020000); \
+      rsB = __builtin_amdgcn_make_buffer_rsrc((void*)(p.B + (long)tn_.n0 * p.ldb), 0, (int)(256u * (uint32_t)p.ldb * 2u), 0x00020000); \
+    }                                                                                                  \
+  }
+#define W4_MFMA(ACC, BF, AF) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(ACC) : "v"(BF), "v"(AF))
+#define W4_MFMA0(ACC, BF, AF) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=a"(ACC) : "v"(BF), "v"(AF))
+#define W4_LDS(DST, ADDR, OFF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(DST) : "v"(ADDR), "n"(OFF))
+#define W4_PIN(F) asm volatile("" : "+v"(F))
+  // MFMA number m of a step (0..63): row i = m >> 3, column block c = m & 7
+#define W4_MF1(MF, FA, FB, M) MF(acc[((M) & 7) >> 2][(M) >> 3][(M) & 3], FB[(M) & 7], FA[(M) >> 3])
+  // read slot r (0..15) -> fragment: fa[0..6], fb[0..7], fa[7]  (a register's last consumer is >= 8 MFMAs behind its reload)
+#define W4_RD(FA, FB, AAD, BAD, R)                                                                     \
+  {                                                                                                    \
+    if ((R) < 7) W4_LDS(FA[(R) < 7 ? (R) : 0], AAD, ((R) < 7 ? (R) : 0) * 2048);                       \
+    else if ((R) < 15) W4_LDS(FB[(R) >= 7 && (R) < 15 ? (R) - 7 : 0], BAD, ((R) >= 7 && (R) < 15 ? (R) - 7 : 0) * 2048); \
+    else W4_LDS(FA[7], AAD, 7 * 2048);                                                                 \
+  }
+#pragma unroll
+  for (int d = 0; d < 16; ++d) W4_PIECE(d, smem);
+  ADVANCE_STREAM();
+#pragma unroll
+  for (int d = 0; d < 16; ++d) W4_PIECE(d, smem + 32768);
+  ADVANCE_STREAM();
+  asm volatile("s_waitcnt vmcnt(16)" ::: "memory");    // K-tile 0 landed (this wave's part)
+  VP_BAR();
+  bf16x8 fa0[8], fb0[8], fa1[8], fb1[8];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) W4_RD(fa0, fb0, aad0, bad0, r);
+  while (true) {
+    f32x4 acc[2][8][4];
+    const TileCoord tcur = tc;
+    if ((p.dbg & 0x10000) && threadIdx.x == 0 && v == (int)blockIdx.x) {
+      vp_dbg_stamps[blockIdx.x * 8 + 1] = wall_clock64();
+      vp_dbg_stamps[blockIdx.x * 8 + 6] = clock64();
+    }
+    for (int kt = 0; kt < nt; ++kt) {
+      const uint32_t co = (uint32_t)(kt & 1) << 16, cn = co ^ 65536u;     // byte offsets of this / the other buffer
+      // ---- step 0: 64 MFMAs on f0; the 16 reads of f1 (ks 1 of this K-tile), one per MFMA
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { W4_PIN(fa0[i]); W4_PIN(fb0[i]); }
+#define W4_STEP0(MF)                                                                                   \
+  _Pragma("unroll") for (int m = 0; m < 64; ++m) {                                                     \
+    if (m < 16 && VAR != 2 && VAR != 4) W4_RD(fa1, fb1, aad1 + co, bad1 + co, m);                      \
+    W4_MF1(MF, fa0, fb0, m);                                                                           \
+  }
+      if (kt == 0) { W4_STEP0(W4_MFMA0) } else { W4_STEP0(W4_MFMA) }
+#undef W4_STEP0
+      // ---- step 1: 8 MFMAs on f1, the K-tile hand-over, then the 16 reads of f0 = fragments (kt+1, ks 0) from the other buffer (one per
+      // MFMA) and the 16 DMA pieces of K-tile kt+2 into the buffer just released, one per 3.5 MFMAs
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { W4_PIN(fa1[i]); W4_PIN(fb1[i]); }
+#pragma unroll
+      for (int m = 0; m < 8; ++m) W4_MF1(W4_MFMA, fa1, fb1, m);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // K-tile kt+1 landed (this wave's part)
+      if (VAR != 3) __builtin_amdgcn_s_barrier();
+      {
+        bf16_t* cb = smem + (kt & 1) * 32768;
+#pragma unroll
+        for (int m = 8; m < 64; ++m) {
+          if (m - 8 < 16 && VAR != 2 && VAR != 4) W4_RD(fa0, fb0, aad0 + cn, bad0 + cn, m - 8);
+          if (VAR != 1 && VAR != 4) {
+#pragma unroll
+            for (int d = 0; d < 16; ++d)
+              if (m == 8 + (7 * d) / 2) W4_PIECE(d, cb);
+          }
+          W4_MF1(W4_MFMA, fa1, fb1, m);
+        }
+      }
+      ADVANCE_STREAM();
+    }
+    if ((p.dbg & 0x10000) && threadIdx.x == 0 && v == (int)blockIdx.x) {
+      vp_dbg_stamps[blockIdx.x * 8 + 2] = wall_clock64();
+      vp_dbg_stamps[blockIdx.x * 8 + 7] = clock64();
+    }
+    asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");   // last MFMA results visible to the compiler's v_accvgpr_reads
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) asm volatile("" : "+a"(acc[h][i][j]));
+    const int vnext = v + gridDim.x;
+    const int mr = tcur.m0 + wr * 128, nc = tcur.n0 + wc * 128;
+    if (!OUT_F32) {
+      bf16_t* stage = smem + 65536 + wave * 4096;
+      epilogue_swz<2>(p, stage, acc[0], mr, nc, lane);
+      epilogue_swz<2>(p, stage, acc[1], mr, nc + 64, lane);
+    } else {
+      float* c = (float*)p.C + (long)(mr + fr) * p.ldc + nc + g * 4;
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) *(f32x4*)(c + (long)(i * 16) * p.ldc + h * 64 + j * 16) = acc[h][i][j];
+    }
+    if (vnext >= ntiles) break;
+    v = vnext;
+    tc = TILE_OF(v);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the trailing dummy DMAs must not outlive the workgroup's LDS
+#undef TILE_OF
+#undef W4_DMA_A
+#undef W4_DMA_B
+#undef W4_PIECE
+#undef ADVANCE_STREAM
+#undef W4_MFMA
+#undef W4_MFMA0
+#undef W4_LDS
+#undef W4_PIN
+#undef W4_MF1
+#undef W4_RD
+}
+
+// ------------------------------------------------------------------------------------------------
 // generic path: any M, N, K, any alignment (register-staged, zero-filled K tail). 64x64x32 tile.
 // ------------------------------------------------------------------------------------------------
 template <bool OUT_F32>
@@ -1100,6 +1285,35 @@ int vp_gemm_bf16(int M, int N, int K, const void* A, long lda, const void* B, lo
   const bool fast = (force_generic != 1) && (K % 64 == 0) && (lda % 8 == 0) && (ldb % 8 == 0) &&
                     ((((uintptr_t)A) | ((uintptr_t)B)) & 15) == 0;
   const long big_tiles = (long)((M + 255) / 256) * ((N + 255) / 256);
+  {
+    static int w4_env = -1;
+    if (w4_env < 0) { const char* e = getenv("VP_GEMM_W4"); w4_env = e ? atoi(e) : 0; }
+    const bool w4_ok = fast && M % 256 == 0 && N % 256 == 0 && K % 128 == 0 && (big_tiles >= 192 || force_generic >= 8) &&
+                       (!out_f32 || (!bias && !residual && (epilogue & 0xff) == EPI_NONE && ldc % 4 == 0 && (((uintptr_t)C) & 15) == 0));
+    if (w4_ok && (force_generic == 8 || (force_generic == 0 && w4_env))) {
+      static bool attr_w4 = false;
+      if (!attr_w4) {
+        (void)hipFuncSetAttribute((const void*)gemm_nt_256w4<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
+        (void)hipFuncSetAttribute((const void*)gemm_nt_256w4<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
+        attr_w4 = true;
+      }
+      const unsigned g4 = (unsigned)(big_tiles > 256 ? 256 : big_tiles);
+      if (out_f32) hipLaunchKernelGGL(gemm_nt_256w4<true>, dim3(g4), dim3(256), 163840, stream, p);
+      else hipLaunchKernelGGL(gemm_nt_256w4<false>, dim3(g4), dim3(256), 163840, stream, p);
+      return vp_check_launch("vp_gemm_bf16");
+    }
+    if (w4_ok && !out_f32 && force_generic >= 9 && force_generic <= 12) {      // timing ablations of the 4-wave kernel (dev only, wrong results)
+      const unsigned g4 = (unsigned)(big_tiles > 256 ? 256 : big_tiles);
+#define W4_ABL(V)                                                                                                              \
+  {                                                                                                                            \
+    (void)hipFuncSetAttribute((const void*)gemm_nt_256w4<false, V>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);       \
+    hipLaunchKernelGGL((gemm_nt_256w4<false, V>), dim3(g4), dim3(256), 163840, stream, p);                                     \
+  }
+      if (force_generic == 9) W4_ABL(1) else if (force_generic == 10) W4_ABL(2) else if (force_generic == 11) W4_ABL(3) else W4_ABL(4)
+#undef W4_ABL
+      return vp_check_launch("vp_gemm_bf16");
+    }
+  }
   if (fast && (force_generic == 7 || (force_generic == 0 && big_tiles >= 192 && M >= 256 && N >= 256))) {   // default large-problem kernel
     static bool attr_p8 = false;
     if (!attr_p8) {
