@@ -1290,7 +1290,7 @@ int vp_gemm_bf16(int M, int N, int K, const void* A, long lda, const void* B, lo
     if (w4_env < 0) { const char* e = getenv("VP_GEMM_W4"); w4_env = e ? atoi(e) : 0; }
     const bool w4_ok = fast && M % 256 == 0 && N % 256 == 0 && K % 128 == 0 && (big_tiles >= 192 || force_generic >= 8) &&
                        (!out_f32 || (!bias && !residual && (epilogue & 0xff) == EPI_NONE && ldc % 4 == 0 && (((uintptr_t)C) & 15) == 0));
-    if (w4_ok && (force_generic == 8 || (force_generic == 0 && w4_env))) {
+    if (w4_ok && (force_generic == 8 || (force_generic == 0 && w4_env == 1))) {
       static bool attr_w4 = false;
       if (!attr_w4) {
         (void)hipFuncSetAttribute((const void*)gemm_nt_256w4<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
