@@ -93,12 +93,14 @@ def test_gemm_4wave_kernel(ops, M, N, K):
     ref = a.float() @ w.float().t()
     close(ops.gemm(ag, wg, force_generic=8), ref, what=f"w4 {M}x{N}x{K}")
     assert torch.equal(ops.gemm(ag, wg, force_generic=8), ops.gemm(ag, wg, force_generic=7))       # same k order per MFMA chain as the 8-phase kernel
+    assert torch.equal(ops.gemm(ag, wg, force_generic=13), ops.gemm(ag, wg, force_generic=7))      # 4-phase variant of the 8-phase kernel
     o32 = ops.gemm(ag, wg, out_f32=True, force_generic=8)
     assert o32.dtype == torch.float32
     assert float((o32.cpu() - ref).abs().max()) <= 2e-5 * float(ref.abs().max()) * max(1.0, K / 256) ** 0.5
     if M * N <= 1 << 20:
         ref2 = F.gelu((ref + b.float()).to(BF).float()).to(BF).float() + r.float()
         close(ops.gemm(ag, wg, bias=dev(b), residual=dev(r), epi=ops.EPI_GELU, force_generic=8), ref2, what="w4 epilogue")
+
 
 
 def test_gemm_8phase_large_k_and_edges(ops):

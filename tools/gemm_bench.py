@@ -30,7 +30,7 @@ for (M, N, K) in SHAPES:
     out = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
     ref = (a[:256].float() @ w.float().t())
     res = {}
-    variants = (("k128", 2), ("k256", 3), ("k256p8", 7), ("k256w4", 8), ("auto", 0))
+    variants = (("k128", 2), ("k256", 3), ("k256p8", 7), ("k256w4", 8), ("k256p4", 13), ("auto", 0))
     only = os.environ.get("BENCH_ONLY")
     if only:
         variants = tuple(v for v in variants if v[0] in only.split(","))

@@ -541,7 +541,7 @@ __global__ __launch_bounds__(512) void gemm_nt_256(GemmArgs p) {
 //     every barrier (the wait at the end of phase k's R retires exactly the piece phase k+1 reads first).
 // ------------------------------------------------------------------------------------------------
 #define STAMP(I) if ((p.dbg & 0x10000) && threadIdx.x == 0 && first_tile) vp_dbg_stamps[blockIdx.x * 8 + (I)] = wall_clock64();
-template <bool OUT_F32>
+template <bool OUT_F32, bool PH4 = false>      // PH4: 4 phases per K-tile (32 MFMAs each, half the barriers), see the loop
 __global__ __launch_bounds__(512) void gemm_nt_256p8(GemmArgs p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   bf16_t* smem = (bf16_t*)smem_raw;                    // [buf][A 256x64 | B 256x64]
@@ -635,10 +635,11 @@ __global__ __launch_bounds__(512) void gemm_nt_256p8(GemmArgs p) {
   ISSUE_PIECE(1, 0);
   ISSUE_PIECE(2, 0);
   ISSUE_PIECE(3, 0);
-  asm volatile("s_waitcnt vmcnt(4)" ::: "memory");     // pieces 0,1 of K-tile 0 landed (this wave's parts)
+  if (PH4) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // pieces 0,1 of K-tile 0 landed (this wave's parts)
   VP_BAR();
   bf16x8 xa[2][4], wb0[2][2], wb1[2][2], xn[4];
-  {                                                    // A(m0, ks=0) fragments of K-tile 0 (later ones are prefetched in phase 4)
+  if (!PH4) {                                          // A(m0, ks=0) fragments of K-tile 0 (later ones are prefetched in phase 4)
     const bf16_t* As = smem;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -668,6 +669,31 @@ __global__ __launch_bounds__(512) void gemm_nt_256p8(GemmArgs p) {
       } else {
         if (vnext < ntiles) tc = TILE_OF(vnext);
         SET_SRC(tc);
+      }
+      if (PH4) {
+        // 4-phase variant: a piece issued in the R part of phase X is retired for BOTH wave groups only after the barrier that ends the M part
+        // of phase X+1 (group 1 runs one barrier behind), so it may be read from the R part of phase X+2 = the same phase of the next K-tile.
+        // ---- phase A: quadrants (m0, n0), (m0, n1): 32 MFMAs.  issues pieces 0,1,2 of the next K-tile; reads A(m0) x8, B(n0) x4, B(n1) x4
+        ISSUE_PIECE(0, cur ^ 1);
+        ISSUE_PIECE(1, cur ^ 1);
+        ISSUE_PIECE(2, cur ^ 1);
+        RD_A(xa, 0);
+        RD_B(wb0, 0);
+        RD_B(wb1, 1);
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // the previous phase B's piece 3 of THIS K-tile landed (this wave's part)
+        VP_BAR();
+        MM(xa, wb0, 0, 0);
+        MM(xa, wb1, 0, 1);
+        VP_BAR();
+        // ---- phase B: quadrants (m1, n1), (m1, n0): 32 MFMAs.  issues piece 3; reads A(m1) x8
+        ISSUE_PIECE(3, cur ^ 1);
+        RD_A(xa, 1);
+        asm volatile("s_waitcnt vmcnt(2)" ::: "memory");   // phase A's pieces 0,1,2 of the next K-tile landed
+        VP_BAR();
+        MM(xa, wb1, 1, 1);
+        MM(xa, wb0, 1, 0);
+        VP_BAR();
+        continue;
       }
       // ---- phase 1: quadrant (m0, n0).  reads: B(n0) x4, A(m0, ks=1) x4  (A(m0, ks=0) came from the previous phase 4)
       ISSUE_PIECE(0, cur ^ 1);
@@ -1064,7 +1090,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #define W4_LDS(DST, ADDR, OFF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(DST) : "v"(ADDR), "n"(OFF))
 #define W4_PIN(F) asm volatile("" : "+v"(F))
   // MFMA number m of a step (0..63): row i = m >> 3, column block c = m & 7
-#define W4_MF1(MF, FA, FB, M) MF(acc[((M) & 7) >> 2][(M) >> 3][(M) & 3], FB[(M) & 7], FA[(M) >> 3])
+#define W4_MF1(MF, FA, FB, M) { if (VAR != 7 && VAR != 8) MF(acc[((M) & 7) >> 2][(M) >> 3][(M) & 3], FB[(M) & 7], FA[(M) >> 3]); }
   // read slot r (0..15) -> fragment: fa[0..6], fb[0..7], fa[7]  (a register's last consumer is >= 8 MFMAs behind its reload)
 #define W4_RD(FA, FB, AAD, BAD, R)                                                                     \
   {                                                                                                    \
@@ -1098,7 +1124,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       for (int i = 0; i < 8; ++i) { W4_PIN(fa0[i]); W4_PIN(fb0[i]); }
 #define W4_STEP0(MF)                                                                                   \
   _Pragma("unroll") for (int m = 0; m < 64; ++m) {                                                     \
-    if (m < 16 && VAR != 2 && VAR != 4) W4_RD(fa1, fb1, aad1 + co, bad1 + co, m);                      \
+    if (m < 16 && VAR != 2 && VAR != 4 && VAR != 7 && VAR != 8) W4_RD(fa1, fb1, aad1 + co, bad1 + co, m);                      \
     W4_MF1(MF, fa0, fb0, m);                                                                           \
   }
       if (kt == 0) { W4_STEP0(W4_MFMA0) } else { W4_STEP0(W4_MFMA) }
@@ -1110,13 +1136,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       for (int i = 0; i < 8; ++i) { W4_PIN(fa1[i]); W4_PIN(fb1[i]); }
 #pragma unroll
       for (int m = 0; m < 8; ++m) W4_MF1(W4_MFMA, fa1, fb1, m);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // K-tile kt+1 landed (this wave's part)
-      if (VAR != 3) __builtin_amdgcn_s_barrier();
+      if (VAR != 8) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // K-tile kt+1 landed (this wave's part)
+      else asm volatile("s_waitcnt vmcnt(48)" ::: "memory");           // (VAR 8: three more K-tiles may stay in flight)
+      if (VAR != 3 && VAR != 8) __builtin_amdgcn_s_barrier();
       {
         bf16_t* cb = smem + (kt & 1) * 32768;
 #pragma unroll
         for (int m = 8; m < 64; ++m) {
-          if (m - 8 < 16 && VAR != 2 && VAR != 4) W4_RD(fa0, fb0, aad0 + cn, bad0 + cn, m - 8);
+          if (m - 8 < 16 && VAR != 2 && VAR != 4 && VAR != 7 && VAR != 8) W4_RD(fa0, fb0, aad0 + cn, bad0 + cn, m - 8);
           if (VAR != 1 && VAR != 4) {
 #pragma unroll
             for (int d = 0; d < 16; ++d)
@@ -1262,6 +1289,12 @@ __global__ __launch_bounds__(256) void transpose_bf16_kernel(const bf16_t* in, b
   }
 }
 
+static bool vp_ph4_enabled() {
+  static int e = -1;
+  if (e < 0) { const char* v = getenv("VP_GEMM_PH4"); e = v ? atoi(v) : 0; }
+  return e != 0;
+}
+
 extern "C" {
 
 int vp_debug_stamps(long* host) {
@@ -1302,14 +1335,14 @@ int vp_gemm_bf16(int M, int N, int K, const void* A, long lda, const void* B, lo
       else hipLaunchKernelGGL(gemm_nt_256w4<false>, dim3(g4), dim3(256), 163840, stream, p);
       return vp_check_launch("vp_gemm_bf16");
     }
-    if (w4_ok && !out_f32 && force_generic >= 9 && force_generic <= 12) {      // timing ablations of the 4-wave kernel (dev only, wrong results)
+    if (w4_ok && !out_f32 && ((force_generic >= 9 && force_generic <= 12) || force_generic == 16 || force_generic == 17)) {      // timing ablations of the 4-wave kernel (dev only, wrong results)
       const unsigned g4 = (unsigned)(big_tiles > 256 ? 256 : big_tiles);
 #define W4_ABL(V)                                                                                                              \
   {                                                                                                                            \
     (void)hipFuncSetAttribute((const void*)gemm_nt_256w4<false, V>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);       \
     hipLaunchKernelGGL((gemm_nt_256w4<false, V>), dim3(g4), dim3(256), 163840, stream, p);                                     \
   }
-      if (force_generic == 9) W4_ABL(1) else if (force_generic == 10) W4_ABL(2) else if (force_generic == 11) W4_ABL(3) else W4_ABL(4)
+      if (force_generic == 9) W4_ABL(1) else if (force_generic == 10) W4_ABL(2) else if (force_generic == 11) W4_ABL(3) else if (force_generic == 16) W4_ABL(7) else if (force_generic == 17) W4_ABL(8) else W4_ABL(4)
 #undef W4_ABL
       return vp_check_launch("vp_gemm_bf16");
     }
@@ -1325,7 +1358,15 @@ int vp_gemm_bf16(int M, int N, int K, const void* A, long lda, const void* B, lo
     // for every output tile); otherwise one block per output tile
     const unsigned g8 = (unsigned)(((K / 64) % 2 == 0 && big_tiles > 256 && !(p.dbg & 0x20000)) ? 256 : big_tiles);
     if (out_f32) hipLaunchKernelGGL(gemm_nt_256p8<true>, dim3(g8), dim3(512), 131072, stream, p);
-    else hipLaunchKernelGGL(gemm_nt_256p8<false>, dim3(g8), dim3(512), 131072, stream, p);
+    else if (vp_ph4_enabled() && force_generic == 0) {
+      static bool attr_p4 = false;
+      if (!attr_p4) { (void)hipFuncSetAttribute((const void*)gemm_nt_256p8<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072); attr_p4 = true; }
+      hipLaunchKernelGGL((gemm_nt_256p8<false, true>), dim3(g8), dim3(512), 131072, stream, p);
+    } else hipLaunchKernelGGL(gemm_nt_256p8<false>, dim3(g8), dim3(512), 131072, stream, p);
+  } else if (fast && force_generic == 13 && !out_f32) {       // 4-phase variant of the 8-phase kernel (A/B testing)
+    (void)hipFuncSetAttribute((const void*)gemm_nt_256p8<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+    const unsigned g8 = (unsigned)(((K / 64) % 2 == 0 && big_tiles > 256 && !(p.dbg & 0x20000)) ? 256 : big_tiles);
+    hipLaunchKernelGGL((gemm_nt_256p8<false, true>), dim3(g8), dim3(512), 131072, stream, p);
   } else if (fast && force_generic != 2 && (force_generic == 3 || (big_tiles >= 192 && M >= 256 && N >= 256))) {
     static bool attr_done = false;
     if (!attr_done) {
@@ -1377,7 +1418,11 @@ int vp_gemm_bf16_swiglu(int mode, int M, int N, int K, const void* A, long lda, 
   }
   const long big_tiles = (long)(M / 256) * (N / 256);
   const unsigned g8 = (unsigned)(((K / 64) % 2 == 0 && big_tiles > 256) ? 256 : big_tiles);
-  hipLaunchKernelGGL(gemm_nt_256p8<false>, dim3(g8), dim3(512), 131072, stream, p);
+  if (vp_ph4_enabled()) {
+    static bool attr_p4 = false;
+    if (!attr_p4) { (void)hipFuncSetAttribute((const void*)gemm_nt_256p8<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072); attr_p4 = true; }
+    hipLaunchKernelGGL((gemm_nt_256p8<false, true>), dim3(g8), dim3(512), 131072, stream, p);
+  } else hipLaunchKernelGGL(gemm_nt_256p8<false>, dim3(g8), dim3(512), 131072, stream, p);
   return vp_check_launch("vp_gemm_bf16_swiglu");
 }
 
