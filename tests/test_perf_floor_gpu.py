@@ -1,0 +1,71 @@
+"""Performance floors for the hot kernels (GPU).  Not a benchmark: the floors sit ~35 % under what round 1 measures on an MI355X
+(`profiles/`, `tools/gemm_bench.py`, `tools/attn_bench.py`), so that box-to-box spread (+-5 %) never trips them but a structural regression
+does -- e.g. the shared attention forward losing one of its two blocks per CU to 20 extra VGPRs (0.44 -> 0.61 ms) went unnoticed for a
+day because only parity was tested."""
+import math
+import os
+import sys
+
+import pytest
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from visper_lm_amd import ops as o
+    return o
+
+
+def _ms(fn, n=6):
+    fn(); fn()
+    torch.cuda.synchronize()
+    best = 1e9
+    for _ in range(3):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        best = min(best, e0.elapsed_time(e1) / n)
+    return best
+
+
+def test_gemm_floor(ops):
+    """Decoder-shaped GEMMs on the default large-problem kernel: measured 1.20-1.48 PFLOP/s; floor 0.85."""
+    for (M, N, K) in [(16384, 4096, 4096), (16384, 14336, 4096)]:
+        a = torch.randn(M, K, device="cuda", dtype=torch.bfloat16)
+        w = torch.randn(N, K, device="cuda", dtype=torch.bfloat16) * 0.05
+        out = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+        ms = _ms(lambda: ops.gemm(a, w, out=out))
+        tf = 2.0 * M * N * K / ms / 1e9
+        assert tf > 850.0, f"gemm {M}x{N}x{K}: {tf:.0f} TFLOP/s"
+
+
+def test_gemm_tn_floor(ops):
+    """Transpose-free weight-gradient GEMM: measured 1.10-1.24 PFLOP/s at the decoder shapes; floor 0.75."""
+    M, N, K = 4096, 4096, 16384
+    dy = torch.randn(K, M, device="cuda", dtype=torch.bfloat16)
+    x = torch.randn(K, N, device="cuda", dtype=torch.bfloat16)
+    out = torch.empty(M, N, device="cuda", dtype=torch.float32)
+    ms = _ms(lambda: ops.gemm_tn(dy, x, out=out))
+    tf = 2.0 * M * N * K / ms / 1e9
+    assert tf > 750.0, f"gemm_tn: {tf:.0f} TFLOP/s"
+
+
+def test_attention_floor(ops):
+    """Llama-3-8B train-step attention (B 8, 32/8 heads, S 2048, D 128, causal): measured fwd 0.42-0.44 ms, bwd 1.19-1.26 ms."""
+    B, Hq, Hkv, S, D = 8, 32, 8, 2048, 128
+    qkv = torch.randn(B, S, (Hq + 2 * Hkv) * D, device="cuda", dtype=torch.bfloat16)
+    q = qkv[..., :Hq * D].unflatten(-1, (Hq, D))
+    k = qkv[..., Hq * D:(Hq + Hkv) * D].unflatten(-1, (Hkv, D))
+    v = qkv[..., (Hq + Hkv) * D:].unflatten(-1, (Hkv, D))
+    do = torch.randn(B, S, Hq, D, device="cuda", dtype=torch.bfloat16)
+    o, lse = ops.attn_fwd(q, k, v, True)
+    fwd = _ms(lambda: ops.attn_fwd(q, k, v, True))
+    bwd = _ms(lambda: ops.attn_bwd(q, k, v, o, lse, do, True))
+    assert fwd < 0.60, f"attention forward {fwd:.3f} ms"
+    assert bwd < 1.70, f"attention backward {bwd:.3f} ms"
