@@ -148,6 +148,16 @@ int vp_attn_bwd(int B, int Hq, int Hkv, int Sq, int Skv, int D, const void* q, l
                 long dk_bs, long dk_ts, void* dv, long dv_bs, long dv_ts, float* delta, const int* kv_len, int causal,
                 int window, float scale, vp_stream_t stream);
 
+/* vp_attn_bwd with the RoPE backward of dq / dk fused into the stores (HF LlamaAttention.forward rotates q, k with
+ * apply_rotary_pos_emb before SDPA, modeling_llama.py; autograd rotates dq / dk back).  D = 128, causal only.  rope_cos /
+ * rope_sin: fp32 [positions, 64] as for vp_rope; rope_pos: int32 [B, S] position ids or NULL (position = row index).
+ * Bit-identical to vp_attn_bwd followed by vp_rope(inverse = 1) on dq and dk. */
+int vp_attn_bwd_rope(int B, int Hq, int Hkv, int Sq, int Skv, int D, const void* q, long q_bs, long q_ts, const void* k, long k_bs,
+                     long k_ts, const void* v, long v_bs, long v_ts, const void* o, long o_bs, long o_ts, const float* lse,
+                     const void* dout, long do_bs, long do_ts, void* dq, long dq_bs, long dq_ts, void* dk, long dk_bs, long dk_ts,
+                     void* dv, long dv_bs, long dv_ts, float* delta, const int* kv_len, int causal, int window, float scale,
+                     const float* rope_cos, const float* rope_sin, const int* rope_pos, vp_stream_t stream);
+
 /* ---- losses.  NTP CE (ola_llama.py:121-136: logits.float(), shifted CrossEntropyLoss, ignore -100);
  * embedding distillation (base_ola_vlm.py:289-320 _emb_loss; ola_utils.py:108-125
  * calculate_contrastive_loss; :96-106 dist_collect -> tgt_all is the rank-ordered all-gather). */

@@ -253,6 +253,34 @@ def test_gemm_tn_weight_gradient(ops, M, N, K):
         ops._lib.call("vp_gemm_tn_bf16", 200, 256, 64, dyg.data_ptr(), dyg.stride(0), xg.data_ptr(), N, out.data_ptr(), N, 1, 0, None)
 
 
+def test_attn_bwd_fused_rope(ops):
+    """dq / dk rotated back inside the D=128 backward kernels == vp_attn_bwd followed by vp_rope(inverse), bit for bit (GQA, ragged S)."""
+    B, Hq, Hkv, S, D = 2, 8, 2, 300, 128
+    qkv = dev(rnd(B, S, (Hq + 2 * Hkv) * D, seed=80))
+    q = qkv[..., :Hq * D].unflatten(-1, (Hq, D)); k = qkv[..., Hq * D:(Hq + Hkv) * D].unflatten(-1, (Hkv, D))
+    v = qkv[..., (Hq + Hkv) * D:].unflatten(-1, (Hkv, D))
+    do = dev(rnd(B, S, Hq, D, seed=81))
+    o, lse = ops.attn_fwd(q, k, v, True)
+    cos_t, sin_t = ops.rope_tables(S, D, 500000.0, "cuda")
+    d1 = torch.zeros_like(qkv); d2 = torch.zeros_like(qkv)
+    views = lambda d: (d[..., :Hq * D].unflatten(-1, (Hq, D)), d[..., Hq * D:(Hq + Hkv) * D].unflatten(-1, (Hkv, D)),
+                       d[..., (Hq + Hkv) * D:].unflatten(-1, (Hkv, D)))
+    a, b_, c = views(d1)
+    ops.attn_bwd(q, k, v, o, lse, do, True, dq=a, dk=b_, dv=c)
+    ops.rope_(d1.view(B * S, -1), B * S, S, Hq + Hkv, D, cos_t, sin_t, inverse=True)
+    a, b_, c = views(d2)
+    ops.attn_bwd(q, k, v, o, lse, do, True, dq=a, dk=b_, dv=c, rope=(cos_t, sin_t))
+    assert torch.equal(d1, d2)
+    pos = (torch.arange(S, device="cuda", dtype=torch.int32)[None, :] + torch.tensor([[3], [0]], device="cuda", dtype=torch.int32)).clamp_max(S - 1).contiguous()
+    d3 = torch.zeros_like(qkv)
+    a, b_, c = views(d1)
+    ops.attn_bwd(q, k, v, o, lse, do, True, dq=a, dk=b_, dv=c)
+    ops.rope_(d1.view(B * S, -1), B * S, S, Hq + Hkv, D, cos_t, sin_t, pos=pos.view(-1), inverse=True)
+    a, b_, c = views(d3)
+    ops.attn_bwd(q, k, v, o, lse, do, True, dq=a, dk=b_, dv=c, rope=(cos_t, sin_t, pos))
+    assert torch.equal(d1, d3)
+
+
 @pytest.mark.parametrize("kind", [1, 3])
 def test_act(ops, kind):
     x, d = rnd(40, 64, seed=22), rnd(40, 64, seed=23)

@@ -54,6 +54,8 @@ _SIGS = {
     "vp_attn_fwd_bias": [i, i, i, i, i, i, p, l, l, p, l, l, p, l, l, p, l, l, p, p, i, i, f, p, p, i, p],
     "vp_attn_bwd": [i, i, i, i, i, i, p, l, l, p, l, l, p, l, l, p, l, l, p, p, l, l, p, l, l, p, l, l, p, l, l, p, p,
                     i, i, f, p],
+    "vp_attn_bwd_rope": [i, i, i, i, i, i, p, l, l, p, l, l, p, l, l, p, l, l, p, p, l, l, p, l, l, p, l, l, p, l, l, p, p,
+                    i, i, f, p, p, p, p],
     "vp_ce_fwd_bwd": [l, i, p, l, p, p, f, i, p],
     "vp_emb_loss_nblk": [l],
     "vp_sumsq_nblk": [l],

@@ -36,6 +36,11 @@ struct AttnParams {
   const float* bias_h;
   const float* bias_b;
   int bias_nb;
+  // optional fused RoPE backward (D = 128 DMA-ring kernels only): dq / dk leave the kernels already rotated back (HF apply_rotary_pos_emb
+  // autograd, same rounding points as vp_rope(inverse=1) applied to the bf16 dq / dk).  cos / sin fp32 [positions, 64]; pos int [B, S] or NULL
+  const float* rope_cos;
+  const float* rope_sin;
+  const int* rope_pos;
 };
 
 #define LOG2E 1.4426950408889634f
@@ -443,13 +448,43 @@ static __device__ __forceinline__ bf16x8 tr_join(s16x4 lo, s16x4 hi) {
 }
 #define ATTN_LGKM(N) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory")
 #define ATTN_PIN(F) asm volatile("" : "+v"(F))
+
+// store one row's 128 features (this lane: blocks d = 0..7, features d*16 + 4g + r) as bf16, optionally rotated back by RoPE^T:
+// x1 = feature f < 64, x2 = feature f + 64; out1 = bf(bf(x1 c) + bf(x2 s)), out2 = bf(bf(x2 c) + bf(-x1 s))  (vp_rope with inverse = 1)
+template <bool ROPE>
+static __device__ __forceinline__ void store_row128(bf16_t* dst, const f32x4 (&acc)[8], float scale, int g, const float* cs, const float* sn) {
+  if (!ROPE) {
+#pragma unroll
+    for (int d = 0; d < 8; ++d) {
+      bf16x4 a;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) a[r] = (short)f2bf(acc[d][r] * scale);
+      *(bf16x4*)(dst + d * 16 + 4 * g) = a;
+    }
+  } else {
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+      const f32x4 c4 = *(const f32x4*)(cs + d * 16 + 4 * g), s4 = *(const f32x4*)(sn + d * 16 + 4 * g);
+      bf16x4 a, b;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float x1 = bfround(acc[d][r] * scale), x2 = bfround(acc[d + 4][r] * scale);
+        const float ss = -s4[r];
+        a[r] = (short)f2bf(bfround(x1 * c4[r]) + bfround(-x2 * ss));
+        b[r] = (short)f2bf(bfround(x2 * c4[r]) + bfround(x1 * ss));
+      }
+      *(bf16x4*)(dst + d * 16 + 4 * g) = a;
+      *(bf16x4*)(dst + 64 + d * 16 + 4 * g) = b;
+    }
+  }
+}
 #ifndef DKDV_KT
 #define DKDV_KT 2
 #endif
 constexpr int DKDV128_STAGE = 2 * 32 * 128 + 128;     // bf16 units: Q tile | dO tile | 32 (lse, delta) fp32 pairs
 constexpr int DKDV128_LDS = 4 * DKDV128_STAGE * 2;    // bytes
 
-template <bool CAUSAL, int KT>      // KT = 16-key column tiles per wave: 2 -> 4 waves x 32 keys, 1 -> 8 waves x 16 keys (128 keys per block)
+template <bool CAUSAL, int KT, bool ROPE = false>      // KT = 16-key column tiles per wave: 2 -> 4 waves x 32 keys, 1 -> 8 waves x 16 keys (128 keys per block)
 __global__ __launch_bounds__(64 * (8 / KT)) __attribute__((amdgpu_waves_per_eu(KT == 2 ? 2 : 4, KT == 2 ? 2 : 4)))
 void attn_bwd_dkdv128_kernel(AttnParams p) {
   constexpr int D = 128, NKS = 4, NDB = 8, NW = 8 / KT, NI = 8 / NW;      // NI = DMA instructions per wave per 32-row tile
@@ -613,14 +648,9 @@ void attn_bwd_dkdv128_kernel(AttnParams p) {
     if (key < p.Skv) {
       bf16_t* dkp = p.dk + (long)b * p.dk_bs + (long)key * p.dk_ts + (long)hk * D;
       bf16_t* dvp = p.dv + (long)b * p.dv_bs + (long)key * p.dv_ts + (long)hk * D;
-#pragma unroll
-      for (int d = 0; d < NDB; ++d) {
-        bf16x4 a, bb;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { a[r] = (short)f2bf(dk[kt][d][r] * p.scale); bb[r] = (short)f2bf(dv[kt][d][r]); }
-        *(bf16x4*)(dkp + d * 16 + 4 * g) = a;
-        *(bf16x4*)(dvp + d * 16 + 4 * g) = bb;
-      }
+      const long pp = ROPE ? (p.rope_pos ? (long)p.rope_pos[(long)b * p.Skv + key] : (long)key) * 64 : 0;
+      store_row128<ROPE>(dkp, dk[kt], p.scale, g, p.rope_cos + pp, p.rope_sin + pp);
+      store_row128<false>(dvp, dv[kt], 1.f, g, nullptr, nullptr);
     }
   }
 }
@@ -751,7 +781,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(AttnParams p) {
 constexpr int DQ128_STAGE = 2 * 32 * 128;             // bf16 units: K tile | V tile
 constexpr int DQ128_LDS = 4 * DQ128_STAGE * 2;        // bytes
 
-template <bool CAUSAL>
+template <bool CAUSAL, bool ROPE = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_bwd_dq128_kernel(AttnParams p) {
   constexpr int D = 128, NKS = 4, NDB = 8;
   extern __shared__ __attribute__((aligned(16))) unsigned char attn_smem[];
@@ -905,13 +935,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int qrow = qw0 + qt * 16 + (lane & 15);
     if (qrow < p.Sq) {
       bf16_t* dqp = p.dq + (long)b * p.dq_bs + (long)qrow * p.dq_ts + (long)h * D;
-#pragma unroll
-      for (int d = 0; d < NDB; ++d) {
-        bf16x4 a;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) a[r] = (short)f2bf(dq[qt][d][r] * p.scale);
-        *(bf16x4*)(dqp + d * 16 + 4 * (lane >> 4)) = a;
-      }
+      const long pp = ROPE ? (p.rope_pos ? (long)p.rope_pos[(long)b * p.Sq + qrow] : (long)(qrow + p.Skv - p.Sq)) * 64 : 0;
+      store_row128<ROPE>(dqp, dq[qt], p.scale, lane >> 4, p.rope_cos + pp, p.rope_sin + pp);
     }
   }
 }
@@ -962,7 +987,17 @@ static int launch_bwd(const AttnParams& p, int causal, hipStream_t s) {
       (void)hipFuncSetAttribute((const void*)attn_bwd_dq128_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, DQ128_LDS);
       attr2 = true;
     }
-    if (causal) {
+    if (p.rope_cos) {                                   // fused RoPE backward: its own instantiations (training: causal only)
+      if (!causal) { vp_set_error("vp_attn_bwd_rope: causal attention only"); return VP_ERR_UNSUPPORTED_SHAPE; }
+      static bool attr3 = false;
+      if (!attr3) {
+        (void)hipFuncSetAttribute((const void*)attn_bwd_dkdv128_kernel<true, DKDV_KT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, DKDV128_LDS);
+        (void)hipFuncSetAttribute((const void*)attn_bwd_dq128_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, DQ128_LDS);
+        attr3 = true;
+      }
+      hipLaunchKernelGGL((attn_bwd_dkdv128_kernel<true, DKDV_KT, true>), g1, dim3(64 * (8 / DKDV_KT)), DKDV128_LDS, s, p);
+      hipLaunchKernelGGL((attn_bwd_dq128_kernel<true, true>), g2, dim3(256), DQ128_LDS, s, p);
+    } else if (causal) {
       hipLaunchKernelGGL((attn_bwd_dkdv128_kernel<true, DKDV_KT>), g1, dim3(64 * (8 / DKDV_KT)), DKDV128_LDS, s, p);
       hipLaunchKernelGGL((attn_bwd_dq128_kernel<true>), g2, dim3(256), DQ128_LDS, s, p);
     } else {
@@ -1051,6 +1086,30 @@ int vp_attn_bwd(int B, int Hq, int Hkv, int Sq, int Skv, int D, const void* q, l
     case 96: return launch_bwd<96>(p, causal, s);
     default: return launch_bwd<128>(p, causal, s);
   }
+}
+
+// vp_attn_bwd with the RoPE backward of dq / dk fused into the stores (reference: HF LlamaAttention.forward applies apply_rotary_pos_emb
+// to q, k before SDPA -- modeling_llama.py; its autograd rotates dq / dk back).  D = 128, causal only.  rope_cos / rope_sin: fp32
+// [positions, 64] as for vp_rope; rope_pos: int32 [B, S] position ids or NULL (position = row index).  Same numbers as vp_attn_bwd
+// followed by vp_rope(inverse = 1) on dq and dk.
+int vp_attn_bwd_rope(int B, int Hq, int Hkv, int Sq, int Skv, int D, const void* q, long q_bs, long q_ts, const void* k, long k_bs,
+                     long k_ts, const void* v, long v_bs, long v_ts, const void* o, long o_bs, long o_ts, const float* lse,
+                     const void* dout, long do_bs, long do_ts, void* dq, long dq_bs, long dq_ts, void* dk, long dk_bs, long dk_ts,
+                     void* dv, long dv_bs, long dv_ts, float* delta, const int* kv_len, int causal, int window, float scale,
+                     const float* rope_cos, const float* rope_sin, const int* rope_pos, hipStream_t s) {
+  int e = check_attn("vp_attn_bwd_rope", B, Hq, Hkv, Sq, Skv, D);
+  if (e) return e;
+  VP_REQUIRE(lse && delta && dout && dq && dk && dv && rope_cos && rope_sin, VP_ERR_BAD_ARG, "vp_attn_bwd_rope: null pointer");
+  VP_REQUIRE(D == 128 && causal, VP_ERR_UNSUPPORTED_SHAPE, "vp_attn_bwd_rope: head_dim 128, causal only (got %d, causal %d)", D, causal);
+  VP_REQUIRE(((((uintptr_t)rope_cos) | ((uintptr_t)rope_sin)) & 15) == 0, VP_ERR_BAD_ARG, "vp_attn_bwd_rope: tables must be 16-byte aligned");
+  AttnParams p{};
+  p.q = (const bf16_t*)q; p.k = (const bf16_t*)k; p.v = (const bf16_t*)v; p.o = (bf16_t*)o; p.lse = (float*)lse;
+  p.dout = (const bf16_t*)dout; p.dq = (bf16_t*)dq; p.dk = (bf16_t*)dk; p.dv = (bf16_t*)dv; p.delta = delta;
+  p.q_bs = q_bs; p.q_ts = q_ts; p.k_bs = k_bs; p.k_ts = k_ts; p.v_bs = v_bs; p.v_ts = v_ts; p.o_bs = o_bs; p.o_ts = o_ts;
+  p.do_bs = do_bs; p.do_ts = do_ts; p.dq_bs = dq_bs; p.dq_ts = dq_ts; p.dk_bs = dk_bs; p.dk_ts = dk_ts; p.dv_bs = dv_bs; p.dv_ts = dv_ts;
+  p.B = B; p.Hq = Hq; p.Hkv = Hkv; p.Sq = Sq; p.Skv = Skv; p.window = window; p.kv_len = kv_len; p.scale = scale;
+  p.rope_cos = rope_cos; p.rope_sin = rope_sin; p.rope_pos = rope_pos;
+  return launch_bwd<128>(p, causal, s);
 }
 
 }  // extern "C"

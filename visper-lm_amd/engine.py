@@ -20,6 +20,8 @@ fp32 grads, Adam moments) so the DP all-reduce and the fused AdamW are one launc
 """
 from __future__ import annotations
 
+import os
+
 import math
 from collections import OrderedDict
 
@@ -885,9 +887,13 @@ class Engine:
             dq4 = dqkv.view(B, S, -1)[..., :nh * hd].view(B, S, nh, hd)
             dk4 = dqkv.view(B, S, -1)[..., nh * hd:(nh + nkv) * hd].view(B, S, nkv, hd)
             dv4 = dqkv.view(B, S, -1)[..., (nh + nkv) * hd:].view(B, S, nkv, hd)
-            ops.attn_bwd(q4, k4, v4, att, lse, d_att.view(B, S, nh, hd), causal=True, window=window, kv_len=kv_len,
-                         dq=dq4, dk=dk4, dv=dv4)
-            ops.rope_(dqkv, M, S, nh + nkv, hd, cos_t, sin_t, inverse=True)
+            if hd == 128 and not os.environ.get("VP_NO_FUSED_ROPE"):     # RoPE^T of dq / dk fused into the attention-backward stores
+                ops.attn_bwd(q4, k4, v4, att, lse, d_att.view(B, S, nh, hd), causal=True, window=window, kv_len=kv_len,
+                             dq=dq4, dk=dk4, dv=dv4, rope=(cos_t, sin_t))
+            else:
+                ops.attn_bwd(q4, k4, v4, att, lse, d_att.view(B, S, nh, hd), causal=True, window=window, kv_len=kv_len,
+                             dq=dq4, dk=dk4, dv=dv4)
+                ops.rope_(dqkv, M, S, nh + nkv, hd, cos_t, sin_t, inverse=True)
             d_xn = ops.gemm(dqkv, fz[o + "wqkv_T"])
             if train_llm:
                 xn, _ = ops.rmsnorm_fwd(x_in, fz[o + "ln1"], cfg.rms_norm_eps, save_rstd=False)

@@ -432,7 +432,7 @@ def attn_fwd_bias(q, k, v, bias_h=None, bias_b=None, scale=None):
     return out
 
 
-def attn_bwd(q, k, v, o, lse, dout, causal, scale=None, window=0, kv_len=None, dq=None, dk=None, dv=None):
+def attn_bwd(q, k, v, o, lse, dout, causal, scale=None, window=0, kv_len=None, dq=None, dk=None, dv=None, rope=None):
     B, Sq, Hq, D = q.shape
     _, Skv, Hkv, _ = k.shape
     if scale is None:
@@ -446,6 +446,13 @@ def attn_bwd(q, k, v, o, lse, dout, causal, scale=None, window=0, kv_len=None, d
     delta = torch.empty(3, B, Hq, Sq, device=q.device, dtype=torch.float32)   # delta + (lse, delta) pairs
     qb, qt = _bshd(q); kb, kt = _bshd(k); vb, vt = _bshd(v); ob, ot = _bshd(o); gb, gt = _bshd(dout)
     dqb, dqt = _bshd(dq); dkb, dkt = _bshd(dk); dvb, dvt = _bshd(dv)
+    if rope is not None:                                  # (cos, sin[, pos]): dq / dk come out rotated back (D = 128, causal)
+        cos_t, sin_t = rope[0], rope[1]
+        pos = rope[2] if len(rope) > 2 else None
+        _lib.call("vp_attn_bwd_rope", B, Hq, Hkv, Sq, Skv, D, _p(q), qb, qt, _p(k), kb, kt, _p(v), vb, vt, _p(o), ob, ot, _p(lse),
+                  _p(dout), gb, gt, _p(dq), dqb, dqt, _p(dk), dkb, dkt, _p(dv), dvb, dvt, _p(delta), _p(kv_len),
+                  1 if causal else 0, window, scale, _p(cos_t), _p(sin_t), _p(pos), _stream())
+        return dq, dk, dv
     _lib.call("vp_attn_bwd", B, Hq, Hkv, Sq, Skv, D, _p(q), qb, qt, _p(k), kb, kt, _p(v), vb, vt, _p(o), ob, ot, _p(lse),
               _p(dout), gb, gt, _p(dq), dqb, dqt, _p(dk), dkb, dkt, _p(dv), dvb, dvt, _p(delta), _p(kv_len),
               1 if causal else 0, window, scale, _stream())
