@@ -584,6 +584,7 @@ void attn_bwd_dkdv128_kernel(AttnParams p) {
         f32x4 s[KT], dp[KT];
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt) { s[kt] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[kt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks) {
           const bf16x8 qa = *(const bf16x8*)(Qs + (rbase ^ (ks * 32)) + qt * 2048);
@@ -595,6 +596,7 @@ void attn_bwd_dkdv128_kernel(AttnParams p) {
           }
           if (ks & 1) __builtin_amdgcn_sched_barrier(0);     // bound the scheduler's look-ahead: fragments for <= 2 k-steps live
         }
+        __builtin_amdgcn_s_setprio(0);
         const f32x4 l0 = *(const f32x4*)(ld + (qt * 16 + 4 * g) * 2), l1 = *(const f32x4*)(ld + (qt * 16 + 4 * g) * 2 + 4);
         const float lse_r[4] = {l0[0], l0[2], l1[0], l1[2]}, del_r[4] = {l0[1], l0[3], l1[1], l1[3]};
 #pragma unroll
@@ -622,6 +624,7 @@ void attn_bwd_dkdv128_kernel(AttnParams p) {
         dsf[kt] = __builtin_bit_cast(bf16x8, u32x4{dsk[kt][0][0], dsk[kt][0][1], dsk[kt][1][0], dsk[kt][1][1]});
       }
       const uint32_t qs_addr = attn_lds_addr(Qs);      // dO tile = +8192 bytes, rows +16 = +4096 bytes
+      __builtin_amdgcn_s_setprio(1);                  // MFMA bursts at raised priority: the co-resident block's VALU/LDS work yields (-3 %)
 #pragma unroll
       for (int d = 0; d < NDB; ++d) {
         const uint32_t ta_ = qs_addr + 2u * (uint32_t)(tbase ^ (d * 16));
@@ -639,6 +642,7 @@ void attn_bwd_dkdv128_kernel(AttnParams p) {
         for (int kt = 0; kt < KT; ++kt) dk[kt][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tq, dsf[kt], dk[kt][d], 0, 0, 0);
         if (d & 1) __builtin_amdgcn_sched_barrier(0);
       }
+      __builtin_amdgcn_s_setprio(0);
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // trailing (dummy) DMAs must not outlive the block's LDS
@@ -927,6 +931,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         kh = nh;
         if (d & 1) __builtin_amdgcn_sched_barrier(0);
       }
+
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // trailing (dummy) DMAs must not outlive the block's LDS
