@@ -819,7 +819,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
     const long sidx = ((long)b * p.Hq + h) * p.Sq + qrc;
     lse[qt] = p.lse[sidx];
-    dlt[qt] = p.delta[sidx];
+    // delta = rowsum(dO * O) is computed here instead of in a pre-pass kernel (every (b, h, q) row belongs to exactly one wave of this
+    // grid; the dO fragments are already in registers); the (lse, delta) pairs go to the workspace the dK/dV kernel streams from, so
+    // this kernel is launched first
+    const bf16_t* op_ = p.o + (long)b * p.o_bs + (long)qrc * p.o_ts + (long)h * D;
+    float part = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+      const bf16x8 ov = *(const bf16x8*)(op_ + ks * 32 + (lane >> 4) * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) part = fmaf(bf2f((bf16_t)dof[qt][ks][e]), bf2f((bf16_t)ov[e]), part);
+    }
+    part += __shfl_xor(part, 16, 64);
+    part += __shfl_xor(part, 32, 64);
+    dlt[qt] = part;
+    if ((lane >> 4) == 0 && qw0 + qt * 16 + (lane & 15) < p.Sq) {
+      p.delta[sidx] = part;
+      *(float2*)(p.delta + (long)p.B * p.Hq * p.Sq + 2 * sidx) = float2{lse[qt], part};
+    }
   }
   f32x4 dq[2][NDB];
 #pragma unroll
@@ -979,7 +996,7 @@ static int launch_fwd(const AttnParams& p, int causal, hipStream_t s) {
 template <int D>
 static int launch_bwd(const AttnParams& p, int causal, hipStream_t s) {
   const long rows = (long)p.B * p.Hq * p.Sq;
-  hipLaunchKernelGGL((attn_delta_kernel<D>), dim3((unsigned)min(8192L, (rows + 15) / 16)), dim3(256), 0, s, p);
+  if (D != 128) hipLaunchKernelGGL((attn_delta_kernel<D>), dim3((unsigned)min(8192L, (rows + 15) / 16)), dim3(256), 0, s, p);
   static bool attr = false;
   if (!attr) {
     (void)hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<D, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kv_lds_bytes<D>());
@@ -1004,14 +1021,14 @@ static int launch_bwd(const AttnParams& p, int causal, hipStream_t s) {
         (void)hipFuncSetAttribute((const void*)attn_bwd_dq128_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, DQ128_LDS);
         attr3 = true;
       }
+      hipLaunchKernelGGL((attn_bwd_dq128_kernel<true, true>), g2, dim3(256), DQ128_LDS, s, p);          // dQ first: it also writes delta
       hipLaunchKernelGGL((attn_bwd_dkdv128_kernel<true, DKDV_KT, true>), g1, dim3(64 * (8 / DKDV_KT)), DKDV128_LDS, s, p);
-      hipLaunchKernelGGL((attn_bwd_dq128_kernel<true, true>), g2, dim3(256), DQ128_LDS, s, p);
     } else if (causal) {
-      hipLaunchKernelGGL((attn_bwd_dkdv128_kernel<true, DKDV_KT>), g1, dim3(64 * (8 / DKDV_KT)), DKDV128_LDS, s, p);
       hipLaunchKernelGGL((attn_bwd_dq128_kernel<true>), g2, dim3(256), DQ128_LDS, s, p);
+      hipLaunchKernelGGL((attn_bwd_dkdv128_kernel<true, DKDV_KT>), g1, dim3(64 * (8 / DKDV_KT)), DKDV128_LDS, s, p);
     } else {
-      hipLaunchKernelGGL((attn_bwd_dkdv128_kernel<false, DKDV_KT>), g1, dim3(64 * (8 / DKDV_KT)), DKDV128_LDS, s, p);
       hipLaunchKernelGGL((attn_bwd_dq128_kernel<false>), g2, dim3(256), DQ128_LDS, s, p);
+      hipLaunchKernelGGL((attn_bwd_dkdv128_kernel<false, DKDV_KT>), g1, dim3(64 * (8 / DKDV_KT)), DKDV128_LDS, s, p);
     }
   } else if (causal) {
     hipLaunchKernelGGL((attn_bwd_dkdv_kernel<D, true>), g1, dim3(512), 0, s, p);
