@@ -59,9 +59,10 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const bf16_t* __restri
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
-  bf16x8 xv[NCH], gv[NCH];
+  bf16x8 xv[NCH], gv[NCH], rv[NCH];
   load_row<NCH>(x + (long)row * ld, H, lane, xv);
   load_row<NCH>(dy + (long)row * ld, H, lane, gv);
+  if (dres) load_row<NCH>(dres + (long)row * ld, H, lane, rv);      // all three streams in flight before the row reduction (was: after it)
   const float rstd = rstd_in[row];
   float dot = 0.f;
 #pragma unroll
@@ -80,14 +81,12 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const bf16_t* __restri
     const int e = (c * 64 + lane) * 8;
     if (e < H) {
       const bf16x8 wv = *(const bf16x8*)(w + e);
-      bf16x8 rv;
-      if (dres) rv = *(const bf16x8*)(dres + (long)row * ld + e);
       bf16x8 o;
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const float g = bf2f((bf16_t)wv[j]) * bf2f((bf16_t)gv[c][j]);
         float d = rstd * (g - bf2f((bf16_t)xv[c][j]) * coef);
-        if (dres) d += bf2f((bf16_t)rv[j]);
+        if (dres) d += bf2f((bf16_t)rv[c][j]);
         o[j] = (short)f2bf(d);
       }
       *(bf16x8*)(dx + (long)row * ld + e) = o;
