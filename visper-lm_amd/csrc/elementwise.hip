@@ -157,12 +157,27 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const bf16_t* __res
   }
 }
 // out[c] (+)= scale * sum_s part[s, c]
-__global__ void colsum_finish_kernel(const float* __restrict__ part, float* __restrict__ out, int nslab, int N, float scale,
-                                     int accumulate) {
-  for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < N; c += gridDim.x * blockDim.x) {
-    float a = 0.f;
-    for (int s = 0; s < nslab; ++s) a += part[(long)s * N + c];
-    a *= scale;
+__global__ __launch_bounds__(256) void colsum_finish_kernel(const float* __restrict__ part, float* __restrict__ out, int nslab, int N,
+                                                            float scale, int accumulate) {
+  // 64 columns per block, the slabs split over the block's 4 waves with 4 independent partial sums each (the old one-thread-per-column
+  // serial loop over up to 256 slabs took 45 us; this is launch-bound)
+  __shared__ float red[4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), sg = threadIdx.x >> 6;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  if (c < N) {
+    int s = sg;
+    for (; s + 12 < nslab; s += 16) {
+      a0 += part[(long)s * N + c];
+      a1 += part[(long)(s + 4) * N + c];
+      a2 += part[(long)(s + 8) * N + c];
+      a3 += part[(long)(s + 12) * N + c];
+    }
+    for (; s < nslab; s += 4) a0 += part[(long)s * N + c];
+  }
+  red[sg][threadIdx.x & 63] = (a0 + a1) + (a2 + a3);
+  __syncthreads();
+  if (sg == 0 && c < N) {
+    const float a = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x])) * scale;
     out[c] = accumulate ? out[c] + a : a;
   }
 }
@@ -381,7 +396,7 @@ int vp_colsum_partial(long M, int N, const void* x, long ld, float* part, int ro
 
 int vp_colsum_finish(int nslab, int N, const float* part, float* out, float scale, int accumulate, hipStream_t s) {
   VP_REQUIRE(nslab > 0 && N > 0, VP_ERR_BAD_ARG, "vp_colsum_finish: bad args");
-  hipLaunchKernelGGL(colsum_finish_kernel, dim3((N + 255) / 256), dim3(256), 0, s, part, out, nslab, N, scale, accumulate);
+  hipLaunchKernelGGL(colsum_finish_kernel, dim3((N + 63) / 64), dim3(256), 0, s, part, out, nslab, N, scale, accumulate);
   return vp_check_launch("vp_colsum_finish");
 }
 
