@@ -64,6 +64,14 @@ int vp_gemm_bf16_swiglu(int mode, int M, int N, int K, const void* A, long lda, 
 int vp_gemm_tn_bf16(int M, int N, int K, const void* A, long lda, const void* B, long ldb, void* C, long ldc, int out_f32,
                     int accumulate, vp_stream_t stream);
 
+/* Dynamic tile scheduling of the persistent GEMM kernel (per-XCD claim counters): switch it on when collectives (RCCL) run
+ * concurrently with the GEMMs -- a CU held by another kernel then costs its own share instead of stalling the static grid
+ * (Engine.set_distributed does this for world > 1; the reference leaves this to DeepSpeed's stream overlap,
+ * scripts/zero2.json "overlap_comm").  Returns the previous setting.  Off by default. */
+int vp_gemm_set_dynamic(int on);
+/* dev aid (tools/gemm_interference.py): `blocks` workgroups pinning 64 KB of LDS each and spinning for `cycles` shader cycles. */
+int vp_debug_occupy(int blocks, long cycles, vp_stream_t stream);
+
 /* dev aid (tools/gemm_stamps.py): per-block timestamps written by gemm_nt_256p8 when VP_GEMM_DBG=65536; 256*8 longs. */
 int vp_debug_stamps(long* host);
 

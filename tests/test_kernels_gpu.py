@@ -281,6 +281,31 @@ def test_attn_bwd_fused_rope(ops):
     assert torch.equal(d1, d3)
 
 
+def test_gemm_dynamic_tile_scheduling(ops):
+    """Per-XCD dynamic tile claims == the static walk, bit for bit, launch after launch (the kernel re-arms its counters), with and without
+    a stand-in collective holding 24 CUs; also the fused SwiGLU launches."""
+    M, N, K = 4608, 4096, 256                         # 18 x 16 = 288 tiles: persistent grid, 1-2 tiles per block
+    a, w = dev(rnd(M, K, seed=90)), dev(rnd(N, K, scale=0.1, seed=91))
+    ref = ops.gemm(a, w)
+    M2, F2 = 8192, 4096                               # 32 x 32 tiles of [gate|up]
+    x2, wgu = dev(rnd(M2, 256, seed=92)), ops.interleave_gate_up(dev(rnd(2 * F2, 256, scale=0.1, seed=93)))
+    gu_ref, act_ref = ops.gemm_swiglu_fwd(x2, wgu)
+    prev = ops._lib.raw("vp_gemm_set_dynamic", 1)
+    try:
+        for it in range(4):
+            if it == 2:
+                side = torch.cuda.Stream()
+                with torch.cuda.stream(side):
+                    ops._lib.call("vp_debug_occupy", 24, 3000000, torch.cuda.current_stream().cuda_stream)
+            assert torch.equal(ops.gemm(a, w), ref)
+            gu, act = ops.gemm_swiglu_fwd(x2, wgu)
+            assert torch.equal(gu, gu_ref) and torch.equal(act, act_ref)
+        torch.cuda.synchronize()
+    finally:
+        ops._lib.raw("vp_gemm_set_dynamic", prev)
+    assert torch.equal(ops.gemm(a, w), ref)
+
+
 @pytest.mark.parametrize("kind", [1, 3])
 def test_act(ops, kind):
     x, d = rnd(40, 64, seed=22), rnd(40, 64, seed=23)

@@ -14,6 +14,8 @@
 // ends up with 4 consecutive output columns of one token row.  Block ids are remapped XCD-aware so tiles sharing an operand
 // panel sit in one XCD's L2.
 #include "common.h"
+#include <mutex>
+#include <unordered_map>
 #include <cstdlib>
 
 enum { EPI_NONE = 0, EPI_GELU = 1, EPI_QUICK_GELU = 2, EPI_RELU = 3 };
@@ -36,6 +38,8 @@ struct GemmArgs {
   long ldc2;
   const bf16_t* aux;
   long ldaux;
+  // dynamic tile scheduling (8-phase kernel, persistent grid only): 8 per-XCD claim counters + a done counter, or NULL = static v += 256
+  int* sched;
 };
 
 __device__ __forceinline__ float apply_epi(float v, int epi) {
@@ -622,6 +626,8 @@ __global__ __launch_bounds__(512) void gemm_nt_256p8(GemmArgs p) {
 
   int v = blockIdx.x;
   bool first_tile = true;
+  __shared__ int s_next;
+  const bool dyn = p.sched != nullptr && gridDim.x == 256;
   STAMP(0);
   int sbm = 0, sbn = 0;                                // super-block walk when the (persistent) grid and the tile grid allow it
   if (gridDim.x == 256 && !(p.dbg & 0x40000)) {
@@ -657,7 +663,15 @@ __global__ __launch_bounds__(512) void gemm_nt_256p8(GemmArgs p) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     const TileCoord tcur = tc;
-    const int vnext = v + gridDim.x;
+    int vnext = v + gridDim.x;
+    // Dynamic scheduling (used when another kernel, e.g. an RCCL collective, may hold some CUs: a block that starts late would otherwise
+    // do its whole static share after everyone else has finished).  Each XCD's 32 resident blocks claim the XCD's tiles in order from a
+    // per-XCD counter, so tile v still runs on XCD v & 7 and the super-block walk keeps its L2 residency.  The claim for the NEXT tile is made
+    // here, at the start of the current one; every wave reads it a K loop (many barriers) later.
+    if (dyn && tid == 0) {
+      const int kq = atomicAdd(p.sched + (blockIdx.x & 7), 1);
+      s_next = (kq >> 5) * 256 + (kq & 31) * 8 + (int)(blockIdx.x & 7);
+    }
     for (int t = 0; t < nt; ++t) {
       const int cur = t & 1;
       const bf16_t* As = smem + cur * 32768;
@@ -667,6 +681,7 @@ __global__ __launch_bounds__(512) void gemm_nt_256p8(GemmArgs p) {
 #pragma unroll
         for (int pc = 0; pc < 4; ++pc) { src[pc][0] += 64; src[pc][1] += 64; }
       } else {
+        if (dyn) vnext = __builtin_amdgcn_readfirstlane(*(volatile int*)&s_next);
         if (vnext < ntiles) tc = TILE_OF(vnext);
         SET_SRC(tc);
       }
@@ -767,6 +782,15 @@ __global__ __launch_bounds__(512) void gemm_nt_256p8(GemmArgs p) {
     VP_BAR();                                          // every wave is done with the staging slices before the next DMA lands there
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the final dummy DMAs must not outlive the workgroup's LDS
+  if (dyn && tid == 0) {                               // the last block out re-arms the counters for the next launch on this stream
+    __threadfence();
+    if (atomicAdd(p.sched + 8, 1) == (int)gridDim.x - 1) {
+#pragma unroll
+      for (int x = 0; x < 8; ++x) p.sched[x] = 32;
+      p.sched[8] = 0;
+      __threadfence();
+    }
+  }
   first_tile = true;
   STAMP(5);
 #undef SET_SRC
@@ -1289,6 +1313,33 @@ __global__ __launch_bounds__(256) void transpose_bf16_kernel(const bf16_t* in, b
   }
 }
 
+// Dynamic tile scheduling of the persistent 8-phase kernel: off by default (single GPU: nothing else runs beside the GEMMs), switched on by
+// vp_gemm_set_dynamic(1) / VP_GEMM_DYN=1 when collectives run concurrently.  One 9-int counter block per stream, created on first use (the
+// only device memory the library owns); the kernel re-arms it itself, so launches on one stream need no host work in between.
+__global__ void occupy_kernel(long cycles) {
+  extern __shared__ unsigned char occ_lds[];
+  occ_lds[threadIdx.x] = 1;
+  const long t0 = clock64();
+  while (clock64() - t0 < cycles) __builtin_amdgcn_s_sleep(8);
+  if (occ_lds[threadIdx.x] == 77) occ_lds[0] = 2;
+}
+static int g_dyn_mode = -1;
+static int* vp_sched_for(hipStream_t s) {
+  if (g_dyn_mode < 0) { const char* v = getenv("VP_GEMM_DYN"); g_dyn_mode = v ? atoi(v) : 0; }
+  if (!g_dyn_mode) return nullptr;
+  static std::mutex mu;
+  static std::unordered_map<hipStream_t, int*> tab;
+  std::lock_guard<std::mutex> lk(mu);
+  auto it = tab.find(s);
+  if (it != tab.end()) return it->second;
+  int* d = nullptr;
+  if (hipMalloc(&d, 9 * sizeof(int)) != hipSuccess) return nullptr;
+  const int init[9] = {32, 32, 32, 32, 32, 32, 32, 32, 0};
+  if (hipMemcpy(d, init, sizeof(init), hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(d); return nullptr; }
+  tab[s] = d;
+  return d;
+}
+
 static bool vp_ph4_enabled() {
   static int e = -1;
   if (e < 0) { const char* v = getenv("VP_GEMM_PH4"); e = v ? atoi(v) : 0; }
@@ -1296,6 +1347,24 @@ static bool vp_ph4_enabled() {
 }
 
 extern "C" {
+
+// 1: the persistent GEMM claims its tiles dynamically (per-XCD counters) so that CUs held by a concurrent kernel (RCCL) only cost their own
+// share; 0: static assignment (default).  Returns the previous setting.
+int vp_gemm_set_dynamic(int on) {
+  const int prev = g_dyn_mode > 0 ? 1 : 0;
+  g_dyn_mode = on ? 1 : 0;
+  return prev;
+}
+
+// dev aid (tools/gemm_interference.py): `blocks` workgroups that each pin 64 KB of LDS (so no 8-phase GEMM block fits beside them) and spin
+// for `cycles` shader cycles -- a stand-in for a collective kernel holding CUs
+int vp_debug_occupy(int blocks, long cycles, hipStream_t stream) {
+  VP_REQUIRE(blocks > 0 && cycles > 0, VP_ERR_BAD_ARG, "vp_debug_occupy: bad args");
+  static bool attr = false;
+  if (!attr) { (void)hipFuncSetAttribute((const void*)occupy_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 65536); attr = true; }
+  hipLaunchKernelGGL(occupy_kernel, dim3(blocks), dim3(64), 65536, stream, cycles);
+  return vp_check_launch("vp_debug_occupy");
+}
 
 int vp_debug_stamps(long* host) {
   return hipMemcpyFromSymbol(host, HIP_SYMBOL(vp_dbg_stamps), sizeof(long) * 256 * 8) == hipSuccess ? 0 : 1;
@@ -1357,6 +1426,7 @@ int vp_gemm_bf16(int M, int N, int K, const void* A, long lda, const void* B, lo
     // persistent (one block per CU streaming its output tiles) when the K-tile count is even (buffer parity is then the same
     // for every output tile); otherwise one block per output tile
     const unsigned g8 = (unsigned)(((K / 64) % 2 == 0 && big_tiles > 256 && !(p.dbg & 0x20000)) ? 256 : big_tiles);
+    if (g8 == 256) p.sched = vp_sched_for(stream);
     if (out_f32) hipLaunchKernelGGL(gemm_nt_256p8<true>, dim3(g8), dim3(512), 131072, stream, p);
     else if (vp_ph4_enabled() && force_generic == 0) {
       static bool attr_p4 = false;
@@ -1418,6 +1488,7 @@ int vp_gemm_bf16_swiglu(int mode, int M, int N, int K, const void* A, long lda, 
   }
   const long big_tiles = (long)(M / 256) * (N / 256);
   const unsigned g8 = (unsigned)(((K / 64) % 2 == 0 && big_tiles > 256) ? 256 : big_tiles);
+  if (g8 == 256) p.sched = vp_sched_for(stream);
   if (vp_ph4_enabled()) {
     static bool attr_p4 = false;
     if (!attr_p4) { (void)hipFuncSetAttribute((const void*)gemm_nt_256p8<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072); attr_p4 = true; }

@@ -369,6 +369,10 @@ class Engine:
 
     def set_distributed(self, rank, world):
         self.rank, self.world = rank, world
+        # with collectives running beside the GEMMs the persistent kernel claims its tiles dynamically (a CU held by an RCCL kernel then
+        # costs its own share instead of stalling the whole static grid); single GPU keeps the static walk
+        if self.dev.type == "cuda" and os.environ.get("VP_GEMM_DYN") is None:
+            ops._lib.raw("vp_gemm_set_dynamic", 1 if world > 1 else 0)
 
     def _reducer(self):
         from .parallel import GradReducer
