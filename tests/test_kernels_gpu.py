@@ -290,6 +290,8 @@ def test_gemm_dynamic_tile_scheduling(ops):
     M2, F2 = 8192, 4096                               # 32 x 32 tiles of [gate|up]
     x2, wgu = dev(rnd(M2, 256, seed=92)), ops.interleave_gate_up(dev(rnd(2 * F2, 256, scale=0.1, seed=93)))
     gu_ref, act_ref = ops.gemm_swiglu_fwd(x2, wgu)
+    dyt, xt = dev(rnd(512, 4352, seed=94)), dev(rnd(512, 4096, seed=95))       # TN weight gradient, 17 x 16 tiles
+    tn_ref = ops.gemm_tn(dyt, xt)
     prev = ops._lib.raw("vp_gemm_set_dynamic", 1)
     try:
         for it in range(4):
@@ -300,6 +302,7 @@ def test_gemm_dynamic_tile_scheduling(ops):
             assert torch.equal(ops.gemm(a, w), ref)
             gu, act = ops.gemm_swiglu_fwd(x2, wgu)
             assert torch.equal(gu, gu_ref) and torch.equal(act, act_ref)
+            assert torch.equal(ops.gemm_tn(dyt, xt), tn_ref)
         torch.cuda.synchronize()
     finally:
         ops._lib.raw("vp_gemm_set_dynamic", prev)

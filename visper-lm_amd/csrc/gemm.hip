@@ -906,6 +906,8 @@ __global__ __launch_bounds__(512) void gemm_tn_256p8(GemmArgs p) {
 #define END_R() asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); VP_BAR();     /* ds_reads keep flying across the barrier; the MFMAs wait for them */
 
   int v = blockIdx.x;
+  __shared__ int s_next;
+  const bool dyn = p.sched != nullptr && gridDim.x == 256;
   int sbm = 0, sbn = 0;                                // super-block walk when the (persistent) grid and the tile grid allow it
   if (gridDim.x == 256 && !(p.dbg & 0x40000)) {
     if (tiles_m % 16 == 0 && tiles_n % 16 == 0) { sbm = 16; sbn = 16; }
@@ -936,7 +938,11 @@ __global__ __launch_bounds__(512) void gemm_tn_256p8(GemmArgs p) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     const TileCoord tcur = tc;
-    const int vnext = v + gridDim.x;
+    int vnext = v + gridDim.x;
+    if (dyn && tid == 0) {                               // dynamic per-XCD tile claim for the NEXT tile (see gemm_nt_256p8)
+      const int kq = atomicAdd(p.sched + (blockIdx.x & 7), 1);
+      s_next = (kq >> 5) * 256 + (kq & 31) * 8 + (int)(blockIdx.x & 7);
+    }
     for (int t = 0; t < nt; ++t) {
       const int cur = t & 1;
       const uint32_t co = (uint32_t)cur << 16;        // byte offset of the current buffer
@@ -945,6 +951,7 @@ __global__ __launch_bounds__(512) void gemm_tn_256p8(GemmArgs p) {
 #pragma unroll
         for (int pc = 0; pc < 4; ++pc) { const long st_ = (pc == 0 || pc == 3) ? stepA : stepB; src[pc][0] += st_; src[pc][1] += st_; }
       } else {
+        if (dyn) vnext = __builtin_amdgcn_readfirstlane(*(volatile int*)&s_next);
         if (vnext < ntiles) tc = TILE_OF(vnext);
         SET_SRC(tc);
       }
@@ -1025,6 +1032,15 @@ __global__ __launch_bounds__(512) void gemm_tn_256p8(GemmArgs p) {
     VP_BAR();                                          // every wave is done with the staging slices before the next DMA lands there
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the final dummy DMAs must not outlive the workgroup's LDS
+  if (dyn && tid == 0) {                               // the last block out re-arms the counters for the next launch on this stream
+    __threadfence();
+    if (atomicAdd(p.sched + 8, 1) == (int)gridDim.x - 1) {
+#pragma unroll
+      for (int x = 0; x < 8; ++x) p.sched[x] = 32;
+      p.sched[8] = 0;
+      __threadfence();
+    }
+  }
 #undef SET_SRC
 #undef TILE_OF
 #undef ISSUE_PIECE
@@ -1520,6 +1536,7 @@ int vp_gemm_tn_bf16(int M, int N, int K, const void* A, long lda, const void* B,
   }
   const long big_tiles = (long)(M / 256) * (N / 256);
   const unsigned g8 = (unsigned)(((K / 64) % 2 == 0 && big_tiles > 256) ? 256 : big_tiles);
+  if (g8 == 256) p.sched = vp_sched_for(stream);
   if (out_f32) hipLaunchKernelGGL(gemm_tn_256p8<true>, dim3(g8), dim3(512), 131072, stream, p);
   else hipLaunchKernelGGL(gemm_tn_256p8<false>, dim3(g8), dim3(512), 131072, stream, p);
   return vp_check_launch("vp_gemm_tn_bf16");
