@@ -336,9 +336,37 @@ def run_data_path():
         img = Image.fromarray((np.arange(w * h * 3).reshape(h, w, 3) % 251).astype(np.uint8), "RGB")
         sq = expand2square(img, (122, 116, 104))
         res["squares"].append({"size": [w, h], "out": np.asarray(sq).tolist()})
+    # the supervised collator: ola_vlm/train/ola_vlm_train.py does not import under the installed transformers (Trainer-side private APIs), so
+    # the class definition alone is compiled from the reference file (read in place, at generation time only) and run as is
+    import ast
+    import dataclasses
+    import typing
+    import transformers
+    ref_file = os.path.join(REF, "ola_vlm", "train", "ola_vlm_train.py")
+    tree = ast.parse(open(ref_file).read(), filename=ref_file)
+    node = [n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == "DataCollatorForSupervisedDataset"][0]
+    ns = {"torch": torch, "transformers": transformers, "dataclass": dataclasses.dataclass, "Sequence": typing.Sequence, "Dict": typing.Dict,
+          "IGNORE_INDEX": -100}
+    exec(compile(ast.Module(body=[node], type_ignores=[]), ref_file, "exec"), ns)
+    coll = ns["DataCollatorForSupervisedDataset"](tokenizer=types.SimpleNamespace(pad_token_id=0, model_max_length=9))
+    cases = []
+    for ragged in (False, True):
+        inst = []
+        for i, L in enumerate((5, 12, 9)):
+            ids = torch.arange(1, L + 1) + 10 * i
+            side = 5 if (ragged and i == 1) else 4
+            inst.append(dict(input_ids=ids, labels=ids.clone().masked_fill(ids % 3 == 0, -100), image=torch.full((3, side, side), float(i)),
+                             pil_image=None, seg_mask=int(i != 1), depth_mask=int(i == 1), gen_mask=1))
+        b = coll(inst)
+        cases.append({"ragged": ragged, "input_ids": b["input_ids"].tolist(), "labels": b["labels"].tolist(),
+                      "attention_mask": b["attention_mask"].long().tolist(), "images_is_list": isinstance(b["images"], list),
+                      "images_shape": None if isinstance(b["images"], list) else list(b["images"].shape),
+                      "keys": sorted(b.keys()), "seg_mask": b["seg_mask"].tolist(), "depth_mask": b["depth_mask"].tolist(),
+                      "gen_mask": b["gen_mask"].tolist(), "seg_mask_dtype": str(b["seg_mask"].dtype)})
+    res["collator"] = cases
     with open(os.path.join(OUT, "data_path.json"), "w") as fh:
         json.dump(res, fh)
-    print("data_path: ", res["with_bos"][1])
+    print("data_path: ", res["with_bos"][1], "| collator keys", cases[0]["keys"])
 
 
 def run_dinov2_teacher():

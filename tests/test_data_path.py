@@ -58,6 +58,27 @@ def test_collator_pads_truncates_and_masks_like_the_reference():
     assert isinstance(data.Collator(pad, mx, pin_memory=False)(inst)["images"], list)
 
 
+def test_collator_matches_the_reference_class():
+    """Fixture produced by the reference's own DataCollatorForSupervisedDataset (class body compiled from ola_vlm_train.py:881-925 at
+    generation time, oracle/gen_golden.py data): same keys, padding, truncation, mask, image stacking rule and task-mask tensors."""
+    for case in G["collator"]:
+        inst = []
+        for i, L in enumerate((5, 12, 9)):
+            ids = torch.arange(1, L + 1) + 10 * i
+            side = 5 if (case["ragged"] and i == 1) else 4
+            inst.append(dict(input_ids=ids, labels=ids.clone().masked_fill(ids % 3 == 0, IGNORE_INDEX), image=torch.full((3, side, side), float(i)),
+                             pil_image=None, seg_mask=int(i != 1), depth_mask=int(i == 1), gen_mask=1))
+        b = data.Collator(0, 9, pin_memory=False)(inst)
+        assert sorted(b.keys()) == case["keys"]
+        assert b["input_ids"].tolist() == case["input_ids"] and b["labels"].tolist() == case["labels"]
+        assert b["attention_mask"].long().tolist() == case["attention_mask"] and b["attention_mask"].dtype == torch.bool
+        assert isinstance(b["images"], list) == case["images_is_list"]
+        if not case["images_is_list"]:
+            assert list(b["images"].shape) == case["images_shape"]
+        for k in ("seg_mask", "depth_mask", "gen_mask"):
+            assert b[k].tolist() == case[k] and str(b[k].dtype) == case["seg_mask_dtype"]
+
+
 def test_adapter_state_selects_the_projector_only():
     named = [("model.mm_projector.0.weight", torch.zeros(2, 2)), ("model.embed_tokens.weight", torch.zeros(3, 2)),
              ("image_gen_heads.0.projector.proj_in.weight", torch.zeros(1))]
