@@ -150,6 +150,7 @@ def main():
     ap.add_argument("--workload", default="llama3_8b", choices=["llama3_8b", "convnext", "phi3", "ift"],
                     help="llama3_8b = BASELINE configs[1] (the headline metric); convnext = configs[3]; phi3 = configs[4] (secondary)")
     ap.add_argument("--lr", type=float, default=1e-3)
+    ap.add_argument("--same-batch", action="store_true", help="A/B aid: replay one batch (splice-plan cache hit) instead of a fresh one per step")
     ap.add_argument("--force-dist", action="store_true", help="initialise the RCCL process group even with one rank (test hook)")
     args = ap.parse_args()
 
@@ -203,7 +204,21 @@ def main():
     eng = Engine(cfg, device=dev)
     eng.set_distributed(rank, world)
     eng.init_random(seed=0)                       # identical weights on every rank
-    batch = make_batch(cfg, args.batch, args.text_len, rank, dev)
+    # A FRESH batch every step, as a dataloader delivers it (ola_vlm_train.py:882-925): new input_ids / labels each step, so the host
+    # splice plan (ola_arch.py:256-444 restated in splice.host_plan), its H2D copy and the head tables are paid inside the timed
+    # region; images / teacher targets rotate through 4 distinct sets already resident in HBM.
+    n_total = args.warmup + args.steps
+    pool = [make_batch(cfg, args.batch, args.text_len, rank + 1000 * j, dev) for j in range(4)]
+    gi = torch.Generator().manual_seed(4321 + rank)
+    fresh = []
+    for j in range(n_total):
+        b = dict(pool[j % len(pool)])
+        ids = torch.randint(0, 1000, (args.batch, args.text_len), generator=gi)
+        ids[:, cfg.num_sys_tokens] = -200
+        lab = ids.clone()
+        lab[:, :cfg.num_sys_tokens + 7] = -100
+        b["input_ids"], b["labels"] = ids, lab
+        fresh.append(b)
 
     from visper_lm_amd import optim
     total_steps = 2181                                  # LLaVA-558K / global batch 256 (scripts/train/pretrain.sh), 3 % warm-up, cosine
@@ -211,7 +226,7 @@ def main():
     it = [0]
 
     def step():
-        out = eng.train_step(batch)
+        out = eng.train_step(fresh[it[0] % n_total] if not args.same_batch else fresh[0])
         eng.optimizer_step(lr=args.lr, lr_mult=optim.cosine_with_warmup(it[0], total_steps, n_warm))   # wd 0, no clipping: pretrain.sh
         it[0] += 1
         return out
@@ -276,7 +291,7 @@ def main():
                                        "ift": "SURVEY f-2: CLIP-ViT-L/14-336 + Llama-3-8B IFT step (NTP only, whole LLM trainable)"}[args.workload],
                           "global_batch": args.batch * world, "per_gpu_batch": args.batch, "seq_len": S, "text_len": args.text_len,
                           "parallelism": f"dp{world}", "decoder_layers": cfg.num_hidden_layers, "loss": round(loss, 4),
-                          "depth_decoder": bool(cfg.depth_decoder),
+                          "depth_decoder": bool(cfg.depth_decoder), "fresh_batch_per_step": not args.same_batch,
                           "valid": args.layers is None},
                "roofline": roof}
         if world == 1 and not args.no_cpu_baseline and args.workload == "llama3_8b":

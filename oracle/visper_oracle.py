@@ -42,6 +42,8 @@ def make_config(**kw) -> SimpleNamespace:
         vocab_size=128256, hidden_size=4096, intermediate_size=14336, num_hidden_layers=32,
         num_attention_heads=32, num_key_value_heads=8, rms_norm_eps=1e-5, rope_theta=500000.0,
         sliding_window=None,
+        sliding_window_inclusive=False,   # False: transformers 5.x mask (keys with q-k < window; the goldens were generated under 5.x);
+                                          # True: transformers 4.41.1, the reference's pin (q-k <= window: tril diagonal = -window-1)
         # vision tower (CLIP-ViT-L/14-336)
         vit_hidden=1024, vit_inter=4096, vit_layers=24, vit_heads=16, vit_image=336, vit_patch=14,
         vit_eps=1e-5, mm_vision_select_layer=-2, mm_vision_select_feature="patch",
@@ -302,7 +304,9 @@ def decoder_forward(inputs_embeds, position_ids, attention_mask, W, cfg, prefix=
     neg = torch.finfo(x.dtype).min
     causal = torch.ones(S, S, dtype=torch.bool).tril()
     if cfg.sliding_window is not None:
-        causal = causal & ~torch.ones(S, S, dtype=torch.bool).tril(-int(cfg.sliding_window))
+        # HF 4.41.1 AttentionMaskConverter._make_causal_mask masks tril(diagonal = -window - 1) -> window + 1 visible keys;
+        # HF 5.x masking_utils.sliding_window_overlay keeps kv > q - window -> window visible keys
+        causal = causal & ~torch.ones(S, S, dtype=torch.bool).tril(-(int(cfg.sliding_window) + int(getattr(cfg, "sliding_window_inclusive", False))))
     allow = causal[None, None]
     if attention_mask is not None:
         allow = allow & attention_mask.bool()[:, None, None, :]

@@ -438,3 +438,82 @@ def test_clip_image_embed_teacher_padded_head_dim():
     with torch.no_grad():
         ref = O.clip_image_embeds(images.to(BF).float(), {k: v.to(BF).float() for k, v in W.items()}, nh, P)
     assert float((got - ref).abs().max() / ref.abs().max()) < 3e-2
+
+
+def test_left_padding_ntp_matches_oracle():
+    """ola_arch.py:408-427 with tokenizer_padding_side == "left" (ragged batch, NTP only: aux heads + ragged left padding are refused,
+    see splice.host_plan): loss and every gradient equal the oracle's left-padded run; labels / attention_mask / position_ids and the
+    real rows of inputs_embeds / hidden are presented right-aligned exactly like the reference lays them out."""
+    from oracle import cases, visper_oracle as O
+    from visper_lm_amd.config import VisperConfig
+    from visper_lm_amd.engine import Engine
+    from parity import check, rel, max_rel, grad_err
+    ocfg, W, batch, g = cases.tiny_llama_case()
+    ocfg = O.make_config(**{**vars(ocfg), "aux_mode": "", "num_task_tokens": 0, "tokenizer_padding_side": "left"})
+    batch = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in batch.items() if k in ("input_ids", "labels", "attention_mask", "images")}
+    batch["attention_mask"][1, 42:] = False
+    eng = Engine(VisperConfig(**vars(ocfg)))
+    eng.load_weights(W)
+    out = eng.train_step(_to_gpu_batch(batch))
+    tr = [k for k in eng.ps.index]
+    Wq = {k: v.to(BF).float() for k, v in W.items()}
+    for k in tr:
+        Wq[k] = Wq[k].clone().requires_grad_(True)
+    bq = {k: (v.to(BF).float() if (torch.is_tensor(v) and v.is_floating_point()) else v) for k, v in batch.items()}
+    ref = O.forward(Wq, bq, ocfg)
+    ref["loss"].backward()
+    plan = out["plan"]
+    assert plan["side"] == "left" and not plan["full"]
+    assert torch.equal(plan["labels"], ref["labels"])
+    am = plan["attention_mask"]
+    check("left_pad/loss_rel", rel(out["loss"], ref["loss"]), 2e-3)
+    emb, remb = out["inputs_embeds"].float().cpu(), ref["inputs_embeds"].detach()
+    assert float(emb[~am].abs().max()) == 0.0 and float(remb[~am].abs().max()) == 0.0          # pad rows are zeros on the left
+    check("left_pad/inputs_embeds_maxrel", max_rel(emb[am], remb[am]), 1e-2)
+    check("left_pad/hidden_real_rows_maxrel", max_rel(out["hidden"].float().cpu()[am], ref["hidden"].detach()[am]), 3e-2)
+    for k in tr:
+        want = Wq[k].grad
+        got = eng.ps.g(k).detach().float().cpu()
+        if want is None:
+            assert float(got.abs().max()) == 0.0, k
+            continue
+        c, n = grad_err(got, want)
+        check(f"left_pad/grad/{k}/one_minus_cos", c, 3e-2)
+        check(f"left_pad/grad/{k}/norm_dev", n, 0.1)
+
+
+def test_checkpoint_resume_is_bitwise(tmp_path):
+    """the PT run must persist heads / task tokens / logit scales and the optimizer state (llava_trainer.py:997-1016 +
+    HF Trainer checkpoints, resume at ola_vlm_train.py:1306-1309): 2 steps + save + load into a FRESH engine + 2 steps ==
+    4 uninterrupted steps, bit for bit; weights-only loading gives the bf16-rounded parameters."""
+    from oracle import cases
+    from safetensors.torch import load_file
+    from visper_lm_amd import data
+    from visper_lm_amd.config import VisperConfig
+    from visper_lm_amd.engine import Engine
+    ocfg, W, batch, g = cases.tiny_llama_case()
+    b = _to_gpu_batch(batch)
+
+    def fresh():
+        e = Engine(VisperConfig(**vars(ocfg)))
+        e.load_weights(W)
+        return e
+
+    def steps(e, n):
+        for _ in range(n):
+            e.train_step(b)
+            e.optimizer_step(lr=1e-3, weight_decay=0.01)
+    a = fresh(); steps(a, 4)
+    c = fresh(); steps(c, 2)
+    data.save_checkpoint(c, str(tmp_path))
+    sd = load_file(str(tmp_path / "trainable.safetensors"))
+    assert sorted(sd) == sorted(c.ps.index) and any("_heads." in k for k in sd) and "seg_logit_scale" in sd
+    assert sd["model.special_depth_tokens"].dtype == torch.bfloat16 and sd["seg_logit_scale"].dtype == torch.float32
+    d = fresh()
+    loaded = data.load_checkpoint(d, str(tmp_path))
+    assert sorted(loaded) == sorted(d.ps.index) and d.ps.step == 2
+    steps(d, 2)
+    assert torch.equal(a.ps.master, d.ps.master) and torch.equal(a.ps.exp_avg_sq, d.ps.exp_avg_sq) and torch.equal(a.ps.shadow, d.ps.shadow)
+    e = fresh()
+    data.load_checkpoint(e, str(tmp_path), resume_optimizer=False)
+    assert e.ps.step == 0 and torch.equal(e.ps.shadow, c.ps.shadow)

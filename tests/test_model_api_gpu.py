@@ -121,3 +121,70 @@ def test_attached_gpu_teachers_feed_the_step():
     out1 = model(**common, depth_pixels=px)
     out2 = model(**common, depth_target=t.forward(px))
     assert torch.isfinite(out1.loss) and torch.equal(out1.loss.detach(), out2.loss.detach())
+
+
+def _mirror_from_tiny():
+    from oracle import cases
+    from visper_lm_amd.model import OlaLlavaLlamaForCausalLM, OlaLlavaLlamaConfig
+    ocfg, W, batch, g = cases.tiny_llama_case()
+    model = OlaLlavaLlamaForCausalLM(OlaLlavaLlamaConfig(**vars(ocfg)), init="empty")
+    sd = {k.replace("model.vision_tower.vision_tower.", "model.vision_tower.vision_tower.vision_model.")
+          if k.startswith("model.vision_tower.vision_tower.") else k: v for k, v in W.items()}
+    model.load_state_dict(sd, strict=True)
+    model.reload_frozen()
+    B = batch["input_ids"].shape[0]
+    kw = dict(input_ids=batch["input_ids"], attention_mask=batch["attention_mask"], labels=batch["labels"], images=batch["images"].cuda(),
+              gen_mask=torch.ones(B).cuda(), seg_mask=torch.ones(B).cuda(), depth_mask=torch.ones(B).cuda(),
+              gen_target=batch["gen_target"].cuda(), depth_target=batch["depth_target"].cuda(), seg_target=batch["seg_target"].cuda())
+    return model, kw
+
+
+def test_model_api_with_engine_optimizer_makes_progress():
+    """model(**batch).loss.backward() + Engine.optimizer_step must train — the nn.Parameters and the engine's
+    flat master are ONE state: the loss falls, state_dict() moves, and a second model built from that state_dict reproduces the loss."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    model, kw = _mirror_from_tiny()
+    before = {k: v.clone() for k, v in model.state_dict().items() if "mm_projector" in k or "_heads.0.projector.proj_in" in k}
+    losses = []
+    for i in range(4):
+        out = model(**kw)
+        out.loss.backward()
+        losses.append(float(out.loss))
+        if i % 2 == 0:
+            model.optimizer_step(lr=1e-3)                        # convenience wrapper ...
+        else:
+            model._get_engine().optimizer_step(lr=1e-3)          # ... and the INTEGRATION.md recipe (engine stepped behind the model's back)
+    assert losses[-1] < losses[0] - 1e-3 and all(b < a for a, b in zip(losses, losses[1:])), losses
+    sd = model.state_dict()
+    assert all(not torch.equal(sd[k], v) for k, v in before.items())
+    eng = model._get_engine()
+    for n in ("model.mm_projector.0.weight", "image_seg_heads.0.projector.proj_in.weight"):
+        assert torch.equal(sd[n], eng.ps.p(n).to(sd[n].dtype).reshape(sd[n].shape))
+    final = float(model(**kw).loss)
+    from visper_lm_amd.model import OlaLlavaLlamaForCausalLM
+    clone = OlaLlavaLlamaForCausalLM(model.config, init="empty")
+    clone.load_state_dict(sd, strict=True)
+    clone.reload_frozen()
+    assert abs(float(clone(**kw).loss) - final) < 2e-2 * abs(final)          # bf16 state_dict vs the fp32 master it was cast from
+
+
+def test_model_api_with_external_torch_optimizer():
+    """HF Trainer's shape (ola_vlm_train.py:1297-1309): torch.optim.AdamW over model.parameters() steps the nn.Parameters; the
+    engine picks the new values up through their version counters."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    model, kw = _mirror_from_tiny()
+    opt = torch.optim.AdamW([p for p in model.parameters() if p.requires_grad], lr=1e-3, weight_decay=0.0)
+    losses = []
+    for _ in range(3):
+        opt.zero_grad(set_to_none=True)
+        out = model(**kw)
+        out.loss.backward()
+        opt.step()
+        losses.append(float(out.loss))
+    assert losses[2] < losses[1] < losses[0], losses
+    eng = model._get_engine()
+    model._sync_trainable()
+    p = dict(model.named_parameters())["model.mm_projector.2.weight"]
+    assert torch.equal(eng.ps.w("model.mm_projector.2.weight"), p.detach().to(torch.bfloat16))

@@ -20,6 +20,9 @@ class VisperConfig:
             vocab_size=128256, hidden_size=4096, intermediate_size=14336, num_hidden_layers=32,
             num_attention_heads=32, num_key_value_heads=8, rms_norm_eps=1e-5, rope_theta=500000.0,
             sliding_window=None, max_position_embeddings=8192,
+            # which HF release defines the sliding-window mask: False = transformers 5.x (keys with q-k < window), True = 4.41.1, the
+            # reference's pin (README.md:57; q-k <= window, i.e. window+1 keys: AttentionMaskConverter tril(diagonal=-window-1))
+            sliding_window_inclusive=False,
             # CLIP-ViT-L/14-336 tower (multimodal_encoder/clip_encoder.py)
             mm_vision_tower="openai/clip-vit-large-patch14-336",
             vit_hidden=1024, vit_inter=4096, vit_layers=24, vit_heads=16, vit_image=336, vit_patch=14, vit_eps=1e-5,
@@ -88,7 +91,7 @@ def phi3_mini(**kw) -> VisperConfig:
     """BASELINE.json configs[4]: Phi-3-mini-4k (H 3072, 32 MHA heads x 96, FF 8192, V 32064, theta 1e4, window 2047)."""
     d = dict(arch="phi3", vocab_size=32064, hidden_size=3072, intermediate_size=8192, num_hidden_layers=32,
              num_attention_heads=32, num_key_value_heads=32, rope_theta=10000.0, sliding_window=2047,
-             max_position_embeddings=4096)
+             sliding_window_inclusive=True, max_position_embeddings=4096)
     d.update(kw)
     c = VisperConfig(**d)
     c.model_type = "ola_phi3"

@@ -110,3 +110,30 @@ def load_mm_projector(engine, path: str) -> List[str]:
             loaded.append(name)
     engine.ps.refresh_shadow()
     return loaded
+
+
+def save_checkpoint(engine, out_dir: str) -> None:
+    """What the reference's PT trainer leaves in a checkpoint directory that matters for the path (llava_trainer.py:997-1016 +
+    HF Trainer._save_checkpoint): `mm_projector.bin` (the adapter, loaded by the IFT stage through --pretrain_mm_mlp_adapter),
+    the trained modules under their reference names (heads, special_*_tokens, *_logit_scale, projector; the IFT stage reads them
+    through model_name_or_path: ola_vlm_train.py:1015-1021) as `trainable.safetensors`, and the optimizer state for resume
+    (`trainer.train(resume_from_checkpoint=...)`, ola_vlm_train.py:1306-1309) as `optimizer.pt`."""
+    import os
+    from safetensors.torch import save_file
+    os.makedirs(out_dir, exist_ok=True)
+    save_mm_projector(engine, os.path.join(out_dir, "mm_projector.bin"))
+    save_file({k: v.detach().cpu().contiguous() for k, v in engine.state_dict().items()}, os.path.join(out_dir, "trainable.safetensors"),
+              metadata={"format": "pt"})
+    torch.save(engine.optimizer_state_dict(), os.path.join(out_dir, "optimizer.pt"))
+
+
+def load_checkpoint(engine, ckpt_dir: str, resume_optimizer: bool = True) -> List[str]:
+    """Inverse of save_checkpoint.  With `resume_optimizer` the fp32 master and AdamW moments are restored, so continuing is bitwise
+    identical to never having stopped; without it only the (bf16) weights are loaded, like starting the next stage from this one."""
+    import os
+    from safetensors.torch import load_file
+    loaded = engine.load_state_dict(load_file(os.path.join(ckpt_dir, "trainable.safetensors")), strict=False)
+    opt = os.path.join(ckpt_dir, "optimizer.pt")
+    if resume_optimizer and os.path.exists(opt):
+        engine.load_optimizer_state_dict(torch.load(opt, map_location="cpu"))
+    return loaded

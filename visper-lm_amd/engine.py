@@ -33,7 +33,7 @@ from .config import IGNORE_INDEX, IMAGE_TOKEN_INDEX, layer_indices
 
 BF16 = torch.bfloat16
 F32 = torch.float32
-N_IMG_TOK = 576   # the reference hard-codes 576 image tokens in the head slicing (base_ola_vlm.py:415-418)
+from .splice import N_IMG_TOK
 
 TASK_SPEC = {   # task -> (config attr, layer key, weight key, logit-scale name, heads module name)
     "depth": ("image_depth", "depth_layer_indices", "depth_loss_weight", "depth_logit_scale", "image_depth_heads"),
@@ -395,6 +395,53 @@ class Engine:
         if getattr(self, "train_llm", False):
             self.refresh_transposes()
 
+    # ------------------------------------------------------------------------------------------ state I/O
+    def state_dict(self, dtype=BF16):
+        """{reference state-dict name: tensor} of every TRAINABLE parameter (fp32 master -> `dtype`, the reference's bf16 by default;
+        logit scales stay fp32 like the reference's nn.Parameter(torch.tensor(2.0))): what HF `trainer.save_model` persists of the
+        trained modules — projector, heads, special_*_tokens, *_logit_scale (PT), plus the LLM when it trains (IFT)."""
+        out = OrderedDict()
+        for n, (_, _, shp) in self.ps.index.items():
+            t = self.ps.p(n).detach().reshape(shp)
+            out[n] = t.clone() if len(shp) == 0 else t.to(dtype)
+        return out
+
+    def load_state_dict(self, sd, strict=True):
+        """Load trainable parameters by reference name (a checkpoint of a previous stage / run); returns the names loaded."""
+        ps = self.ps
+        missing = [n for n in ps.index if n not in sd]
+        if strict and missing:
+            raise KeyError(f"missing trainable parameters: {missing[:5]}{'...' if len(missing) > 5 else ''}")
+        loaded = []
+        for n in ps.index:
+            if n in sd:
+                ps.p(n).copy_(sd[n].detach().to(device=self.dev, dtype=F32).reshape(ps.p(n).shape))
+                loaded.append(n)
+        ps.refresh_shadow()
+        if getattr(self, "train_llm", False):
+            self.refresh_transposes()
+        return loaded
+
+    def optimizer_state_dict(self):
+        """AdamW state for exact resume: step counter + the flat fp32 master and moments (the fp32 master is part of the optimizer
+        state exactly as in DeepSpeed's bf16 optimizer: the bf16 model weights alone do not reproduce the trajectory)."""
+        ps = self.ps
+        z = lambda t: None if t is None else t.detach().cpu().clone()
+        return dict(step=ps.step, names=list(ps.index), offsets=[ps.index[n][0] for n in ps.index], total=ps.total,
+                    master=z(ps.master), exp_avg=z(ps.exp_avg), exp_avg_sq=z(ps.exp_avg_sq))
+
+    def load_optimizer_state_dict(self, st):
+        ps = self.ps
+        if list(st["names"]) != list(ps.index) or int(st["total"]) != ps.total:
+            raise ValueError("optimizer state was saved for a different trainable set / layout")
+        ps.step = int(st["step"])
+        ps.master.copy_(st["master"].to(self.dev))
+        for k in ("exp_avg", "exp_avg_sq"):
+            setattr(ps, k, None if st[k] is None else st[k].to(device=self.dev, dtype=F32).clone())
+        ps.refresh_shadow()
+        if getattr(self, "train_llm", False):
+            self.refresh_transposes()
+
     def vit_layers_run(self):
         sel = self.cfg.mm_vision_select_layer
         return self.cfg.vit_layers + 1 + sel if sel < 0 else sel
@@ -574,103 +621,48 @@ class Engine:
 
     # ------------------------------------------------------------------------------------------ splice plan (host)
     def build_plan(self, input_ids, attention_mask, labels):
-        """Host restatement of prepare_inputs_labels_for_multimodal's index bookkeeping (ola_arch.py:256-444):
-        returns gather tables instead of concatenating tensors.  Right padding only."""
+        """splice.host_plan (the index bookkeeping of prepare_inputs_labels_for_multimodal, ola_arch.py:256-444) + ONE pinned
+        int32 buffer -> one async H2D copy of every table.  A fresh batch every step costs ~1 ms of host time, which runs under the
+        previous step's GPU work; identical batches hit a small cache."""
+        from . import splice
         cfg = self.cfg
-        if cfg.tokenizer_padding_side != "right":
-            raise NotImplementedError("left padding is not supported by the MI355X splice (reference default is right)")
-        ids = input_ids.detach().cpu().numpy().astype(np.int64)
-        B, T = ids.shape
-        am = np.ones((B, T), bool) if attention_mask is None else attention_mask.detach().cpu().numpy().astype(bool)
-        lab = np.full((B, T), IGNORE_INDEX, np.int64) if labels is None else labels.detach().cpu().numpy().astype(np.int64)
-        key = (ids.tobytes(), am.tobytes(), lab.tobytes())
+        ids = np.ascontiguousarray(input_ids.detach().cpu().numpy().astype(np.int64, copy=False))
+        am = None if attention_mask is None else attention_mask.detach().cpu().numpy().astype(bool, copy=False)
+        lab = None if labels is None else labels.detach().cpu().numpy().astype(np.int64, copy=False)
+        key = (ids.tobytes(), None if am is None else am.tobytes(), None if lab is None else lab.tobytes(), cfg.tokenizer_padding_side)
         if key in self._plan_cache:
             return self._plan_cache[key]
-        order = cfg.token_order
-        nt = cfg.num_task_tokens
-        n_tok_rows = nt * len(order) if nt > 0 else 0
-        seqs = []
-        img_idx = 0
-        for b in range(B):
-            idb, lb = ids[b][am[b]], lab[b][am[b]]
-            kind, row, lo = [], [], []
-            pos = np.nonzero(idb == IMAGE_TOKEN_INDEX)[0]
-            if len(pos) == 0:
-                kind += [0] * len(idb); row += idb.tolist(); lo += lb.tolist()
-                img_idx += 1                                        # reference consumes one (empty) feature slot
-            else:
-                bounds = [-1] + pos.tolist() + [len(idb)]
-                for i in range(len(bounds) - 1):
-                    seg = idb[bounds[i] + 1:bounds[i + 1]]
-                    kind += [0] * len(seg); row += seg.tolist(); lo += lb[bounds[i] + 1:bounds[i + 1]].tolist()
-                    if i < len(pos):
-                        kind += [1] * N_IMG_TOK
-                        row += list(range(img_idx * N_IMG_TOK, (img_idx + 1) * N_IMG_TOK))
-                        lo += [IGNORE_INDEX] * N_IMG_TOK
-                        img_idx += 1
-                        kind += [2] * n_tok_rows; row += list(range(n_tok_rows)); lo += [IGNORE_INDEX] * n_tok_rows
-            mx = cfg.tokenizer_model_max_length
-            if mx is not None:
-                kind, row, lo = kind[:mx], row[:mx], lo[:mx]
-            seqs.append((kind, row, lo))
-        n_img = img_idx
-        S = max(len(s[0]) for s in seqs)
-        S_pad = S
-        kind = np.full((B, S_pad), -1, np.int32)
-        row = np.zeros((B, S_pad), np.int32)
-        lab2 = np.full((B, S_pad), IGNORE_INDEX, np.int64)
-        lens = np.zeros(B, np.int32)
-        for b, (k, r, lo) in enumerate(seqs):
-            n = len(k)
-            kind[b, :n], row[b, :n], lab2[b, :n], lens[b] = k, r, lo, n
-        shift = np.full((B, S_pad), IGNORE_INDEX, np.int64)
-        shift[:, :-1] = lab2[:, 1:]
-        # backward tables
-        img_dst = np.full(n_img * N_IMG_TOK, -1, np.int32)          # image-feature row -> row of the [B*S] sequence
-        tok_src = np.full((max(n_tok_rows, 1), B), -1, np.int32)     # task-token row j -> its position in every sample
-        for b in range(B):
-            for s in range(lens[b]):
-                if kind[b, s] == 1:
-                    img_dst[row[b, s]] = b * S_pad + s
-                elif kind[b, s] == 2:
-                    tok_src[row[b, s], b] = b * S_pad + s
-        dev = self.dev
-        plan = dict(B=B, S=S_pad, n_img=n_img, kind=torch.from_numpy(kind.reshape(-1)).to(dev), row=torch.from_numpy(row.reshape(-1)).to(dev),
-                    labels=torch.from_numpy(lab2), shift_labels=torch.from_numpy(shift.reshape(-1)).to(dev),
-                    n_valid=int((shift != IGNORE_INDEX).sum()), lens=torch.from_numpy(lens).to(dev), lens_host=lens,
-                    img_dst=torch.from_numpy(img_dst).to(dev), tok_src=torch.from_numpy(tok_src.reshape(-1)).to(dev),
-                    n_tok_rows=n_tok_rows, full=bool((lens == S_pad).all()),
-                    attention_mask=torch.from_numpy(np.arange(S_pad)[None, :] < lens[:, None]))
-        plan["heads"] = self._head_tables(plan)
+        hp = splice.host_plan(cfg, self.tasks, ids, am, lab)
+        plan = {k: hp[k] for k in ("B", "S", "n_img", "n_valid", "lens_host", "n_tok_rows", "full", "side", "tok_cnt")}
+        for k in ("labels", "attention_mask", "position_ids"):
+            plan[k] = torch.from_numpy(hp[k])
+        tabs = hp["tables"]                                           # name -> int32 array
+        offs, tot = {}, 0
+        for name, a in tabs.items():
+            offs[name] = (tot, a.size)
+            tot += (a.size + 3) // 4 * 4                              # 16-byte aligned slices
+        host = torch.empty(max(tot, 4), dtype=torch.int32, pin_memory=True)
+        hv = host.numpy()
+        for name, a in tabs.items():
+            o, n = offs[name]
+            hv[o:o + n] = a.reshape(-1)
+        devbuf = host.to(self.dev, non_blocking=True)
+        shift_h = torch.from_numpy(hp["shift_labels"]).pin_memory()
+        plan["_host_bufs"] = (host, shift_h)                          # keep the pinned sources alive until the async copies ran
+        plan["shift_labels"] = shift_h.to(self.dev, non_blocking=True)
+        view = lambda name: devbuf[offs[name][0]:offs[name][0] + offs[name][1]]
+        for name in ("kind", "row", "lens", "img_dst", "tok_src", "embed_idx"):
+            plan[name] = view(name)
+        plan["present"] = (view("present_kind"), view("present")) if "present" in offs else None
+        heads = hp["heads"]
+        for task, h in heads.items():
+            h["rows"] = view("rows:" + task)
+        plan["heads"] = heads
+        plan["inv"] = {l: view(f"inv:{l}") for l in self.tapped if f"inv:{l}" in offs}
         if len(self._plan_cache) > 8:
             self._plan_cache.clear()
         self._plan_cache[key] = plan
         return plan
-
-    def _head_tables(self, plan):
-        """forward_emb_predictor's token selection (base_ola_vlm.py:413-441) as per-task row tables into [B*S]."""
-        cfg = self.cfg
-        B, S = plan["B"], plan["S"]
-        ns, nt, order = cfg.num_sys_tokens, cfg.num_task_tokens, cfg.token_order
-        out = {}
-        for task in sorted({t for t, _, _ in self.tasks}):        # SORTED: every rank must issue the all-gathers in the same order
-            k = order.index(task)
-            s0 = ns + N_IMG_TOK + nt * k
-            end = ns + N_IMG_TOK + nt * len(order)
-            if nt == 0 or S < 600:
-                sel = list(range(S)) if cfg.pass_text_to_aux else list(range(min(S, ns + N_IMG_TOK)))
-            else:
-                sel = list(range(ns + N_IMG_TOK)) + list(range(s0, s0 + nt))
-                if cfg.pass_text_to_aux:
-                    sel += list(range(end, S))
-            sel = np.asarray(sel, np.int32)
-            rows = (np.arange(B, dtype=np.int32)[:, None] * S + sel[None, :]).reshape(-1)
-            if cfg.pass_text_to_aux:
-                lat_x = np.arange(ns + N_IMG_TOK, ns + N_IMG_TOK + nt)           # positions inside x
-            else:
-                lat_x = np.arange(len(sel) - nt, len(sel))
-            out[task] = dict(n_x=len(sel), rows=torch.from_numpy(rows).to(self.dev), sel=sel, lat_x=lat_x)
-        return out
 
     # ------------------------------------------------------------------------------------------ embed
     def _embed(self, images, plan):
@@ -700,11 +692,21 @@ class Engine:
         ops.gather_rows(srcs, plan["kind"], plan["row"], H, x)
         return x, feats, z1, a1, img
 
+    def present(self, x2d, plan):
+        """[B*S, C] rows in the kernels' left-aligned layout -> [B, S, C] as the reference lays them out (identity for right
+        padding; right-aligned with zero pad rows for tokenizer_padding_side == "left")."""
+        B, S = plan["B"], plan["S"]
+        if plan["present"] is None:
+            return x2d.view(B, S, -1)
+        out = torch.empty_like(x2d)
+        ops.gather_rows([x2d], plan["present"][0], plan["present"][1], x2d.shape[-1], out)
+        return out.view(B, S, -1)
+
     def splice_forward(self, input_ids, attention_mask, labels, images):
         """prepare_inputs_labels_for_multimodal's tensor outputs (ola_arch.py:256-444): (inputs_embeds [B,S,H], plan)."""
         plan = self.build_plan(input_ids, attention_mask, labels)
         x, *_ = self._embed(images.to(self.dev), plan)
-        return x.view(plan["B"], plan["S"], -1), plan
+        return self.present(x, plan), plan
 
     # ------------------------------------------------------------------------------------------ the step
     def train_step(self, batch, compute_grads=True):
@@ -728,7 +730,7 @@ class Engine:
         # ---- vision tower + projector + splice (a1..a5)
         x, feats, z1, a1, img = self._embed(batch["images"], plan)
         out["image_features"] = img
-        out["inputs_embeds"] = x.view(B, S, H)
+        out["inputs_embeds"] = self.present(x, plan)
         nt = cfg.num_task_tokens
 
         # ---- decoder (a6)
@@ -736,7 +738,8 @@ class Engine:
         Fi = cfg.intermediate_size
         cos_t, sin_t = self.rope(S)
         kv_len = None if plan["full"] else plan["lens"]
-        window = int(cfg.sliding_window) if cfg.sliding_window else 0
+        # kernels keep keys with q - key < window; transformers 4.41.1 (the reference's pin) keeps q - key <= sliding_window
+        window = (int(cfg.sliding_window) + int(bool(getattr(cfg, "sliding_window_inclusive", False)))) if cfg.sliding_window else 0
         L = cfg.num_hidden_layers
         saved = []
         states = {}
@@ -768,7 +771,7 @@ class Engine:
         hidden, rstd_f = ops.rmsnorm_fwd(x, fz["norm"], cfg.rms_norm_eps)
         if (L - 1) in self.tapped:
             states[L - 1] = hidden              # layer_states[-1] is the post-norm state (ola_llama.py:117-119)
-        out["hidden"] = hidden.view(B, S, H)
+        out["hidden"] = self.present(hidden, plan)
 
         # ---- lm_head + NTP loss (a7), row-chunked; dlogits -> d_hidden in the same sweep
         n_valid = plan["n_valid"]
@@ -790,7 +793,7 @@ class Engine:
         text_loss = ops.sum_f32(row_loss, gscale)
         out["text_loss"] = text_loss
         if logits_keep is not None:
-            out["logits"] = torch.cat(logits_keep, 0).view(B, S, -1)
+            out["logits"] = self.present(torch.cat(logits_keep, 0), plan)
 
         # ---- heads + embedding losses (a8..a14), forward and backward back-to-back per head
         d_state = {}
@@ -835,17 +838,21 @@ class Engine:
             for _, p in parts:
                 cat[off:off + p.shape[0]] = p
                 off += p.shape[0]
-            ikey = ("inv", l, tuple(t for t, _ in parts))
-            if ikey not in plan:                         # inverse row table: state row -> row of `cat` per head (or -1)
-                inv = np.full((M, len(parts)), -1, np.int32)
-                off = 0
-                for j, (task, p) in enumerate(parts):
-                    rows = plan["heads"][task]["rows"].cpu().numpy()
-                    inv[rows, j] = off + np.arange(p.shape[0], dtype=np.int32)
-                    off += p.shape[0]
-                plan[ikey] = torch.from_numpy(inv.reshape(-1)).to(dev)
+            if len(parts) == len([1 for _, _, idx in self.tasks if idx == l]) and l in plan["inv"]:
+                inv_t = plan["inv"][l]                   # built on the host with the plan (no D2H sync in the step)
+            else:                                        # some head of this layer had no target: build the table for the heads that ran
+                ikey = ("inv", l, tuple(t for t, _ in parts))
+                if ikey not in plan:
+                    inv = np.full((M, len(parts)), -1, np.int32)
+                    off = 0
+                    for j, (task, p) in enumerate(parts):
+                        rows = plan["heads"][task]["rows_host"]
+                        inv[rows, j] = off + np.arange(p.shape[0], dtype=np.int32)
+                        off += p.shape[0]
+                    plan[ikey] = torch.from_numpy(inv.reshape(-1)).to(dev)
+                inv_t = plan[ikey]
             ds = torch.empty(M, H, device=dev, dtype=BF16)
-            ops.gather_sum_rows(cat, plan[ikey], len(parts), 1.0, ds)
+            ops.gather_sum_rows(cat, inv_t, len(parts), 1.0, ds)
             d_state[l] = ds
 
         # ---- decoder backward (dgrad only: LLM frozen)
@@ -907,18 +914,16 @@ class Engine:
                 self._reduce_range(*self._llm_ranges[o])        # this layer's gradients are final
             dx = ops.rmsnorm_bwd(d_xn, x_in, fz[o + "ln1"], rstd1, dres=d_h1)
             saved[l] = None
-        out["d_inputs_embeds"] = dx.view(B, S, H)
+        out["d_inputs_embeds"] = self.present(dx, plan)
         if train_llm:                                           # embed_tokens.weight.grad: scatter-add of the text rows
-            if "embed_idx" not in plan:
-                plan["embed_idx"] = torch.where(plan["kind"] == 0, plan["row"], torch.full_like(plan["row"], -1)).to(torch.int32)
             ops.scatter_add_rows_(ps.g("model.embed_tokens.weight"), dx, plan["embed_idx"])
 
         # ---- splice backward: image rows -> projector, task-token rows -> special-token parameters
-        d_img = torch.empty(plan["n_img"] * N_IMG_TOK, H, device=dev, dtype=BF16)
+        d_img = torch.empty(max(plan["n_img"], 1) * N_IMG_TOK, H, device=dev, dtype=BF16)
         ops.gather_sum_rows(dx, plan["img_dst"], 1, 1.0, d_img)
         if plan["n_tok_rows"] > 0:
             d_tok = torch.empty(plan["n_tok_rows"], H, device=dev, dtype=F32)
-            ops.gather_sum_rows(dx, plan["tok_src"], B, 1.0, d_tok)
+            ops.gather_sum_rows(dx, plan["tok_src"], plan["tok_cnt"], 1.0, d_tok)
             for k, task in enumerate(cfg.token_order):
                 name = f"model.special_{task}_tokens"
                 g = ps.g(name)

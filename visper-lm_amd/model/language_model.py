@@ -130,16 +130,47 @@ class BaseOLA_VLM:
         return self._engine
 
     def _sync_trainable(self):
-        """nn.Parameters are the source of truth (an external optimizer may have stepped them): refresh the engine's
-        fp32 master + bf16 shadow (one flat cast kernel)."""
+        """Keep ONE source of truth between the nn.Parameters (what `state_dict()` / an external torch optimizer see) and the
+        engine's flat fp32 master (what `Engine.optimizer_step` updates):
+          * the engine stepped since the last sync (its step counter moved)  -> master is newer: write it back into the Parameters;
+          * a Parameter was modified in place since the last sync (its autograd version counter moved: optimizer.step(),
+            load_state_dict, manual edits) -> it is newer: copy it into master and refresh the bf16 shadow.
+        Both directions are no-ops when nothing changed, so a forward costs no copies in steady state with the engine's optimizer."""
         eng = self._get_engine()
-        for n, p in zip(self._trainable_names, self._trainable_params):
-            eng.ps.p(n).copy_(p.detach().reshape(eng.ps.p(n).shape))
-        eng.ps.refresh_shadow()
+        ps = eng.ps
+        seen = self.__dict__.setdefault("_seen", {"step": ps.step, "ver": None})
+        if ps.step != seen["step"]:
+            with torch.no_grad():
+                for n, p in zip(self._trainable_names, self._trainable_params):
+                    p.copy_(ps.p(n).reshape(p.shape))
+            seen["step"] = ps.step
+            seen["ver"] = [p._version for p in self._trainable_params]
+            return
+        vers = [p._version for p in self._trainable_params]
+        if seen["ver"] is None:                                   # first call: the engine was loaded from these very Parameters
+            seen["ver"] = vers
+            return
+        dirty = [i for i, (a, b) in enumerate(zip(vers, seen["ver"])) if a != b]
+        if dirty:
+            for i in dirty:
+                n, p = self._trainable_names[i], self._trainable_params[i]
+                ps.p(n).copy_(p.detach().reshape(ps.p(n).shape))
+            ps.refresh_shadow()
+            if getattr(eng, "train_llm", False):
+                eng.refresh_transposes()
+            seen["ver"] = vers
+
+    def optimizer_step(self, lr, **kw):
+        """Engine.optimizer_step (fused AdamW on the flat fp32 master, DP mean folded in) + write-back into the nn.Parameters, so
+        `state_dict()` / `save_pretrained` always see the trained weights.  The reference leaves this to HF Trainer + DeepSpeed
+        (ola_vlm_train.py:1297-1309); an external torch optimizer over `model.parameters()` works too (see _sync_trainable)."""
+        self._get_engine().optimizer_step(lr, **kw)
+        self._sync_trainable()
 
     def reload_frozen(self):
         """Call after load_state_dict(): rebuilds the engine's fused / pre-transposed frozen weights."""
         self._engine = None
+        self.__dict__.pop("_seen", None)
 
 
 class _OlaCausalLMBase(OlaLlavaMetaForCausalLM, BaseOLA_VLM, nn.Module):

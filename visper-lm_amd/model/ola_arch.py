@@ -70,9 +70,7 @@ class OlaLlavaMetaForCausalLM:
         S = plan["S"]
         new_labels = None if labels is None else plan["labels"].to(input_ids.device)
         am = None if attention_mask is None else plan["attention_mask"].to(device=input_ids.device, dtype=attention_mask.dtype)
-        pid = None
-        if position_ids is not None:
-            pid = (torch.arange(S)[None] * plan["attention_mask"].long()).to(input_ids.device)
+        pid = None if position_ids is None else plan["position_ids"].to(input_ids.device)
         return None, pid, am, past_key_values, embeds, new_labels
 
     def initialize_vision_tokenizer(self, model_args, tokenizer):      # ola_arch.py:446-489: tokenizer plumbing only

@@ -1,0 +1,166 @@
+"""Host index plan of the multimodal splice — prepare_inputs_labels_for_multimodal's bookkeeping (ola_arch.py:256-444),
+append_special_tokens' row layout (ola_arch.py:224-254) and forward_emb_predictor's token selection (base_ola_vlm.py:413-441) —
+as integer tables that drive the HIP row gathers (`vp_gather_rows`, `vp_gather_sum_rows`).  Pure numpy, no device, no per-token
+Python loops (one pass per sample and per <image> segment): ~1 ms for B=8, T=1449.
+
+Padding side (ola_arch.py:408-427): the kernels always run the sequences LEFT-ALIGNED (real tokens at rows 0..len-1, keys beyond
+`lens` masked, RoPE position = row index = the reference's position_ids of the real tokens in both modes).  With
+tokenizer_padding_side == "left" only the PRESENTATION changes: labels / attention_mask / position_ids and the per-row outputs
+(inputs_embeds, hidden, logits) are re-laid right-aligned through the `present` table.  The reference's pad rows carry no defined
+values (eager attention averages all keys there, flash-attention drops them); they are zeros here."""
+from __future__ import annotations
+
+import numpy as np
+
+from .config import IGNORE_INDEX, IMAGE_TOKEN_INDEX
+
+N_IMG_TOK = 576   # the reference hard-codes 576 image tokens in the head slicing (base_ola_vlm.py:415-418)
+
+
+def head_tables(cfg, tasks, B, S):
+    """forward_emb_predictor's token selection as per-task row tables into the [B*S] state (host arrays).
+    tasks: [(task, head_i, layer_idx)] (Engine.tasks)."""
+    ns, nt, order = cfg.num_sys_tokens, cfg.num_task_tokens, cfg.token_order
+    out = {}
+    if not tasks or S <= ns:                                   # ola_llama.py:139: heads only run when the sequence carries an image
+        return out
+    for task in sorted({t for t, _, _ in tasks}):              # SORTED: every rank must issue the all-gathers in the same order
+        k = order.index(task)
+        s0 = ns + N_IMG_TOK + nt * k
+        end = ns + N_IMG_TOK + nt * len(order)
+        if nt == 0 or S < 600:
+            sel = np.arange(S if cfg.pass_text_to_aux else min(S, ns + N_IMG_TOK), dtype=np.int32)
+        else:
+            parts = [np.arange(ns + N_IMG_TOK, dtype=np.int32), np.arange(s0, s0 + nt, dtype=np.int32)]
+            if cfg.pass_text_to_aux:
+                parts.append(np.arange(end, S, dtype=np.int32))
+            sel = np.concatenate(parts)
+        rows = (np.arange(B, dtype=np.int32)[:, None] * S + sel[None, :]).reshape(-1)
+        if cfg.pass_text_to_aux:
+            lat_x = np.arange(ns + N_IMG_TOK, ns + N_IMG_TOK + nt)               # positions of the gen latents inside x
+        else:
+            lat_x = np.arange(len(sel) - nt, len(sel))
+        out[task] = dict(n_x=len(sel), rows_host=rows, sel=sel, lat_x=lat_x)
+    return out
+
+
+def inverse_tables(tasks, heads, M):
+    """Per tapped layer: state row -> row of the concatenated head-input gradients, one column per head reading that layer
+    (-1 = not read), in `tasks` order — the backward of the heads' row gathers as ONE gather-sum."""
+    out = {}
+    for l in sorted({idx for _, _, idx in tasks}):
+        tl = [t for t, _, idx in tasks if idx == l]
+        if not tl or not all(t in heads for t in tl):
+            continue
+        inv = np.full((M, len(tl)), -1, np.int32)
+        off = 0
+        for j, t in enumerate(tl):
+            rows = heads[t]["rows_host"]
+            inv[rows, j] = off + np.arange(rows.size, dtype=np.int32)
+            off += rows.size
+        out[l] = inv
+    return out
+
+
+def host_plan(cfg, tasks, ids, am=None, lab=None):
+    """ids [B,T] int64 (IMAGE_TOKEN_INDEX marks an image), am [B,T] bool or None, lab [B,T] int64 or None ->
+    dict(B, S, lens_host, labels, attention_mask, position_ids, shift_labels, tables{name: int32 array}, heads, ...).
+
+    tables: kind/row  [B*S]  gather source (0 = embed_tokens, 1 = image features, 2 = task-token rows, -1 = zeros) and row in it
+            img_dst   [n_img*576]       image-feature row -> its row of [B*S] (-1: truncated away / unused slot)
+            tok_src   [n_tok_rows, n_img]   task-token row j of image i -> its row of [B*S]
+            embed_idx [B*S]  token id of text rows (-1 elsewhere): embed_tokens scatter-add when the LLM trains
+            present(_kind) [B*S]  only for ragged left padding: presented row -> physical row
+            rows:<task>, inv:<layer>  head gathers (head_tables / inverse_tables)."""
+    side = getattr(cfg, "tokenizer_padding_side", "right")
+    if side not in ("right", "left"):
+        raise ValueError(f"tokenizer_padding_side={side!r}")
+    B, T = ids.shape
+    if am is None:
+        am = np.ones((B, T), bool)
+    if lab is None:
+        lab = np.full((B, T), IGNORE_INDEX, np.int64)
+    nt = cfg.num_task_tokens
+    n_tok_rows = nt * len(cfg.token_order) if nt > 0 else 0
+    blk = N_IMG_TOK + n_tok_rows
+    blk_kind = np.concatenate([np.full(N_IMG_TOK, 1, np.int32), np.full(n_tok_rows, 2, np.int32)])
+    blk_lab = np.full(blk, IGNORE_INDEX, np.int64)
+    img_rows = np.arange(N_IMG_TOK, dtype=np.int32)
+    tok_rows = np.arange(n_tok_rows, dtype=np.int32)
+    mx = cfg.tokenizer_model_max_length
+    seqs = []
+    img_idx = 0
+    for b in range(B):
+        idb, lb = ids[b][am[b]], lab[b][am[b]]
+        pos = np.flatnonzero(idb == IMAGE_TOKEN_INDEX)
+        if pos.size == 0:
+            k, r, lo, im = np.zeros(idb.size, np.int32), idb.astype(np.int32), lb, np.full(idb.size, -1, np.int32)
+            img_idx += 1                                        # the reference consumes one (empty) feature slot: ola_arch.py:347-354
+        else:
+            ks, rs, ls, ims = [], [], [], []
+            bounds = np.concatenate(([-1], pos, [idb.size]))
+            for i in range(bounds.size - 1):
+                lo_, hi_ = int(bounds[i]) + 1, int(bounds[i + 1])
+                ks.append(np.zeros(hi_ - lo_, np.int32)); rs.append(idb[lo_:hi_].astype(np.int32)); ls.append(lb[lo_:hi_])
+                ims.append(np.full(hi_ - lo_, -1, np.int32))
+                if i < pos.size:
+                    ks.append(blk_kind); rs.append(img_rows + img_idx * N_IMG_TOK); rs.append(tok_rows); ls.append(blk_lab)
+                    ims.append(np.full(blk, img_idx, np.int32))
+                    img_idx += 1
+            k, r, lo, im = np.concatenate(ks), np.concatenate(rs), np.concatenate(ls), np.concatenate(ims)
+        if mx is not None:
+            k, r, lo, im = k[:mx], r[:mx], lo[:mx], im[:mx]
+        seqs.append((k, r, lo, im))
+    n_img = img_idx
+    lens = np.array([s[0].size for s in seqs], np.int32)
+    S = int(lens.max())
+    M = B * S
+    kind = np.full((B, S), -1, np.int32)
+    row = np.zeros((B, S), np.int32)
+    imgi = np.full((B, S), -1, np.int32)
+    lab2 = np.full((B, S), IGNORE_INDEX, np.int64)
+    for b, (k, r, lo, im) in enumerate(seqs):
+        n = k.size
+        kind[b, :n], row[b, :n], lab2[b, :n], imgi[b, :n] = k, r, lo, im
+    shift = np.full((B, S), IGNORE_INDEX, np.int64)            # ola_llama.py:128-131: logits[..., :-1] vs labels[..., 1:]
+    shift[:, :-1] = lab2[:, 1:]
+    full = bool((lens == S).all())
+    fk, fr, fi = kind.reshape(-1), row.reshape(-1), imgi.reshape(-1)
+    posn = np.arange(M, dtype=np.int32)
+    img_dst = np.full(max(n_img, 1) * N_IMG_TOK, -1, np.int32)
+    m1 = fk == 1
+    img_dst[fr[m1]] = posn[m1]
+    tok_src = np.full((max(n_tok_rows, 1), max(n_img, 1)), -1, np.int32)
+    m2 = fk == 2
+    tok_src[fr[m2], fi[m2]] = posn[m2]
+    embed_idx = np.where(fk == 0, fr, -1).astype(np.int32)
+    col = np.arange(S, dtype=np.int32)[None, :]
+    real = col < lens[:, None]                                   # physical (left-aligned) validity
+    plan = dict(B=B, S=S, n_img=n_img, n_valid=int((shift != IGNORE_INDEX).sum()), lens_host=lens, n_tok_rows=n_tok_rows,
+                full=full, side=side, tok_cnt=max(n_img, 1), shift_labels=shift.reshape(-1))
+    tables = dict(kind=fk, row=fr, lens=lens, img_dst=img_dst, tok_src=tok_src.reshape(-1), embed_idx=embed_idx)
+    if side == "left" and not full:
+        src = col - (S - lens)[:, None]                          # presented column c shows physical column c - (S - len)
+        ok = src >= 0
+        present = np.where(ok, np.arange(B, dtype=np.int32)[:, None] * S + src, -1).astype(np.int32)
+        plan["labels"] = np.where(ok, np.take_along_axis(lab2, np.maximum(src, 0).astype(np.int64), 1), IGNORE_INDEX)
+        plan["attention_mask"] = ok.copy()
+        plan["position_ids"] = np.where(ok, src, 0).astype(np.int64)
+        tables["present"] = present.reshape(-1)
+        tables["present_kind"] = np.where(present.reshape(-1) >= 0, 0, -1).astype(np.int32)
+    else:
+        plan["labels"] = lab2
+        plan["attention_mask"] = real.copy()
+        plan["position_ids"] = np.where(real, col, 0).astype(np.int64)
+    heads = head_tables(cfg, tasks, B, S)
+    if heads and side == "left" and not full:
+        raise NotImplementedError(
+            "distillation heads with a RAGGED left-padded batch: the reference slices head inputs by absolute position "
+            "(base_ola_vlm.py:414-427), which only lines up with right padding (its training scripts' setting)")
+    for task, h in heads.items():
+        tables["rows:" + task] = h["rows_host"]
+    for l, inv in inverse_tables(tasks, heads, M).items():
+        tables[f"inv:{l}"] = inv.reshape(-1)
+    plan["tables"] = tables
+    plan["heads"] = heads
+    return plan
