@@ -171,9 +171,15 @@ int vp_attn_bwd_rope(int B, int Hq, int Hkv, int Sq, int Skv, int D, const void*
  * calculate_contrastive_loss; :96-106 dist_collect -> tgt_all is the rank-ordered all-gather). */
 int vp_ce_fwd_bwd(long rows, int V, void* logits, long ld, const long* labels, float* row_loss, float grad_scale,
                   int write_grad, vp_stream_t stream);
-int vp_emb_loss_nblk(long D);
+/* vp_emb_loss_fwd: ONE launch (streaming MFMA/dot2 pass + deterministic last-block tree + the B x Bw softmax); out3 = {emb_loss, sl1,
+ * contrastive} exactly as _emb_loss returns them (not yet multiplied by the task weight); coef (2B + B*Bw + 1 floats) carries the
+ * backward coefficients and d loss / d logit_scale in its last slot.  workspace: vp_emb_loss_workspace(B, Bw, D) floats, uninitialised.
+ * 0 < B <= 64 local predictions, B <= Bw <= 1024 gathered targets (rank-ordered, rank r's rows at r*B), D % 8 == 0; pred [B,D] and
+ * tgt_all [Bw,D] bf16 row-major, 16-byte aligned.  logit_scale NULL = no contrastive term.  Calls on DIFFERENT streams may overlap
+ * only if their stream handles hash to different counter slots (8 slots); calls on one stream are always safe. */
+long vp_emb_loss_workspace(int B, int Bw, long D);
 int vp_emb_loss_fwd(int B, int Bw, long D, int rank, const void* pred, const void* tgt_all, const float* mask,
-                    const float* logit_scale, float w_contrastive, float* out3, float* coef, float* part,
+                    const float* logit_scale, float w_contrastive, float* out3, float* coef, float* workspace,
                     vp_stream_t stream);
 int vp_emb_loss_bwd(int B, int Bw, long D, int rank, const void* pred, const void* tgt_all, const float* coef,
                     float grad_out, void* dpred, vp_stream_t stream);

@@ -7,8 +7,15 @@ import numpy as np
 import pytest
 import torch
 
+from parity import check, max_rel, grad_err
+
 pytestmark = pytest.mark.gpu
 BF = torch.bfloat16
+
+
+def _trip_err(mine, theirs):
+    """worst relative error over the (emb, sl1, con) triple of one head-layer call; absolute 1e-6 floor for exact zeros."""
+    return max(abs(float(a) - float(b)) / max(abs(float(b)), 1e-6) for a, b in zip(mine, theirs))
 
 
 def _to_gpu_batch(batch):
@@ -57,55 +64,52 @@ def test_dpt_depth_pred_matches_oracle_and_reference_golden(tiny):
     with torch.no_grad():
         ref = O.dpt_depth_pred(feats, {k: v.detach() for k, v in Wq.items()})
     err = (dp - ref).abs()
-    assert float(err.mean()) < 1e-2 and float(err.max()) < 8e-2, (float(err.mean()), float(err.max()))
+    check("tiny/depth_pred_mean_abs_vs_oracle", err.mean(), 1e-2)
+    check("tiny/depth_pred_max_abs_vs_oracle", err.max(), 8e-2)
     gerr = (dp[:, ::5, ::5].numpy() - g["depth_pred_sub"])
-    assert float(np.abs(gerr).mean()) < 2e-2, float(np.abs(gerr).mean())
+    check("tiny/depth_pred_mean_abs_vs_reference_golden", np.abs(gerr).mean(), 2e-2)
 
 
 def test_losses_match_oracle_and_reference_golden(tiny):
+    """north-star tolerance: losses within 1e-3 relative of the reference's CPU path.  Bounds = measured error x ~3 (parity.check logs
+    the measured values): vs the fp32-math oracle on the same bf16 weights, and vs the reference's own fp32 golden (which also carries
+    the bf16 rounding of the weights themselves)."""
     out, ref, g = tiny["out"], tiny["ref"], tiny["g"]
-    # north-star tolerance: 1e-3 relative would hold for fp32; bf16 through 4 layers + 128k-way softmax: 1e-2 here
-    assert rel(out["text_loss"], ref["text_loss"]) < 5e-3, (float(out["text_loss"]), float(ref["text_loss"]))
-    assert rel(out["loss"], ref["loss"]) < 5e-3
-    assert rel(out["loss"], g["keep_loss"]) < 1e-2
+    check("tiny/text_loss_rel_vs_oracle", rel(out["text_loss"], ref["text_loss"]), 1e-3)
+    check("tiny/loss_rel_vs_oracle", rel(out["loss"], ref["loss"]), 1e-3)
+    check("tiny/loss_rel_vs_reference_golden", rel(out["loss"], g["keep_loss"]), 1e-3)
     names = [("depth", 2), ("seg", 1), ("seg", 2), ("gen", 3)]
     for i, key in enumerate(names):
         mine = out["layer_losses"][key].float().cpu().numpy()
         theirs = np.array([float(x) for x in ref["layer_losses"][key]])
-        assert np.allclose(mine, theirs, rtol=2e-2, atol=2e-3), (key, mine, theirs)
-        assert np.allclose(mine, g["keep_layer_losses"][i], rtol=3e-2, atol=3e-3), (key, mine, g["keep_layer_losses"][i])
+        check(f"tiny/layer_loss/{key[0]}@{key[1]}_vs_oracle", _trip_err(mine, theirs), 5e-3)
+        check(f"tiny/layer_loss/{key[0]}@{key[1]}_vs_reference_golden", _trip_err(mine, g["keep_layer_losses"][i]), 1e-2)
 
 
 def test_hidden_states_and_logits(tiny):
     out, ref = tiny["out"], tiny["ref"]
-    emb = out["inputs_embeds"].float().cpu()
-    assert torch.allclose(emb, ref["inputs_embeds"].detach(), rtol=2e-2, atol=2e-2)
-    hid = out["hidden"].float().cpu()
-    rh = ref["hidden"].detach()
-    err = (hid - rh).abs().max() / rh.abs().max()
-    assert err < 3e-2, float(err)
-    lg = out["logits"].float().cpu()
-    rl = ref["logits"].detach()
+    check("tiny/inputs_embeds_maxrel", max_rel(out["inputs_embeds"].cpu(), ref["inputs_embeds"].detach()), 1e-2)
+    check("tiny/hidden_maxrel", max_rel(out["hidden"].cpu(), ref["hidden"].detach()), 3e-2)
+    lg, rl = out["logits"].float().cpu(), ref["logits"].detach()
     assert lg.shape == rl.shape
-    err = (lg - rl).abs().max() / rl.abs().max()
-    assert err < 3e-2, float(err)
+    check("tiny/logits_maxrel", max_rel(lg, rl), 3e-2)
 
 
 def test_gradients_match_oracle(tiny):
     grads, Wq, g = tiny["grads"], tiny["Wq"], tiny["g"]
     none_ref = set(json.loads(str(g["keep_grad_none"])))
-    worst = {}
     for k in tiny["tr"]:
         mine = grads[k].reshape(-1)
         if k in none_ref:
             assert float(mine.abs().sum()) == 0.0, k        # unused params (depth linear_2/3): zero-filled
             continue
         theirs = Wq[k].grad.reshape(-1)
-        cos = float(torch.dot(mine, theirs) / (mine.norm() * theirs.norm() + 1e-30))
-        nr = float(mine.norm() / (theirs.norm() + 1e-30))
-        worst[k] = (cos, nr)
-        assert cos > 0.98 and 0.9 < nr < 1.1, (k, cos, nr)
-    print(sorted(worst.items(), key=lambda kv: kv[1][0])[:5])
+        if mine.numel() == 1:                                # logit scales: a sum of a few signed terms
+            check(f"tiny/grad/{k}_abs", abs(float(mine) - float(theirs)), 0.05 * abs(float(theirs)) + 1e-3)
+            continue
+        c, n = grad_err(mine, theirs)
+        check(f"tiny/grad/{k}/one_minus_cos", c, 2e-2)
+        check(f"tiny/grad/{k}/norm_dev", n, 5e-2)
 
 
 def test_as_released_mask_zeroing(tiny):
@@ -116,7 +120,7 @@ def test_as_released_mask_zeroing(tiny):
     eng = Engine(cfg)
     eng.load_weights(tiny["W"])
     out = eng.train_step(_to_gpu_batch(tiny["batch"]))
-    assert rel(out["loss"], tiny["g"]["released_loss"]) < 1e-2
+    check("tiny/released_loss_rel_vs_reference_golden", rel(out["loss"], tiny["g"]["released_loss"]), 1e-3)
     assert float(out["loss"]) == float(out["text_loss"])
     for k in eng.ps.index:
         if "_heads." in k or k.endswith("logit_scale"):
@@ -153,16 +157,19 @@ def test_phi3_path_matches_oracle_and_reference_golden():
     eng = Engine(VisperConfig(**vars(ocfg)))
     eng.load_weights(W)
     out = eng.train_step(_to_gpu_batch(batch))
-    assert rel(out["loss"], g["keep_loss"]) < 1e-2, (float(out["loss"]), float(g["keep_loss"]))
+    check("tiny_phi3/loss_rel_vs_reference_golden", rel(out["loss"], g["keep_loss"]), 1e-3)
     names = [("depth", 2), ("seg", 1), ("seg", 2), ("gen", 3)]
     for i, key in enumerate(names):
         mine = out["layer_losses"][key].float().cpu().numpy()
-        assert np.allclose(mine, g["keep_layer_losses"][i], rtol=3e-2, atol=3e-3), (key, mine, g["keep_layer_losses"][i])
+        check(f"tiny_phi3/layer_loss/{key[0]}@{key[1]}_vs_reference_golden", _trip_err(mine, g["keep_layer_losses"][i]), 1e-2)
     none_ref = set(json.loads(str(g["keep_grad_none"])))
     for k in eng.ps.index:
         got = float(eng.ps.g(k).float().norm())
         ref = 0.0 if k in none_ref else float(g[f"keep_gradnorm::{k}"])
-        assert abs(got - ref) <= 0.1 * ref + 1e-6, (k, got, ref)
+        if ref == 0.0:
+            assert got == 0.0, k
+        else:
+            check(f"tiny_phi3/gradnorm/{k}_rel", abs(got - ref) / ref, 5e-2)
 
 
 def test_convnext_tower_matches_oracle():
@@ -194,7 +201,7 @@ def test_convnext_tower_matches_oracle():
     assert err < 3e-2, float(err)
 
 
-def _edge_case(ocfg_kw, mutate, min_cos=0.97):
+def _edge_case(ocfg_kw, mutate, min_cos=0.98, tag="edge"):
     """Engine vs the fp32 oracle (same bf16-rounded weights / inputs) on a mutated copy of the tiny Llama case."""
     from oracle import cases, visper_oracle as O
     from visper_lm_amd.config import VisperConfig
@@ -213,27 +220,27 @@ def _edge_case(ocfg_kw, mutate, min_cos=0.97):
     bq = {k: (v.to(BF).float() if (torch.is_tensor(v) and v.is_floating_point() and not k.endswith("_mask")) else v) for k, v in batch.items()}
     ref = O.forward(Wq, bq, ocfg)
     ref["loss"].backward()
-    assert rel(out["text_loss"], ref["text_loss"]) < 5e-3, (float(out["text_loss"]), float(ref["text_loss"]))
-    assert rel(out["loss"], ref["loss"]) < 5e-3, (float(out["loss"]), float(ref["loss"]))
+    check(f"{tag}/text_loss_rel", rel(out["text_loss"], ref["text_loss"]), 1e-3)
+    check(f"{tag}/loss_rel", rel(out["loss"], ref["loss"]), 1e-3)
     for key, trip in ref["layer_losses"].items():
         mine = out["layer_losses"][key].float().cpu().numpy()
-        assert np.allclose(mine, [float(x) for x in trip], rtol=2e-2, atol=2e-3), (key, mine, trip)
+        check(f"{tag}/layer_loss/{key[0]}@{key[1]}", _trip_err(mine, [float(x) for x in trip]), 5e-3)
     for k in eng.ps.index:
         got = eng.ps.g(k).detach().float().cpu()
         want = Wq[k].grad
         if want is None:
             assert float(got.abs().max()) == 0.0, k
             continue
-        mine, theirs = got.reshape(-1), want.reshape(-1)          # same bar as test_gradients_match_oracle (bf16 vs fp32)
+        mine, theirs = got.reshape(-1), want.reshape(-1)
         if mine.numel() == 1:                                      # logit scales: a sum of a few signed terms, so absolute slack too
-            assert abs(float(mine) - float(theirs)) <= 0.25 * abs(float(theirs)) + 2e-3, (k, float(mine), float(theirs))
+            check(f"{tag}/grad/{k}_abs", abs(float(mine) - float(theirs)), 0.05 * abs(float(theirs)) + 1e-3)
             continue
         if float(theirs.norm()) == 0.0:
             assert float(mine.norm()) < 1e-6, k
             continue
-        cos = float(torch.dot(mine, theirs) / (mine.norm() * theirs.norm() + 1e-30))
-        nr = float(mine.norm() / (theirs.norm() + 1e-30))
-        assert cos > min_cos and 0.9 < nr < 1.1, (k, cos, nr)
+        c, n = grad_err(mine, theirs)
+        check(f"{tag}/grad/{k}/one_minus_cos", c, 1.0 - min_cos)
+        check(f"{tag}/grad/{k}/norm_dev", n, 5e-2)
     return out, ref
 
 
@@ -242,7 +249,7 @@ def test_edge_ragged_right_padded_batch():
     shorter than sample 0, so its tail rows are padding (labels -100, keys masked by kv_len)."""
     def mutate(b):
         b["attention_mask"][1, 42:] = False
-    out, ref = _edge_case({}, mutate)
+    out, ref = _edge_case({}, mutate, tag="edge_ragged")
     assert out["plan"]["S"] == ref["labels"].shape[1]
 
 
@@ -252,12 +259,12 @@ def test_edge_sample_without_image():
         b["input_ids"][1, 38] = 7
     # the text-only sample feeds ~600 rows of padding-position states into every head's cross-attention: the softmax gradients
     # (to_q / to_kv) are the noisiest in bf16, hence the slightly wider bar
-    _edge_case({}, mutate, min_cos=0.95)
+    _edge_case({}, mutate, min_cos=0.95, tag="edge_no_image")
 
 
 def test_edge_truncation():
     """ola_arch.py:394-397 truncates the spliced sequence (658 rows here) to tokenizer_model_max_length."""
-    out, ref = _edge_case({"tokenizer_model_max_length": 652}, lambda b: None)      # keeps 8 supervised tokens per sample
+    out, ref = _edge_case({"tokenizer_model_max_length": 652}, lambda b: None, tag="edge_trunc")      # keeps 8 supervised tokens per sample
     assert out["plan"]["S"] == 652 == ref["labels"].shape[1]
 
 
@@ -267,7 +274,7 @@ def test_edge_short_sequence_head_path():
     def mutate(b):
         b["input_ids"][:, 38] = 7
         b.pop("gen_target", None); b.pop("gen_mask", None)
-    out, ref = _edge_case({"aux_mode": "depth-seg"}, mutate)
+    out, ref = _edge_case({"aux_mode": "depth-seg"}, mutate, tag="edge_short")
     assert out["plan"]["S"] == 59
 
 
@@ -293,18 +300,15 @@ def test_ift_stage_llm_weight_gradients_match_oracle(arch):
     bq = {k: (v.to(BF).float() if (torch.is_tensor(v) and v.is_floating_point()) else v) for k, v in batch.items()}
     ref = O.forward(Wq, bq, ocfg)
     ref["loss"].backward()
-    assert rel(out["loss"], ref["loss"]) < 5e-3, (float(out["loss"]), float(ref["loss"]))
-    worst = []
+    check(f"ift_{arch}/loss_rel", rel(out["loss"], ref["loss"]), 1e-3)
     for k in tr:
         mine = eng.ps.g(k).detach().float().cpu().reshape(-1)
         if Wq[k].grad is None:                                       # heads / task tokens of the fixture: unused without aux tasks
             assert float(mine.abs().max()) == 0.0, k
             continue
-        theirs = Wq[k].grad.reshape(-1)
-        cos = float(torch.dot(mine, theirs) / (mine.norm() * theirs.norm() + 1e-30))
-        nr = float(mine.norm() / (theirs.norm() + 1e-30))
-        worst.append((cos, nr, k))
-        assert cos > 0.97 and 0.9 < nr < 1.1, (k, cos, nr)
+        c, n = grad_err(mine, Wq[k].grad.reshape(-1))
+        check(f"ift_{arch}/grad/{k}/one_minus_cos", c, 3e-2)
+        check(f"ift_{arch}/grad/{k}/norm_dev", n, 5e-2)
     l0 = float(out["loss"])
     for _ in range(3):
         eng.optimizer_step(lr=2e-4)
@@ -324,17 +328,20 @@ def test_ift_stage_matches_reference_golden():
     eng = Engine(VisperConfig(**vars(ocfg), train_llm=True))
     eng.load_weights(W)
     out = eng.train_step(_to_gpu_batch(batch))
-    assert rel(out["loss"], g["loss"]) < 1e-2, (float(out["loss"]), float(g["loss"]))
+    check("ift_golden/loss_rel_vs_reference_golden", rel(out["loss"], g["loss"]), 1e-3)
     tr = json.loads(str(g["trainable"]))
     assert sorted(eng.ps.index) == tr
     for k in tr:
         got = eng.ps.g(k).detach().float().cpu()
         ref_norm = float(g[f"gradnorm::{k}"])
-        assert abs(float(got.norm()) - ref_norm) <= 0.1 * ref_norm + 1e-7, (k, float(got.norm()), ref_norm)
+        if ref_norm == 0.0:
+            assert float(got.norm()) < 1e-7, k
+        else:
+            check(f"ift_golden/gradnorm/{k}_rel", abs(float(got.norm()) - ref_norm) / ref_norm, 5e-2)
         mine, theirs = torch.from_numpy(cases.sub(got, 128)), torch.from_numpy(g[f"gradsub::{k}"])
         if float(theirs.norm()) > 0:
-            cos = float(torch.dot(mine, theirs) / (mine.norm() * theirs.norm() + 1e-30))
-            assert cos > 0.95, (k, cos)
+            c, _ = grad_err(mine, theirs)
+            check(f"ift_golden/gradsub/{k}/one_minus_cos", c, 5e-2)
 
 
 def test_dinov2_depth_teacher_matches_oracle_and_reference_golden():

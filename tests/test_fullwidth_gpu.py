@@ -10,6 +10,7 @@ S=4096, sliding window) of the HIP step against the CPU oracle on identical rand
 Bounds are measured error x ~3 (tests/parity.py logs the measured values on every run)."""
 import json
 import os
+import time
 
 import pytest
 import torch
@@ -49,10 +50,14 @@ def _gpu(batch):
     return {k: (v.cuda() if (k == "images" or k.endswith("_target") or k.endswith("_mask")) else v) for k, v in batch.items()}
 
 
-def _run(cfg, B, T, oracle_dtype, tag, bounds, logit_rows=64):
-    from oracle import visper_oracle as O
+def _frob(got, want):
+    """relative Frobenius error ||got - want|| / ||want||."""
+    g, w = got.double(), want.double()
+    return float((g - w).norm() / w.norm().clamp_min(1e-300))
+
+
+def _hip_step(cfg, B, T):
     from visper_lm_amd.engine import Engine, is_trainable
-    torch.set_num_threads(min(64, os.cpu_count() or 1))
     W = _weights(cfg)
     batch = _batch(cfg, B, T)
     eng = Engine(cfg)
@@ -60,46 +65,82 @@ def _run(cfg, B, T, oracle_dtype, tag, bounds, logit_rows=64):
     eng.keep_logits = True
     out = eng.train_step(_gpu(batch))
     torch.cuda.synchronize()
-    tr = [k for k in W if is_trainable(k)]
+    S = out["plan"]["S"]
+    rows = torch.linspace(0, S - 1, 64).long()
+    got = dict(S=S, rows=rows, text_loss=float(out["text_loss"]), loss=float(out["loss"]),
+               layer_losses={k: v.float().cpu() for k, v in out["layer_losses"].items()},
+               inputs_embeds=out["inputs_embeds"].float().cpu(), hidden=out["hidden"].float().cpu(),
+               logits=out["logits"][:, rows].float().cpu(), grads={k: eng.ps.g(k).detach().float().cpu().clone() for k in eng.ps.index})
+    Wc = {k: v.detach().cpu() for k, v in W.items() if not k.startswith("da_v2_head.")}
+    tr = [k for k in Wc if is_trainable(k)]
+    del eng, out, W
+    torch.cuda.empty_cache()
+    return got, Wc, batch, tr
+
+
+def _oracle_step(cfg, Wc, batch, tr, dtype, rows):
+    from oracle import visper_oracle as O
+    torch.set_num_threads(min(64, os.cpu_count() or 1))
     ocfg = O.make_config(**{k: v for k, v in cfg.to_dict().items() if k in vars(O.make_config())})
     Wo = {}
-    for k, v in W.items():
-        if k.startswith("da_v2_head."):
-            continue
-        t = v.detach().cpu()
-        t = t.float() if (oracle_dtype == torch.float32 or t.dim() == 0) else t
+    for k, v in Wc.items():
+        t = v.float() if (dtype == torch.float32 or v.dim() == 0) else v
         Wo[k] = t.clone().requires_grad_(True) if k in tr else t
-    del W
-    bo = {k: (v.to(oracle_dtype) if (torch.is_tensor(v) and v.is_floating_point() and not k.endswith("_mask")) else v) for k, v in batch.items()}
+    bo = {k: (v.to(dtype) if (torch.is_tensor(v) and v.is_floating_point() and not k.endswith("_mask")) else v) for k, v in batch.items()}
+    t0 = time.time()
     ref = O.forward(Wo, bo, ocfg)
     ref["loss"].backward()
-    check(f"{tag}/text_loss_rel", rel(out["text_loss"], ref["text_loss"]), bounds["loss"])
-    check(f"{tag}/loss_rel", rel(out["loss"], ref["loss"]), bounds["loss"])
+    res = dict(text_loss=float(ref["text_loss"]), loss=float(ref["loss"]), seconds=time.time() - t0,
+               layer_losses={k: torch.tensor([float(x) for x in v]) for k, v in ref["layer_losses"].items()},
+               inputs_embeds=ref["inputs_embeds"].detach().float(), hidden=ref["hidden"].detach().float(),
+               logits=ref["logits"].detach()[:, rows].float(),
+               grads={k: (None if Wo[k].grad is None else Wo[k].grad.detach().float()) for k in tr})
+    return res
+
+
+def _compare(tag, got, ref, bounds):
+    """Every metric is logged (parity.check); `bounds` may omit a key to log without asserting (bound = inf)."""
+    bd = lambda k: bounds.get(k, float("inf"))
+    check(f"{tag}/text_loss_rel", rel(got["text_loss"], ref["text_loss"]), bd("loss"))
+    check(f"{tag}/loss_rel", rel(got["loss"], ref["loss"]), bd("loss"))
     for key, trip in ref["layer_losses"].items():
-        mine = out["layer_losses"][key].float().cpu()
+        mine = got["layer_losses"][key]
         for j, nm in enumerate(("emb", "sl1", "con")):
-            check(f"{tag}/layer_loss/{key[0]}@{key[1]}/{nm}_rel", rel(mine[j], trip[j]), bounds["layer_loss"])
-    check(f"{tag}/inputs_embeds_maxrel", max_rel(out["inputs_embeds"].cpu(), ref["inputs_embeds"].detach()), bounds["embeds"])
-    check(f"{tag}/hidden_maxrel", max_rel(out["hidden"].cpu(), ref["hidden"].detach()), bounds["hidden"])
-    S = out["plan"]["S"]
-    rows = torch.linspace(0, S - 1, logit_rows).long()
-    check(f"{tag}/logits_maxrel", max_rel(out["logits"][:, rows].cpu(), ref["logits"].detach()[:, rows]), bounds["logits"])
-    worst_c, worst_n = 0.0, 0.0
-    for k in eng.ps.index:
-        got = eng.ps.g(k).detach().float().cpu()
-        want = Wo[k].grad
+            if abs(float(trip[j])) > 1e-9:
+                check(f"{tag}/layer_loss/{key[0]}@{key[1]}/{nm}_rel", rel(mine[j], trip[j]), bd("layer_loss"))
+    for nm in ("inputs_embeds", "hidden", "logits"):
+        check(f"{tag}/{nm}_frob", _frob(got[nm], ref[nm]), bd(nm + "_frob"))
+        check(f"{tag}/{nm}_maxrel", max_rel(got[nm], ref[nm]), bd(nm + "_max"))
+    worst_c = worst_n = 0.0
+    for k, want in ref["grads"].items():
+        mine = got["grads"][k]
         if want is None:                                        # depth linear_2 / linear_3 only feed the no-grad DPT decoder
-            assert float(got.abs().max()) == 0.0, k
+            if mine is not None:
+                assert float(mine.abs().max()) == 0.0, k
             continue
-        if got.numel() == 1:
-            check(f"{tag}/grad/{k}_rel", rel(got, want), bounds["grad_scalar"])
+        if mine is None:
             continue
-        c, n = grad_err(got, want.float())
+        if want.numel() == 1:                                   # logit scales: a sum of signed terms -> absolute slack
+            sb = (bd("grad_scalar_rel") * abs(float(want)) + bd("grad_scalar_abs")) if "grad_scalar_rel" in bounds else float("inf")
+            check(f"{tag}/grad/{k}_abs(ref {float(want):+.3e})", abs(float(mine) - float(want)), sb)
+            continue
+        c, n = grad_err(mine, want)
         worst_c, worst_n = max(worst_c, c), max(worst_n, n)
-        check(f"{tag}/grad/{k}/one_minus_cos", c, bounds["grad_cos"])
-        check(f"{tag}/grad/{k}/norm_dev", n, bounds["grad_norm"])
-    print(f"[parity] {tag}: worst 1-cos {worst_c:.2e}, worst norm deviation {worst_n:.2e}, S={S}")
-    return out, ref
+        check(f"{tag}/grad/{k}/one_minus_cos", c, bd("grad_cos"))
+        check(f"{tag}/grad/{k}/norm_dev", n, bd("grad_norm"))
+    print(f"[parity] {tag}: worst gradient 1-cos {worst_c:.2e}, worst norm deviation {worst_n:.2e}")
+
+
+def _run(cfg, B, T, oracle_dtype, tag, bounds):
+    got, Wc, batch, tr = _hip_step(cfg, B, T)
+    ref = _oracle_step(cfg, Wc, batch, tr, oracle_dtype, got["rows"])
+    print(f"[parity] {tag}: oracle ({oracle_dtype}) fwd+bwd took {ref['seconds']:.1f} s on {torch.get_num_threads()} threads, S={got['S']}")
+    _compare(tag, got, ref, bounds)
+    return got, ref
+
+
+TIGHT = dict(loss=1e-3, layer_loss=5e-3, inputs_embeds_frob=1e-2, hidden_frob=2e-2, logits_frob=2e-2, inputs_embeds_max=2e-2,
+             hidden_max=5e-2, logits_max=5e-2, grad_scalar_rel=0.05, grad_scalar_abs=1e-4, grad_cos=1e-2, grad_norm=3e-2)
 
 
 def test_fullwidth_llama_step_all_heads_vs_fp32_oracle():
@@ -110,30 +151,50 @@ def test_fullwidth_llama_step_all_heads_vs_fp32_oracle():
     cfg.image_seg = dict(cfg.image_seg, seg_layer_indices="1")
     cfg.image_depth = dict(cfg.image_depth, depth_layer_indices="2")
     cfg.image_gen = dict(cfg.image_gen, img_layer_indices="2")
-    bounds = dict(loss=1e-3, layer_loss=5e-3, embeds=2e-2, hidden=3e-2, logits=3e-2, grad_scalar=0.1, grad_cos=2e-2, grad_norm=5e-2)
-    out, _ = _run(cfg, 2, 128, torch.float32, "fullwidth_llama_L2", bounds)
-    assert out["plan"]["S"] == 127 + 576 + 24
+    got, _ = _run(cfg, 2, 128, torch.float32, "fullwidth_llama_L2", TIGHT)
+    assert got["S"] == 127 + 576 + 24
 
 
-def test_config0_full_depth_vs_reference_style_bf16_cpu_path():
-    """BASELINE.json configs[0] exactly: random-init CLIP-ViT-L + Llama-3-8B (32 layers), 1 distill layer (seg@18), text length 128,
-    2 images, against the oracle executed like the reference's CPU PyTorch path (bf16 weights and activations, PyTorch bf16 ops).
-    The CPU bf16 path is itself only reproducible to ~1.6e-3 between runs; bounds state what is measured."""
+def _mem_available_gb():
+    try:
+        for line in open("/proc/meminfo"):
+            if line.startswith("MemAvailable"):
+                return int(line.split()[1]) / 1e6
+    except OSError:
+        pass
+    return 0.0
+
+
+def test_config0_full_depth_vs_fp32_truth_and_reference_style_bf16_cpu_path():
+    """BASELINE.json configs[0] exactly: random-init CLIP-ViT-L + Llama-3-8B (all 32 layers), 1 distill layer (seg@18), text length 128,
+    2 images.  Three runs on identical weights / batch: the HIP step, the oracle in fp32 arithmetic (the numerical truth for these bf16
+    weights) and the oracle executed like the reference's CPU PyTorch path (bf16 weights and activations, PyTorch bf16 ops).  Asserted:
+    HIP vs truth and HIP vs the bf16 CPU path; logged beside them: the bf16 CPU path's own distance from the truth (the reference's
+    noise floor; SURVEY 6 measured 1.6e-3 between two of its own runs)."""
     from visper_lm_amd.config import llama3_8b
     cfg = llama3_8b(aux_mode="seg")
-    bounds = dict(loss=2e-3, layer_loss=2e-2, embeds=2e-2, hidden=6e-2, logits=6e-2, grad_scalar=0.3, grad_cos=5e-2, grad_norm=0.1)
-    out, _ = _run(cfg, 2, 128, BF, "config0_full_depth_bf16", bounds)
-    assert out["plan"]["S"] == 127 + 576 + 8
+    got, Wc, batch, tr = _hip_step(cfg, 2, 128)
+    assert got["S"] == 127 + 576 + 8
+    refb = _oracle_step(cfg, Wc, batch, tr, BF, got["rows"])
+    print(f"[parity] config0: bf16 CPU oracle fwd+bwd {refb['seconds']:.1f} s")
+    deep = dict(TIGHT, hidden_frob=5e-2, logits_frob=5e-2, hidden_max=0.2, logits_max=0.2, layer_loss=1e-2, grad_cos=3e-2, grad_norm=6e-2,
+                grad_scalar_rel=0.2, grad_scalar_abs=1e-3)
+    _compare("config0_vs_bf16_cpu_path", got, refb, deep)
+    if _mem_available_gb() < 70:
+        pytest.skip("fp32 truth leg needs ~40 GB of host memory")
+    ref32 = _oracle_step(cfg, Wc, batch, tr, torch.float32, got["rows"])
+    print(f"[parity] config0: fp32 CPU oracle fwd+bwd {ref32['seconds']:.1f} s")
+    _compare("config0_vs_fp32_truth", got, ref32, deep)
+    _compare("config0_INFO_bf16_cpu_path_vs_fp32_truth", refb, ref32, {})
 
 
 def test_fullwidth_phi3_long_context_vs_fp32_oracle():
     """configs[4] shapes: Phi-3-mini width, S=4096 (> sliding window 2047, so the window mask is live), D=96 attention, fused qkv_proj /
-    gate_up_proj; B=1, two layers, heads at full width (depth head D=3072)."""
+    gate_up_proj; two layers, heads at full width (depth head D=3072).  B=2 so that the contrastive term is live."""
     from visper_lm_amd.config import phi3_mini
     cfg = phi3_mini(num_hidden_layers=2, vit_layers=4)
     cfg.image_seg = dict(cfg.image_seg, seg_layer_indices="1")
     cfg.image_depth = dict(cfg.image_depth, depth_layer_indices="2")
     cfg.image_gen = dict(cfg.image_gen, img_layer_indices="2")
-    bounds = dict(loss=1e-3, layer_loss=5e-3, embeds=2e-2, hidden=3e-2, logits=3e-2, grad_scalar=0.1, grad_cos=2e-2, grad_norm=5e-2)
-    out, _ = _run(cfg, 1, 3497, torch.float32, "fullwidth_phi3_S4096_L2", bounds)
-    assert out["plan"]["S"] == 4096
+    got, _ = _run(cfg, 2, 3497, torch.float32, "fullwidth_phi3_S4096_L2", TIGHT)
+    assert got["S"] == 4096

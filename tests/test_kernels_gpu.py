@@ -453,7 +453,12 @@ def test_ce(ops):
 
 
 @pytest.mark.parametrize("B,world,rank,shape,mask", [(3, 1, 0, (3, 40, 1024), [1., 0., 1.]), (2, 4, 2, (2, 96, 24), [1., 1.]),
-                                                     (8, 1, 0, (8, 1, 1024), [1.] * 8), (4, 2, 1, (4, 1536, 6, 6), [1., 1., 0., 1.])])
+                                                     (8, 1, 0, (8, 1, 1024), [1.] * 8), (4, 2, 1, (4, 1536, 6, 6), [1., 1., 0., 1.]),
+                                                     # the reference's pretrain.sh runs 32 per device on 8 devices (Bw = 256); odd local
+                                                     # batches; feature length not a multiple of the 32-wide k-step; several target chunks (Bw > 128)
+                                                     (32, 8, 5, (32, 40, 64), [1.] * 31 + [0.]), (12, 3, 1, (12, 1000), [1.] * 12),
+                                                     (20, 4, 3, (20, 7, 24), [0.5] * 20), (8, 8, 7, (8, 576, 64), [1.] * 8),
+                                                     (64, 16, 9, (64, 264), [1.] * 64)])
 def test_emb_loss(ops, B, world, rank, shape, mask):
     from oracle import visper_oracle as O
     D = math.prod(shape[1:])
@@ -471,6 +476,34 @@ def test_emb_loss(ops, B, world, rank, shape, mask):
     dp = ops.emb_loss_bwd(dev(pred).reshape(B, D), dev(tg_all), coef, 0.5, rank=rank)
     close(dp.reshape(shape), pr.grad, rtol=3e-2, atol=2e-2 * float(pr.grad.abs().max()), what="emb loss dpred")
     close(coef[-1:] * 0.5, ls.grad[None], rtol=5e-3, atol=1e-6, what="dlogit_scale")
+    # one launch, deterministic tree reduction: bitwise identical on a second call (and the ticket counters re-armed themselves)
+    out3b, coefb = ops.emb_loss_fwd(dev(pred).reshape(B, D), dev(tg_all), torch.tensor(mask).cuda(), torch.tensor([2.0]).cuda(), 0.3,
+                                    rank=rank)
+    assert torch.equal(out3, out3b) and torch.equal(coef, coefb)
+
+
+def test_emb_loss_full_size_world8(ops):
+    """K11 at the config-2 seg shape (D = 1536*576) with 8 ranks' gathered targets: statistics against fp64 on a feature subsample-free
+    full reduction (torch on the GPU is only the checker here), no-contrastive variant, and the shapes the C ABI refuses."""
+    B, Bw, D, rank = 8, 64, 1536 * 576, 3
+    g = torch.Generator(device="cuda").manual_seed(5)
+    pred = (torch.randn(B, D, device="cuda", generator=g) * 1.3).to(torch.bfloat16)
+    tgt = torch.randn(Bw, D, device="cuda", generator=g).to(torch.bfloat16)
+    mask = torch.ones(B, device="cuda")
+    out3, coef = ops.emb_loss_fwd(pred, tgt, mask, torch.tensor([2.0]).cuda(), 0.3, rank=rank)
+    p64, t64 = pred.double(), tgt.double()
+    own = t64[rank * B:(rank + 1) * B]
+    d = (p64 - own).abs()
+    sl1 = torch.where(d < 1, 0.5 * d * d, d - 0.5).mean()
+    z = (F.normalize(p64, dim=-1) @ F.normalize(t64, dim=-1).t()) * min(math.exp(2.0), 100.0)
+    con = 0.3 * F.cross_entropy(z, torch.arange(B, device="cuda") + rank * B)
+    close(out3.double().cpu(), torch.stack([sl1 + con, sl1, con]).cpu(), rtol=1e-4, atol=1e-6, what="emb loss full size")
+    out3n, coefn = ops.emb_loss_fwd(pred, tgt, mask, None, 0.3, rank=rank)
+    assert float(out3n[2]) == 0.0 and abs(float(out3n[1]) - float(sl1)) < 1e-4 * float(sl1) and float(coefn[B:-1].abs().max()) == 0.0
+    with pytest.raises(RuntimeError):
+        ops.emb_loss_fwd(pred[:, :1004].contiguous(), tgt[:, :1004].contiguous(), mask, None, 0.3)       # D % 8 != 0
+    with pytest.raises(RuntimeError):
+        ops.emb_loss_fwd(pred, tgt[:4], mask, None, 0.3)                                               # Bw < B
 
 
 def test_dpt_conv_helpers(ops):

@@ -59,12 +59,13 @@ _SIGS = {
     "vp_attn_bwd_rope": [i, i, i, i, i, i, p, l, l, p, l, l, p, l, l, p, l, l, p, p, l, l, p, l, l, p, l, l, p, l, l, p, p,
                     i, i, f, p, p, p, p],
     "vp_ce_fwd_bwd": [l, i, p, l, p, p, f, i, p],
-    "vp_emb_loss_nblk": [l],
+    "vp_emb_loss_workspace": [i, i, l],
     "vp_sumsq_nblk": [l],
     "vp_emb_loss_fwd": [i, i, l, i, p, p, p, p, f, p, p, p, p],
     "vp_emb_loss_bwd": [i, i, l, i, p, p, p, f, p, p],
     "vp_adamw": [l, p, p, p, p, p, f, f, f, f, f, i, f, p],
 }
+_RET_LONG = {"vp_emb_loss_workspace"}
 EXPORTS = ["vp_last_error_string"] + list(_SIGS)
 
 _lib = None
@@ -83,7 +84,7 @@ def load():
         for name, args in _SIGS.items():
             fn = getattr(lib, name)
             fn.argtypes = args
-            fn.restype = C.c_int
+            fn.restype = C.c_long if name in _RET_LONG else C.c_int
         _lib = lib
     return _lib
 
@@ -97,5 +98,5 @@ def call(name, *args):
 
 
 def raw(name, *args):
-    """Call returning the raw int (for query functions such as vp_emb_loss_nblk / vp_version)."""
+    """Call returning the raw int (for query functions such as vp_emb_loss_workspace / vp_version)."""
     return getattr(load(), name)(*args)

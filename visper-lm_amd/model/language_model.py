@@ -209,6 +209,12 @@ class _OlaCausalLMBase(OlaLlavaMetaForCausalLM, BaseOLA_VLM, nn.Module):
     def get_model(self):
         return self.model
 
+    def state_dict(self, *args, **kwargs):
+        """nn.Module.state_dict after pulling in anything the engine's optimizer trained since the last forward."""
+        if self._engine is not None:
+            self._sync_trainable()
+        return super().state_dict(*args, **kwargs)
+
     def _collect_targets(self, pil_images, kw, B, dev):
         t = {}
         for task, getter in (("gen", "_get_gen_feats"), ("depth", "_get_dav2_feats"), ("seg", "_get_seg_targets")):

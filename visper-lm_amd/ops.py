@@ -473,9 +473,8 @@ def emb_loss_fwd(pred, tgt_all, mask, logit_scale, w_con, rank=0):
     -> out3 f32 [3] = (emb_loss, sl1, contrastive), coef (saved for backward)."""
     B, D = pred.shape
     Bw = tgt_all.shape[0]
-    nblk = _lib.raw("vp_emb_loss_nblk", D)
-    njc = (Bw + 7) // 8
-    part = torch.empty(njc * nblk * 88, device=pred.device, dtype=torch.float32)
+    assert pred.is_contiguous() and tgt_all.is_contiguous() and tgt_all.shape[1] == D
+    part = torch.empty(max(1, _lib.raw("vp_emb_loss_workspace", B, Bw, D)), device=pred.device, dtype=torch.float32)
     coef = torch.empty(2 * B + B * Bw + 1, device=pred.device, dtype=torch.float32)
     out3 = torch.empty(3, device=pred.device, dtype=torch.float32)
     _lib.call("vp_emb_loss_fwd", B, Bw, D, rank, _p(pred), _p(tgt_all), _p(mask), _p(logit_scale), w_con, _p(out3), _p(coef),
