@@ -178,6 +178,8 @@ int vp_ce_fwd_bwd(long rows, int V, void* logits, long ld, const long* labels, f
  * tgt_all [Bw,D] bf16 row-major, 16-byte aligned.  logit_scale NULL = no contrastive term.  Calls on DIFFERENT streams may overlap
  * only if their stream handles hash to different counter slots (8 slots); calls on one stream are always safe. */
 long vp_emb_loss_workspace(int B, int Bw, long D);
+/* dev aid (tools/emb_loss_debug.py): device buffer of 8 int64 for in-kernel wall-clock stamps of later vp_emb_loss_fwd calls; NULL = off */
+int vp_debug_emb_loss_stamps(long long* dev_buf);
 int vp_emb_loss_fwd(int B, int Bw, long D, int rank, const void* pred, const void* tgt_all, const float* mask,
                     const float* logit_scale, float w_contrastive, float* out3, float* coef, float* workspace,
                     vp_stream_t stream);
@@ -188,6 +190,24 @@ int vp_emb_loss_bwd(int B, int Bw, long D, int rank, const void* pred, const voi
  * the flat fp32 master buffer, bf16 shadow refreshed in the same pass. */
 int vp_adamw(long n, float* p, const float* g, float* m, float* v, void* bf16_shadow, float lr, float beta1, float beta2,
              float eps, float weight_decay, int step, float grad_scale, vp_stream_t stream);
+
+/* ---- data-parallel exchange points, RCCL over xGMI with the library's own side stream + hipEvent fences.  Replaces
+ * DeepSpeed ZeRO-2's gradient reduction (scripts/zero2.json:16-22, launched by scripts/train/pretrain.sh:15) and diffdist's
+ * all_gather of the contrastive targets (ola_utils.py:96-106).  One process per GPU; rank 0 creates the unique id
+ * (vp_comm_unique_id_bytes() bytes) and distributes it out of band; vp_comm_init is collective.  RCCL is resolved at run time
+ * (the librccl already loaded in the process, e.g. PyTorch's, else librccl.so[.1]).
+ *   vp_comm_allreduce_async: in-place SUM of `count` elements (dtype 0 = fp32, 1 = bf16, 2 = int32) on the communicator's side
+ *     stream, ordered after the work already queued on `compute_stream`; returns at once (overlaps the rest of the backward pass).
+ *   vp_comm_wait: `compute_stream` waits on the device for every all-reduce issued since the last wait; the host never blocks.
+ *   vp_comm_allgather: recv[world*count] = rank-ordered concatenation of send[count], on `stream`. */
+int vp_comm_unique_id_bytes(void);
+int vp_comm_unique_id(void* id_out);
+int vp_comm_init(int rank, int world, const void* id, void** comm_out);
+int vp_comm_allreduce_async(void* comm, void* buf, long count, int dtype, vp_stream_t compute_stream);
+int vp_comm_wait(void* comm, vp_stream_t compute_stream);
+int vp_comm_allgather(void* comm, const void* send, void* recv, long count, int dtype, vp_stream_t stream);
+int vp_comm_info(void* comm, int* rank, int* world);
+int vp_comm_destroy(void* comm);
 
 #ifdef __cplusplus
 }

@@ -193,3 +193,169 @@ def test_model_api_with_external_torch_optimizer():
     model._sync_trainable()
     p = dict(model.named_parameters())["model.mm_projector.2.weight"]
     assert torch.equal(eng.ps.w("model.mm_projector.2.weight"), p.detach().to(torch.bfloat16))
+
+
+# ------------------------------------------------------------------------------------------------ trainer-shaped loops
+def _instances(batch):
+    """Dataset items exactly as LazySupervisedDataset yields them (ola_vlm_train.py:774-880): 1-D ids / labels, one image tensor, the
+    PIL image (here: its index — the teachers are replaced by synthetic targets) and the per-sample task masks."""
+    n = batch["input_ids"].shape[0]
+    return [dict(input_ids=batch["input_ids"][i], labels=batch["labels"][i], image=batch["images"][i], pil_image=i,
+                 seg_mask=1, depth_mask=1, gen_mask=1) for i in range(n)]
+
+
+def _teacher_hooks(model, batch):
+    """Frozen-teacher features as the reference's hooks return them (base_ola_vlm.py:323-397), looked up by the 'PIL image' index."""
+    dev = "cuda"
+    model._get_gen_feats = lambda pil, device: torch.stack([batch["gen_target"][i] for i in pil]).to(dev)
+    model._get_dav2_feats = lambda pil, device: ([(torch.stack([batch["depth_target"][i] for i in pil]).to(dev), None)], None)
+    model._get_seg_targets = lambda pil, preds: torch.stack([batch["seg_target"][i] for i in pil]).to(dev)
+
+
+def _oracle_adamw_curve(ocfg, W, batch, trainable, steps, lr):
+    """The reference's training semantics on the CPU: fp32 autograd through the oracle + torch.optim.AdamW (HF `adamw_torch`,
+    weight decay 0: pretrain.sh) on the trainable leaves, starting from the same bf16-rounded weights."""
+    from oracle import visper_oracle as O
+    BF = torch.bfloat16
+    Wq = {k: v.to(BF).float() for k, v in W.items()}
+    for k in trainable:
+        Wq[k] = Wq[k].clone().requires_grad_(True)
+    bq = {k: (v.to(BF).float() if (torch.is_tensor(v) and v.is_floating_point() and not k.endswith("_mask")) else v) for k, v in batch.items()}
+    opt = torch.optim.AdamW([Wq[k] for k in trainable], lr=lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0)
+    losses = []
+    for _ in range(steps):
+        opt.zero_grad(set_to_none=True)
+        out = O.forward(Wq, bq, ocfg)
+        out["loss"].backward()
+        opt.step()
+        losses.append(float(out["loss"]))
+    return losses
+
+
+def test_collator_to_model_to_engine_optimizer_pt_stage_matches_oracle_adamw():
+    """what HF Trainer does per step (ola_vlm_train.py:1297-1327: collator -> model(**batch) -> loss.backward() ->
+    optimizer.step()) driven through the drop-in class for 3 steps, against the oracle stepping torch.optim.AdamW."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from oracle import cases
+    from visper_lm_amd import data
+    ocfg, W, batch, g = cases.tiny_llama_case()
+    model, _ = _mirror_from_tiny()
+    _teacher_hooks(model, batch)
+    coll = data.Collator(pad_token_id=0, model_max_length=4096)
+    lr, steps = 1e-3, 3
+    losses = []
+    for _ in range(steps):
+        b = coll(_instances(batch))
+        out = model(**{k: (v.cuda() if k == "images" else v) for k, v in b.items()})
+        out["loss"].backward()
+        model.optimizer_step(lr=lr)
+        losses.append(float(out.loss))
+    ref = _oracle_adamw_curve(ocfg, W, batch, json.loads(str(g["trainable"])), steps, lr)
+    for i, (a, r) in enumerate(zip(losses, ref)):
+        check(f"trainer_loop_pt/step{i}_loss_rel_vs_oracle_adamw", abs(a - r) / abs(r), 2e-3)
+    check("trainer_loop_pt/loss_drop_rel_dev", abs((losses[0] - losses[-1]) - (ref[0] - ref[-1])) / abs(ref[0] - ref[-1]), 0.1)
+    assert losses[-1] < losses[0]
+
+
+def test_llava_llama_ift_mirror_drop_in():
+    """VERDICT r1 #1 / north_star: the LlavaMetaForCausalLM / LlavaLlamaForCausalLM surface (llava_arch.py:210,295-298;
+    llava_llama.py:51,73-119).  Reference golden (its own LlavaLlamaForCausalLM): loss and every parameter-gradient norm through
+    `.loss.backward()`; the Parameters ARE the engine's flat store (no second copy of the LLM); 3 collator -> model -> optimizer
+    steps follow the oracle's AdamW curve; sharded safetensors save_pretrained / from_pretrained round trip."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import tempfile
+    from oracle import cases
+    from visper_lm_amd import data
+    from visper_lm_amd.model import LlavaLlamaForCausalLM, LlavaConfig, LlavaMetaForCausalLM, CausalLMOutputWithPast
+    ocfg, W, batch, g = cases.tiny_ift_case()
+    cfg = LlavaConfig(**vars(ocfg))
+    assert cfg.train_llm and not cfg.aux_heads and cfg.model_type == "llava_llama"
+    model = LlavaLlamaForCausalLM(cfg, init="empty")
+    assert isinstance(model, LlavaMetaForCausalLM)
+    sd = {k.replace("model.vision_tower.vision_tower.", "model.vision_tower.vision_tower.vision_model.")
+          if k.startswith("model.vision_tower.vision_tower.") else k: v for k, v in W.items()}
+    model.load_state_dict(sd, strict=True)
+    tr = json.loads(str(g["trainable"]))
+    assert sorted(n for n, p in model.named_parameters() if p.requires_grad) == tr
+    kw = dict(input_ids=batch["input_ids"], attention_mask=batch["attention_mask"], labels=batch["labels"], images=batch["images"].cuda())
+    out = model(**kw)
+    assert isinstance(out, CausalLMOutputWithPast) and out["loss"] is out.loss and out[0] is out.loss
+    check("ift_mirror/loss_rel_vs_reference_golden", abs(float(out.loss) - float(g["loss"])) / float(g["loss"]), 1e-3)
+    out.loss.backward()
+    named = dict(model.named_parameters())
+    for k in tr:
+        ref = float(g[f"gradnorm::{k}"])
+        got = float(named[k].grad.float().norm())
+        if ref == 0.0:
+            assert got < 1e-7, k
+        else:
+            check(f"ift_mirror/gradnorm/{k}_rel_vs_reference_golden", abs(got - ref) / ref, 5e-2)
+    eng = model._get_engine()
+    for k in ("model.layers.0.self_attn.q_proj.weight", "lm_head.weight", "model.embed_tokens.weight", "model.mm_projector.0.bias"):
+        assert named[k].data_ptr() == eng.ps.w(k).data_ptr(), k                  # Parameter == view of the bf16 shadow
+    feats = model.encode_images(batch["images"].cuda())
+    assert feats.shape == (2, 576, cfg.hidden_size)
+    r = model.prepare_inputs_labels_for_multimodal(batch["input_ids"], None, batch["attention_mask"], None, batch["labels"], batch["images"].cuda())
+    assert r[0] is None and r[4].shape[:2] == r[5].shape
+    # ---- 3 trainer-shaped steps vs the oracle's AdamW
+    coll = data.Collator(pad_token_id=0, model_max_length=4096)
+    inst = [dict(input_ids=batch["input_ids"][i], labels=batch["labels"][i], image=batch["images"][i]) for i in range(2)]
+    lr, losses = 2e-4, []
+    for _ in range(3):
+        b = coll(inst)
+        o = model(**{k: (v.cuda() if k == "images" else v) for k, v in b.items()})
+        o.loss.backward()
+        model.optimizer_step(lr=lr)
+        losses.append(float(o.loss))
+    ref = _oracle_adamw_curve(ocfg, W, batch, tr, 3, lr)
+    for i, (a, r_) in enumerate(zip(losses, ref)):
+        check(f"ift_mirror/step{i}_loss_rel_vs_oracle_adamw", abs(a - r_) / abs(r_), 3e-3)
+    assert losses[-1] < losses[0]
+    # ---- HF-style persistence: shards + index, bitwise state, same loss
+    with tempfile.TemporaryDirectory() as d:
+        model.save_pretrained(d, max_shard_size=200_000)
+        import os
+        assert os.path.exists(os.path.join(d, "model.safetensors.index.json")) and os.path.exists(os.path.join(d, "config.json"))
+        clone = LlavaLlamaForCausalLM.from_pretrained(d)
+        a, b_ = model.state_dict(), clone.state_dict()
+        assert sorted(a) == sorted(b_) and all(torch.equal(a[k], b_[k]) for k in a)
+        l1, l2 = float(model(**kw).loss), float(clone(**kw).loss)
+        assert l1 == l2, (l1, l2)
+
+
+def test_hf_trainer_drives_the_pt_mirror():
+    """The reference's own driver: transformers.Trainer (LLaVATrainer's base, llava_trainer.py:217) with the supervised collator,
+    its torch AdamW and gradient clipping, 3 optimizer steps on the drop-in class — the loss must fall and the trained state must be
+    what the engine runs on."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import tempfile
+    from oracle import cases
+    from transformers import Trainer, TrainingArguments
+    from visper_lm_amd import data
+    ocfg, W, batch, g = cases.tiny_llama_case()
+    model, kw = _mirror_from_tiny()
+    _teacher_hooks(model, batch)
+    l0 = float(model(**kw).loss)
+
+    class DS(torch.utils.data.Dataset):
+        def __len__(self):
+            return 8
+
+        def __getitem__(self, i):
+            return _instances(batch)[i % 2]
+    with tempfile.TemporaryDirectory() as d:
+        args = TrainingArguments(output_dir=d, per_device_train_batch_size=2, max_steps=3, learning_rate=1e-3, weight_decay=0.0,
+                                 lr_scheduler_type="constant", logging_steps=1, save_strategy="no", report_to=[], bf16=True,
+                                 remove_unused_columns=False, dataloader_num_workers=0, dataloader_pin_memory=False, seed=0)
+        trainer = Trainer(model=model, args=args, train_dataset=DS(), data_collator=data.Collator(0, 4096, pin_memory=False))
+        res = trainer.train()
+    assert res.global_step == 3 and torch.isfinite(torch.tensor(res.training_loss))
+    l1 = float(model(**kw).loss)
+    assert l1 < l0 - 1e-3, (l0, l1)
+    eng = model._get_engine()
+    p = dict(model.named_parameters())["model.mm_projector.0.weight"]
+    assert p.data_ptr() == eng.ps.w("model.mm_projector.0.weight").data_ptr()
+    assert torch.equal(eng.ps.p("model.mm_projector.0.weight").to(torch.bfloat16).view(p.shape), p.detach())   # master follows the Trainer's steps

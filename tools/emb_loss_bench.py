@@ -15,7 +15,7 @@ def t(fn, n=20):
     return e0.elapsed_time(e1) / n
 
 
-B = 8
+B = int(os.environ.get("EL_B", "8"))
 for name, D in (("gen", 1024), ("depth", 576 * 1024), ("seg", 1536 * 576)):
     for world in (1, 8):
         Bw = B * world

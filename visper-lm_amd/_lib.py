@@ -60,10 +60,19 @@ _SIGS = {
                     i, i, f, p, p, p, p],
     "vp_ce_fwd_bwd": [l, i, p, l, p, p, f, i, p],
     "vp_emb_loss_workspace": [i, i, l],
+    "vp_debug_emb_loss_stamps": [p],
     "vp_sumsq_nblk": [l],
     "vp_emb_loss_fwd": [i, i, l, i, p, p, p, p, f, p, p, p, p],
     "vp_emb_loss_bwd": [i, i, l, i, p, p, p, f, p, p],
     "vp_adamw": [l, p, p, p, p, p, f, f, f, f, f, i, f, p],
+    "vp_comm_unique_id_bytes": [],
+    "vp_comm_unique_id": [p],
+    "vp_comm_init": [i, i, p, p],
+    "vp_comm_allreduce_async": [p, p, l, i, p],
+    "vp_comm_wait": [p, p],
+    "vp_comm_allgather": [p, p, p, l, i, p],
+    "vp_comm_info": [p, p, p],
+    "vp_comm_destroy": [p],
 }
 _RET_LONG = {"vp_emb_loss_workspace"}
 EXPORTS = ["vp_last_error_string"] + list(_SIGS)

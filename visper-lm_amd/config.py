@@ -33,6 +33,7 @@ class VisperConfig:
             # distillation (ola_vlm_train.py:1149-1229)
             aux_mode="gen-depth-seg", num_task_tokens=8, contrastive_loss_weight=0.3, use_contrastive=True,
             pass_text_to_aux=True, task_token_format="emb",
+            aux_heads=True,        # False: task tokens are spliced but no distillation heads exist (the IFT-stage LlavaLlamaForCausalLM)
             image_gen=dict(depth=1, dim_head=32, num_heads=4, num_tokens=1, output_dim=1024, ff_mult=1,
                            img_layer_indices="20", img_loss_weight=0.5),
             image_depth=dict(depth=1, dim_head=32, num_heads=4, num_tokens=576, output_dim=1024, ff_mult=1,

@@ -17,6 +17,7 @@
 // BACKWARD = one streaming launch: dpred[b,:] = g * ( a_b * clamp(p_b - t_own(b), -1, 1) + sum_j c_bj * t_j - e_b * p_b ).
 // Any local batch B <= 64 and any gathered batch Bw <= 1024 (the reference's pretrain.sh runs 32 per device on 8 devices: Bw = 256).
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -24,8 +25,6 @@ constexpr int G1 = 32;                 // blocks per first-level reduction group
 constexpr int MAX_GROUPS = 1024;       // njc * ngrp
 constexpr int N_SLOTS = 8;             // independent counter sets (one per stream hash) so that calls on different streams do not collide
 __device__ unsigned g_counters[N_SLOTS][1 + MAX_GROUPS];   // zero at module load; every launch leaves its slot zeroed again
-
-typedef __attribute__((ext_vector_type(2))) __bf16 bf2_t;
 
 struct ElArgs {
   const bf16_t* pred;
@@ -40,12 +39,22 @@ struct ElArgs {
   long D;
   int B, Bw, rank, nblk, njc, ngrp, slot;
   float w_con;
+  long long* dbg;    // dev aid: 8 wall-clock stamps (100 MHz) of the finishing block, or null
 };
 
+// device-coherent (agent-scope, sc1) accesses for data that crosses workgroups on different XCDs
+__device__ __forceinline__ void cstore(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float cload(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// sum of the 8 products of two bf16x8 vectors, fp32 FMAs.  (v_dot2_f32_bf16 is NOT used: on gfx950 its sums of squares came out up
+// to 13 % off in tools/emb_loss_debug.py, while the MFMA dot products from the same registers were exact to 1e-7.)
 __device__ __forceinline__ float dot8(bf16x8 a, bf16x8 b, float c) {
   const u32x4 ua = __builtin_bit_cast(u32x4, a), ub = __builtin_bit_cast(u32x4, b);
 #pragma unroll
-  for (int i = 0; i < 4; ++i) c = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2_t, ua[i]), __builtin_bit_cast(bf2_t, ub[i]), c, false);
+  for (int i = 0; i < 4; ++i) {
+    c = fmaf(__builtin_bit_cast(float, ua[i] << 16), __builtin_bit_cast(float, ub[i] << 16), c);
+    c = fmaf(__builtin_bit_cast(float, ua[i] & 0xffff0000u), __builtin_bit_cast(float, ub[i] & 0xffff0000u), c);
+  }
   return c;
 }
 
@@ -68,12 +77,12 @@ __device__ __forceinline__ float smooth_l1_8(bf16x8 p, bf16x8 t, float c) {
 //   coef[2B+B*Bw]         d loss / d logit_scale parameter
 // mask semantics: sl1 = mean_all(sl1_elem * mask_b); con = w * mean_b(CE_b) * mean_b(mask_b)  (the outer-product broadcast of
 // base_ola_vlm.py:312-316).
-__device__ void el_finalize(const ElArgs& a, float* ce, float* dce) {
-  const int t = threadIdx.x, B = a.B, Bw = a.Bw;
-  const float* PT = a.fin;
-  const float* TT = a.fin + (long)B * Bw;
-  const float* PP = TT + Bw;
-  const float* SL = PP + B;
+__device__ void el_finalize(const ElArgs& a, float* PT, int ldpt, const float* TT, const float* PP, const float* SL, float* ce,
+                            float* dce) {
+  // 256 threads.  Phase A: every (b, j) logit in parallel, written IN PLACE of its dot product (PT is LDS when all gathered targets
+  // fit one chunk, else the global workspace).  Phase B: one wave per local row, lane-strided over the gathered targets with shuffle
+  // reductions.  (A serial loop per row cost ~170 ns per target: 30 us at Bw = 64.)
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6, B = a.B, Bw = a.Bw;
   const bool has_con = a.logit_scale != nullptr;
   float scale = 0.f, dscale_dls = 0.f;
   if (has_con) {
@@ -81,54 +90,76 @@ __device__ void el_finalize(const ElArgs& a, float* ce, float* dce) {
     scale = fminf(e, 100.f);
     dscale_dls = e < 100.f ? e : 0.f;
   }
+  // mask -> LDS once (ce / dce double as scratch until phase B): a serial loop of dependent global loads per thread cost 4 us
+  if (t < 64) { ce[t] = t < B ? a.mask[t] : 0.f; dce[t] = 0.f; }
+  __syncthreads();
   float msum = 0.f;
-  for (int b = 0; b < B; ++b) msum += a.mask[b];
+  for (int b = 0; b < B; ++b) msum += ce[b];
   const float mmean = msum / (float)B;
+  const float mymask = t < 64 ? ce[t] : 0.f;
+  __syncthreads();
+  for (int idx = t; idx < B * Bw; idx += 256) {
+    const int b = idx / Bw, j = idx - b * Bw;
+    float* z = PT + (long)b * ldpt + j;
+    *z = has_con ? scale * *z / (fmaxf(sqrtf(PP[b]), 1e-12f) * fmaxf(sqrtf(TT[j]), 1e-12f)) : 0.f;
+  }
   if (t < B) {
-    a.coef[t] = a.mask[t] / ((float)B * (float)a.D);
-    if (has_con) {
-      const float np = fmaxf(sqrtf(PP[t]), 1e-12f);
-      const float* pt = PT + (long)t * Bw;
-      float mx = -1e30f;
-      for (int j = 0; j < Bw; ++j) mx = fmaxf(mx, scale * pt[j] / (np * fmaxf(sqrtf(TT[j]), 1e-12f)));
-      float se = 0.f;
-      for (int j = 0; j < Bw; ++j) se += __expf(scale * pt[j] / (np * fmaxf(sqrtf(TT[j]), 1e-12f)) - mx);
-      const float lse = mx + __logf(se);
-      const int own = a.rank * B + t;
-      ce[t] = lse - scale * pt[own] / (np * fmaxf(sqrtf(TT[own]), 1e-12f));
-      float e_b = 0.f, dls = 0.f;
-      const float gz = a.w_con * mmean / (float)B;                 // d con / d Z_bj = w * mmean / B * (softmax_bj - onehot)
-      for (int j = 0; j < Bw; ++j) {
-        const float nt = fmaxf(sqrtf(TT[j]), 1e-12f);
-        const float z = scale * pt[j] / (np * nt);
-        float dz = __expf(z - lse);
-        if (j == own) dz -= 1.f;
-        dz *= gz;
-        const float cbj = dz * scale / (np * nt);
-        a.coef[2 * B + (long)t * Bw + j] = cbj;
-        e_b += cbj * pt[j] / (np * np);
-        dls += dz * (scale > 0.f ? z / scale : 0.f) * dscale_dls;
-      }
-      a.coef[B + t] = e_b;
-      dce[t] = dls;
-    } else {
-      a.coef[B + t] = 0.f;
-      for (int j = 0; j < Bw; ++j) a.coef[2 * B + (long)t * Bw + j] = 0.f;
+    a.coef[t] = mymask / ((float)B * (float)a.D);
+    if (!has_con) a.coef[B + t] = 0.f;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+  __syncthreads();
+  for (int b = wv; b < B; b += 4) {
+    const float* z = PT + (long)b * ldpt;
+    float* cb = a.coef + 2 * B + (long)b * Bw;
+    if (!has_con) {
+      for (int j = lane; j < Bw; j += 64) cb[j] = 0.f;
+      continue;
+    }
+    const float gz = a.w_con * mmean / (float)B;                   // d con / d Z_bj = w * mmean / B * (softmax_bj - onehot)
+    const float np = fmaxf(sqrtf(PP[b]), 1e-12f);
+    const int own = a.rank * B + b;
+    float mx = -1e30f;
+    for (int j = lane; j < Bw; j += 64) mx = fmaxf(mx, z[j]);
+    mx = wave_max(mx);
+    float se = 0.f;
+    for (int j = lane; j < Bw; j += 64) se += __expf(z[j] - mx);
+    se = wave_sum(se);
+    const float lse = mx + __logf(se);
+    float e_b = 0.f, dls = 0.f;
+    for (int j = lane; j < Bw; j += 64) {
+      const float zj = z[j], nt = fmaxf(sqrtf(TT[j]), 1e-12f);
+      float dz = __expf(zj - lse);
+      if (j == own) dz -= 1.f;
+      dz *= gz;
+      const float cbj = dz * scale / (np * nt);
+      cb[j] = cbj;
+      e_b += cbj * (zj * nt / (scale * np));                        // = c_bj * (p_b . t_j) / |p_b|^2
+      dls += dz * (zj / scale) * dscale_dls;
+    }
+    e_b = wave_sum(e_b);
+    dls = wave_sum(dls);
+    if (lane == 0) {
+      ce[b] = lse - z[own];
+      dce[b] = dls;
+      a.coef[B + b] = e_b;
     }
   }
   __syncthreads();
-  if (t == 0) {
-    float s1 = 0.f, cm = 0.f, dl = 0.f;
-    for (int b = 0; b < B; ++b) {
-      s1 += SL[b] * a.mask[b];
-      if (has_con) { cm += ce[b]; dl += dce[b]; }
+  // masked smooth-L1 sum, CE sum, d/dlogit_scale sum: wave 0, fixed shuffle order
+  if (wv == 0) {
+    float s1 = lane < B ? SL[lane] * mymask : 0.f;
+    float cm = (has_con && lane < B) ? ce[lane] : 0.f;
+    float dl = (has_con && lane < B) ? dce[lane] : 0.f;
+    s1 = wave_sum(s1); cm = wave_sum(cm); dl = wave_sum(dl);
+    if (lane == 0) {
+      s1 /= ((float)B * (float)a.D);
+      const float con = has_con ? a.w_con * (cm / (float)B) * mmean : 0.f;
+      a.out3[0] = s1 + con;
+      a.out3[1] = s1;
+      a.out3[2] = con;
+      a.coef[2 * B + (long)B * Bw] = dl;
     }
-    s1 /= ((float)B * (float)a.D);
-    const float con = has_con ? a.w_con * (cm / (float)B) * mmean : 0.f;
-    a.out3[0] = s1 + con;
-    a.out3[1] = s1;
-    a.out3[2] = con;
-    a.coef[2 * B + (long)B * Bw] = dl;
   }
 }
 
@@ -143,6 +174,8 @@ __global__ __launch_bounds__(256) void emb_loss_fwd_kernel(const ElArgs a) {
   const int jc = blockIdx.y, bx = blockIdx.x, tid = threadIdx.x;
   const int lane = tid & 63, wv = tid >> 6, r = lane & 15, g = lane >> 4;
   const bool first = jc == 0;
+  const long long t_start = a.dbg ? wall_clock64() : 0;
+  if (a.dbg && bx == 0 && jc == 0 && tid == 0) a.dbg[0] = t_start;
   const long D = a.D;
   const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
   f32x4 acc[NPB][NG];
@@ -171,38 +204,57 @@ __global__ __launch_bounds__(256) void emb_loss_fwd_kernel(const ElArgs a) {
     tt[ng] = 0.f;
   }
   const long nsteps = (D + 31) >> 5;
-#pragma unroll 2
-  for (long s = (long)bx * 4 + wv; s < nsteps; s += (long)gridDim.x * 4) {
-    const long off0 = s * 32 + g * 8;
-    const bool ok = off0 < D;                                  // D % 8 == 0: a lane's 8-vector is wholly inside or outside
-    const long off = ok ? off0 : 0;
-    bf16x8 pa[NPB], tb[NG], ow[NPB];
+  const long stride = (long)gridDim.x * 4;
+  // The local sample of pred row r is gathered target rank*B + r.  When rank*B is a multiple of 16 that row sits in THIS lane's
+  // fragment of target group own_g + pb (chunk 0), so the smooth-L1 term needs no extra load; otherwise it is re-read (L1-resident).
+  const int own_g = (a.rank * a.B) >> 4;
+  const bool own_in_regs = first && ((a.rank * a.B) & 15) == 0 && own_g + NPB <= NG;
+  // DEPTH k-steps per round: all their 16-byte fragment loads are issued before the first MFMA (registers: DEPTH * (2 NPB + NG) * 4)
+  constexpr int DEPTH = (2 * NPB + NG) <= 4 ? 4 : ((2 * NPB + NG) <= 8 ? 2 : 1);
+  for (long s0 = (long)bx * 4 + wv; s0 < nsteps; s0 += DEPTH * stride) {
+    bf16x8 pa[DEPTH][NPB], tb[DEPTH][NG], ow[DEPTH][NPB];
+    bool ok[DEPTH];
 #pragma unroll
-    for (int pb = 0; pb < NPB; ++pb) pa[pb] = *(const bf16x8*)(prow[pb] + off);
+    for (int d = 0; d < DEPTH; ++d) {
+      const long s = s0 + d * stride;
+      const long off0 = s * 32 + g * 8;
+      ok[d] = s < nsteps && off0 < D;                          // D % 8 == 0: a lane's 8-vector is wholly inside or outside
+      const long off = ok[d] ? off0 : 0;
 #pragma unroll
-    for (int ng = 0; ng < NG; ++ng) tb[ng] = *(const bf16x8*)(trow[ng] + off);
-    if (first) {
+      for (int pb = 0; pb < NPB; ++pb) pa[d][pb] = *(const bf16x8*)(prow[pb] + off);
 #pragma unroll
-      for (int pb = 0; pb < NPB; ++pb) ow[pb] = *(const bf16x8*)(orow[pb] + off);
+      for (int ng = 0; ng < NG; ++ng) tb[d][ng] = *(const bf16x8*)(trow[ng] + off);
+#pragma unroll
+      for (int pb = 0; pb < NPB; ++pb) ow[d][pb] = (first && !own_in_regs) ? *(const bf16x8*)(orow[pb] + off) : zero8;
     }
 #pragma unroll
-    for (int pb = 0; pb < NPB; ++pb) pa[pb] = (ok && pok[pb]) ? pa[pb] : zero8;
+    for (int d = 0; d < DEPTH; ++d) {
 #pragma unroll
-    for (int ng = 0; ng < NG; ++ng) tb[ng] = (ok && tok[ng]) ? tb[ng] : zero8;
+      for (int pb = 0; pb < NPB; ++pb) pa[d][pb] = (ok[d] && pok[pb]) ? pa[d][pb] : zero8;
 #pragma unroll
-    for (int pb = 0; pb < NPB; ++pb)
+      for (int ng = 0; ng < NG; ++ng) tb[d][ng] = (ok[d] && tok[ng]) ? tb[d][ng] : zero8;
 #pragma unroll
-      for (int ng = 0; ng < NG; ++ng) acc[pb][ng] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pa[pb], tb[ng], acc[pb][ng], 0, 0, 0);
+      for (int pb = 0; pb < NPB; ++pb)
 #pragma unroll
-    for (int ng = 0; ng < NG; ++ng) tt[ng] = dot8(tb[ng], tb[ng], tt[ng]);
-    if (first) {
+        for (int ng = 0; ng < NG; ++ng)
+          acc[pb][ng] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pa[d][pb], tb[d][ng], acc[pb][ng], 0, 0, 0);
 #pragma unroll
-      for (int pb = 0; pb < NPB; ++pb) {
-        pp[pb] = dot8(pa[pb], pa[pb], pp[pb]);
-        sl[pb] = (ok && pok[pb]) ? smooth_l1_8(pa[pb], ow[pb], sl[pb]) : sl[pb];
+      for (int ng = 0; ng < NG; ++ng) tt[ng] = dot8(tb[d][ng], tb[d][ng], tt[ng]);
+      if (first) {
+#pragma unroll
+        for (int pb = 0; pb < NPB; ++pb) {
+          pp[pb] = dot8(pa[d][pb], pa[d][pb], pp[pb]);
+          bf16x8 o = ow[d][pb];
+          if (own_in_regs) {
+#pragma unroll
+            for (int ng = 0; ng < NG; ++ng) o = (ng == own_g + pb) ? tb[d][ng] : o;
+          }
+          sl[pb] = (ok[d] && pok[pb]) ? smooth_l1_8(pa[d][pb], o, sl[pb]) : sl[pb];
+        }
       }
     }
   }
+  const long long t_stream = a.dbg ? wall_clock64() : 0;
   // lane partials of the per-row sums: fold the 4 k-groups of the wave
 #pragma unroll
   for (int ng = 0; ng < NG; ++ng) { tt[ng] += __shfl_xor(tt[ng], 16, 64); tt[ng] += __shfl_xor(tt[ng], 32, 64); }
@@ -237,64 +289,86 @@ __global__ __launch_bounds__(256) void emb_loss_fwd_kernel(const ElArgs a) {
     }
     __syncthreads();
   }
+  // Cross-block traffic (partials, tickets) goes through DEVICE-COHERENT accesses (agent-scope relaxed atomics = sc1 loads / stores
+  // that bypass the per-XCD L2's non-coherent lines), ordered by vmcnt(0) + the workgroup barrier.  A __threadfence() here would
+  // write back and invalidate the whole 4 MB L2 of the XCD once per wave: measured 118 us instead of ~10 for the depth loss.
   float* mine = a.part + ((long)jc * a.nblk + bx) * NS;
-  for (int i = tid; i < NS; i += 256) mine[i] = red[i];
+  for (int i = tid; i < NS; i += 256) cstore(mine + i, red[i]);
   // ---- level 1: the last block of each group of G1 sums the group's partials (fixed order)
   unsigned* cnt = g_counters[a.slot];
   const int grp = bx / G1, gsz = min(G1, a.nblk - grp * G1);
-  __threadfence();
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   __syncthreads();
-  if (tid == 0) ticket = atomicAdd(&cnt[1 + jc * a.ngrp + grp], 1u);
+  if (tid == 0) ticket = __hip_atomic_fetch_add(&cnt[1 + jc * a.ngrp + grp], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   __syncthreads();
   if (ticket != (unsigned)(gsz - 1)) return;
-  __threadfence();
+  const long long t_ticket1 = a.dbg ? wall_clock64() : 0;
+  const int B = a.B, Bw = a.Bw;
+  // final statistics: in LDS (`red`, the partial's own layout) when one chunk holds every gathered target, else in the workspace
+  const bool in_lds = a.njc == 1;
+  float* PT = in_lds ? red : a.fin;
+  const int ldpt = in_lds ? TC : Bw;
+  float* TT = in_lds ? red + PB * TC : a.fin + (long)B * Bw;
+  float* PP = in_lds ? TT + TC : TT + Bw;
+  float* SL = in_lds ? PP + PB : PP + B;
+  auto scatter = [&](int c, int i, float v) {                   // statistic i of target chunk c -> its place in PT | TT | PP | SL
+    if (in_lds) { red[i] = v; return; }
+    if (i < PB * TC) {
+      const int b = i / TC, j = c * TC + i % TC;
+      if (b < B && j < Bw) PT[(long)b * Bw + j] = v;
+    } else if (i < PB * TC + TC) {
+      const int j = c * TC + (i - PB * TC);
+      if (j < Bw) TT[j] = v;
+    } else if (c == 0) {
+      const int k = i - PB * TC - TC;
+      if (k < PB) { if (k < B) PP[k] = v; }
+      else if (k - PB < B) SL[k - PB] = v;
+    }
+  };
+  const bool single = a.njc * a.ngrp == 1;                       // one group in total: its reducer is the finisher
   {
     const float* src = a.part + ((long)jc * a.nblk + (long)grp * G1) * NS;
     float* dst = a.part2 + ((long)jc * a.ngrp + grp) * NS;
     for (int i = tid; i < NS; i += 256) {
-      float s = 0.f;
-#pragma unroll 8
-      for (int q = 0; q < gsz; ++q) s += src[(long)q * NS + i];
-      dst[i] = s;
+      float v[G1];
+#pragma unroll
+      for (int q = 0; q < G1; ++q) v[q] = q < gsz ? cload(src + (long)q * NS + i) : 0.f;
+      float sum = 0.f;
+#pragma unroll
+      for (int q = 0; q < G1; ++q) sum += v[q];
+      if (single) scatter(0, i, sum);
+      else cstore(dst + i, sum);
     }
   }
-  if (tid == 0) cnt[1 + jc * a.ngrp + grp] = 0;                  // re-arm for the next launch
-  // ---- level 2: the last group reducer sums the group partials of every chunk and finishes
-  __threadfence();
-  __syncthreads();
-  if (tid == 0) ticket = atomicAdd(&cnt[0], 1u);
-  __syncthreads();
-  if (ticket != (unsigned)(a.njc * a.ngrp - 1)) return;
-  __threadfence();
-  if (tid == 0) cnt[0] = 0;
-  {
-    const int B = a.B, Bw = a.Bw;
-    float* PT = a.fin;
-    float* TT = a.fin + (long)B * Bw;
-    float* PP = TT + Bw;
-    float* SL = PP + B;
+  if (tid == 0) __hip_atomic_store(&cnt[1 + jc * a.ngrp + grp], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm
+  if (!single) {
+    // ---- level 2: the last group reducer sums the group partials of every chunk and finishes
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();
+    if (tid == 0) ticket = __hip_atomic_fetch_add(&cnt[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (ticket != (unsigned)(a.njc * a.ngrp - 1)) return;
+    if (tid == 0) __hip_atomic_store(&cnt[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     for (int c = 0; c < a.njc; ++c) {
       const float* src = a.part2 + (long)c * a.ngrp * NS;
       for (int i = tid; i < NS; i += 256) {
-        float s = 0.f;
-        for (int q = 0; q < a.ngrp; ++q) s += src[(long)q * NS + i];
-        if (i < PB * TC) {
-          const int b = i / TC, j = c * TC + i % TC;
-          if (b < B && j < Bw) PT[(long)b * Bw + j] = s;
-        } else if (i < PB * TC + TC) {
-          const int j = c * TC + (i - PB * TC);
-          if (j < Bw) TT[j] = s;
-        } else if (c == 0) {
-          const int k = i - PB * TC - TC;
-          if (k < PB) { if (k < B) PP[k] = s; }
-          else if (k - PB < B) SL[k - PB] = s;
-        }
+        float v[G1];
+#pragma unroll
+        for (int q = 0; q < G1; ++q) v[q] = q < a.ngrp ? cload(src + (long)q * NS + i) : 0.f;       // ngrp <= 32 (nblk <= 1024)
+        float sum = 0.f;
+#pragma unroll
+        for (int q = 0; q < G1; ++q) sum += v[q];
+        scatter(c, i, sum);
       }
     }
   }
-  __threadfence();
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");       // the statistics were written by this very block
   __syncthreads();
-  el_finalize(a, ce, dce);
+  const long long t_reduced = a.dbg ? wall_clock64() : 0;
+  el_finalize(a, PT, ldpt, TT, PP, SL, ce, dce);
+  if (a.dbg && tid == 0) {
+    a.dbg[1] = t_start; a.dbg[2] = t_stream; a.dbg[3] = t_ticket1; a.dbg[4] = t_reduced; a.dbg[5] = wall_clock64();
+  }
 }
 
 // dpred[b,d] = gout * ( a_b * clamp(p - t_own, -1, 1) + sum_j c_bj * t_j[d] - e_b * p[b,d] ); grid (feature slabs, ceil(B/8)):
@@ -362,7 +436,9 @@ ElPlan el_plan(int B, int Bw, long D) {
   p.njc = (groups + p.ng - 1) / p.ng;
   const long nsteps = (D + 31) / 32;
   // >= 2 k-steps per wave, at most 1024 streaming blocks per chunk (4 per CU) and MAX_GROUPS first-level groups in total
-  long nblk = max(1L, min(1024L, (nsteps + 7) / 8));
+  static const long cap = getenv("VP_EL_NBLK") ? atol(getenv("VP_EL_NBLK")) : 512L;       // dev knob (tools/emb_loss_bench.py)
+  static const long spw = getenv("VP_EL_SPW") ? atol(getenv("VP_EL_SPW")) : 2L;             // target k-steps per wave
+  long nblk = max(1L, min(min(cap, 1024L), (nsteps + 4 * spw - 1) / (4 * spw)));
   while (p.njc * ((nblk + G1 - 1) / G1) > MAX_GROUPS) nblk /= 2;
   p.nblk = (int)nblk;
   p.ngrp = (p.nblk + G1 - 1) / G1;
@@ -382,7 +458,12 @@ void el_launch(int ng, dim3 grid, hipStream_t s, const ElArgs& a) {
 
 }  // namespace
 
+long long* g_dbg = nullptr;
+
 extern "C" {
+
+// dev aid (tools/emb_loss_debug.py): device buffer of 8 int64 receiving wall-clock stamps of the next vp_emb_loss_fwd calls (NULL = off)
+int vp_debug_emb_loss_stamps(long long* dev_buf) { g_dbg = dev_buf; return VP_OK; }
 
 // fp32 workspace of vp_emb_loss_fwd, in floats: per-block partials + group partials + final statistics (contents need not be
 // initialised; nothing is kept between calls).
@@ -409,6 +490,7 @@ int vp_emb_loss_fwd(int B, int Bw, long D, int rank, const void* pred, const voi
   a.D = D; a.B = B; a.Bw = Bw; a.rank = rank; a.nblk = p.nblk; a.njc = p.njc; a.ngrp = p.ngrp;
   a.slot = (int)((((uintptr_t)s) >> 6) % N_SLOTS);
   a.w_con = w_contrastive;
+  a.dbg = g_dbg;
   const dim3 grid(p.nblk, p.njc);
   if (p.npb == 1) el_launch<1>(p.ng, grid, s, a);
   else if (p.npb == 2) el_launch<2>(p.ng, grid, s, a);

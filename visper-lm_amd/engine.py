@@ -450,7 +450,7 @@ class Engine:
         cfg = self.cfg
         self.tasks = []          # [(task, head_i, layer_idx)]
         for task in ("depth", "seg", "gen"):                      # reference call order: ola_llama.py:139-141
-            if task in cfg.token_order and hasattr(cfg, TASK_SPEC[task][0]):
+            if task in cfg.token_order and hasattr(cfg, TASK_SPEC[task][0]) and getattr(cfg, "aux_heads", True):
                 hc = getattr(cfg, TASK_SPEC[task][0])
                 for i, idx in enumerate(layer_indices(hc[TASK_SPEC[task][1]])):
                     self.tasks.append((task, i, idx))

@@ -7,3 +7,6 @@ from .language_model import (OlaLlavaLlamaConfig, OlaLlavaLlamaModel, OlaLlavaLl
                              OlaLlavaPhi3Config, OlaLlavaPhi3Model, OlaLlavaPhi3ForCausalLM,
                              OlaCausalLLMOutputWithPast, BaseOLA_VLM)
 from .builders import build_vision_tower, build_vision_projector, CLIPVisionTower    # noqa: F401
+from .llava import (LlavaConfig, LlavaPhi3Config, LlavaMetaModel, LlavaMetaForCausalLM, LlavaLlamaModel, LlavaPhi3Model,    # noqa: F401
+                    LlavaLlamaForCausalLM, LlavaPhi3ForCausalLM, CausalLMOutputWithPast)
+from .hf_auto import register_auto_classes                                            # noqa: F401

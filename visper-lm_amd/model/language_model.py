@@ -7,6 +7,7 @@ HIP engine inside ONE autograd node: `out.loss.backward()` delivers `.grad` for 
 (projector, heads, task tokens, logit scales) exactly like the reference's autograd would."""
 from __future__ import annotations
 
+import dataclasses
 from dataclasses import dataclass
 from typing import List, Optional, Tuple
 
@@ -20,8 +21,25 @@ from .builders import ParamTree, CLIPVisionTower, CLIPConvNextVisionTower
 from .ola_arch import OlaLlavaMetaModel, OlaLlavaMetaForCausalLM
 
 
+class _ModelOutput:
+    """The slice of transformers.utils.ModelOutput that trainers rely on: `out["loss"]`, `out[0]`, `"loss" in out`, `.to_tuple()`
+    (HF Trainer.compute_loss reads `outputs["loss"] if isinstance(outputs, dict) else outputs[0]`)."""
+
+    def to_tuple(self):
+        return tuple(getattr(self, f.name) for f in dataclasses.fields(self) if getattr(self, f.name) is not None)
+
+    def __getitem__(self, k):
+        return getattr(self, k) if isinstance(k, str) else self.to_tuple()[k]
+
+    def __contains__(self, k):
+        return isinstance(k, str) and getattr(self, k, None) is not None
+
+    def keys(self):
+        return [f.name for f in dataclasses.fields(self) if getattr(self, f.name) is not None]
+
+
 @dataclass
-class OlaCausalLLMOutputWithPast:
+class OlaCausalLLMOutputWithPast(_ModelOutput):
     """ola_llama.py:39-44 (CausalLMOutputWithPast + the four embedding fields)."""
     loss: Optional[torch.Tensor] = None
     logits: Optional[torch.Tensor] = None
@@ -77,7 +95,7 @@ class _VisperStep(torch.autograd.Function):
 
 
 class BaseOLA_VLM:
-    """base_ola_vlm.py:38-168 attribute surface (mode, layer indices, loss weights, logit scales) + engine plumbing."""
+    """base_ola_vlm.py:38-168 attribute surface (mode, layer indices, loss weights, logit scales) and the frozen-teacher hooks."""
 
     def init_heads(self, config):                      # base_ola_vlm.py:104-168 (parameters come from the manifest)
         from ..config import layer_indices
@@ -117,75 +135,23 @@ class BaseOLA_VLM:
     def _get_seg_targets(self, pil_images, seg_preds):
         raise NotImplementedError("frozen OneFormer teacher is out of scope: pass seg_target= or override _get_seg_targets")
 
-    # ---- engine plumbing
-    def _get_engine(self) -> Engine:
-        if self._engine is None:
-            dev = next(self.parameters()).device
-            eng = Engine(self.config, device=dev)
-            eng.load_weights({k: v for k, v in self.state_dict().items()})
-            self._engine = eng
-            self._trainable_names = [n for n in eng.ps.index]
-            named = dict(self.named_parameters())
-            self._trainable_params = [named[n] for n in self._trainable_names]
-        return self._engine
 
-    def _sync_trainable(self):
-        """Keep ONE source of truth between the nn.Parameters (what `state_dict()` / an external torch optimizer see) and the
-        engine's flat fp32 master (what `Engine.optimizer_step` updates):
-          * the engine stepped since the last sync (its step counter moved)  -> master is newer: write it back into the Parameters;
-          * a Parameter was modified in place since the last sync (its autograd version counter moved: optimizer.step(),
-            load_state_dict, manual edits) -> it is newer: copy it into master and refresh the bf16 shadow.
-        Both directions are no-ops when nothing changed, so a forward costs no copies in steady state with the engine's optimizer."""
-        eng = self._get_engine()
-        ps = eng.ps
-        seen = self.__dict__.setdefault("_seen", {"step": ps.step, "ver": None})
-        if ps.step != seen["step"]:
-            with torch.no_grad():
-                for n, p in zip(self._trainable_names, self._trainable_params):
-                    p.copy_(ps.p(n).reshape(p.shape))
-            seen["step"] = ps.step
-            seen["ver"] = [p._version for p in self._trainable_params]
-            return
-        vers = [p._version for p in self._trainable_params]
-        if seen["ver"] is None:                                   # first call: the engine was loaded from these very Parameters
-            seen["ver"] = vers
-            return
-        dirty = [i for i, (a, b) in enumerate(zip(vers, seen["ver"])) if a != b]
-        if dirty:
-            for i in dirty:
-                n, p = self._trainable_names[i], self._trainable_params[i]
-                ps.p(n).copy_(p.detach().reshape(ps.p(n).shape))
-            ps.refresh_shadow()
-            if getattr(eng, "train_llm", False):
-                eng.refresh_transposes()
-            seen["ver"] = vers
-
-    def optimizer_step(self, lr, **kw):
-        """Engine.optimizer_step (fused AdamW on the flat fp32 master, DP mean folded in) + write-back into the nn.Parameters, so
-        `state_dict()` / `save_pretrained` always see the trained weights.  The reference leaves this to HF Trainer + DeepSpeed
-        (ola_vlm_train.py:1297-1309); an external torch optimizer over `model.parameters()` works too (see _sync_trainable)."""
-        self._get_engine().optimizer_step(lr, **kw)
-        self._sync_trainable()
-
-    def reload_frozen(self):
-        """Call after load_state_dict(): rebuilds the engine's fused / pre-transposed frozen weights."""
-        self._engine = None
-        self.__dict__.pop("_seen", None)
-
-
-class _OlaCausalLMBase(OlaLlavaMetaForCausalLM, BaseOLA_VLM, nn.Module):
-    model_cls = OlaLlavaLlamaModel
+class EngineModule(nn.Module):
+    """nn.Module whose parameters carry the reference's state-dict names and whose compute runs on the HIP engine: parameter
+    creation from the manifest (params.param_shapes), engine construction, the Parameter <-> flat-store aliasing, optimizer step,
+    HF-style save_pretrained / from_pretrained (safetensors shards + config.json)."""
+    model_cls = None
 
     def __init__(self, config, device="cuda", dtype=torch.bfloat16, init="random", seed=0):
         nn.Module.__init__(self)
         self.config = config
         self.vocab_size = config.vocab_size
-        self.NUM_SYS_TOKENS = config.num_sys_tokens                   # ola_llama.py:65-69 / ola_phi3.py:68
         self.steps = 0
         self._engine = None
         self._last = None
         self.model = self.model_cls()
         self.model.config = config
+        train_llm = bool(getattr(config, "train_llm", False))
         shapes = param_shapes(config, vit_nested=True)
         gen = torch.Generator(device=device).manual_seed(seed) if init == "random" else None
         top = ParamTree()
@@ -195,7 +161,7 @@ class _OlaCausalLMBase(OlaLlavaMetaForCausalLM, BaseOLA_VLM, nn.Module):
                 tower = (CLIPConvNextVisionTower if config.is_convnext else CLIPVisionTower)(config.mm_vision_tower, args=config)
                 tower.__dict__["_owner"] = self          # plain attribute: NOT a registered child (would create a module cycle)
                 self.model.add_module("vision_tower", tower)
-            tgt.add(rel, shp, device, dtype if len(shp) else torch.float32, requires_grad=is_trainable(name))
+            tgt.add(rel, shp, device, dtype if len(shp) else torch.float32, requires_grad=is_trainable(name, train_llm))
             if gen is not None:
                 p = dict(tgt.named_parameters())[rel]
                 p.data.copy_(init_value(name, shp, gen, device, p.dtype))
@@ -204,16 +170,160 @@ class _OlaCausalLMBase(OlaLlavaMetaForCausalLM, BaseOLA_VLM, nn.Module):
         for k, p in list(top._parameters.items()):                   # *_logit_scale
             self.register_parameter(k, p)
         self.model.initialize_special_tokens(config)
-        self.init_heads(config)
 
     def get_model(self):
         return self.model
 
     def state_dict(self, *args, **kwargs):
-        """nn.Module.state_dict after pulling in anything the engine's optimizer trained since the last forward."""
+        """nn.Module.state_dict after folding in in-place edits of the Parameters (see _sync_trainable)."""
         if self._engine is not None:
             self._sync_trainable()
         return super().state_dict(*args, **kwargs)
+
+    def _get_engine(self) -> Engine:
+        """Builds the engine from this module's state_dict, then makes every TRAINABLE nn.Parameter a VIEW of the engine's flat
+        parameter store (bf16 parameters alias the bf16 shadow the kernels read, fp32 ones alias the fp32 master): one copy of the
+        weights, `state_dict()` / `save_pretrained` always see what `Engine.optimizer_step` trained, and an external torch optimizer
+        stepping the Parameters writes straight into the kernels' weights.  (The 8 B-parameter IFT model therefore costs no second
+        copy of the LLM.)"""
+        if self._engine is None:
+            dev = next(self.parameters()).device
+            eng = Engine(self.config, device=dev)
+            eng.load_weights({k: v for k, v in nn.Module.state_dict(self).items()})
+            self._engine = eng
+            self._trainable_names = [n for n in eng.ps.index]
+            named = dict(self.named_parameters())
+            self._trainable_params = [named[n] for n in self._trainable_names]
+            self._alias = []
+            for n, p in zip(self._trainable_names, self._trainable_params):
+                if p.dtype == torch.bfloat16:
+                    p.data = eng.ps.w(n).view(p.shape)
+                    self._alias.append("shadow")
+                elif p.dtype == torch.float32:
+                    p.data = eng.ps.p(n).view(p.shape)
+                    self._alias.append("master")
+                else:
+                    self._alias.append(None)
+            self.__dict__["_seen"] = {"step": eng.ps.step, "ver": [p._version for p in self._trainable_params]}
+        return self._engine
+
+    def _sync_trainable(self):
+        """Parameters that were modified in place since the last sync (their autograd version counter moved: an external
+        optimizer.step(), load_state_dict, manual edits) are propagated to the other half of the store: a bf16 Parameter IS the
+        shadow -> copy it into the fp32 master; an fp32 Parameter IS the master -> refresh its bf16 shadow.  Kernel-side updates
+        (Engine.optimizer_step: fused AdamW writes master and shadow together) need no action.  No-op in steady state."""
+        eng = self._get_engine()
+        ps = eng.ps
+        seen = self._seen
+        vers = [p._version for p in self._trainable_params]
+        dirty = [i for i, (a, b) in enumerate(zip(vers, seen["ver"])) if a != b]
+        if dirty:
+            for i in dirty:
+                n, p, al = self._trainable_names[i], self._trainable_params[i], self._alias[i]
+                if al == "shadow":
+                    ps.p(n).copy_(p.detach().reshape(ps.p(n).shape))
+                elif al == "master":
+                    ps.w(n).copy_(p.detach().reshape(ps.w(n).shape))
+                else:
+                    ps.p(n).copy_(p.detach().reshape(ps.p(n).shape))
+                    ps.w(n).copy_(p.detach().reshape(ps.w(n).shape))
+            if getattr(eng, "train_llm", False):
+                eng.refresh_transposes()
+            seen["ver"] = vers
+        seen["step"] = ps.step
+
+    def optimizer_step(self, lr, **kw):
+        """Engine.optimizer_step (fused AdamW on the flat fp32 master + bf16 shadow, DP mean folded in).  The nn.Parameters alias
+        that store, so `state_dict()` / `save_pretrained` see the trained weights at once.  The reference leaves this to HF Trainer +
+        DeepSpeed (ola_vlm_train.py:1297-1309); an external torch optimizer over `model.parameters()` works too (_sync_trainable)."""
+        self._sync_trainable()                                   # fold in external edits first (they would be overwritten otherwise)
+        self._get_engine().optimizer_step(lr, **kw)
+
+    def reload_frozen(self):
+        """Call after load_state_dict(): rebuilds the engine's fused / pre-transposed frozen weights."""
+        self._engine = None
+        self.__dict__.pop("_seen", None)
+
+
+    # ---- HF-style persistence (f-4): what `trainer.save_model` / `from_pretrained(model_name_or_path)` exchange between the stages
+    # (ola_vlm_train.py:228-249, 1015-1021; train.py loads the PT output directory the same way)
+    def save_pretrained(self, save_directory, max_shard_size=5 * 2 ** 30):
+        """config.json + model.safetensors (or model-0000i-of-0000n.safetensors + model.safetensors.index.json above
+        `max_shard_size` bytes, the HF sharded layout), every parameter under its reference name in its own dtype."""
+        import json
+        import os
+        from safetensors.torch import save_file
+        os.makedirs(save_directory, exist_ok=True)
+        sd = {k: v.detach().contiguous() for k, v in self.state_dict().items()}
+        shards, cur, size = [], {}, 0
+        for k, v in sd.items():
+            nb = v.numel() * v.element_size()
+            if cur and size + nb > max_shard_size:
+                shards.append(cur)
+                cur, size = {}, 0
+            cur[k] = v
+            size += nb
+        shards.append(cur)
+        cfgd = {k: (list(v) if isinstance(v, tuple) else v) for k, v in self.config.to_dict().items()}
+        cfgd["model_type"] = getattr(self.config, "model_type", "ola_llama")
+        cfgd["architectures"] = [type(self).__name__]
+        with open(os.path.join(save_directory, "config.json"), "w") as fh:
+            json.dump(cfgd, fh, indent=1, sort_keys=True)
+        if len(shards) == 1:
+            save_file({k: v.cpu() for k, v in shards[0].items()}, os.path.join(save_directory, "model.safetensors"), metadata={"format": "pt"})
+            return
+        index = {"metadata": {"total_size": sum(v.numel() * v.element_size() for v in sd.values())}, "weight_map": {}}
+        for i, sh in enumerate(shards):
+            fn = f"model-{i + 1:05d}-of-{len(shards):05d}.safetensors"
+            save_file({k: v.cpu() for k, v in sh.items()}, os.path.join(save_directory, fn), metadata={"format": "pt"})
+            for k in sh:
+                index["weight_map"][k] = fn
+        with open(os.path.join(save_directory, "model.safetensors.index.json"), "w") as fh:
+            json.dump(index, fh, indent=1)
+
+    @classmethod
+    def from_pretrained(cls, directory, device="cuda", dtype=torch.bfloat16, strict=True, **config_overrides):
+        """Inverse of save_pretrained; also reads a directory written by HF `save_pretrained` of the reference classes (same key names;
+        keys this configuration does not have — e.g. the PT stage's heads when loading into the IFT class — are skipped unless strict)."""
+        import json
+        import os
+        from safetensors import safe_open
+        with open(os.path.join(directory, "config.json")) as fh:
+            cfgd = json.load(fh)
+        cfgd.pop("architectures", None)
+        mt = cfgd.pop("model_type", None)
+        cfgd.update(config_overrides)
+        config = cls.config_class(**cfgd)
+        if mt is not None:
+            config.model_type = mt
+        model = cls(config, device=device, dtype=dtype, init="empty")
+        idx = os.path.join(directory, "model.safetensors.index.json")
+        files = sorted(set(json.load(open(idx))["weight_map"].values())) if os.path.exists(idx) else ["model.safetensors"]
+        own = dict(nn.Module.state_dict(model))
+        seen = set()
+        with torch.no_grad():
+            for fn in files:
+                with safe_open(os.path.join(directory, fn), framework="pt", device="cpu") as f:
+                    for k in f.keys():
+                        if k in own:
+                            own[k].copy_(f.get_tensor(k).to(own[k].dtype))
+                            seen.add(k)
+                        elif strict:
+                            raise KeyError(f"unexpected key {k!r} in {fn}")
+        missing = [k for k in own if k not in seen]
+        if strict and missing:
+            raise KeyError(f"missing keys: {missing[:5]}{'...' if len(missing) > 5 else ''}")
+        model._missing_keys = missing
+        return model
+
+
+class _OlaCausalLMBase(OlaLlavaMetaForCausalLM, BaseOLA_VLM, EngineModule):
+    model_cls = OlaLlavaLlamaModel
+
+    def __init__(self, config, device="cuda", dtype=torch.bfloat16, init="random", seed=0):
+        EngineModule.__init__(self, config, device=device, dtype=dtype, init=init, seed=seed)
+        self.NUM_SYS_TOKENS = config.num_sys_tokens                   # ola_llama.py:65-69 / ola_phi3.py:68
+        self.init_heads(config)
 
     def _collect_targets(self, pil_images, kw, B, dev):
         t = {}

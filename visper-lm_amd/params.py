@@ -35,17 +35,18 @@ def param_shapes(cfg, vit_nested=True, with_vit=True) -> "OrderedDict[str, tuple
     nh, nkv, hd = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim
     order = cfg.token_order
     nt = cfg.num_task_tokens
-    if "gen" in order and hasattr(cfg, "image_gen"):
+    heads = order if getattr(cfg, "aux_heads", True) else []          # IFT-stage classes (llava_llama.py) carry task tokens but no heads
+    if "gen" in heads and hasattr(cfg, "image_gen"):
         sh["gen_logit_scale"] = ()
-    if "depth" in order and hasattr(cfg, "image_depth"):
+    if "depth" in heads and hasattr(cfg, "image_depth"):
         sh["depth_logit_scale"] = ()
-    if "seg" in order and hasattr(cfg, "image_seg"):
+    if "seg" in heads and hasattr(cfg, "image_seg"):
         sh["seg_logit_scale"] = ()
-    if "gen" in order and hasattr(cfg, "image_gen"):
+    if "gen" in heads and hasattr(cfg, "image_gen"):
         hc = cfg.image_gen
         for i in range(len(layer_indices(hc["img_layer_indices"]))):
             _resampler(f"image_gen_heads.{i}.projector.", hc["output_dim"], H, hc["output_dim"], hc, sh)   # gen_head.py:48-57
-    if "depth" in order and hasattr(cfg, "image_depth"):
+    if "depth" in heads and hasattr(cfg, "image_depth"):
         hc = cfg.image_depth
         for i in range(len(layer_indices(hc["depth_layer_indices"]))):
             _resampler(f"image_depth_heads.{i}.projector.", H, H, hc["output_dim"], hc, sh)                 # da_v2_head.py:427-436 (dim = llm hidden)
@@ -53,7 +54,7 @@ def param_shapes(cfg, vit_nested=True, with_vit=True) -> "OrderedDict[str, tuple
                 p = f"image_depth_heads.{i}.linear_{j}."
                 sh[p + "0.weight"] = (hc["output_dim"], hc["output_dim"]); sh[p + "0.bias"] = (hc["output_dim"],)
                 sh[p + "2.weight"] = (hc["output_dim"], hc["output_dim"]); sh[p + "2.bias"] = (hc["output_dim"],)
-    if "seg" in order and hasattr(cfg, "image_seg"):
+    if "seg" in heads and hasattr(cfg, "image_seg"):
         hc = cfg.image_seg
         for i in range(len(layer_indices(hc["seg_layer_indices"]))):
             _resampler(f"image_seg_heads.{i}.projector.", hc["output_dim"], H, hc["output_dim"], hc, sh)    # oneformer_head.py:233-242
@@ -120,7 +121,7 @@ def param_shapes(cfg, vit_nested=True, with_vit=True) -> "OrderedDict[str, tuple
     sh["model.mm_projector.0.weight"] = (H, cfg.mm_hidden_size); sh["model.mm_projector.0.bias"] = (H,)
     sh["model.mm_projector.2.weight"] = (H, H); sh["model.mm_projector.2.bias"] = (H,)
     sh["lm_head.weight"] = (V, H)
-    if "depth" in order and hasattr(cfg, "image_depth"):
+    if "depth" in heads and hasattr(cfg, "image_depth"):
         sh.update(dpt_param_shapes())
     return sh
 
