@@ -279,10 +279,35 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     prof, ops.GEMM_PROF = ops.GEMM_PROF, None
+    diag = None
     if dist is not None:
+        # self-diagnosis of a multi-GPU run: every rank's own step time and the two exchange points timed alone (blocking, HIP events)
+        mine = dt / args.steps * 1e3
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, round(mine, 2))
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t)
+
+        def timed(fn, n=5):
+            fn(); fence()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(n):
+                fn()
+            e1.record(); torch.cuda.synchronize()
+            return round(e0.elapsed_time(e1) / n, 3)
+        red = eng._reducer()
+
+        def reduce_all():
+            red.start_early(); red.finish()
+        from visper_lm_amd.parallel import all_gather_rows
+        seg_t = fresh[0].get("seg_target")
+        diag = {"per_rank_ms_per_step": per_rank, "grad_allreduce_ms_alone": timed(reduce_all),
+                "grad_bytes_on_wire": int(eng.ps.grad.numel() * (2 if red.reduce_dtype == torch.bfloat16 else 4)),
+                "grad_reduce_dtype": str(red.reduce_dtype).replace("torch.", ""), "transport": "native" if eng.comm is not None else "torch",
+                "target_allgather_ms_alone": (timed(lambda: all_gather_rows(seg_t.reshape(args.batch, -1).contiguous(), eng.comm))
+                                              if seg_t is not None else None)}
     S = out["plan"]["S"]
     loss = float(out["loss"])
     ms = dt / args.steps * 1e3
@@ -326,6 +351,8 @@ def main():
                           "depth_decoder": bool(cfg.depth_decoder), "fresh_batch_per_step": not args.same_batch,
                           "valid": args.layers is None},
                "roofline": roof}
+        if diag is not None:
+            res["multi_gpu"] = diag
         if args.workload in ("llama3_8b", "convnext", "phi3"):
             roof["k11"] = {"what": "distillation-loss reduction vp_emb_loss_fwd/bwd alone, HIP events, per call (launch included)",
                            "peak_GBps": 8000.0, "world1": k11_probe(cfg, args.batch, 1, dev), "world8_shaped": k11_probe(cfg, args.batch, 8, dev)}

@@ -45,6 +45,18 @@ def _worker(rank, world, port, ret):
         red2.finish()                                            # remaining [0, 4): projector / embeddings
         assert torch.allclose(g2, torch.arange(20, dtype=torch.float32) * sum(r + 1 for r in range(world)))
         assert red2.pending == [] and red2.done == []
+        # fp32 on the wire gives the exact sum; the default bf16 buckets (the reference's ZeRO-2 reduces bf16 gradients) round each
+        # rank's bucket to bf16, sum, and write the result back into the fp32 buffer
+        g3 = (torch.arange(20, dtype=torch.float32) * 0.37 + 0.011) * (rank + 1)
+        red3 = GradReducer(g3.clone(), split=8, reduce_dtype=torch.float32)
+        red3.start_early(); red3.finish()
+        exact = (torch.arange(20, dtype=torch.float32) * 0.37 + 0.011) * sum(r + 1 for r in range(world))
+        assert torch.allclose(red3.g, exact, rtol=1e-6)
+        red4 = GradReducer(g3.clone(), split=8)
+        assert red4.reduce_dtype == torch.bfloat16
+        red4.start_early(); red4.finish()
+        want = sum(((torch.arange(20, dtype=torch.float32) * 0.37 + 0.011) * (r + 1)).to(torch.bfloat16).float() for r in range(world))
+        assert torch.allclose(red4.g, want.to(torch.bfloat16).float(), rtol=1e-2) and torch.allclose(red4.g, exact, rtol=2e-2)
         ret[rank] = True
     finally:
         dist.destroy_process_group()

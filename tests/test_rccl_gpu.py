@@ -30,6 +30,45 @@ print("RCCL_OK")
 '''
 
 
+NATIVE = r'''
+import os, sys, torch
+sys.path.insert(0, os.environ["VP_ROOT"])
+torch.cuda.set_device(0)
+from visper_lm_amd.parallel import NativeComm, GradReducer, all_gather_rows
+c = NativeComm(rank=0, world=1)                       # vp_comm_unique_id + vp_comm_init: RCCL resolved inside libvisper_hip.so
+g = torch.arange(4096, device="cuda", dtype=torch.float32)
+g.mul_(2.0)                                           # queued on the compute stream BEFORE the reduce: the side stream must wait for it
+c.allreduce_async(g[0:1024]); c.allreduce_async(g[1024:4096])
+c.wait()                                              # the compute stream waits for both buckets (device-side)
+g.add_(1.0)
+torch.cuda.synchronize()
+assert torch.equal(g.cpu(), torch.arange(4096, dtype=torch.float32) * 2 + 1)
+b = torch.randn(8, 1000, device="cuda").to(torch.bfloat16)
+for _ in range(70):                                   # more buckets than event slots: the ring of fences recycles
+    c.allreduce_async(b)
+c.wait(); torch.cuda.synchronize()
+t = torch.randn(8, 1024, device="cuda").to(torch.bfloat16)
+out = c.allgather(t); torch.cuda.synchronize()
+assert out.shape == (8, 1024) and torch.equal(out.cpu(), t.cpu())
+assert all_gather_rows(t, c) is t                     # world 1: no copy
+r = GradReducer(g, split=100, comm=c); r.start_early(); r.finish()
+c.close(); c.close()
+print("NATIVE_COMM_OK")
+'''
+
+
+def test_native_comm_world1():
+    """vp_comm_* (include/visper_hip.h) on one GPU: communicator creation through the C ABI, side-stream all-reduce fenced against the
+    compute stream in both directions, all-gather, more in-flight buckets than fence slots, destroy.  Multi-rank numerics of the same
+    call sequence are covered over gloo on the CPU; the 8-GPU run is the driver's."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, VP_ROOT=root, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-c", NATIVE], env=env, capture_output=True, text=True, timeout=240)
+    assert "NATIVE_COMM_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
 def test_rccl_calls_world1():
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")

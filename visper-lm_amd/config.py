@@ -42,6 +42,7 @@ class VisperConfig:
                            seg_layer_indices="18", seg_loss_weight=0.5),
             tokenizer_model_max_length=4096, tokenizer_padding_side="right",
             zero_masks=False,      # True reproduces the as-released `mask.zero_()` (base_ola_vlm.py:472-473,...)
+            grad_reduce_dtype="bf16",   # DP gradient buckets on the wire: "bf16" (the reference's ZeRO-2 reduces bf16 gradients) | "fp32"
             train_llm=False,       # True = IFT-stage trainability: the whole LLM gets weight gradients + AdamW
             depth_decoder=False,   # True also runs the frozen DPT decoder on every depth head (base_ola_vlm.py:462-470 -> depth_preds)
         )

@@ -158,6 +158,7 @@ class Engine:
         self._rope = {}
         self._plan_cache = {}
         self._red = None
+        self.comm = None       # parallel.NativeComm when the C ABI's own communicator carries the collectives (set_distributed)
         self.keep_logits = False
 
     def _load_frozen_decoder(self, W, d):
@@ -367,8 +368,18 @@ class Engine:
         """Random-init weights of the configured architecture, generated on the device (bench / smoke runs)."""
         self.load_weights(LazyRandomWeights(self.cfg, self.dev, seed))
 
-    def set_distributed(self, rank, world):
+    def set_distributed(self, rank, world, transport=None):
+        """transport "torch" (default): torch.distributed collectives (backend nccl = RCCL); "native": the C ABI's own communicator
+        (vp_comm_*: RCCL + side stream + event fences inside libvisper_hip.so).  VP_COMM overrides the default."""
         self.rank, self.world = rank, world
+        transport = transport or os.environ.get("VP_COMM", "torch")
+        if transport not in ("torch", "native"):
+            raise ValueError(f"transport={transport!r}")
+        self.comm = None
+        if transport == "native" and self.dev.type == "cuda":
+            from .parallel import NativeComm
+            self.comm = NativeComm(rank, world)
+        self._red = None
         # with collectives running beside the GEMMs the persistent kernel claims its tiles dynamically (a CU held by an RCCL kernel then
         # costs its own share instead of stalling the whole static grid); single GPU keeps the static walk
         if self.dev.type == "cuda" and os.environ.get("VP_GEMM_DYN") is None:
@@ -377,7 +388,8 @@ class Engine:
     def _reducer(self):
         from .parallel import GradReducer
         if self._red is None or self._red.g is not self.ps.grad:
-            self._red = GradReducer(self.ps.grad, self.ps.split)
+            wire = torch.float32 if str(getattr(self.cfg, "grad_reduce_dtype", "bf16")) in ("fp32", "float32") else BF16
+            self._red = GradReducer(self.ps.grad, self.ps.split, comm=getattr(self, "comm", None), reduce_dtype=wire)
         return self._red
 
     def finish_grads(self):
@@ -962,7 +974,7 @@ class Engine:
             else:
                 flat = tg.reshape(Bn, -1).contiguous()
             from .parallel import all_gather_rows
-            allt = all_gather_rows(flat) if self.world > 1 else flat
+            allt = all_gather_rows(flat, getattr(self, "comm", None)) if self.world > 1 else flat
             mask = batch.get(f"{task}_mask")
             mask = torch.ones(Bn, device=self.dev, dtype=F32) if mask is None else mask.to(device=self.dev, dtype=F32)
             if self.cfg.zero_masks:
