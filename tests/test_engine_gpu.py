@@ -169,7 +169,7 @@ def test_phi3_path_matches_oracle_and_reference_golden():
         if ref == 0.0:
             assert got == 0.0, k
         else:
-            check(f"tiny_phi3/gradnorm/{k}_rel", abs(got - ref) / ref, 5e-2)
+            check(f"tiny_phi3/gradnorm/{k}_rel", abs(got - ref) / ref, 0.15 if eng.ps.g(k).numel() == 1 else 3e-2)
 
 
 def test_convnext_tower_matches_oracle():

@@ -58,7 +58,7 @@ def test_forward_backward_like_reference(setup):
         if ref == 0.0:
             assert got == 0.0, n
         else:
-            check(f"model_api/gradnorm/{n}_rel_vs_reference_golden", abs(got - ref) / ref, 5e-2)
+            check(f"model_api/gradnorm/{n}_rel_vs_reference_golden", abs(got - ref) / ref, 0.15 if p.numel() == 1 else 3e-2)
 
 
 def test_encode_images_and_prepare_inputs(setup):
@@ -213,19 +213,23 @@ def _teacher_hooks(model, batch):
 
 
 def _oracle_adamw_curve(ocfg, W, batch, trainable, steps, lr):
-    """The reference's training semantics on the CPU: fp32 autograd through the oracle + torch.optim.AdamW (HF `adamw_torch`,
-    weight decay 0: pretrain.sh) on the trainable leaves, starting from the same bf16-rounded weights."""
+    """The reference's training semantics on the CPU: autograd through the oracle + torch.optim.AdamW (HF `adamw_torch`, weight decay
+    0: pretrain.sh) on fp32 MASTER copies of the trainable parameters, with the forward run on their bf16 rounding (straight-through) —
+    DeepSpeed's bf16 mode, which the reference trains in (scripts/zero2.json "bf16": auto): a step smaller than half a bf16 ulp of a
+    weight does not reach the forward until the master has drifted far enough, exactly as on the engine's master/shadow pair."""
     from oracle import visper_oracle as O
     BF = torch.bfloat16
     Wq = {k: v.to(BF).float() for k, v in W.items()}
-    for k in trainable:
-        Wq[k] = Wq[k].clone().requires_grad_(True)
+    master = {k: Wq[k].clone().requires_grad_(True) for k in trainable}
     bq = {k: (v.to(BF).float() if (torch.is_tensor(v) and v.is_floating_point() and not k.endswith("_mask")) else v) for k, v in batch.items()}
-    opt = torch.optim.AdamW([Wq[k] for k in trainable], lr=lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0)
+    opt = torch.optim.AdamW(list(master.values()), lr=lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0)
     losses = []
     for _ in range(steps):
         opt.zero_grad(set_to_none=True)
-        out = O.forward(Wq, bq, ocfg)
+        Wf = dict(Wq)
+        for k, p in master.items():
+            Wf[k] = p + (p.detach().to(BF).float() - p.detach()) if p.dim() > 0 else p       # logit scales stay fp32 (reference: fp32 Parameter)
+        out = O.forward(Wf, bq, ocfg)
         out["loss"].backward()
         opt.step()
         losses.append(float(out["loss"]))

@@ -81,7 +81,7 @@ class _VisperStep(torch.autograd.Function):
         owner._last = out
         ctx.owner = owner
         ctx.names = owner._trainable_names
-        return out["loss"].reshape(())
+        return out["loss"].reshape(()).clone()          # a fresh tensor: trainers scale the loss in place (HF Trainer: `loss *= ...`)
 
     @staticmethod
     def backward(ctx, gout):
