@@ -22,6 +22,7 @@
 //    with scale*log2(e) folded into one FMA; the O rescale is skipped while the running max grows < 2^8.
 // Log-sum-exp is kept in the log2 domain: lse2 = m + log2(l) with scores pre-multiplied by scale*log2(e).
 #include "common.h"
+#include <stdlib.h>
 
 struct AttnParams {
   const bf16_t* q; const bf16_t* k; const bf16_t* v; bf16_t* o; float* lse;
@@ -968,10 +969,236 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 }
 
 // ================================================================================================
+// forward for D = 128 (the decoder's shape).  Block = 4 waves x 32 query rows of one q head (two 16-row MFMA column tiles per wave, so
+// every K / V fragment read from LDS feeds TWO MFMAs: the 8-wave x 16-row kernel above needs 256 B/clk of LDS reads per CU to keep the
+// matrix pipe fed, twice what the LDS delivers); K / V stream through a 4-stage ring of 32-key tiles (global_load_lds, swizzled source
+// chunks, counted vmcnt, one raw s_barrier per tile) like the backward kernels.  The loop is software-pipelined ACROSS tiles:
+//   A(it): mask, running max, (rare) rescale                          -- small VALU block with the wave-uniform branch
+//   B(it): S(it+1) = K(it+1) Q^T MFMAs  ||  exp2 / row sums / bf16 packing of tile it     -- ONE basic block, sched_group_barrier
+//   C(it): O += V(it)^T P(it) MFMAs fed by transposing LDS reads
+// so the matrix pipe works under the softmax arithmetic of the same wave, and the second wave of the SIMD (other block) fills the rest.
+// ================================================================================================
+constexpr int FWD128_STAGE = 2 * 32 * 128;            // bf16 units: K tile | V tile
+constexpr int FWD128_LDS = 4 * FWD128_STAGE * 2;      // bytes
+
+template <bool CAUSAL>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_fwd128_kernel(AttnParams p) {
+  constexpr int D = 128, NKS = 4, NDB = 8;
+  extern __shared__ __attribute__((aligned(16))) unsigned char attn_smem[];
+  bf16_t* const ring = (bf16_t*)attn_smem;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int nqb = (p.Sq + 127) >> 7;
+  const int qb = nqb - 1 - (int)blockIdx.z;            // z is the slowest dispatch index: heavy (late) causal blocks first
+  const int hx = blockIdx.x;
+  const int h = (p.Hq & 7) == 0 ? (hx & 7) * (p.Hq >> 3) + (hx >> 3) : hx;     // whole GQA groups per XCD
+  const int b = blockIdx.y, hk = h / (p.Hq / p.Hkv);
+  const int q0 = qb * 128, qw0 = q0 + wave * 32;
+  const int kvlen = p.kv_len ? min(p.kv_len[b], p.Skv) : p.Skv;
+  const int off = p.Skv - p.Sq;
+  const float c = p.scale * LOG2E;
+
+  bf16x8 qf[2][NKS];
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt) {
+    const int qrc = min(qw0 + qt * 16 + (lane & 15), p.Sq - 1);          // clamped (unconditional loads); rows >= Sq are never stored
+    const bf16_t* qp = p.q + (long)b * p.q_bs + (long)qrc * p.q_ts + (long)h * D;
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) qf[qt][ks] = *(const bf16x8*)(qp + ks * 32 + (lane >> 4) * 8);
+  }
+  f32x4 oacc[2][NDB];
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+    for (int d = 0; d < NDB; ++d) oacc[qt][d] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float m[2] = {-1e30f, -1e30f}, l[2] = {0.f, 0.f};   // m is kept PRE-scaled: m = c * max(raw score)
+
+  int kend = kvlen;
+  if (CAUSAL) kend = min(kend, q0 + 128 + off);
+  int kstart = 0;
+  if (p.window > 0) kstart = max(0, (q0 + off - p.window + 1)) & ~31;
+  const int nit = kend > kstart ? (kend - kstart + 31) / 32 : 0;
+  // tiles this WAVE needs (the rest lie entirely above its causal diagonal): it <= last_w
+  const int last_w = CAUSAL ? min(nit - 1, (qw0 + 31 + off - kstart) >> 5) : nit - 1;
+  const char* kb = (const char*)(p.k + (long)b * p.k_bs + (long)hk * D);
+  const char* vb = (const char*)(p.v + (long)b * p.v_bs + (long)hk * D);
+
+  auto issue = [&](int t, int st, int ln) {            // lane-derived values are re-derived per call (nothing lane-derived stays live)
+    const int k0 = kstart + min(t, nit - 1) * 32;
+    const int drow = wave * 4 + (ln >> 4);
+    const int dch = ((ln & 15) ^ (drow & 15)) * 8;
+    bf16_t* sb = ring + st * FWD128_STAGE;
+    const unsigned r0 = (unsigned)min(k0 + drow, p.Skv - 1), r1 = (unsigned)min(k0 + drow + 16, p.Skv - 1);
+    const unsigned kts = (unsigned)p.k_ts, vts = (unsigned)p.v_ts;
+    ATTN_GLDS(kb + (size_t)((r0 * kts + dch) * 2u), sb + wave * 512, 16);
+    ATTN_GLDS(kb + (size_t)((r1 * kts + dch) * 2u), sb + (4 + wave) * 512, 16);
+    ATTN_GLDS(vb + (size_t)((r0 * vts + dch) * 2u), sb + 4096 + wave * 512, 16);
+    ATTN_GLDS(vb + (size_t)((r1 * vts + dch) * 2u), sb + 4096 + (4 + wave) * 512, 16);
+  };
+  f32x4 sc[2][2], sn[2][2];                            // [kt][qt] raw scores of the current / next tile
+#define FWD_QK(DST, KS_PTR, RB)                                                                               \
+  _Pragma("unroll") for (int kt = 0; kt < 2; ++kt) {                                                          \
+    _Pragma("unroll") for (int qt = 0; qt < 2; ++qt) DST[kt][qt] = f32x4{0.f, 0.f, 0.f, 0.f};                  \
+    _Pragma("unroll") for (int ks = 0; ks < NKS; ++ks) {                                                      \
+      const bf16x8 ka = *(const bf16x8*)((KS_PTR) + ((RB) ^ (ks * 32)) + kt * 2048);                           \
+      _Pragma("unroll") for (int qt = 0; qt < 2; ++qt)                                                        \
+        DST[kt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka, qf[qt][ks], DST[kt][qt], 0, 0, 0);          \
+    }                                                                                                         \
+  }
+  if (nit > 0) {
+    issue(0, 0, lane); issue(1, 1, lane); issue(2, 2, lane);
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // tile 0 landed (this wave's part)
+    __builtin_amdgcn_s_barrier();
+    {
+      const int fr = lane & 15, g = lane >> 4;
+      const int rbase = fr * 128 + ((g ^ fr) << 3);
+      FWD_QK(sc, ring, rbase)
+    }
+  }
+  for (int it = 0; it < nit; ++it) {
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // tile it+1 landed (this wave's part); tile it+2 may still be in flight
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    int ln = threadIdx.x & 63;
+    asm volatile("" : "+v"(ln));
+    issue(it + 3, (it + 3) & 3, ln);                   // stage of tile it-1: every wave is past its last read of it
+    const int fr = ln & 15, g = ln >> 4;
+    const int rbase = fr * 128 + ((g ^ fr) << 3);
+    const int trow = 4 * g + (fr >> 2);
+    const int tbase = trow * 128 + ((((ln & 3) >> 1) ^ trow) << 3) + (ln & 1) * 4;
+    const bf16_t* Vs = ring + (it & 3) * FWD128_STAGE + 4096;
+    const bf16_t* Kn = ring + ((it + 1) & 3) * FWD128_STAGE;
+    const int k0 = kstart + it * 32;
+    if (it <= last_w) {
+      // ---- A: mask, running max, rare rescale
+      const bool need_mask = (qw0 + 32 > p.Sq) || (k0 + 32 > kvlen) || (CAUSAL && (k0 + 31 > qw0 + off)) || (p.window > 0);
+      if (need_mask) {
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+          for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int key = k0 + kt * 16 + 4 * g + r, qrow = qw0 + qt * 16 + fr;
+              const bool ok = key < kvlen && (!CAUSAL || key <= qrow + off) && (p.window <= 0 || key > qrow + off - p.window);
+              sc[kt][qt][r] = ok ? sc[kt][qt][r] : -INFINITY;
+            }
+      }
+      float mx[2];
+#pragma unroll
+      for (int qt = 0; qt < 2; ++qt) {
+        float v = fmaxf(fmaxf(fmaxf(sc[0][qt][0], sc[0][qt][1]), fmaxf(sc[0][qt][2], sc[0][qt][3])),
+                        fmaxf(fmaxf(sc[1][qt][0], sc[1][qt][1]), fmaxf(sc[1][qt][2], sc[1][qt][3])));
+        v = fmaxf(v, __shfl_xor(v, 16, 64));
+        v = fmaxf(v, __shfl_xor(v, 32, 64));
+        mx[qt] = v * c;
+      }
+      if (!__all(mx[0] <= m[0] + RESCALE_THR && mx[1] <= m[1] + RESCALE_THR)) {     // rare after the first tiles
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+          const float mnew = fmaxf(m[qt], mx[qt]);
+          const float alpha = fast_exp2(m[qt] - mnew);
+          l[qt] *= alpha;
+#pragma unroll
+          for (int d = 0; d < NDB; ++d) oacc[qt][d] *= alpha;
+          m[qt] = mnew;
+        }
+      }
+      // ---- B: next tile's QK^T MFMAs under this tile's exp2 / row sums / packing (one basic block)
+      const bool have_next = it + 1 <= last_w;
+      u32x4 pk[2];
+      __builtin_amdgcn_sched_barrier(0);
+      if (have_next) {
+        FWD_QK(sn, Kn, rbase)
+      }
+#pragma unroll
+      for (int qt = 0; qt < 2; ++qt) {
+        float rs = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float e = fast_exp2(fmaf(sc[kt][qt][r], c, -m[qt]));
+            sc[kt][qt][r] = e;
+            rs += e;
+          }
+        rs += __shfl_xor(rs, 16, 64);
+        rs += __shfl_xor(rs, 32, 64);
+        l[qt] += rs;
+        pk[qt] = u32x4{pack_bf16x2(sc[0][qt][0], sc[0][qt][1]), pack_bf16x2(sc[0][qt][2], sc[0][qt][3]),
+                       pack_bf16x2(sc[1][qt][0], sc[1][qt][1]), pack_bf16x2(sc[1][qt][2], sc[1][qt][3])};
+      }
+      if (have_next) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          if (i < 8) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);          // 1 LDS read
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                     // 1 MFMA
+          __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);                     // 4 VALU
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      // ---- C: O += V^T P
+      const bf16x8 pf0 = __builtin_bit_cast(bf16x8, pk[0]), pf1 = __builtin_bit_cast(bf16x8, pk[1]);
+      const uint32_t vs_addr = attn_lds_addr(Vs);      // rows +16 = +4096 bytes
+      s16x4 vl = tr_read_asm<0>(vs_addr + 2u * (uint32_t)tbase), vh = tr_read_asm<4096>(vs_addr + 2u * (uint32_t)tbase);
+#pragma unroll
+      for (int d = 0; d < NDB; ++d) {
+        s16x4 nl = vl, nh = vh;
+        if (d + 1 < NDB) {                                // one fragment ahead
+          const uint32_t na = vs_addr + 2u * (uint32_t)(tbase ^ ((d + 1) * 16));
+          nl = tr_read_asm<0>(na);
+          nh = tr_read_asm<4096>(na);
+          ATTN_LGKM(2);
+        } else {
+          ATTN_LGKM(0);
+        }
+        bf16x8 vtf = tr_join(vl, vh);
+        ATTN_PIN(vtf);
+        oacc[0][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vtf, pf0, oacc[0][d], 0, 0, 0);
+        oacc[1][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vtf, pf1, oacc[1][d], 0, 0, 0);
+        vl = nl;
+        vh = nh;
+        if (d & 1) __builtin_amdgcn_sched_barrier(0);
+      }
+      if (have_next) {
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+          for (int qt = 0; qt < 2; ++qt) sc[kt][qt] = sn[kt][qt];
+      }
+    }
+  }
+#undef FWD_QK
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // trailing (dummy) DMAs must not outlive the block's LDS
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt) {
+    const int qrow = qw0 + qt * 16 + (lane & 15);
+    if (qrow < p.Sq) {
+      const float inv = l[qt] > 0.f ? 1.f / l[qt] : 0.f;
+      bf16_t* op = p.o + (long)b * p.o_bs + (long)qrow * p.o_ts + (long)h * D;
+#pragma unroll
+      for (int d = 0; d < NDB; ++d) {
+        bf16x4 o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = (short)f2bf(oacc[qt][d][r] * inv);
+        *(bf16x4*)(op + d * 16 + 4 * (lane >> 4)) = o;
+      }
+      if (p.lse && (lane >> 4) == 0) p.lse[((long)b * p.Hq + h) * p.Sq + qrow] = (l[qt] > 0.f) ? m[qt] + log2f(l[qt]) : -1e30f;
+    }
+  }
+}
+
+// ================================================================================================
 // C ABI
 // ================================================================================================
 template <int D>
 static constexpr int kv_lds_bytes() { return 4 * 64 * (D + 16) * 2; }     // K,V tiles x 2 buffers
+
+static bool vp_fwd128_enabled() {                      // VP_ATTN_FWD128=0 falls back to the 8-wave x 16-row kernel (A/B aid)
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("VP_ATTN_FWD128"); v = e ? atoi(e) : 1; }
+  return v != 0;
+}
 
 template <int D>
 static int launch_fwd(const AttnParams& p, int causal, hipStream_t s) {
@@ -984,6 +1211,17 @@ static int launch_fwd(const AttnParams& p, int causal, hipStream_t s) {
     attr = true;
   }
   dim3 grid(p.Hq, p.B, (p.Sq + 127) / 128);
+  if (D == 128 && !p.bias_h && !p.bias_b && vp_fwd128_enabled()) {      // DMA-ring kernel (32 query rows per wave)
+    static bool attr128 = false;
+    if (!attr128) {
+      (void)hipFuncSetAttribute((const void*)attn_fwd128_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, FWD128_LDS);
+      (void)hipFuncSetAttribute((const void*)attn_fwd128_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, FWD128_LDS);
+      attr128 = true;
+    }
+    if (causal) hipLaunchKernelGGL((attn_fwd128_kernel<true>), grid, dim3(256), FWD128_LDS, s, p);
+    else hipLaunchKernelGGL((attn_fwd128_kernel<false>), grid, dim3(256), FWD128_LDS, s, p);
+    return vp_check_launch("vp_attn_fwd");
+  }
   if (p.bias_h || p.bias_b) {
     if (causal) hipLaunchKernelGGL((attn_fwd_kernel<D, true, true>), grid, dim3(512), kv_lds_bytes<D>(), s, p);
     else hipLaunchKernelGGL((attn_fwd_kernel<D, false, true>), grid, dim3(512), kv_lds_bytes<D>(), s, p);

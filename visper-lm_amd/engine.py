@@ -71,6 +71,7 @@ class ParamStore:
         self.exp_avg = None
         self.exp_avg_sq = None
         self.step = 0
+        self.version = 0          # bumped whenever the bf16 shadow changes (optimizer step, loads, external edits): keys derived caches
 
     def _v(self, buf, name):
         off, n, shp = self.index[name]
@@ -90,6 +91,17 @@ class ParamStore:
 
     def refresh_shadow(self):
         ops.cast_to_bf16(self.master, out=self.shadow)
+        self.version += 1
+
+    def fused(self, names, buf=None):
+        """View over parameters that sit back to back in the flat buffer (q|k|v, gate|up, to_q|to_kv) as ONE [sum(rows), cols] matrix."""
+        off0, off = self.index[names[0]][0], self.index[names[0]][0]
+        cols = self.index[names[0]][2][1]
+        for n in names:
+            o, cnt, shp = self.index[n]
+            assert o == off and cnt % 64 == 0 and shp[1] == cols, f"{n} is not contiguous with its fusion partners"
+            off += cnt
+        return (self.shadow if buf is None else buf)[off0:off].view(-1, cols)
 
     def zero_grad(self):
         self.grad.zero_()
@@ -110,6 +122,7 @@ class ParamStore:
             self.exp_avg = torch.zeros_like(self.master)
             self.exp_avg_sq = torch.zeros_like(self.master)
         self.step += 1
+        self.version += 1
         if max_grad_norm is not None:
             grad_scale = grad_scale * optim.clip_coefficient(self.grad_norm(grad_scale), max_grad_norm)
         key = (float(weight_decay), mm_projector_lr)
@@ -156,7 +169,8 @@ class Engine:
         self.fz = {}           # frozen, kernel-ready weights
         self.ps = None         # ParamStore
         self._rope = {}
-        self._plan_cache = {}
+        self._plan_cache = {}          # per-batch splice plans (small LRU-ish cache: identical batches reuse their tables)
+        self._static = {}              # shape-keyed device tables that never depend on the batch contents
         self._red = None
         self.comm = None       # parallel.NativeComm when the C ABI's own communicator carries the collectives (set_distributed)
         self.keep_logits = False
@@ -494,14 +508,14 @@ class Engine:
                 Cp = cfg.cnx_dims[i - 1]
                 x, _, _ = ops.layernorm_fwd(x, fz[f"cnx.{i}.ds_ln_w"], fz[f"cnx.{i}.ds_ln_b"], cfg.cnx_eps, save_stats=False)
                 key = ("cnx_ds", B, Hc, Wc)
-                if key not in self._plan_cache:                      # 2x2/s2 patch rows: (b, y2, x2, dy, dx) -> source pixel row
+                if key not in self._static:                          # 2x2/s2 patch rows: (b, y2, x2, dy, dx) -> source pixel row
                     bb = torch.arange(B, device=dev).view(B, 1, 1, 1, 1)
                     y2 = torch.arange(Hc // 2, device=dev).view(1, -1, 1, 1, 1)
                     x2 = torch.arange(Wc // 2, device=dev).view(1, 1, -1, 1, 1)
                     dy = torch.arange(2, device=dev).view(1, 1, 1, 2, 1)
                     dx = torch.arange(2, device=dev).view(1, 1, 1, 1, 2)
-                    self._plan_cache[key] = ((bb * Hc + 2 * y2 + dy) * Wc + 2 * x2 + dx).reshape(-1).to(torch.int32)
-                rows = self._plan_cache[key]
+                    self._static[key] = ((bb * Hc + 2 * y2 + dy) * Wc + 2 * x2 + dx).reshape(-1).to(torch.int32)
+                rows = self._static[key]
                 Hc, Wc = Hc // 2, Wc // 2
                 patches = torch.empty(B * Hc * Wc * 4, Cp, device=dev, dtype=BF16)
                 ops.gather_rows([x], torch.zeros(rows.numel(), device=dev, dtype=torch.int32), rows, Cp, patches)
@@ -529,8 +543,11 @@ class Engine:
         a = torch.zeros(B * g * g, kp, device=self.dev, dtype=BF16)
         a[:, :3 * P * P] = cols
         h = torch.empty(B, N, C, device=self.dev, dtype=BF16)
-        for b in range(B):       # patch rows + learned positions (residual epilogue), CLS row precomputed
-            ops.gemm(a[b * g * g:(b + 1) * g * g], fz["vit.patch_w"], residual=fz["vit.pos"], out=h[b, 1:])
+        pkey = ("vit_pos", B)
+        if pkey not in self._static:                                 # learned positions repeated per sample: the GEMM's residual operand
+            self._static[pkey] = fz["vit.pos"].repeat(B, 1).contiguous()
+        pe = ops.gemm(a, fz["vit.patch_w"], residual=self._static[pkey])          # ONE GEMM for the whole batch (+ positions in the epilogue)
+        ops.copy2d_(h.view(B, N * C)[:, C:], pe.view(B, g * g * C))                  # patch rows behind each sample's CLS row
         h[:, 0] = fz["vit.cls_pos"]
         x, _, _ = ops.layernorm_fwd(h.view(B * N, C), fz["vit.pre_layrnorm.weight"], fz["vit.pre_layrnorm.bias"], cfg.vit_eps,
                                     save_stats=False)
@@ -620,11 +637,20 @@ class Engine:
         else:
             ops.gemm(dyT, xT, out=g2)
 
+    def _wT(self, key, w):
+        """[in, out] copy of a trainable weight for its dgrad GEMM, cached until the bf16 shadow changes (ParamStore.version)."""
+        c = self.__dict__.setdefault("_wT_cache", {"v": -1, "t": {}})
+        if c["v"] != self.ps.version:
+            c["v"], c["t"] = self.ps.version, {}
+        if key not in c["t"]:
+            c["t"][key] = _tp(w)
+        return c["t"][key]
+
     def _lin_bwd(self, x2d, dy2d, wname, bname=None, need_dx=True):
         ps = self.ps
         dx = None
         if need_dx:
-            dx = ops.gemm(dy2d, _tp(ps.w(wname)))
+            dx = ops.gemm(dy2d, self._wT(wname, ps.w(wname)))
         self._wgrad(x2d, dy2d, ps.g(wname))
         if bname is not None:
             ops.colsum(dy2d, out=ps.g(bname))
@@ -1001,29 +1027,49 @@ class Engine:
         assert hc["depth"] == 1, "reference scripts use depth=1 resampler heads"
         a, f = pf + "layers.0.0.", pf + "layers.0.1."
         T = n + nq
-        # -- inputs: [x_b ; latents_b] per batch, contiguous (kv_input = cat(x, latents): resampler.py:59)
-        xin = torch.empty(B, T, H, device=dev, dtype=BF16)
-        xg = torch.empty(B * n, H, device=dev, dtype=BF16)
-        ops.gather_rows([state], torch.zeros(B * n, device=dev, dtype=torch.int32), tb["rows"], H, xg)
-        xin[:, :n] = xg.view(B, n, H)
-        if task == "gen":
-            lat0 = xg.view(B, n, H)[:, tb["lat_x"][0]:tb["lat_x"][-1] + 1]              # 8 hidden rows (base_ola_vlm.py:437-439)
+        # -- inputs: [x_b ; latents_b] per batch, contiguous (kv_input = cat(x, latents): resampler.py:59), built by ONE row gather from
+        #    two sources: the tapped layer state and the latent source (the (576,H) task-token parameter for depth / seg; for gen the 8
+        #    task-token rows of the state itself, or their per-sample mean when num_queries is not a multiple of 8: resampler.py:207-212)
+        nl = cfg.num_task_tokens if task == "gen" else ps.w(f"model.special_{task}_tokens").shape[0]
+        mode = "same" if nl == nq else ("tile" if (nq > 1 and nq % nl == 0) else "mean")
+        tkey = ("xin", task, B, S, n, nq, mode)
+        if tkey not in self._static:                              # static per (task, batch shape): kind / row tables of the [B*T] gather
+            bb = np.arange(B, dtype=np.int32)[:, None]
+            kind = np.zeros((B, T), np.int32)
+            rowt = np.zeros((B, T), np.int32)
+            rowt[:, :n] = bb * S + tb["sel"][None, :]
+            if task == "gen" and mode != "mean":
+                lat_rows = bb * S + tb["sel"][tb["lat_x"]][None, :]                     # state rows of the 8 gen task tokens
+                rowt[:, n:] = np.tile(lat_rows, (1, nq // nl))
+            elif task == "gen":
+                kind[:, n:] = 1
+                rowt[:, n:] = bb                                                       # row b of the per-sample mean
+            else:
+                kind[:, n:] = 1
+                rowt[:, n:] = np.tile(np.arange(nl, dtype=np.int32), nq // nl)[None, :] if mode != "mean" else 0
+            mean_idx = (bb * S + tb["sel"][tb["lat_x"]][None, :]).reshape(-1).astype(np.int32) if task == "gen" else None
+            # backward of the latent rows: parameter row i (depth / seg) <- sum over batch and tile copies of dxin rows
+            lat_bwd = None
+            if task != "gen":
+                reps = nq // nl if mode == "tile" else 1
+                src = (bb[:, :, None] * T + n + (np.arange(reps, dtype=np.int32)[None, :, None] * nl + np.arange(nl, dtype=np.int32)[None, None, :]))
+                lat_bwd = np.ascontiguousarray(src.transpose(2, 0, 1).reshape(nl, B * reps)) if mode != "mean" else None
+            up = lambda a: None if a is None else torch.from_numpy(np.ascontiguousarray(a).reshape(-1)).to(dev)
+            self._static[tkey] = dict(kind=up(kind), row=up(rowt), mean_idx=up(mean_idx), lat_bwd=up(lat_bwd),
+                                          lat_cnt=0 if lat_bwd is None else lat_bwd.shape[1])
+        xt = self._static[tkey]
+        state2 = state.view(-1, H)
+        if task != "gen":
+            lat_src = ps.w(f"model.special_{task}_tokens")
+            if mode == "mean":                                                          # mean over the parameter rows (resampler.py:212)
+                lat_src = lat_src.float().mean(0, keepdim=True).to(BF16)
+        elif mode == "mean":
+            lat_src = torch.empty(B, H, device=dev, dtype=BF16)
+            ops.gather_sum_rows(state2, xt["mean_idx"], nl, 1.0 / nl, lat_src)
         else:
-            lat0 = ps.w(f"model.special_{task}_tokens")[None].expand(B, -1, -1)
-        nl = lat0.shape[1]
-        if nl == nq:
-            xin[:, n:] = lat0
-            mode = "same"
-        elif nq > 1 and nq % nl == 0:
-            xin[:, n:] = lat0.repeat(1, nq // nl, 1)
-            mode = "tile"
-        else:                                                                           # mean over the latents (resampler.py:212)
-            latc = lat0.contiguous().view(B * nl, H)
-            idxm = torch.arange(B * nl, device=dev, dtype=torch.int32)
-            mean = torch.empty(B, H, device=dev, dtype=BF16)
-            ops.gather_sum_rows(latc, idxm, nl, 1.0 / nl, mean)
-            xin[:, n:] = mean[:, None].expand(B, nq, H)
-            mode = "mean"
+            lat_src = state2
+        xin = torch.empty(B, T, H, device=dev, dtype=BF16)
+        ops.gather_rows([state2, lat_src], xt["kind"], xt["row"], H, xin)
         xin2 = xin.view(B * T, H)
         Dm = ps.w(pf + "proj_in.weight").shape[0]
         P = ops.gemm(xin2, ps.w(pf + "proj_in.weight"), bias=ps.w(pf + "proj_in.bias")).view(B, T, Dm)
@@ -1035,7 +1081,7 @@ class Engine:
         nlat, ml_, rl = ops.layernorm_fwd(Pl, ps.w(a + "norm2.weight"), ps.w(a + "norm2.bias"))
         Nn[:, :n] = nx.view(B, n, Dm)
         Nn[:, n:] = nlat.view(B, nq, Dm)
-        wqkv = torch.cat([ps.w(a + "to_q.weight"), ps.w(a + "to_kv.weight")], 0).contiguous()     # [3*inner, Dm]
+        wqkv = ps.fused([a + "to_q.weight", a + "to_kv.weight"])                                   # [3*inner, Dm]: adjacent in the flat store
         QKV = ops.gemm(Nn.view(B * T, Dm), wqkv).view(B, T, 3 * inner)
         q4 = QKV[:, n:, :inner].unflatten(-1, (heads, dh))
         k4 = QKV[:, :, inner:2 * inner].unflatten(-1, (heads, dh))
@@ -1103,10 +1149,8 @@ class Engine:
                      dq=dQKV[:, n:, :inner].unflatten(-1, (heads, dh)), dk=dQKV[:, :, inner:2 * inner].unflatten(-1, (heads, dh)),
                      dv=dQKV[:, :, 2 * inner:].unflatten(-1, (heads, dh)))
         dQKV2 = dQKV.view(B * T, 3 * inner)
-        dNn = ops.gemm(dQKV2, _tp(wqkv)).view(B, T, Dm)
-        gq = torch.empty(3 * inner, Dm, device=dev, dtype=F32)
-        self._wgrad(Nn.view(B * T, Dm), dQKV2, gq)
-        ps.g(a + "to_q.weight").copy_(gq[:inner]); ps.g(a + "to_kv.weight").copy_(gq[inner:])
+        dNn = ops.gemm(dQKV2, self._wT(a + "to_q|to_kv", wqkv)).view(B, T, Dm)
+        self._wgrad(Nn.view(B * T, Dm), dQKV2, ps.fused([a + "to_q.weight", a + "to_kv.weight"], ps.grad))
         dPx, dw, db = ops.layernorm_bwd(dNn[:, :n].contiguous().view(B * n, Dm), Px, ps.w(a + "norm1.weight"), mx_, rx)
         ps.g(a + "norm1.weight").copy_(dw); ps.g(a + "norm1.bias").copy_(db)
         dPl, dw, db = ops.layernorm_bwd(dNn[:, n:].contiguous().view(B * nq, Dm), Pl, ps.w(a + "norm2.weight"), ml_, rl,
@@ -1117,18 +1161,24 @@ class Engine:
         dP[:, n:] = dPl.view(B, nq, Dm)
         dxin = self._lin_bwd(xin2, dP.view(B * T, Dm), pf + "proj_in.weight", pf + "proj_in.bias").view(B, T, H)
         dxg = dxin[:, :n].contiguous()                                                  # grads of the gathered state rows
-        dlat_in = dxin[:, n:]                                                           # [B, nq, H]
-        # latents' gradient: fold the tile / mean expansion, then route to hidden rows (gen) or the parameter
-        if mode == "same":
-            dlat0 = dlat_in.float()
-        elif mode == "tile":
-            dlat0 = dlat_in.float().reshape(B, nq // nl, nl, H).sum(1)
+        # latents' gradient: the transpose of the forward row gather -> the (576,H) parameter (depth / seg) or the 8 hidden rows (gen)
+        dxin2 = dxin.view(B * T, H)
+        if task != "gen":
+            gpar = ps.g(f"model.special_{task}_tokens")
+            if mode == "mean":                                                          # every parameter row gets sum(dlat) / nl
+                tot = dxin[:, n:].float().sum((0, 1)) / nl
+                gpar.add_(tot[None, :].expand_as(gpar))
+            else:
+                ops.gather_sum_rows(dxin2, xt["lat_bwd"], xt["lat_cnt"], 1.0, gpar, accumulate=True)
         else:
-            dlat0 = (dlat_in.float().sum(1, keepdim=True) / nl).expand(B, nl, H)
-        if task == "gen":
             lo = int(tb["lat_x"][0])
+            dlat_in = dxin[:, n:]
+            if mode == "same":
+                dlat0 = dlat_in.float()
+            elif mode == "tile":
+                dlat0 = dlat_in.float().reshape(B, nq // nl, nl, H).sum(1)
+            else:
+                dlat0 = (dlat_in.float().sum(1, keepdim=True) / nl).expand(B, nl, H)
             dxg[:, lo:lo + nl] = (dxg[:, lo:lo + nl].float() + dlat0).to(BF16)
-        else:
-            self._acc(ps.g(f"model.special_{task}_tokens"), dlat0.sum(0).contiguous())
         res["dx"] = dxg.view(B * n, H)
         return res

@@ -227,6 +227,7 @@ class EngineModule(nn.Module):
                 else:
                     ps.p(n).copy_(p.detach().reshape(ps.p(n).shape))
                     ps.w(n).copy_(p.detach().reshape(ps.w(n).shape))
+            ps.version += 1                                      # derived caches (transposed dgrad copies) follow the shadow
             if getattr(eng, "train_llm", False):
                 eng.refresh_transposes()
             seen["ver"] = vers
