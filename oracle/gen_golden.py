@@ -364,6 +364,21 @@ def run_data_path():
                       "keys": sorted(b.keys()), "seg_mask": b["seg_mask"].tolist(), "depth_mask": b["depth_mask"].tolist(),
                       "gen_mask": b["gen_mask"].tolist(), "seg_mask_dtype": str(b["seg_mask"].dtype)})
     res["collator"] = cases
+    # process_images (ola_vlm/mm_utils.py:309-333) through HF's own CLIPImageProcessor (the object clip_encoder.py:31 loads), built
+    # offline with the openai/clip-vit-large-patch14-336 preprocessor settings; three synthetic PIL images (wide, tall, small square)
+    from ola_vlm.mm_utils import process_images
+    from transformers import CLIPImageProcessor
+    ip = CLIPImageProcessor(size={"shortest_edge": 336}, crop_size={"height": 336, "width": 336}, do_center_crop=True, do_normalize=True,
+                            do_resize=True, do_rescale=True, do_convert_rgb=True, resample=3,
+                            image_mean=[0.48145466, 0.4578275, 0.40821073], image_std=[0.26862954, 0.26130258, 0.27577711])
+    pis = {}
+    for mode in ("pad", "square"):         # any other string takes the default branch (None would crash the reference: `"anyres_max" in None`)
+        imgs = [Image.fromarray(((np.arange(w * h * 3).reshape(h, w, 3) * 7 + 13 * (np.arange(h)[:, None, None] % 5)) % 253).astype(np.uint8), "RGB")
+                for (w, h) in ((90, 41), (37, 120), (24, 24))]
+        px = process_images(imgs, ip, types.SimpleNamespace(image_aspect_ratio=mode))
+        pis[str(mode)] = {"shape": list(px.shape), "sub": px[:, :, ::17, ::13].numpy().astype(np.float64).round(6).tolist(),
+                          "mean": float(px.double().mean()), "absmax": float(px.abs().max())}
+    res["process_images"] = pis
     with open(os.path.join(OUT, "data_path.json"), "w") as fh:
         json.dump(res, fh)
     print("data_path: ", res["with_bos"][1], "| collator keys", cases[0]["keys"])

@@ -84,3 +84,22 @@ def test_adapter_state_selects_the_projector_only():
              ("image_gen_heads.0.projector.proj_in.weight", torch.zeros(1))]
     assert list(data.adapter_state(named)) == ["model.mm_projector.0.weight"]
     assert list(data.adapter_state(named, use_im_start_end=True)) == ["model.mm_projector.0.weight", "model.embed_tokens.weight"]
+
+
+def test_process_images_matches_reference_with_hf_clip_processor():
+    """ola_vlm/mm_utils.py:309-333 driven with HF's CLIPImageProcessor in the generator (tests/golden/data_path.json "process_images"):
+    `data.process_images` + `data.ClipImageProcessor` (PIL + numpy restatement of the openai/clip-vit-large-patch14-336 preprocessing)
+    reproduce the reference's pixel tensors for the "pad" mode of the training scripts and the default mode."""
+    from PIL import Image
+    imgs = [Image.fromarray(((np.arange(w * h * 3).reshape(h, w, 3) * 7 + 13 * (np.arange(h)[:, None, None] % 5)) % 253).astype(np.uint8), "RGB")
+            for (w, h) in ((90, 41), (37, 120), (24, 24))]
+    ip = data.ClipImageProcessor()
+    for mode, ref in G["process_images"].items():
+        px = data.process_images(imgs, ip, types.SimpleNamespace(image_aspect_ratio=mode))
+        assert list(px.shape) == ref["shape"] and px.dtype == torch.float32
+        sub = px[:, :, ::17, ::13].numpy()
+        assert np.abs(sub - np.array(ref["sub"])).max() < 2e-6, (mode, np.abs(sub - np.array(ref["sub"])).max())
+        assert abs(float(px.double().mean()) - ref["mean"]) < 1e-6
+    import pytest
+    with pytest.raises(NotImplementedError):
+        data.process_images(imgs, ip, types.SimpleNamespace(image_aspect_ratio="anyres"))

@@ -1073,16 +1073,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       // ---- A: mask, running max, rare rescale
       const bool need_mask = (qw0 + 32 > p.Sq) || (k0 + 32 > kvlen) || (CAUSAL && (k0 + 31 > qw0 + off)) || (p.window > 0);
       if (need_mask) {
+        // key = k0 + 4g + (kt*16 + r): visible iff  kt*16 + r < hi[qt]  and  kt*16 + r > lo[qt]  (two ints per query tile)
+        const int kl = kvlen - k0 - 4 * g;
 #pragma unroll
-        for (int kt = 0; kt < 2; ++kt)
+        for (int qt = 0; qt < 2; ++qt) {
+          const int dq_ = qw0 + qt * 16 + fr + off - k0 - 4 * g;                  // (qrow + off) - (k0 + 4g)
+          const int hi = CAUSAL ? min(kl, dq_ + 1) : kl;
+          const int lo = p.window > 0 ? dq_ - p.window : -1;
 #pragma unroll
-          for (int qt = 0; qt < 2; ++qt)
+          for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-              const int key = k0 + kt * 16 + 4 * g + r, qrow = qw0 + qt * 16 + fr;
-              const bool ok = key < kvlen && (!CAUSAL || key <= qrow + off) && (p.window <= 0 || key > qrow + off - p.window);
-              sc[kt][qt][r] = ok ? sc[kt][qt][r] : -INFINITY;
+              const int e = kt * 16 + r;
+              sc[kt][qt][r] = (e < hi && e > lo) ? sc[kt][qt][r] : -INFINITY;
             }
+        }
       }
       float mx[2];
 #pragma unroll
@@ -1107,34 +1112,54 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       // ---- B: next tile's QK^T MFMAs under this tile's exp2 / row sums / packing (one basic block)
       const bool have_next = it + 1 <= last_w;
       u32x4 pk[2];
+      float rs[2] = {0.f, 0.f};
+      // softmax element i of this lane's 16: (qt, kt, r) = (i >> 3, (i >> 2) & 1, i & 3)
+#define FWD_EL(I, CC)                                                                                         \
+  {                                                                                                           \
+    const float e_ = fast_exp2(fmaf(sc[((I) >> 2) & 1][(I) >> 3][(I) & 3], CC, -m[(I) >> 3]));                \
+    sc[((I) >> 2) & 1][(I) >> 3][(I) & 3] = e_;                                                               \
+    rs[(I) >> 3] += e_;                                                                                       \
+  }
       __builtin_amdgcn_sched_barrier(0);
       if (have_next) {
-        FWD_QK(sn, Kn, rbase)
+        // Hand-interleaved: MFMA j of S(it+1) is followed by the fma / exp2 / add of element j of tile it, with a scheduling fence
+        // after each pair (sched_group_barrier masks left hipcc's order bunched: 6 MFMAs, then 11 exps).  K fragments are read one
+        // k-step ahead.
+        float c2 = c;
+        asm volatile("" : "+v"(c2));                    // this copy of the softmax arithmetic must stay inside the block
+        bf16x8 ka[2], kn[2];
+        ka[0] = *(const bf16x8*)(Kn + rbase);
+        ka[1] = *(const bf16x8*)(Kn + rbase + 2048);
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+          if (ks + 1 < NKS) {
+            kn[0] = *(const bf16x8*)(Kn + (rbase ^ ((ks + 1) * 32)));
+            kn[1] = *(const bf16x8*)(Kn + (rbase ^ ((ks + 1) * 32)) + 2048);
+          }
+#pragma unroll
+          for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt) {
+              sn[kt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka[kt], qf[qt][ks], ks == 0 ? f32x4{0.f, 0.f, 0.f, 0.f} : sn[kt][qt], 0, 0, 0);
+              FWD_EL(ks * 4 + kt * 2 + qt, c2)
+              __builtin_amdgcn_sched_barrier(0);
+            }
+          ka[0] = kn[0];
+          ka[1] = kn[1];
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) FWD_EL(i, c)
       }
+#undef FWD_EL
 #pragma unroll
       for (int qt = 0; qt < 2; ++qt) {
-        float rs = 0.f;
-#pragma unroll
-        for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const float e = fast_exp2(fmaf(sc[kt][qt][r], c, -m[qt]));
-            sc[kt][qt][r] = e;
-            rs += e;
-          }
-        rs += __shfl_xor(rs, 16, 64);
-        rs += __shfl_xor(rs, 32, 64);
-        l[qt] += rs;
+        float t = rs[qt];
+        t += __shfl_xor(t, 16, 64);
+        t += __shfl_xor(t, 32, 64);
+        l[qt] += t;
         pk[qt] = u32x4{pack_bf16x2(sc[0][qt][0], sc[0][qt][1]), pack_bf16x2(sc[0][qt][2], sc[0][qt][3]),
                        pack_bf16x2(sc[1][qt][0], sc[1][qt][1]), pack_bf16x2(sc[1][qt][2], sc[1][qt][3])};
-      }
-      if (have_next) {
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          if (i < 8) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);          // 1 LDS read
-          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                     // 1 MFMA
-          __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);                     // 4 VALU
-        }
       }
       __builtin_amdgcn_sched_barrier(0);
       // ---- C: O += V^T P

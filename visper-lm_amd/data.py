@@ -47,6 +47,68 @@ def expand2square(pil_img, background_color):
     return result
 
 
+OPENAI_CLIP_MEAN = (0.48145466, 0.4578275, 0.40821073)
+OPENAI_CLIP_STD = (0.26862954, 0.26130258, 0.27577711)
+
+
+class ClipImageProcessor:
+    """The CLIP image pre-processing the reference gets from HF `CLIPImageProcessor.from_pretrained(vision_tower)` (clip_encoder.py:31;
+    openai/clip-vit-large-patch14-336: resize shortest edge -> 336 bicubic, center crop 336, rescale 1/255, normalise with the OpenAI
+    mean / std, RGB), restated with PIL + numpy so the host data path needs neither transformers nor the hub.  Same interface as the
+    HF object for what process_images touches: `.preprocess(images, return_tensors="pt")["pixel_values"]`, `.image_mean`, `.crop_size`."""
+
+    def __init__(self, size: int = 336, crop_size: int = 336, image_mean=OPENAI_CLIP_MEAN, image_std=OPENAI_CLIP_STD):
+        self.size = {"shortest_edge": size}
+        self.crop_size = {"height": crop_size, "width": crop_size}
+        self.image_mean, self.image_std = list(image_mean), list(image_std)
+
+    def _one(self, img):
+        import numpy as np
+        from PIL import Image
+        img = img.convert("RGB")
+        w, h = img.size
+        short, long = (w, h) if w <= h else (h, w)
+        ns = self.size["shortest_edge"]
+        nl = int(ns * long / short)                                      # HF get_resize_output_image_size(default_to_square=False)
+        nw, nh = (ns, nl) if w <= h else (nl, ns)
+        img = img.resize((nw, nh), resample=Image.BICUBIC)
+        a = np.asarray(img)                                              # [H, W, 3] uint8
+        ch, cw = self.crop_size["height"], self.crop_size["width"]
+        top, left = (nh - ch) // 2, (nw - cw) // 2
+        if top < 0 or left < 0:                                          # HF center_crop pads with zeros when the image is smaller
+            pad = np.zeros((max(nh, ch), max(nw, cw), 3), a.dtype)
+            pt, pl = (pad.shape[0] - nh) // 2, (pad.shape[1] - nw) // 2
+            pad[pt:pt + nh, pl:pl + nw] = a
+            a, nh, nw = pad, pad.shape[0], pad.shape[1]
+            top, left = (nh - ch) // 2, (nw - cw) // 2
+        a = a[top:top + ch, left:left + cw].astype(np.float32) * np.float32(1.0 / 255.0)
+        a = (a - np.asarray(self.image_mean, np.float32)) / np.asarray(self.image_std, np.float32)
+        return torch.from_numpy(np.ascontiguousarray(a.transpose(2, 0, 1)))
+
+    def preprocess(self, images, return_tensors="pt"):
+        if not isinstance(images, (list, tuple)):
+            images = [images]
+        return {"pixel_values": torch.stack([self._one(im) for im in images])}
+
+    __call__ = preprocess
+
+
+def process_images(images, image_processor, model_cfg):
+    """ola_vlm/mm_utils.py:309-333 for the aspect-ratio modes the training scripts use: "pad" (scripts/train/*.sh: expand to a square
+    filled with the processor's mean colour, then pre-process each image) and the default (pre-process the list as is).  The anyres /
+    highres / crop_split tilings are inference-time options of other checkpoints and are refused."""
+    mode = getattr(model_cfg, "image_aspect_ratio", None)
+    if mode in ("highres", "anyres", "crop_split") or (isinstance(mode, str) and "anyres_max" in mode):
+        raise NotImplementedError(f"image_aspect_ratio={mode!r}: only 'pad' and the default are part of the training data path")
+    if mode == "pad":
+        bg = tuple(int(x * 255) for x in image_processor.image_mean)
+        out = [image_processor.preprocess(expand2square(im, bg), return_tensors="pt")["pixel_values"][0] for im in images]
+        if all(x.shape == out[0].shape for x in out):
+            return torch.stack(out, dim=0)
+        return out
+    return image_processor.preprocess(list(images), return_tensors="pt")["pixel_values"]
+
+
 class Collator:
     def __init__(self, pad_token_id: int, model_max_length: int, pin_memory: bool = True):
         self.pad, self.max_len, self.pin = int(pad_token_id), int(model_max_length), pin_memory
