@@ -485,8 +485,9 @@ def run_units():
     res["nocon_out"] = np.array([float(e), float(l1), float(c)], dtype=np.float64)
     # TaskTokenResampler: gen-like (1 query from 8 latents) and seg-like (16 queries tiled from 8... uses mean path)
     for name, (dim, nq, emb, out_dim, nlat) in {"rs_gen": (64, 1, 48, 64, 8), "rs_tile": (32, 16, 48, 40, 8),
-                                               "rs_same": (32, 12, 48, 40, 12), "rs_mean": (32, 6, 48, 40, 4)}.items():
-        m = TaskTokenResampler(dim=dim, depth=1, dim_head=32, num_queries=nq, heads=4, embedding_dim=emb,
+                                               "rs_same": (32, 12, 48, 40, 12), "rs_mean": (32, 6, 48, 40, 4),
+                                               "rs_deep": (32, 12, 48, 40, 12)}.items():        # rs_deep: depth = 2 (resampler.py:217)
+        m = TaskTokenResampler(dim=dim, depth=2 if name == "rs_deep" else 1, dim_head=32, num_queries=nq, heads=4, embedding_dim=emb,
                                output_dim=out_dim, ff_mult=1)
         shapes = {k: tuple(v.shape) for k, v in m.state_dict().items()}
         m.load_state_dict({k: WT.param(f"{name}.{k}", s) for k, s in shapes.items()})

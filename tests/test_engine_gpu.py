@@ -524,3 +524,47 @@ def test_checkpoint_resume_is_bitwise(tmp_path):
     e = fresh()
     data.load_checkpoint(e, str(tmp_path), resume_optimizer=False)
     assert e.ps.step == 0 and torch.equal(e.ps.shadow, c.ps.shadow)
+
+
+def test_resampler_depth_two_heads_match_oracle():
+    """resampler.py:217-219 loops over `depth` Perceiver blocks (the scripts use 1): depth = 2 for all three heads, HIP vs the fp32 oracle
+    (itself pinned against the reference's TaskTokenResampler(depth=2): tests/golden/units.npz rs_deep)."""
+    from oracle import cases, visper_oracle as O, weights as WT
+    from visper_lm_amd.config import VisperConfig
+    from visper_lm_amd.engine import Engine
+    from visper_lm_amd.params import param_shapes
+    ocfg, W, batch, g = cases.tiny_llama_case()
+    kw = dict(vars(ocfg))
+    for k in ("image_gen", "image_seg", "image_depth"):
+        kw[k] = dict(kw[k], depth=2)
+    ocfg2 = O.make_config(**kw)
+    cfg = VisperConfig(**kw)
+    W = dict(W)
+    for k, s in param_shapes(cfg, vit_nested=False).items():
+        if k not in W:
+            W[k] = WT.param(k, s)                                     # the second block's parameters
+    eng = Engine(cfg)
+    eng.load_weights(W)
+    out = eng.train_step(_to_gpu_batch(batch))
+    tr = [k for k in eng.ps.index]
+    assert any(".layers.1.0.to_q.weight" in k for k in tr)
+    Wq = {k: v.to(BF).float() for k, v in W.items()}
+    for k in tr:
+        Wq[k] = Wq[k].clone().requires_grad_(True)
+    bq = {k: (v.to(BF).float() if (torch.is_tensor(v) and v.is_floating_point() and not k.endswith("_mask")) else v) for k, v in batch.items()}
+    ref = O.forward(Wq, bq, ocfg2)
+    ref["loss"].backward()
+    check("depth2/loss_rel", rel(out["loss"], ref["loss"]), 1e-3)
+    for key, trip in ref["layer_losses"].items():
+        check(f"depth2/layer_loss/{key[0]}@{key[1]}", _trip_err(out["layer_losses"][key].float().cpu().numpy(), [float(x) for x in trip]), 1e-2)
+    for k in tr:
+        want = Wq[k].grad
+        got = eng.ps.g(k).detach().float().cpu()
+        if want is None:
+            assert float(got.abs().max()) == 0.0, k
+            continue
+        if got.numel() == 1:
+            continue
+        c, n = grad_err(got, want)
+        check(f"depth2/grad/{k}/one_minus_cos", c, 3e-2)
+        check(f"depth2/grad/{k}/norm_dev", n, 6e-2)

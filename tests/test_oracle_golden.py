@@ -40,7 +40,8 @@ def test_contrastive_saturation_and_nocontrastive():
 
 
 @pytest.mark.parametrize("name,dims", [("rs_gen", (64, 1, 48, 64, 8)), ("rs_tile", (32, 16, 48, 40, 8)),
-                                       ("rs_same", (32, 12, 48, 40, 12)), ("rs_mean", (32, 6, 48, 40, 4))])
+                                       ("rs_same", (32, 12, 48, 40, 12)), ("rs_mean", (32, 6, 48, 40, 4)),
+                                       ("rs_deep", (32, 12, 48, 40, 12))])
 def test_task_token_resampler(name, dims):
     g = cases.load_golden("units.npz")
     dim, nq, emb, out_dim, nlat = dims
@@ -48,7 +49,7 @@ def test_task_token_resampler(name, dims):
     W = {f"h.{k}": WT.param(f"{name}.{k}", s) for k, s in man.items()}
     x = WT.tensor(f"{name}.x", (2, 50, emb))
     lat = WT.tensor(f"{name}.lat", (2, nlat, emb))
-    out = O.task_token_resampler(x, lat, W, "h.", dict(num_tokens=nq, num_heads=4, dim_head=32, depth=1))
+    out = O.task_token_resampler(x, lat, W, "h.", dict(num_tokens=nq, num_heads=4, dim_head=32, depth=2 if name == "rs_deep" else 1))
     _close(out.numpy(), g[f"{name}_out"], 1e-4, 1e-5)
 
 

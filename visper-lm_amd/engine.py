@@ -1024,8 +1024,6 @@ class Engine:
         n, nq, heads, dh = tb["n_x"], hc["num_tokens"], hc["num_heads"], hc["dim_head"]
         inner = heads * dh
         pf = f"{hname}.{i}.projector."
-        assert hc["depth"] == 1, "reference scripts use depth=1 resampler heads"
-        a, f = pf + "layers.0.0.", pf + "layers.0.1."
         T = n + nq
         # -- inputs: [x_b ; latents_b] per batch, contiguous (kv_input = cat(x, latents): resampler.py:59), built by ONE row gather from
         #    two sources: the tapped layer state and the latent source (the (576,H) task-token parameter for depth / seg; for gen the 8
@@ -1073,26 +1071,34 @@ class Engine:
         xin2 = xin.view(B * T, H)
         Dm = ps.w(pf + "proj_in.weight").shape[0]
         P = ops.gemm(xin2, ps.w(pf + "proj_in.weight"), bias=ps.w(pf + "proj_in.bias")).view(B, T, Dm)
-        # -- norm1 on x rows, norm2 on latent rows
-        Nn = torch.empty(B, T, Dm, device=dev, dtype=BF16)
         Px = P[:, :n].contiguous().view(B * n, Dm)
-        Pl = P[:, n:].contiguous().view(B * nq, Dm)
-        nx, mx_, rx = ops.layernorm_fwd(Px, ps.w(a + "norm1.weight"), ps.w(a + "norm1.bias"))
-        nlat, ml_, rl = ops.layernorm_fwd(Pl, ps.w(a + "norm2.weight"), ps.w(a + "norm2.bias"))
-        Nn[:, :n] = nx.view(B, n, Dm)
-        Nn[:, n:] = nlat.view(B, nq, Dm)
-        wqkv = ps.fused([a + "to_q.weight", a + "to_kv.weight"])                                   # [3*inner, Dm]: adjacent in the flat store
-        QKV = ops.gemm(Nn.view(B * T, Dm), wqkv).view(B, T, 3 * inner)
-        q4 = QKV[:, n:, :inner].unflatten(-1, (heads, dh))
-        k4 = QKV[:, :, inner:2 * inner].unflatten(-1, (heads, dh))
-        v4 = QKV[:, :, 2 * inner:].unflatten(-1, (heads, dh))
-        att, lse = ops.attn_fwd(q4, k4, v4, causal=False, scale=1.0 / math.sqrt(dh))
-        att2 = att.view(B * nq, inner)
-        lat1 = ops.gemm(att2, ps.w(a + "to_out.weight"), residual=Pl)
-        y, mf, rf = ops.layernorm_fwd(lat1, ps.w(f + "0.weight"), ps.w(f + "0.bias"))
-        zf = ops.gemm(y, ps.w(f + "1.weight"))
-        af = ops.act_fwd(zf, ops.EPI_GELU)
-        lat2 = ops.gemm(af, ps.w(f + "3.weight"), residual=lat1)
+        lat = P[:, n:].contiguous().view(B * nq, Dm)
+        # -- `depth` Perceiver blocks (resampler.py:217-219): latents = attn(x, latents) + latents; latents = ff(latents) + latents.
+        #    x (the projected token rows) is the same for every block; each block has its own norm1 / norm2 / projections.
+        blocks = []
+        for dpt in range(int(hc["depth"])):
+            a, f = f"{pf}layers.{dpt}.0.", f"{pf}layers.{dpt}.1."
+            Nn = torch.empty(B, T, Dm, device=dev, dtype=BF16)
+            nx, mx_, rx = ops.layernorm_fwd(Px, ps.w(a + "norm1.weight"), ps.w(a + "norm1.bias"))
+            nlat, ml_, rl = ops.layernorm_fwd(lat, ps.w(a + "norm2.weight"), ps.w(a + "norm2.bias"))
+            Nn[:, :n] = nx.view(B, n, Dm)
+            Nn[:, n:] = nlat.view(B, nq, Dm)
+            wqkv = ps.fused([a + "to_q.weight", a + "to_kv.weight"])                               # [3*inner, Dm]: adjacent in the flat store
+            QKV = ops.gemm(Nn.view(B * T, Dm), wqkv).view(B, T, 3 * inner)
+            q4 = QKV[:, n:, :inner].unflatten(-1, (heads, dh))
+            k4 = QKV[:, :, inner:2 * inner].unflatten(-1, (heads, dh))
+            v4 = QKV[:, :, 2 * inner:].unflatten(-1, (heads, dh))
+            att, lse = ops.attn_fwd(q4, k4, v4, causal=False, scale=1.0 / math.sqrt(dh))
+            att2 = att.view(B * nq, inner)
+            lat1 = ops.gemm(att2, ps.w(a + "to_out.weight"), residual=lat)
+            y, mf, rf = ops.layernorm_fwd(lat1, ps.w(f + "0.weight"), ps.w(f + "0.bias"))
+            zf = ops.gemm(y, ps.w(f + "1.weight"))
+            af = ops.act_fwd(zf, ops.EPI_GELU)
+            lat2 = ops.gemm(af, ps.w(f + "3.weight"), residual=lat1)
+            if compute_grads:
+                blocks.append((a, f, Nn, mx_, rx, lat, ml_, rl, wqkv, q4, k4, v4, att, lse, att2, lat1, y, mf, rf, zf, af))
+            lat = lat2
+        lat2 = lat
         po = ops.gemm(lat2, ps.w(pf + "proj_out.weight"), bias=ps.w(pf + "proj_out.bias"))
         vout, mo, ro = ops.layernorm_fwd(po, ps.w(pf + "norm_out.weight"), ps.w(pf + "norm_out.bias"))
         Do = vout.shape[-1]
@@ -1137,25 +1143,29 @@ class Engine:
             dvout = dpred
         d_po, dw, db = ops.layernorm_bwd(dvout, po, ps.w(pf + "norm_out.weight"), mo, ro)
         ps.g(pf + "norm_out.weight").copy_(dw); ps.g(pf + "norm_out.bias").copy_(db)
-        d_lat2 = self._lin_bwd(lat2, d_po, pf + "proj_out.weight", pf + "proj_out.bias")
-        d_af = self._lin_bwd(af, d_lat2, f + "3.weight")
-        d_zf = ops.act_bwd(d_af, zf, ops.EPI_GELU)
-        d_y = self._lin_bwd(y, d_zf, f + "1.weight")
-        d_lat1, dw, db = ops.layernorm_bwd(d_y, lat1, ps.w(f + "0.weight"), mf, rf, dres=d_lat2)
-        ps.g(f + "0.weight").copy_(dw); ps.g(f + "0.bias").copy_(db)
-        d_att = self._lin_bwd(att2, d_lat1, a + "to_out.weight")
-        dQKV = torch.zeros(B, T, 3 * inner, device=dev, dtype=BF16)
-        ops.attn_bwd(q4, k4, v4, att, lse, d_att.view(B, nq, heads, dh), causal=False, scale=1.0 / math.sqrt(dh),
-                     dq=dQKV[:, n:, :inner].unflatten(-1, (heads, dh)), dk=dQKV[:, :, inner:2 * inner].unflatten(-1, (heads, dh)),
-                     dv=dQKV[:, :, 2 * inner:].unflatten(-1, (heads, dh)))
-        dQKV2 = dQKV.view(B * T, 3 * inner)
-        dNn = ops.gemm(dQKV2, self._wT(a + "to_q|to_kv", wqkv)).view(B, T, Dm)
-        self._wgrad(Nn.view(B * T, Dm), dQKV2, ps.fused([a + "to_q.weight", a + "to_kv.weight"], ps.grad))
-        dPx, dw, db = ops.layernorm_bwd(dNn[:, :n].contiguous().view(B * n, Dm), Px, ps.w(a + "norm1.weight"), mx_, rx)
-        ps.g(a + "norm1.weight").copy_(dw); ps.g(a + "norm1.bias").copy_(db)
-        dPl, dw, db = ops.layernorm_bwd(dNn[:, n:].contiguous().view(B * nq, Dm), Pl, ps.w(a + "norm2.weight"), ml_, rl,
-                                        dres=d_lat1)          # + residual path lat1 = to_out(.) + Pl
-        ps.g(a + "norm2.weight").copy_(dw); ps.g(a + "norm2.bias").copy_(db)
+        d_lat = self._lin_bwd(lat2, d_po, pf + "proj_out.weight", pf + "proj_out.bias")       # gradient of the latents leaving the last block
+        dPx = None
+        for (a, f, Nn, mx_, rx, lat_in, ml_, rl, wqkv, q4, k4, v4, att, lse, att2, lat1, y, mf, rf, zf, af) in reversed(blocks):
+            d_af = self._lin_bwd(af, d_lat, f + "3.weight")
+            d_zf = ops.act_bwd(d_af, zf, ops.EPI_GELU)
+            d_y = self._lin_bwd(y, d_zf, f + "1.weight")
+            d_lat1, dw, db = ops.layernorm_bwd(d_y, lat1, ps.w(f + "0.weight"), mf, rf, dres=d_lat)
+            ps.g(f + "0.weight").copy_(dw); ps.g(f + "0.bias").copy_(db)
+            d_att = self._lin_bwd(att2, d_lat1, a + "to_out.weight")
+            dQKV = torch.zeros(B, T, 3 * inner, device=dev, dtype=BF16)
+            ops.attn_bwd(q4, k4, v4, att, lse, d_att.view(B, nq, heads, dh), causal=False, scale=1.0 / math.sqrt(dh),
+                         dq=dQKV[:, n:, :inner].unflatten(-1, (heads, dh)), dk=dQKV[:, :, inner:2 * inner].unflatten(-1, (heads, dh)),
+                         dv=dQKV[:, :, 2 * inner:].unflatten(-1, (heads, dh)))
+            dQKV2 = dQKV.view(B * T, 3 * inner)
+            dNn = ops.gemm(dQKV2, self._wT(a + "to_q|to_kv", wqkv)).view(B, T, Dm)
+            self._wgrad(Nn.view(B * T, Dm), dQKV2, ps.fused([a + "to_q.weight", a + "to_kv.weight"], ps.grad))
+            dpx, dw, db = ops.layernorm_bwd(dNn[:, :n].contiguous().view(B * n, Dm), Px, ps.w(a + "norm1.weight"), mx_, rx, dres=dPx)
+            ps.g(a + "norm1.weight").copy_(dw); ps.g(a + "norm1.bias").copy_(db)
+            dPx = dpx                                             # every block reads the same projected tokens: their gradients add up
+            d_lat, dw, db = ops.layernorm_bwd(dNn[:, n:].contiguous().view(B * nq, Dm), lat_in, ps.w(a + "norm2.weight"), ml_, rl,
+                                              dres=d_lat1)        # + residual path lat1 = to_out(.) + latents
+            ps.g(a + "norm2.weight").copy_(dw); ps.g(a + "norm2.bias").copy_(db)
+        dPl = d_lat
         dP = torch.empty(B, T, Dm, device=dev, dtype=BF16)
         dP[:, :n] = dPx.view(B, n, Dm)
         dP[:, n:] = dPl.view(B, nq, Dm)
