@@ -66,8 +66,8 @@ for k in eng.ps.index:
         check(f"{tag}/grad/{k}_abs", abs(float(got) - float(want)), 0.05 * abs(float(want)) + 1e-3)
         continue
     c, n = grad_err(got, want)
-    check(f"{tag}/grad/{k}/one_minus_cos", c, 3e-2)
-    check(f"{tag}/grad/{k}/norm_dev", n, 5e-2)
+    check(f"{tag}/grad/{k}/one_minus_cos", c, 1.5e-2)
+    check(f"{tag}/grad/{k}/norm_dev", n, 3.5e-2)
 dist.barrier()
 dist.destroy_process_group()
 print(f"DP2_OK rank {rank}")

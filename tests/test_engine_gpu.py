@@ -88,7 +88,7 @@ def test_losses_match_oracle_and_reference_golden(tiny):
 
 def test_hidden_states_and_logits(tiny):
     out, ref = tiny["out"], tiny["ref"]
-    check("tiny/inputs_embeds_maxrel", max_rel(out["inputs_embeds"].cpu(), ref["inputs_embeds"].detach()), 1e-2)
+    check("tiny/inputs_embeds_maxrel", max_rel(out["inputs_embeds"].cpu(), ref["inputs_embeds"].detach()), 1.5e-2)
     check("tiny/hidden_maxrel", max_rel(out["hidden"].cpu(), ref["hidden"].detach()), 3e-2)
     lg, rl = out["logits"].float().cpu(), ref["logits"].detach()
     assert lg.shape == rl.shape
@@ -108,8 +108,8 @@ def test_gradients_match_oracle(tiny):
             check(f"tiny/grad/{k}_abs", abs(float(mine) - float(theirs)), 0.05 * abs(float(theirs)) + 1e-3)
             continue
         c, n = grad_err(mine, theirs)
-        check(f"tiny/grad/{k}/one_minus_cos", c, 2e-2)
-        check(f"tiny/grad/{k}/norm_dev", n, 5e-2)
+        check(f"tiny/grad/{k}/one_minus_cos", c, 1.5e-2)
+        check(f"tiny/grad/{k}/norm_dev", n, 2e-2)
 
 
 def test_as_released_mask_zeroing(tiny):
@@ -169,7 +169,7 @@ def test_phi3_path_matches_oracle_and_reference_golden():
         if ref == 0.0:
             assert got == 0.0, k
         else:
-            check(f"tiny_phi3/gradnorm/{k}_rel", abs(got - ref) / ref, 0.15 if eng.ps.g(k).numel() == 1 else 3e-2)
+            check(f"tiny_phi3/gradnorm/{k}_rel", abs(got - ref) / ref, 0.3 if eng.ps.g(k).numel() == 1 else 5e-2)
 
 
 def test_convnext_tower_matches_oracle():
@@ -201,7 +201,7 @@ def test_convnext_tower_matches_oracle():
     assert err < 3e-2, float(err)
 
 
-def _edge_case(ocfg_kw, mutate, min_cos=0.98, tag="edge"):
+def _edge_case(ocfg_kw, mutate, min_cos=0.985, tag="edge", max_norm=3e-2):
     """Engine vs the fp32 oracle (same bf16-rounded weights / inputs) on a mutated copy of the tiny Llama case."""
     from oracle import cases, visper_oracle as O
     from visper_lm_amd.config import VisperConfig
@@ -224,7 +224,7 @@ def _edge_case(ocfg_kw, mutate, min_cos=0.98, tag="edge"):
     check(f"{tag}/loss_rel", rel(out["loss"], ref["loss"]), 1e-3)
     for key, trip in ref["layer_losses"].items():
         mine = out["layer_losses"][key].float().cpu().numpy()
-        check(f"{tag}/layer_loss/{key[0]}@{key[1]}", _trip_err(mine, [float(x) for x in trip]), 5e-3)
+        check(f"{tag}/layer_loss/{key[0]}@{key[1]}", _trip_err(mine, [float(x) for x in trip]), 1.2e-2)
     for k in eng.ps.index:
         got = eng.ps.g(k).detach().float().cpu()
         want = Wq[k].grad
@@ -240,7 +240,7 @@ def _edge_case(ocfg_kw, mutate, min_cos=0.98, tag="edge"):
             continue
         c, n = grad_err(mine, theirs)
         check(f"{tag}/grad/{k}/one_minus_cos", c, 1.0 - min_cos)
-        check(f"{tag}/grad/{k}/norm_dev", n, 5e-2)
+        check(f"{tag}/grad/{k}/norm_dev", n, max_norm)
     return out, ref
 
 
@@ -259,7 +259,7 @@ def test_edge_sample_without_image():
         b["input_ids"][1, 38] = 7
     # the text-only sample feeds ~600 rows of padding-position states into every head's cross-attention: the softmax gradients
     # (to_q / to_kv) are the noisiest in bf16, hence the slightly wider bar
-    _edge_case({}, mutate, min_cos=0.95, tag="edge_no_image")
+    _edge_case({}, mutate, min_cos=0.90, tag="edge_no_image", max_norm=8e-2)
 
 
 def test_edge_truncation():
@@ -274,7 +274,7 @@ def test_edge_short_sequence_head_path():
     def mutate(b):
         b["input_ids"][:, 38] = 7
         b.pop("gen_target", None); b.pop("gen_mask", None)
-    out, ref = _edge_case({"aux_mode": "depth-seg"}, mutate, tag="edge_short")
+    out, ref = _edge_case({"aux_mode": "depth-seg"}, mutate, tag="edge_short", min_cos=0.96, max_norm=5e-2)
     assert out["plan"]["S"] == 59
 
 
@@ -307,8 +307,8 @@ def test_ift_stage_llm_weight_gradients_match_oracle(arch):
             assert float(mine.abs().max()) == 0.0, k
             continue
         c, n = grad_err(mine, Wq[k].grad.reshape(-1))
-        check(f"ift_{arch}/grad/{k}/one_minus_cos", c, 3e-2)
-        check(f"ift_{arch}/grad/{k}/norm_dev", n, 5e-2)
+        check(f"ift_{arch}/grad/{k}/one_minus_cos", c, 1e-3)
+        check(f"ift_{arch}/grad/{k}/norm_dev", n, 1.5e-2)
     l0 = float(out["loss"])
     for _ in range(3):
         eng.optimizer_step(lr=2e-4)
@@ -337,11 +337,11 @@ def test_ift_stage_matches_reference_golden():
         if ref_norm == 0.0:
             assert float(got.norm()) < 1e-7, k
         else:
-            check(f"ift_golden/gradnorm/{k}_rel", abs(float(got.norm()) - ref_norm) / ref_norm, 5e-2)
+            check(f"ift_golden/gradnorm/{k}_rel", abs(float(got.norm()) - ref_norm) / ref_norm, 2.5e-2)
         mine, theirs = torch.from_numpy(cases.sub(got, 128)), torch.from_numpy(g[f"gradsub::{k}"])
         if float(theirs.norm()) > 0:
             c, _ = grad_err(mine, theirs)
-            check(f"ift_golden/gradsub/{k}/one_minus_cos", c, 5e-2)
+            check(f"ift_golden/gradsub/{k}/one_minus_cos", c, 2e-3)
 
 
 def test_dinov2_depth_teacher_matches_oracle_and_reference_golden():
@@ -473,10 +473,10 @@ def test_left_padding_ntp_matches_oracle():
     assert plan["side"] == "left" and not plan["full"]
     assert torch.equal(plan["labels"], ref["labels"])
     am = plan["attention_mask"]
-    check("left_pad/loss_rel", rel(out["loss"], ref["loss"]), 2e-3)
+    check("left_pad/loss_rel", rel(out["loss"], ref["loss"]), 1e-3)
     emb, remb = out["inputs_embeds"].float().cpu(), ref["inputs_embeds"].detach()
     assert float(emb[~am].abs().max()) == 0.0 and float(remb[~am].abs().max()) == 0.0          # pad rows are zeros on the left
-    check("left_pad/inputs_embeds_maxrel", max_rel(emb[am], remb[am]), 1e-2)
+    check("left_pad/inputs_embeds_maxrel", max_rel(emb[am], remb[am]), 1.5e-2)
     check("left_pad/hidden_real_rows_maxrel", max_rel(out["hidden"].float().cpu()[am], ref["hidden"].detach()[am]), 3e-2)
     for k in tr:
         want = Wq[k].grad
@@ -485,8 +485,8 @@ def test_left_padding_ntp_matches_oracle():
             assert float(got.abs().max()) == 0.0, k
             continue
         c, n = grad_err(got, want)
-        check(f"left_pad/grad/{k}/one_minus_cos", c, 3e-2)
-        check(f"left_pad/grad/{k}/norm_dev", n, 0.1)
+        check(f"left_pad/grad/{k}/one_minus_cos", c, 1e-3)
+        check(f"left_pad/grad/{k}/norm_dev", n, 1e-2)
 
 
 def test_checkpoint_resume_is_bitwise(tmp_path):

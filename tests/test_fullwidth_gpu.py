@@ -155,9 +155,12 @@ def _run(cfg, B, T, tag, bounds):
     return got, ref32
 
 
-TIGHT = dict(loss=1e-3, layer_loss=5e-3, inputs_embeds_frob=2e-2, hidden_frob=3e-2, logits_frob=3e-2, inputs_embeds_max=2e-2,
-             hidden_max=5e-2, logits_max=5e-2, grad_scalar_rel=0.05, grad_scalar_abs=1e-4, grad_cos=5e-3, grad_norm=2e-2,
-             grad_vs_baseline=float("inf"))
+# measured (r02, parity_measured.jsonl): loss 1.7e-4, layer losses 1.0e-3, inputs_embeds 6.6e-3, hidden / logits 1.35e-2 (Frobenius) and
+# 1.7e-2 (max); gradients: 1 - cos <= 3e-4 except the depth head (ReLU gates + LayerNorm backward amplify bf16 activation rounding: up to
+# 4.5e-2 — and the bf16 CPU path shows 4.6e-2 on the same parameters, ratio HIP / CPU 0.97-1.01)
+TIGHT = dict(loss=1e-3, layer_loss=5e-3, inputs_embeds_frob=2e-2, hidden_frob=4e-2, logits_frob=4e-2, inputs_embeds_max=2e-2,
+             hidden_max=5e-2, logits_max=5e-2, grad_scalar_rel=0.05, grad_scalar_abs=3e-4, grad_cos=5e-3, grad_norm=2e-2,
+             grad_vs_baseline=1.5)
 
 
 def test_fullwidth_llama_step_all_heads_vs_fp32_oracle():
@@ -194,8 +197,10 @@ def test_config0_full_depth_vs_fp32_truth_and_reference_style_bf16_cpu_path():
     assert got["S"] == 127 + 576 + 8
     refb = _oracle_step(cfg, Wc, batch, tr, BF, got["rows"])
     print(f"[parity] config0: bf16 CPU oracle fwd+bwd {refb['seconds']:.1f} s")
-    deep = dict(TIGHT, hidden_frob=float("inf"), logits_frob=float("inf"), hidden_max=float("inf"), logits_max=float("inf"),
-                layer_loss=1e-2, grad_cos=float("inf"), grad_norm=float("inf"), grad_scalar_rel=float("inf"), grad_scalar_abs=float("inf"))
+    # measured (r02): HIP vs truth: loss 6.5e-5, seg loss 8e-6, hidden / logits 6.6e-2 (32 bf16 layers; the bf16 CPU path: 6.8e-2),
+    # gradients 1 - cos <= 2.7e-3 (bf16 CPU path: 3.0e-3).  HIP vs the bf16 CPU path: loss 1.9e-4, seg contrastive term 1.9e-3.
+    deep = dict(TIGHT, inputs_embeds_frob=4e-2, inputs_embeds_max=4e-2, hidden_frob=0.2, logits_frob=0.2, hidden_max=0.3, logits_max=0.3,
+                layer_loss=1e-2, grad_cos=1e-2, grad_norm=3e-2, grad_scalar_rel=0.3, grad_scalar_abs=3e-6)
     _compare("config0_vs_bf16_cpu_path", got, refb, deep)
     if _mem_available_gb() < 70:
         pytest.skip("fp32 truth leg needs ~40 GB of host memory")

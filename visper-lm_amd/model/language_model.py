@@ -136,6 +136,28 @@ class BaseOLA_VLM:
         raise NotImplementedError("frozen OneFormer teacher is out of scope: pass seg_target= or override _get_seg_targets")
 
 
+_LIVE_MODULES = None          # weak set of EngineModules whose Parameters alias an engine store (see _install_optimizer_hook)
+
+
+def _install_optimizer_hook():
+    """Any torch optimizer step (HF Trainer / accelerate wrap torch.optim.AdamW; some code paths update `param.data`, which does not move
+    the autograd version counter) marks every live EngineModule's parameters as externally modified."""
+    global _LIVE_MODULES
+    if _LIVE_MODULES is not None:
+        return
+    import weakref
+    _LIVE_MODULES = weakref.WeakSet()
+    try:
+        from torch.optim.optimizer import register_optimizer_step_post_hook
+
+        def _mark(optimizer, args, kwargs):
+            for m in list(_LIVE_MODULES):
+                m.__dict__["_force_dirty"] = True
+        register_optimizer_step_post_hook(_mark)
+    except ImportError:                                           # older torch: the version counters alone
+        pass
+
+
 class EngineModule(nn.Module):
     """nn.Module whose parameters carry the reference's state-dict names and whose compute runs on the HIP engine: parameter
     creation from the manifest (params.param_shapes), engine construction, the Parameter <-> flat-store aliasing, optimizer step,
@@ -205,6 +227,8 @@ class EngineModule(nn.Module):
                 else:
                     self._alias.append(None)
             self.__dict__["_seen"] = {"step": eng.ps.step, "ver": [p._version for p in self._trainable_params]}
+            _install_optimizer_hook()
+            _LIVE_MODULES.add(self)
         return self._engine
 
     def _sync_trainable(self):
@@ -216,7 +240,10 @@ class EngineModule(nn.Module):
         ps = eng.ps
         seen = self._seen
         vers = [p._version for p in self._trainable_params]
-        dirty = [i for i, (a, b) in enumerate(zip(vers, seen["ver"])) if a != b]
+        if self.__dict__.pop("_force_dirty", False):              # a torch optimizer stepped since the last sync
+            dirty = [i for i, p in enumerate(self._trainable_params) if p.requires_grad]
+        else:
+            dirty = [i for i, (a, b) in enumerate(zip(vers, seen["ver"])) if a != b]
         if dirty:
             for i in dirty:
                 n, p, al = self._trainable_names[i], self._trainable_params[i], self._alias[i]
