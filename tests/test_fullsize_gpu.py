@@ -101,3 +101,62 @@ def test_train_step_full_size_is_deterministic_and_finite():
     o2 = eng.train_step(batch)
     assert o1["plan"]["S"] == 2048 and torch.isfinite(l1).all() and torch.isfinite(g1).all()
     assert torch.equal(l1, o2["loss"]) and torch.equal(g1, eng.ps.grad)
+
+
+def test_convnext_xxl_tower_full_size_finite_and_deterministic():
+    """BASELINE configs[3] at its real size: CLIP-ConvNeXt-XXL trunk (dims 384/768/1536/3072, depths 3/4/30/3, 768 px -> 576 x 3072;
+    clip_convnext_encoder.py:92-101,150-174) on the HIP path — shapes, finiteness, bitwise run-to-run determinism, and the spatial
+    structure the trunk must keep (rows are (y, x) raster order: a constant image gives identical interior tokens).  The tower stays
+    "parity unpinned" against timm (absent); tests/test_convnext_pin.py pins the restatement piecewise against stock torch.nn modules."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from visper_lm_amd.config import llama3_8b_convnext
+    from visper_lm_amd.engine import Engine
+    cfg = llama3_8b_convnext(num_hidden_layers=1, aux_mode="", num_task_tokens=0, vocab_size=1024)
+    eng = Engine(cfg)
+    eng.init_random(0)
+    g = torch.Generator(device="cuda").manual_seed(3)
+    images = torch.randn(2, 3, 768, 768, device="cuda", generator=g).to(BF)
+    f1 = eng.vit_forward(images)
+    f2 = eng.vit_forward(images)
+    assert tuple(f1.shape) == (2 * 576, 3072) and torch.isfinite(f1.float()).all() and torch.equal(f1, f2)
+    assert float(f1.float().std()) > 0
+    const = torch.full((1, 3, 768, 768), 0.5, device="cuda", dtype=BF)
+    fc = eng.vit_forward(const).view(24, 24, 3072).float()
+    inner = fc[6:18, 6:18].reshape(-1, 3072)                 # receptive fields entirely inside the image see the same input
+    assert float((inner - inner[0]).abs().max()) <= 1e-2 * float(inner.abs().max())
+
+
+def test_attention_d128_dma_ring_forward_matches_default():
+    """The opt-in DMA-ring forward (VP_ATTN_FWD128=1: 4 waves x 32 query rows, lazy row max) against the default kernel on the decoder
+    shape: same lse and outputs up to bf16 rounding (different max bookkeeping), incl. ragged kv_len and a sliding window."""
+    import os
+    import subprocess
+    import sys
+    code = r'''
+import os, sys, torch
+sys.path.insert(0, os.environ["VP_ROOT"])
+from visper_lm_amd import ops
+g = torch.Generator(device="cuda").manual_seed(0)
+B, Hq, Hkv, S, D = 2, 8, 2, 1000, 128
+q = torch.randn(B, S, Hq, D, device="cuda", generator=g).bfloat16(); k = torch.randn(B, S, Hkv, D, device="cuda", generator=g).bfloat16()
+v = torch.randn(B, S, Hkv, D, device="cuda", generator=g).bfloat16()
+kv = torch.tensor([1000, 777], device="cuda", dtype=torch.int32)
+outs = []
+for w in (0, 300):
+    o, lse = ops.attn_fwd(q, k, v, True, window=w, kv_len=kv)
+    outs.append((o.float().cpu(), lse.cpu()))
+torch.save(outs, os.environ["VP_OUT"])
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for flag in ("0", "1"):
+        out = f"/tmp/vp_attn_ab_{flag}.pt"
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, VP_ROOT=root, VP_OUT=out, VP_ATTN_FWD128=flag),
+                           capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res[flag] = torch.load(out)
+    for (o0, l0), (o1, l1) in zip(res["0"], res["1"]):
+        valid = torch.isfinite(l0) & (l0 > -1e29)
+        assert float((o0 - o1).abs().max()) <= 2e-2 * float(o0.abs().max())
+        assert float((l0[valid] - l1[valid]).abs().max()) < 1e-3

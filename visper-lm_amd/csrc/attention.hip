@@ -1089,19 +1089,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             }
         }
       }
-      float mx[2];
+      // LANE-LOCAL max of this lane's 8 scores per query row; the cross-lane row max (two LDS-crossbar shuffles per row, ~100 cycles of
+      // latency each, with no MFMA of this wave in flight) is only formed when some lane sees a score above m + 2^8: with every score
+      // <= m + RESCALE_THR the exponentials stay <= 2^8, so m may lag the true running max (the final O / l ratio does not depend on m)
+      float mloc[2];
 #pragma unroll
-      for (int qt = 0; qt < 2; ++qt) {
-        float v = fmaxf(fmaxf(fmaxf(sc[0][qt][0], sc[0][qt][1]), fmaxf(sc[0][qt][2], sc[0][qt][3])),
-                        fmaxf(fmaxf(sc[1][qt][0], sc[1][qt][1]), fmaxf(sc[1][qt][2], sc[1][qt][3])));
-        v = fmaxf(v, __shfl_xor(v, 16, 64));
-        v = fmaxf(v, __shfl_xor(v, 32, 64));
-        mx[qt] = v * c;
-      }
-      if (!__all(mx[0] <= m[0] + RESCALE_THR && mx[1] <= m[1] + RESCALE_THR)) {     // rare after the first tiles
+      for (int qt = 0; qt < 2; ++qt)
+        mloc[qt] = c * fmaxf(fmaxf(fmaxf(sc[0][qt][0], sc[0][qt][1]), fmaxf(sc[0][qt][2], sc[0][qt][3])),
+                             fmaxf(fmaxf(sc[1][qt][0], sc[1][qt][1]), fmaxf(sc[1][qt][2], sc[1][qt][3])));
+      if (!__all(mloc[0] <= m[0] + RESCALE_THR && mloc[1] <= m[1] + RESCALE_THR)) {     // rare after the first tiles
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt) {
-          const float mnew = fmaxf(m[qt], mx[qt]);
+          float v = mloc[qt];
+          v = fmaxf(v, __shfl_xor(v, 16, 64));
+          v = fmaxf(v, __shfl_xor(v, 32, 64));
+          const float mnew = fmaxf(m[qt], v);
           const float alpha = fast_exp2(m[qt] - mnew);
           l[qt] *= alpha;
 #pragma unroll
@@ -1154,10 +1156,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #undef FWD_EL
 #pragma unroll
       for (int qt = 0; qt < 2; ++qt) {
-        float t = rs[qt];
-        t += __shfl_xor(t, 16, 64);
-        t += __shfl_xor(t, 32, 64);
-        l[qt] += t;
+        l[qt] += rs[qt];                                // per-lane partial row sum (this lane's keys); folded across lanes once, at the end
         pk[qt] = u32x4{pack_bf16x2(sc[0][qt][0], sc[0][qt][1]), pack_bf16x2(sc[0][qt][2], sc[0][qt][3]),
                        pack_bf16x2(sc[1][qt][0], sc[1][qt][1]), pack_bf16x2(sc[1][qt][2], sc[1][qt][3])};
       }
@@ -1165,24 +1164,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       // ---- C: O += V^T P
       const bf16x8 pf0 = __builtin_bit_cast(bf16x8, pk[0]), pf1 = __builtin_bit_cast(bf16x8, pk[1]);
       const uint32_t vs_addr = attn_lds_addr(Vs);      // rows +16 = +4096 bytes
-      s16x4 vl = tr_read_asm<0>(vs_addr + 2u * (uint32_t)tbase), vh = tr_read_asm<4096>(vs_addr + 2u * (uint32_t)tbase);
+      // transposing V reads run PF fragments ahead of the MFMAs that consume them (an LDS round trip is ~4 MFMA issue slots)
+      constexpr int PF = 3;
+      s16x4 vlo[NDB], vhi[NDB];
+#pragma unroll
+      for (int d = 0; d < PF; ++d) {
+        const uint32_t na = vs_addr + 2u * (uint32_t)(tbase ^ (d * 16));
+        vlo[d] = tr_read_asm<0>(na);
+        vhi[d] = tr_read_asm<4096>(na);
+      }
 #pragma unroll
       for (int d = 0; d < NDB; ++d) {
-        s16x4 nl = vl, nh = vh;
-        if (d + 1 < NDB) {                                // one fragment ahead
-          const uint32_t na = vs_addr + 2u * (uint32_t)(tbase ^ ((d + 1) * 16));
-          nl = tr_read_asm<0>(na);
-          nh = tr_read_asm<4096>(na);
-          ATTN_LGKM(2);
-        } else {
-          ATTN_LGKM(0);
-        }
-        bf16x8 vtf = tr_join(vl, vh);
+        if (d + PF < NDB) {
+          const uint32_t na = vs_addr + 2u * (uint32_t)(tbase ^ ((d + PF) * 16));
+          vlo[d + PF] = tr_read_asm<0>(na);
+          vhi[d + PF] = tr_read_asm<4096>(na);
+          ATTN_LGKM(2 * PF);
+        } else if (d + PF == NDB) { ATTN_LGKM(2 * (PF - 1)); }
+        else if (d + PF == NDB + 1) { ATTN_LGKM(PF >= 2 ? 2 * (PF - 2) : 0); }
+        else { ATTN_LGKM(0); }
+        bf16x8 vtf = tr_join(vlo[d], vhi[d]);
         ATTN_PIN(vtf);
         oacc[0][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vtf, pf0, oacc[0][d], 0, 0, 0);
         oacc[1][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vtf, pf1, oacc[1][d], 0, 0, 0);
-        vl = nl;
-        vh = nh;
         if (d & 1) __builtin_amdgcn_sched_barrier(0);
       }
       if (have_next) {
@@ -1197,6 +1201,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // trailing (dummy) DMAs must not outlive the block's LDS
 #pragma unroll
   for (int qt = 0; qt < 2; ++qt) {
+    l[qt] += __shfl_xor(l[qt], 16, 64);
+    l[qt] += __shfl_xor(l[qt], 32, 64);
     const int qrow = qw0 + qt * 16 + (lane & 15);
     if (qrow < p.Sq) {
       const float inv = l[qt] > 0.f ? 1.f / l[qt] : 0.f;
@@ -1219,9 +1225,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 template <int D>
 static constexpr int kv_lds_bytes() { return 4 * 64 * (D + 16) * 2; }     // K,V tiles x 2 buffers
 
-static bool vp_fwd128_enabled() {                      // VP_ATTN_FWD128=0 falls back to the 8-wave x 16-row kernel (A/B aid)
+static bool vp_fwd128_enabled() {                      // VP_ATTN_FWD128=1 selects the DMA-ring forward (measured equal to the default: DESIGN.md 4)
   static int v = -1;
-  if (v < 0) { const char* e = getenv("VP_ATTN_FWD128"); v = e ? atoi(e) : 1; }
+  if (v < 0) { const char* e = getenv("VP_ATTN_FWD128"); v = e ? atoi(e) : 0; }
   return v != 0;
 }
 
