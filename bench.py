@@ -325,7 +325,9 @@ def main():
     achieved = b_fl / (b_ms * 1e-3) / 1e12 if b_ms > 0 else 0.0
     traffic = None                                     # HBM bytes per launch from a separate rocprofv3 --pmc pass (profiles/)
     try:
-        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_p8.json")) as fh:
+        pdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
+        latest = sorted(f for f in os.listdir(pdir) if f.endswith("_pmc_p8.json"))[-1]        # newest round's PMC pass
+        with open(os.path.join(pdir, latest)) as fh:
             traffic = json.load(fh).get("hbm_bytes_per_launch") if args.workload == "llama3_8b" else None
     except (OSError, ValueError):
         pass
