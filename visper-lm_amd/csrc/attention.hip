@@ -42,7 +42,13 @@ struct AttnParams {
   const float* rope_cos;
   const float* rope_sin;
   const int* rope_pos;
+  // dispatch order of the 3-D grid: 0 = (head, batch, tile) with `tile` slowest (all batches of one tile level run together);
+  // 1 = (head, tile, batch) with `batch` slowest: one batch's heads and tiles run together, so an XCD's resident blocks share ONE
+  // (batch, kv-head) K/V set (1 MB at S=2048) instead of eight (8 MB > the 4 MB L2)
+  int order;
 };
+#define VP_BY(P) ((P).order ? (int)blockIdx.z : (int)blockIdx.y)      /* batch index */
+#define VP_BZ(P) ((P).order ? (int)blockIdx.y : (int)blockIdx.z)      /* tile index */
 
 #define LOG2E 1.4426950408889634f
 #define RESCALE_THR 8.0f     // log2 units: skip the O/l rescale while the running max grows by < 2^8 (wave-uniform)
@@ -108,11 +114,11 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(AttnParams p) {
   bf16_t* const Vbuf = Kbuf + 2 * TILE;                // [2][64*LD]   V tiles
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, fr = lane & 15, g = lane >> 4;
   const int nqb = (p.Sq + 127) >> 7;
-  const int qb = nqb - 1 - (int)blockIdx.z;            // z is the slowest dispatch index: heavy (late) causal blocks first
+  const int qb = nqb - 1 - VP_BZ(p);            // z is the slowest dispatch index: heavy (late) causal blocks first
   // blocks are dealt round-robin to the 8 XCDs (x & 7): give each XCD whole GQA groups so K/V tiles are shared in its L2
   const int hx = blockIdx.x;
   const int h = (p.Hq & 7) == 0 ? (hx & 7) * (p.Hq >> 3) + (hx >> 3) : hx;
-  const int b = blockIdx.y, hk = h / (p.Hq / p.Hkv);
+  const int b = VP_BY(p), hk = h / (p.Hq / p.Hkv);
   const int q0 = qb * 128, qw0 = q0 + wave * 16;
   const int qrow = qw0 + fr;
   const int kvlen = p.kv_len ? min(p.kv_len[b], p.Skv) : p.Skv;
@@ -295,8 +301,8 @@ __global__ __launch_bounds__(512) void attn_bwd_dkdv_kernel(AttnParams p) {
   __shared__ __attribute__((aligned(16))) bf16_t dObuf[2 * 32 * LD];
   __shared__ float lse_buf[2 * 32], delta_buf[2 * 32];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, fr = lane & 15, g = lane >> 4;
-  const int hk = blockIdx.x, b = blockIdx.y;           // z (slowest dispatch index) = key block: early keys (most queries) first
-  const int k0 = blockIdx.z * 128, kw0 = k0 + wave * 16, key = kw0 + fr;
+  const int hk = blockIdx.x, b = VP_BY(p);           // z (slowest dispatch index) = key block: early keys (most queries) first
+  const int k0 = VP_BZ(p) * 128, kw0 = k0 + wave * 16, key = kw0 + fr;
   const int kvlen = p.kv_len ? min(p.kv_len[b], p.Skv) : p.Skv;
   const int off = p.Skv - p.Sq;
   const int rep = p.Hq / p.Hkv;
@@ -496,8 +502,8 @@ void attn_bwd_dkdv128_kernel(AttnParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char attn_smem[];
   bf16_t* const ring = (bf16_t*)attn_smem;
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), fr = lane & 15, g = lane >> 4;
-  const int hk = blockIdx.x, b = blockIdx.y;           // z (slowest dispatch index) = key block: early keys (most queries) first
-  const int k0 = blockIdx.z * 128, kw0 = k0 + wave * 16 * KT;
+  const int hk = blockIdx.x, b = VP_BY(p);           // z (slowest dispatch index) = key block: early keys (most queries) first
+  const int k0 = VP_BZ(p) * 128, kw0 = k0 + wave * 16 * KT;
   const int kvlen = p.kv_len ? min(p.kv_len[b], p.Skv) : p.Skv;
   const int off = p.Skv - p.Sq;
   const int rep = p.Hq / p.Hkv;
@@ -675,11 +681,11 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(AttnParams p) {
   bf16_t* const Vbuf = Kbuf + 2 * TILE;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, fr = lane & 15, g = lane >> 4;
   const int nqb = (p.Sq + 127) >> 7;
-  const int qb = nqb - 1 - (int)blockIdx.z;
+  const int qb = nqb - 1 - VP_BZ(p);
   // blocks are dealt round-robin to the 8 XCDs (x & 7): give each XCD whole GQA groups so K/V tiles are shared in its L2
   const int hx = blockIdx.x;
   const int h = (p.Hq & 7) == 0 ? (hx & 7) * (p.Hq >> 3) + (hx >> 3) : hx;
-  const int b = blockIdx.y, hk = h / (p.Hq / p.Hkv);
+  const int b = VP_BY(p), hk = h / (p.Hq / p.Hkv);
   const int q0 = qb * 128, qw0 = q0 + wave * 16, qrow = qw0 + fr;
   const int kvlen = p.kv_len ? min(p.kv_len[b], p.Skv) : p.Skv;
   const int off = p.Skv - p.Sq;
@@ -797,10 +803,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   bf16_t* const ring = (bf16_t*)attn_smem;
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int nqb = (p.Sq + 127) >> 7;
-  const int qb = nqb - 1 - (int)blockIdx.z;            // z is the slowest dispatch index: heavy (late) causal blocks first
+  const int qb = nqb - 1 - VP_BZ(p);            // z is the slowest dispatch index: heavy (late) causal blocks first
   const int hx = blockIdx.x;
   const int h = (p.Hq & 7) == 0 ? (hx & 7) * (p.Hq >> 3) + (hx >> 3) : hx;     // whole GQA groups per XCD
-  const int b = blockIdx.y, hk = h / (p.Hq / p.Hkv);
+  const int b = VP_BY(p), hk = h / (p.Hq / p.Hkv);
   const int q0 = qb * 128, qw0 = q0 + wave * 32;
   const int kvlen = p.kv_len ? min(p.kv_len[b], p.Skv) : p.Skv;
   const int off = p.Skv - p.Sq;
@@ -988,10 +994,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   bf16_t* const ring = (bf16_t*)attn_smem;
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int nqb = (p.Sq + 127) >> 7;
-  const int qb = nqb - 1 - (int)blockIdx.z;            // z is the slowest dispatch index: heavy (late) causal blocks first
+  const int qb = nqb - 1 - VP_BZ(p);            // z is the slowest dispatch index: heavy (late) causal blocks first
   const int hx = blockIdx.x;
   const int h = (p.Hq & 7) == 0 ? (hx & 7) * (p.Hq >> 3) + (hx >> 3) : hx;     // whole GQA groups per XCD
-  const int b = blockIdx.y, hk = h / (p.Hq / p.Hkv);
+  const int b = VP_BY(p), hk = h / (p.Hq / p.Hkv);
   const int q0 = qb * 128, qw0 = q0 + wave * 32;
   const int kvlen = p.kv_len ? min(p.kv_len[b], p.Skv) : p.Skv;
   const int off = p.Skv - p.Sq;
@@ -1054,149 +1060,155 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       FWD_QK(sc, ring, rbase)
     }
   }
-  for (int it = 0; it < nit; ++it) {
-    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // tile it+1 landed (this wave's part); tile it+2 may still be in flight
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-    int ln = threadIdx.x & 63;
-    asm volatile("" : "+v"(ln));
-    issue(it + 3, (it + 3) & 3, ln);                   // stage of tile it-1: every wave is past its last read of it
-    const int fr = ln & 15, g = ln >> 4;
-    const int rbase = fr * 128 + ((g ^ fr) << 3);
-    const int trow = 4 * g + (fr >> 2);
-    const int tbase = trow * 128 + ((((ln & 3) >> 1) ^ trow) << 3) + (ln & 1) * 4;
-    const bf16_t* Vs = ring + (it & 3) * FWD128_STAGE + 4096;
-    const bf16_t* Kn = ring + ((it + 1) & 3) * FWD128_STAGE;
-    const int k0 = kstart + it * 32;
-    if (it <= last_w) {
-      // ---- A: mask, running max, rare rescale
-      const bool need_mask = (qw0 + 32 > p.Sq) || (k0 + 32 > kvlen) || (CAUSAL && (k0 + 31 > qw0 + off)) || (p.window > 0);
-      if (need_mask) {
-        // key = k0 + 4g + (kt*16 + r): visible iff  kt*16 + r < hi[qt]  and  kt*16 + r > lo[qt]  (two ints per query tile)
-        const int kl = kvlen - k0 - 4 * g;
-#pragma unroll
-        for (int qt = 0; qt < 2; ++qt) {
-          const int dq_ = qw0 + qt * 16 + fr + off - k0 - 4 * g;                  // (qrow + off) - (k0 + 4g)
-          const int hi = CAUSAL ? min(kl, dq_ + 1) : kl;
-          const int lo = p.window > 0 ? dq_ - p.window : -1;
-#pragma unroll
-          for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const int e = kt * 16 + r;
-              sc[kt][qt][r] = (e < hi && e > lo) ? sc[kt][qt][r] : -INFINITY;
-            }
-        }
-      }
-      // LANE-LOCAL max of this lane's 8 scores per query row; the cross-lane row max (two LDS-crossbar shuffles per row, ~100 cycles of
-      // latency each, with no MFMA of this wave in flight) is only formed when some lane sees a score above m + 2^8: with every score
-      // <= m + RESCALE_THR the exponentials stay <= 2^8, so m may lag the true running max (the final O / l ratio does not depend on m)
-      float mloc[2];
-#pragma unroll
-      for (int qt = 0; qt < 2; ++qt)
-        mloc[qt] = c * fmaxf(fmaxf(fmaxf(sc[0][qt][0], sc[0][qt][1]), fmaxf(sc[0][qt][2], sc[0][qt][3])),
-                             fmaxf(fmaxf(sc[1][qt][0], sc[1][qt][1]), fmaxf(sc[1][qt][2], sc[1][qt][3])));
-      if (!__all(mloc[0] <= m[0] + RESCALE_THR && mloc[1] <= m[1] + RESCALE_THR)) {     // rare after the first tiles
-#pragma unroll
-        for (int qt = 0; qt < 2; ++qt) {
-          float v = mloc[qt];
-          v = fmaxf(v, __shfl_xor(v, 16, 64));
-          v = fmaxf(v, __shfl_xor(v, 32, 64));
-          const float mnew = fmaxf(m[qt], v);
-          const float alpha = fast_exp2(m[qt] - mnew);
-          l[qt] *= alpha;
-#pragma unroll
-          for (int d = 0; d < NDB; ++d) oacc[qt][d] *= alpha;
-          m[qt] = mnew;
-        }
-      }
-      // ---- B: next tile's QK^T MFMAs under this tile's exp2 / row sums / packing (one basic block)
-      const bool have_next = it + 1 <= last_w;
-      u32x4 pk[2];
-      float rs[2] = {0.f, 0.f};
-      // softmax element i of this lane's 16: (qt, kt, r) = (i >> 3, (i >> 2) & 1, i & 3)
-#define FWD_EL(I, CC)                                                                                         \
+  // One loop trip = two tiles with the roles of the two score buffers swapped (no register copies).  Inside a tile:
+  //   A: mask (diagonal / ragged tiles only), LANE-LOCAL running max; the cross-lane row max (LDS-crossbar shuffles, ~100 cycles each with
+  //      no MFMA of this wave in flight) is only formed when some lane sees a score above m + 2^8: with every score <= m + RESCALE_THR the
+  //      exponentials stay <= 2^8, so m may lag the true running max (the final O / l ratio does not depend on m);
+  //   B: MFMA j of S(next tile) followed by fma(element j) | exp2(element j-1) | add(element j-2) (no dependent pair adjacent), a
+  //      scheduling fence after each slot; K fragments are read one k-step ahead; this copy of the softmax arithmetic is kept inside the
+  //      block by routing the scale through an opaque asm (hipcc would otherwise hoist the code common to both branches);
+  //   C: O += V^T P with the transposing V reads three fragments ahead of their MFMAs.
+#define EL_REF(A, I) A[((I) >> 2) & 1][(I) >> 3][(I) & 3]
+#define FWD_S1(A, I, CC) { EL_REF(A, I) = fmaf(EL_REF(A, I), CC, -m[(I) >> 3]); }
+#define FWD_S2(A, I) { EL_REF(A, I) = fast_exp2(EL_REF(A, I)); }
+#define FWD_S3(A, I) { rs[(I) >> 3][(I) & 1] += EL_REF(A, I); }
+#define FWD_ITER(IT, SC, SN)                                                                                  \
   {                                                                                                           \
-    const float e_ = fast_exp2(fmaf(sc[((I) >> 2) & 1][(I) >> 3][(I) & 3], CC, -m[(I) >> 3]));                \
-    sc[((I) >> 2) & 1][(I) >> 3][(I) & 3] = e_;                                                               \
-    rs[(I) >> 3] += e_;                                                                                       \
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); \
+    __builtin_amdgcn_sched_barrier(0); \
+    __builtin_amdgcn_s_barrier(); \
+    __builtin_amdgcn_sched_barrier(0); \
+    int ln = threadIdx.x & 63; \
+    asm volatile("" : "+v"(ln)); \
+    issue((IT) + 3, ((IT) + 3) & 3, ln); \
+    const int fr = ln & 15, g = ln >> 4; \
+    const int rbase = fr * 128 + ((g ^ fr) << 3); \
+    const int trow = 4 * g + (fr >> 2); \
+    const int tbase = trow * 128 + ((((ln & 3) >> 1) ^ trow) << 3) + (ln & 1) * 4; \
+    const bf16_t* Vs = ring + ((IT) & 3) * FWD128_STAGE + 4096; \
+    const bf16_t* Kn = ring + (((IT) + 1) & 3) * FWD128_STAGE; \
+    const int k0 = kstart + (IT) * 32; \
+    if ((IT) <= last_w) { \
+      const bool need_mask = (qw0 + 32 > p.Sq) || (k0 + 32 > kvlen) || (CAUSAL && (k0 + 31 > qw0 + off)) || (p.window > 0); \
+      if (need_mask) { \
+        const int kl = kvlen - k0 - 4 * g; \
+_Pragma("unroll") \
+        for (int qt = 0; qt < 2; ++qt) { \
+          const int dq_ = qw0 + qt * 16 + fr + off - k0 - 4 * g; \
+          const int hi = CAUSAL ? min(kl, dq_ + 1) : kl; \
+          const int lo = p.window > 0 ? dq_ - p.window : -1; \
+_Pragma("unroll") \
+          for (int kt = 0; kt < 2; ++kt) \
+_Pragma("unroll") \
+            for (int r = 0; r < 4; ++r) { \
+              const int e = kt * 16 + r; \
+              SC[kt][qt][r] = (e < hi && e > lo) ? SC[kt][qt][r] : -INFINITY; \
+            } \
+        } \
+      } \
+      float mloc[2]; \
+_Pragma("unroll") \
+      for (int qt = 0; qt < 2; ++qt) \
+        mloc[qt] = c * fmaxf(fmaxf(fmaxf(SC[0][qt][0], SC[0][qt][1]), fmaxf(SC[0][qt][2], SC[0][qt][3])), \
+                             fmaxf(fmaxf(SC[1][qt][0], SC[1][qt][1]), fmaxf(SC[1][qt][2], SC[1][qt][3]))); \
+      if (!__all(mloc[0] <= m[0] + RESCALE_THR && mloc[1] <= m[1] + RESCALE_THR)) { \
+_Pragma("unroll") \
+        for (int qt = 0; qt < 2; ++qt) { \
+          float v = mloc[qt]; \
+          v = fmaxf(v, __shfl_xor(v, 16, 64)); \
+          v = fmaxf(v, __shfl_xor(v, 32, 64)); \
+          const float mnew = fmaxf(m[qt], v); \
+          const float alpha = fast_exp2(m[qt] - mnew); \
+          l[qt] *= alpha; \
+_Pragma("unroll") \
+          for (int d = 0; d < NDB; ++d) oacc[qt][d] *= alpha; \
+          m[qt] = mnew; \
+        } \
+      } \
+      const bool have_next = (IT) + 1 <= last_w; \
+      u32x4 pk[2]; \
+      float rs[2][2] = {{0.f, 0.f}, {0.f, 0.f}}; \
+      __builtin_amdgcn_sched_barrier(0); \
+      if (have_next) { \
+        float c2 = c; \
+        asm volatile("" : "+v"(c2)); \
+        bf16x8 ka[2], kn[2]; \
+        ka[0] = *(const bf16x8*)(Kn + rbase); \
+        ka[1] = *(const bf16x8*)(Kn + rbase + 2048); \
+_Pragma("unroll") \
+        for (int ks = 0; ks < NKS; ++ks) { \
+          if (ks + 1 < NKS) { \
+            kn[0] = *(const bf16x8*)(Kn + (rbase ^ ((ks + 1) * 32))); \
+            kn[1] = *(const bf16x8*)(Kn + (rbase ^ ((ks + 1) * 32)) + 2048); \
+          } \
+_Pragma("unroll") \
+          for (int kt = 0; kt < 2; ++kt) \
+_Pragma("unroll") \
+            for (int qt = 0; qt < 2; ++qt) { \
+              SN[kt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka[kt], qf[qt][ks], ks == 0 ? f32x4{0.f, 0.f, 0.f, 0.f} : SN[kt][qt], 0, 0, 0); \
+              FWD_S1(SC, ks * 4 + kt * 2 + qt, c2) \
+              if (ks * 4 + kt * 2 + qt >= 1) FWD_S2(SC, (ks * 4 + kt * 2 + qt + 15) & 15) \
+              if (ks * 4 + kt * 2 + qt >= 2) FWD_S3(SC, (ks * 4 + kt * 2 + qt + 14) & 15) \
+              __builtin_amdgcn_sched_barrier(0); \
+            } \
+          ka[0] = kn[0]; \
+          ka[1] = kn[1]; \
+        } \
+        FWD_S2(SC, 15) \
+        FWD_S3(SC, 14) \
+        FWD_S3(SC, 15) \
+      } else { \
+_Pragma("unroll") \
+        for (int i = 0; i < 16; ++i) FWD_S1(SC, i, c) \
+_Pragma("unroll") \
+        for (int i = 0; i < 16; ++i) FWD_S2(SC, i) \
+_Pragma("unroll") \
+        for (int i = 0; i < 16; ++i) FWD_S3(SC, i) \
+      } \
+_Pragma("unroll") \
+      for (int qt = 0; qt < 2; ++qt) { \
+        l[qt] += rs[qt][0] + rs[qt][1]; \
+        pk[qt] = u32x4{pack_bf16x2(SC[0][qt][0], SC[0][qt][1]), pack_bf16x2(SC[0][qt][2], SC[0][qt][3]), \
+                       pack_bf16x2(SC[1][qt][0], SC[1][qt][1]), pack_bf16x2(SC[1][qt][2], SC[1][qt][3])}; \
+      } \
+      __builtin_amdgcn_sched_barrier(0); \
+      const bf16x8 pf0 = __builtin_bit_cast(bf16x8, pk[0]), pf1 = __builtin_bit_cast(bf16x8, pk[1]); \
+      const uint32_t vs_addr = attn_lds_addr(Vs); \
+      constexpr int PF = 3; \
+      s16x4 vlo[NDB], vhi[NDB]; \
+_Pragma("unroll") \
+      for (int d = 0; d < PF; ++d) { \
+        const uint32_t na = vs_addr + 2u * (uint32_t)(tbase ^ (d * 16)); \
+        vlo[d] = tr_read_asm<0>(na); \
+        vhi[d] = tr_read_asm<4096>(na); \
+      } \
+_Pragma("unroll") \
+      for (int d = 0; d < NDB; ++d) { \
+        if (d + PF < NDB) { \
+          const uint32_t na = vs_addr + 2u * (uint32_t)(tbase ^ ((d + PF) * 16)); \
+          vlo[d + PF] = tr_read_asm<0>(na); \
+          vhi[d + PF] = tr_read_asm<4096>(na); \
+          ATTN_LGKM(2 * PF); \
+        } else if (d + PF == NDB) { ATTN_LGKM(2 * (PF - 1)); } \
+        else if (d + PF == NDB + 1) { ATTN_LGKM(PF >= 2 ? 2 * (PF - 2) : 0); } \
+        else { ATTN_LGKM(0); } \
+        bf16x8 vtf = tr_join(vlo[d], vhi[d]); \
+        ATTN_PIN(vtf); \
+        oacc[0][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vtf, pf0, oacc[0][d], 0, 0, 0); \
+        oacc[1][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vtf, pf1, oacc[1][d], 0, 0, 0); \
+        if (d & 1) __builtin_amdgcn_sched_barrier(0); \
+      } \
+    } \
   }
-      __builtin_amdgcn_sched_barrier(0);
-      if (have_next) {
-        // Hand-interleaved: MFMA j of S(it+1) is followed by the fma / exp2 / add of element j of tile it, with a scheduling fence
-        // after each pair (sched_group_barrier masks left hipcc's order bunched: 6 MFMAs, then 11 exps).  K fragments are read one
-        // k-step ahead.
-        float c2 = c;
-        asm volatile("" : "+v"(c2));                    // this copy of the softmax arithmetic must stay inside the block
-        bf16x8 ka[2], kn[2];
-        ka[0] = *(const bf16x8*)(Kn + rbase);
-        ka[1] = *(const bf16x8*)(Kn + rbase + 2048);
-#pragma unroll
-        for (int ks = 0; ks < NKS; ++ks) {
-          if (ks + 1 < NKS) {
-            kn[0] = *(const bf16x8*)(Kn + (rbase ^ ((ks + 1) * 32)));
-            kn[1] = *(const bf16x8*)(Kn + (rbase ^ ((ks + 1) * 32)) + 2048);
-          }
-#pragma unroll
-          for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-            for (int qt = 0; qt < 2; ++qt) {
-              sn[kt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka[kt], qf[qt][ks], ks == 0 ? f32x4{0.f, 0.f, 0.f, 0.f} : sn[kt][qt], 0, 0, 0);
-              FWD_EL(ks * 4 + kt * 2 + qt, c2)
-              __builtin_amdgcn_sched_barrier(0);
-            }
-          ka[0] = kn[0];
-          ka[1] = kn[1];
-        }
-      } else {
-#pragma unroll
-        for (int i = 0; i < 16; ++i) FWD_EL(i, c)
-      }
-#undef FWD_EL
-#pragma unroll
-      for (int qt = 0; qt < 2; ++qt) {
-        l[qt] += rs[qt];                                // per-lane partial row sum (this lane's keys); folded across lanes once, at the end
-        pk[qt] = u32x4{pack_bf16x2(sc[0][qt][0], sc[0][qt][1]), pack_bf16x2(sc[0][qt][2], sc[0][qt][3]),
-                       pack_bf16x2(sc[1][qt][0], sc[1][qt][1]), pack_bf16x2(sc[1][qt][2], sc[1][qt][3])};
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      // ---- C: O += V^T P
-      const bf16x8 pf0 = __builtin_bit_cast(bf16x8, pk[0]), pf1 = __builtin_bit_cast(bf16x8, pk[1]);
-      const uint32_t vs_addr = attn_lds_addr(Vs);      // rows +16 = +4096 bytes
-      // transposing V reads run PF fragments ahead of the MFMAs that consume them (an LDS round trip is ~4 MFMA issue slots)
-      constexpr int PF = 3;
-      s16x4 vlo[NDB], vhi[NDB];
-#pragma unroll
-      for (int d = 0; d < PF; ++d) {
-        const uint32_t na = vs_addr + 2u * (uint32_t)(tbase ^ (d * 16));
-        vlo[d] = tr_read_asm<0>(na);
-        vhi[d] = tr_read_asm<4096>(na);
-      }
-#pragma unroll
-      for (int d = 0; d < NDB; ++d) {
-        if (d + PF < NDB) {
-          const uint32_t na = vs_addr + 2u * (uint32_t)(tbase ^ ((d + PF) * 16));
-          vlo[d + PF] = tr_read_asm<0>(na);
-          vhi[d + PF] = tr_read_asm<4096>(na);
-          ATTN_LGKM(2 * PF);
-        } else if (d + PF == NDB) { ATTN_LGKM(2 * (PF - 1)); }
-        else if (d + PF == NDB + 1) { ATTN_LGKM(PF >= 2 ? 2 * (PF - 2) : 0); }
-        else { ATTN_LGKM(0); }
-        bf16x8 vtf = tr_join(vlo[d], vhi[d]);
-        ATTN_PIN(vtf);
-        oacc[0][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vtf, pf0, oacc[0][d], 0, 0, 0);
-        oacc[1][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vtf, pf1, oacc[1][d], 0, 0, 0);
-        if (d & 1) __builtin_amdgcn_sched_barrier(0);
-      }
-      if (have_next) {
-#pragma unroll
-        for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-          for (int qt = 0; qt < 2; ++qt) sc[kt][qt] = sn[kt][qt];
-      }
-    }
+  for (int it = 0; it < nit; it += 2) {
+    FWD_ITER(it, sc, sn)
+    if (it + 1 < nit) FWD_ITER(it + 1, sn, sc)
   }
+#undef FWD_ITER
+#undef FWD_S1
+#undef FWD_S2
+#undef FWD_S3
+#undef EL_REF
 #undef FWD_QK
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // trailing (dummy) DMAs must not outlive the block's LDS
 #pragma unroll
@@ -1225,6 +1237,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 template <int D>
 static constexpr int kv_lds_bytes() { return 4 * 64 * (D + 16) * 2; }     // K,V tiles x 2 buffers
 
+static int vp_attn_order() {                           // VP_ATTN_ORDER=0|1 (see AttnParams::order)
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("VP_ATTN_ORDER"); v = e ? atoi(e) : 0; }
+  return v;
+}
+
 static bool vp_fwd128_enabled() {                      // VP_ATTN_FWD128=1 selects the DMA-ring forward (measured equal to the default: DESIGN.md 4)
   static int v = -1;
   if (v < 0) { const char* e = getenv("VP_ATTN_FWD128"); v = e ? atoi(e) : 0; }
@@ -1232,7 +1250,9 @@ static bool vp_fwd128_enabled() {                      // VP_ATTN_FWD128=1 selec
 }
 
 template <int D>
-static int launch_fwd(const AttnParams& p, int causal, hipStream_t s) {
+static int launch_fwd(const AttnParams& p_in, int causal, hipStream_t s) {
+  AttnParams p = p_in;
+  p.order = (p.B <= 65535 && (p.Sq + 127) / 128 <= 65535) ? vp_attn_order() : 0;
   static bool attr = false;
   if (!attr) {
     (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<D, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kv_lds_bytes<D>());
@@ -1241,7 +1261,7 @@ static int launch_fwd(const AttnParams& p, int causal, hipStream_t s) {
     (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<D, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kv_lds_bytes<D>());
     attr = true;
   }
-  dim3 grid(p.Hq, p.B, (p.Sq + 127) / 128);
+  const dim3 grid = p.order ? dim3(p.Hq, (p.Sq + 127) / 128, p.B) : dim3(p.Hq, p.B, (p.Sq + 127) / 128);
   if (D == 128 && !p.bias_h && !p.bias_b && vp_fwd128_enabled()) {      // DMA-ring kernel (32 query rows per wave)
     static bool attr128 = false;
     if (!attr128) {
@@ -1263,7 +1283,9 @@ static int launch_fwd(const AttnParams& p, int causal, hipStream_t s) {
   return vp_check_launch("vp_attn_fwd");
 }
 template <int D>
-static int launch_bwd(const AttnParams& p, int causal, hipStream_t s) {
+static int launch_bwd(const AttnParams& p_in, int causal, hipStream_t s) {
+  AttnParams p = p_in;
+  p.order = (p.B <= 65535 && (p.Skv + 127) / 128 <= 65535 && (p.Sq + 127) / 128 <= 65535) ? vp_attn_order() : 0;
   const long rows = (long)p.B * p.Hq * p.Sq;
   if (D != 128) hipLaunchKernelGGL((attn_delta_kernel<D>), dim3((unsigned)min(8192L, (rows + 15) / 16)), dim3(256), 0, s, p);
   static bool attr = false;
@@ -1272,7 +1294,8 @@ static int launch_bwd(const AttnParams& p, int causal, hipStream_t s) {
     (void)hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<D, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kv_lds_bytes<D>());
     attr = true;
   }
-  dim3 g1(p.Hkv, p.B, (p.Skv + 127) / 128), g2(p.Hq, p.B, (p.Sq + 127) / 128);
+  const dim3 g1 = p.order ? dim3(p.Hkv, (p.Skv + 127) / 128, p.B) : dim3(p.Hkv, p.B, (p.Skv + 127) / 128);
+  const dim3 g2 = p.order ? dim3(p.Hq, (p.Sq + 127) / 128, p.B) : dim3(p.Hq, p.B, (p.Sq + 127) / 128);
   if (D == 128) {
     static bool attr2 = false;
     if (!attr2) {
