@@ -1358,7 +1358,9 @@ static int* vp_sched_for(hipStream_t s) {
 
 static bool vp_ph4_enabled() {
   static int e = -1;
-  if (e < 0) { const char* v = getenv("VP_GEMM_PH4"); e = v ? atoi(v) : 0; }
+  // default ON since round 2: in-step A/B on one box, alternating runs: 458.1 / 459.0 ms per step against 461.7 / 462.5 with the 8-phase loop
+  // (GEMM 1337 vs 1324 TFLOP/s), bit-identical results; VP_GEMM_PH4=0 selects the 8-phase loop
+  if (e < 0) { const char* v = getenv("VP_GEMM_PH4"); e = v ? atoi(v) : 1; }
   return e != 0;
 }
 
