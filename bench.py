@@ -331,7 +331,7 @@ def main():
             traffic = json.load(fh).get("hbm_bytes_per_launch") if args.workload == "llama3_8b" else None
     except (OSError, ValueError):
         pass
-    roof = {"bound": "mfma", "kernel": "gemm_nt_256p8 (bf16 MFMA 16x16x32, persistent 256x256x64 tiles, 8-phase ping-pong)",
+    roof = {"bound": "mfma", "kernel": "gemm_nt_256p8 (bf16 MFMA 16x16x32, persistent 256x256x64 tiles, two wave groups in ping-pong, 4 phases per K-tile)",
             "achieved": round(achieved, 1), "peak": PEAK_BF16_TF, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TF, 4),
             "traffic": traffic, "launches_per_step": len(big) // max(args.steps, 1),
             "avg_launch_ms": round(b_ms / max(len(big), 1), 4), "tflop_per_launch": round(b_fl / max(len(big), 1) / 1e12, 4),
