@@ -202,13 +202,16 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(AttnParams p) {
             if (key >= kvlen || (CAUSAL && key > qrow + off) || (p.window > 0 && key <= qrow + off - p.window)) st[kt][r] = -INFINITY;
           }
       }
+      // LANE-LOCAL max of this lane's 16 scores; the cross-lane row max (two LDS-crossbar shuffles, ~100 cycles of latency each) is only
+      // formed when some lane sees a score above m + 2^8: with every score <= m + RESCALE_THR the exponentials stay <= 2^8, so m may lag the
+      // true running max (O / l does not depend on m).  The row sum l is kept per lane and folded across lanes once, after the loop.
       float mx = fmaxf(fmaxf(st[0][0], st[0][1]), fmaxf(st[0][2], st[0][3]));
 #pragma unroll
       for (int kt = 1; kt < 4; ++kt) mx = fmaxf(mx, fmaxf(fmaxf(st[kt][0], st[kt][1]), fmaxf(st[kt][2], st[kt][3])));
-      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
       mx *= c;
       if (!__all(mx <= m + RESCALE_THR)) {            // rare after the first tiles: rescale everything held at the old max
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
         const float mnew = fmaxf(m, mx);
         const float alpha = fast_exp2(m - mnew);
         l *= alpha;
@@ -225,8 +228,6 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(AttnParams p) {
           st[kt][r] = e;
           rs += e;
         }
-      rs += __shfl_xor(rs, 16, 64);
-      rs += __shfl_xor(rs, 32, 64);
       l += rs;
       __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -246,6 +247,8 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(AttnParams p) {
     }
     __syncthreads();
   }
+  l += __shfl_xor(l, 16, 64);
+  l += __shfl_xor(l, 32, 64);
   if (qrow < p.Sq) {
     const float inv = l > 0.f ? 1.f / l : 0.f;
     bf16_t* op = p.o + (long)b * p.o_bs + (long)qrow * p.o_ts + (long)h * D;
