@@ -108,11 +108,24 @@ int vp_comm_init(int rank, int world, const void* id, void** comm_out) {
   c->rank = rank; c->world = world; c->n_pending = 0;
   ncclUniqueId uid;
   memcpy(&uid, id, sizeof(uid));
-  VP_NCCL(g_rccl.CommInitRank(&c->comm, world, uid, rank));
-  VP_HIP(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
-  for (int i = 0; i < MAX_PENDING; ++i) {
-    VP_HIP(hipEventCreateWithFlags(&c->ready[i], hipEventDisableTiming));
-    VP_HIP(hipEventCreateWithFlags(&c->done[i], hipEventDisableTiming));
+  {
+    const ncclResult_t r = g_rccl.CommInitRank(&c->comm, world, uid, rank);
+    if (r != ncclSuccess) {
+      vp_set_error("vp_comm_init: ncclCommInitRank -> %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "rccl error");
+      delete c;
+      return VP_ERR_HIP;
+    }
+  }
+  bool ok = hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) == hipSuccess;
+  int made = 0;
+  for (; ok && made < MAX_PENDING; ++made)
+    ok = hipEventCreateWithFlags(&c->ready[made], hipEventDisableTiming) == hipSuccess &&
+         hipEventCreateWithFlags(&c->done[made], hipEventDisableTiming) == hipSuccess;
+  if (!ok) {                                                // roll back whatever was created: nothing leaks on a failed init
+    vp_set_error("vp_comm_init: could not create the side stream / fence events");
+    (void)g_rccl.CommDestroy(c->comm);
+    delete c;
+    return VP_ERR_HIP;
   }
   *comm_out = c;
   return VP_OK;

@@ -699,6 +699,9 @@ class Engine:
         heads = hp["heads"]
         for task, h in heads.items():
             h["rows"] = view("rows:" + task)
+            h["xin"] = dict(kind=view("xin_kind:" + task), row=view("xin_row:" + task),
+                            mean_idx=view("mean_idx:" + task) if ("mean_idx:" + task) in offs else None,
+                            lat_bwd=view("lat_bwd:" + task) if ("lat_bwd:" + task) in offs else None, lat_cnt=h.get("lat_cnt", 0))
         plan["heads"] = heads
         plan["inv"] = {l: view(f"inv:{l}") for l in self.tapped if f"inv:{l}" in offs}
         if len(self._plan_cache) > 8:
@@ -1028,34 +1031,8 @@ class Engine:
         # -- inputs: [x_b ; latents_b] per batch, contiguous (kv_input = cat(x, latents): resampler.py:59), built by ONE row gather from
         #    two sources: the tapped layer state and the latent source (the (576,H) task-token parameter for depth / seg; for gen the 8
         #    task-token rows of the state itself, or their per-sample mean when num_queries is not a multiple of 8: resampler.py:207-212)
-        nl = cfg.num_task_tokens if task == "gen" else ps.w(f"model.special_{task}_tokens").shape[0]
-        mode = "same" if nl == nq else ("tile" if (nq > 1 and nq % nl == 0) else "mean")
-        tkey = ("xin", task, B, S, n, nq, mode)
-        if tkey not in self._static:                              # static per (task, batch shape): kind / row tables of the [B*T] gather
-            bb = np.arange(B, dtype=np.int32)[:, None]
-            kind = np.zeros((B, T), np.int32)
-            rowt = np.zeros((B, T), np.int32)
-            rowt[:, :n] = bb * S + tb["sel"][None, :]
-            if task == "gen" and mode != "mean":
-                lat_rows = bb * S + tb["sel"][tb["lat_x"]][None, :]                     # state rows of the 8 gen task tokens
-                rowt[:, n:] = np.tile(lat_rows, (1, nq // nl))
-            elif task == "gen":
-                kind[:, n:] = 1
-                rowt[:, n:] = bb                                                       # row b of the per-sample mean
-            else:
-                kind[:, n:] = 1
-                rowt[:, n:] = np.tile(np.arange(nl, dtype=np.int32), nq // nl)[None, :] if mode != "mean" else 0
-            mean_idx = (bb * S + tb["sel"][tb["lat_x"]][None, :]).reshape(-1).astype(np.int32) if task == "gen" else None
-            # backward of the latent rows: parameter row i (depth / seg) <- sum over batch and tile copies of dxin rows
-            lat_bwd = None
-            if task != "gen":
-                reps = nq // nl if mode == "tile" else 1
-                src = (bb[:, :, None] * T + n + (np.arange(reps, dtype=np.int32)[None, :, None] * nl + np.arange(nl, dtype=np.int32)[None, None, :]))
-                lat_bwd = np.ascontiguousarray(src.transpose(2, 0, 1).reshape(nl, B * reps)) if mode != "mean" else None
-            up = lambda a: None if a is None else torch.from_numpy(np.ascontiguousarray(a).reshape(-1)).to(dev)
-            self._static[tkey] = dict(kind=up(kind), row=up(rowt), mean_idx=up(mean_idx), lat_bwd=up(lat_bwd),
-                                          lat_cnt=0 if lat_bwd is None else lat_bwd.shape[1])
-        xt = self._static[tkey]
+        # kind / row tables of the [B*T] gather come with the splice plan (splice.head_tables: one pinned upload per batch, no sync)
+        nl, mode, xt = tb["nl"], tb["mode"], tb["xin"]
         state2 = state.view(-1, H)
         if task != "gen":
             lat_src = ps.w(f"model.special_{task}_tokens")

@@ -18,7 +18,9 @@ N_IMG_TOK = 576   # the reference hard-codes 576 image tokens in the head slicin
 
 
 def head_tables(cfg, tasks, B, S):
-    """forward_emb_predictor's token selection as per-task row tables into the [B*S] state (host arrays).
+    """forward_emb_predictor's token selection as per-task row tables into the [B*S] state (host arrays), plus the tables of each
+    head's input gather [x_b ; latents_b] (TaskTokenResampler.forward, resampler.py:202-216: the latents are tiled to num_queries when
+    that is a multiple of their count, else replaced by their mean) and of its transpose.
     tasks: [(task, head_i, layer_idx)] (Engine.tasks)."""
     ns, nt, order = cfg.num_sys_tokens, cfg.num_task_tokens, cfg.token_order
     out = {}
@@ -40,7 +42,36 @@ def head_tables(cfg, tasks, B, S):
             lat_x = np.arange(ns + N_IMG_TOK, ns + N_IMG_TOK + nt)               # positions of the gen latents inside x
         else:
             lat_x = np.arange(len(sel) - nt, len(sel))
-        out[task] = dict(n_x=len(sel), rows_host=rows, sel=sel, lat_x=lat_x)
+        h = dict(n_x=len(sel), rows_host=rows, sel=sel, lat_x=lat_x)
+        # ---- the head's input gather: kind 0 = layer-state row, kind 1 = latent source row (the (num_tokens, H) task-token parameter for
+        # depth / seg; for gen the state rows of its 8 task tokens, or row b of their per-sample mean)
+        hc = {"gen": cfg.image_gen, "seg": cfg.image_seg, "depth": cfg.image_depth}[task]
+        n, nq = len(sel), int(hc["num_tokens"])
+        nl = nt if task == "gen" else nq                             # gen latents = its nt task-token rows of the state; depth / seg = the
+                                                                     # (num_tokens, H) special_{task}_tokens parameter (ola_arch.py:80-90)
+        mode = "same" if nl == nq else ("tile" if (nq > 1 and nl > 0 and nq % nl == 0) else "mean")
+        T = n + nq
+        bb = np.arange(B, dtype=np.int32)[:, None]
+        kind = np.zeros((B, T), np.int32)
+        rowt = np.zeros((B, T), np.int32)
+        rowt[:, :n] = bb * S + sel[None, :]
+        lat_state = (bb * S + sel[lat_x][None, :]).astype(np.int32) if (task == "gen" and nt > 0 and len(sel) >= nt) else None
+        if task == "gen" and mode != "mean":
+            rowt[:, n:] = np.tile(lat_state, (1, nq // nl))
+        elif task == "gen":
+            kind[:, n:] = 1
+            rowt[:, n:] = bb
+        else:
+            kind[:, n:] = 1
+            rowt[:, n:] = np.tile(np.arange(nl, dtype=np.int32), nq // nl)[None, :] if mode != "mean" else 0
+        h.update(nq=nq, nl=nl, mode=mode, xin_kind=kind.reshape(-1), xin_row=rowt.reshape(-1),
+                 mean_idx=None if lat_state is None else lat_state.reshape(-1))
+        if task != "gen" and mode != "mean":                         # parameter row i <- sum over batch (and tile copies) of its dxin rows
+            reps = nq // nl if mode == "tile" else 1
+            src = bb[:, :, None] * T + n + (np.arange(reps, dtype=np.int32)[None, :, None] * nl + np.arange(nl, dtype=np.int32)[None, None, :])
+            h["lat_bwd"] = np.ascontiguousarray(src.transpose(2, 0, 1).reshape(-1)).astype(np.int32)
+            h["lat_cnt"] = B * reps
+        out[task] = h
     return out
 
 
@@ -159,6 +190,11 @@ def host_plan(cfg, tasks, ids, am=None, lab=None):
             "(base_ola_vlm.py:414-427), which only lines up with right padding (its training scripts' setting)")
     for task, h in heads.items():
         tables["rows:" + task] = h["rows_host"]
+        tables["xin_kind:" + task], tables["xin_row:" + task] = h["xin_kind"], h["xin_row"]
+        if h.get("mean_idx") is not None:
+            tables["mean_idx:" + task] = h["mean_idx"]
+        if "lat_bwd" in h:
+            tables["lat_bwd:" + task] = h["lat_bwd"]
     for l, inv in inverse_tables(tasks, heads, M).items():
         tables[f"inv:{l}"] = inv.reshape(-1)
     plan["tables"] = tables
