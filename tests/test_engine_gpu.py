@@ -95,6 +95,24 @@ def test_hidden_states_and_logits(tiny):
     check("tiny/logits_maxrel", max_rel(lg, rl), 3e-2)
 
 
+def test_labelled_row_compaction_is_exact(tiny):
+    """Without keep_logits only the rows that carry a label go through lm_head + cross-entropy: same loss, bit-identical gradients."""
+    eng = tiny["eng"]
+    eng.keep_logits = False
+    try:
+        out = eng.train_step(_to_gpu_batch(tiny["batch"]))
+        torch.cuda.synchronize()
+    finally:
+        eng.keep_logits = True
+    assert "logits" not in out
+    plan = eng.build_plan(tiny["batch"]["input_ids"], tiny["batch"]["attention_mask"], tiny["batch"]["labels"])
+    assert 0 < plan["n_valid"] < plan["B"] * plan["S"]                      # the compacted path really ran
+    check("tiny/compact/text_loss_rel", rel(out["text_loss"], tiny["out"]["text_loss"]), 1e-6)
+    check("tiny/compact/loss_rel", rel(out["loss"], tiny["out"]["loss"]), 1e-6)
+    for k in eng.ps.index:
+        assert torch.equal(eng.ps.g(k).detach().float().cpu(), tiny["grads"][k]), k
+
+
 def test_gradients_match_oracle(tiny):
     grads, Wq, g = tiny["grads"], tiny["Wq"], tiny["g"]
     none_ref = set(json.loads(str(g["keep_grad_none"])))

@@ -72,6 +72,11 @@ def test_plan_reproduces_oracle_splice(side, kw):
     got = plan["shift_labels"]
     assert sorted(got[got != O.IGNORE_INDEX].tolist()) == sorted(want[want != O.IGNORE_INDEX].tolist())
     assert plan["n_valid"] == int((got != O.IGNORE_INDEX).sum())
+    # labelled-row tables of the lm_head / cross-entropy compaction: exactly the rows with a label, and their inverse
+    t = plan["tables"]
+    assert np.array_equal(t["ce_rows"], np.flatnonzero(got != O.IGNORE_INDEX)) and np.array_equal(plan["ce_labels"], got[t["ce_rows"]])
+    assert np.array_equal(np.flatnonzero(t["ce_inv"] >= 0), t["ce_rows"]) and np.array_equal(t["ce_inv"][t["ce_rows"]], np.arange(t["ce_rows"].size))
+    assert np.array_equal(t["ce_inv_kind"], np.where(t["ce_inv"] >= 0, 0, -1)) and not t["ce_kind"].any()
 
 
 def test_backward_tables_are_the_inverse_of_the_gather():

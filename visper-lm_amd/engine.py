@@ -689,11 +689,13 @@ class Engine:
             o, n = offs[name]
             hv[o:o + n] = a.reshape(-1)
         devbuf = host.to(self.dev, non_blocking=True)
-        shift_h = torch.from_numpy(hp["shift_labels"]).pin_memory()
+        M = plan["B"] * plan["S"]
+        shift_h = torch.from_numpy(np.concatenate([hp["shift_labels"], hp["ce_labels"]])).pin_memory()
         plan["_host_bufs"] = (host, shift_h)                          # keep the pinned sources alive until the async copies ran
-        plan["shift_labels"] = shift_h.to(self.dev, non_blocking=True)
+        shift_d = shift_h.to(self.dev, non_blocking=True)
+        plan["shift_labels"], plan["ce_labels"] = shift_d[:M], shift_d[M:]
         view = lambda name: devbuf[offs[name][0]:offs[name][0] + offs[name][1]]
-        for name in ("kind", "row", "lens", "img_dst", "tok_src", "embed_idx"):
+        for name in ("kind", "row", "lens", "img_dst", "tok_src", "embed_idx", "ce_rows", "ce_inv", "ce_kind", "ce_inv_kind"):
             plan[name] = view(name)
         plan["present"] = (view("present_kind"), view("present")) if "present" in offs else None
         heads = hp["heads"]
@@ -818,23 +820,36 @@ class Engine:
             states[L - 1] = hidden              # layer_states[-1] is the post-norm state (ola_llama.py:117-119)
         out["hidden"] = self.present(hidden, plan)
 
-        # ---- lm_head + NTP loss (a7), row-chunked; dlogits -> d_hidden in the same sweep
+        # ---- lm_head + NTP loss (a7), row-chunked; dlogits -> d_hidden in the same sweep.  Unless the caller wants the logits, only the
+        #      rows that carry a label go through the two vocabulary-wide GEMMs and the cross-entropy (the others have zero loss and zero
+        #      d_logits): their hidden rows are compacted by one row gather, and d_hidden is scattered back with zeros elsewhere
         n_valid = plan["n_valid"]
         gscale = 1.0 / n_valid if n_valid > 0 else float("nan")
-        d_hidden = torch.empty(M, H, device=dev, dtype=BF16) if compute_grads else None
-        row_loss = torch.empty(M, device=dev, dtype=F32)
+        compact = (not self.keep_logits) and 0 < n_valid < M
+        if compact:
+            h_ce = torch.empty(n_valid, H, device=dev, dtype=BF16)
+            ops.gather_rows([hidden], plan["ce_kind"], plan["ce_rows"], H, h_ce)
+            lab_ce, Mc = plan["ce_labels"], n_valid
+        else:
+            h_ce, lab_ce, Mc = hidden, plan["shift_labels"], M
+        d_hce = torch.empty(Mc, H, device=dev, dtype=BF16) if compute_grads else None
+        row_loss = torch.empty(Mc, device=dev, dtype=F32)
         logits_keep = [] if self.keep_logits else None
         R = self.lm_chunk_rows
-        for r0 in range(0, M, R):
-            r1 = min(M, r0 + R)
-            lg = ops.gemm(hidden[r0:r1], fz["lm_head"])
+        for r0 in range(0, Mc, R):
+            r1 = min(Mc, r0 + R)
+            lg = ops.gemm(h_ce[r0:r1], fz["lm_head"])
             if logits_keep is not None:
                 logits_keep.append(lg.clone())
-            row_loss[r0:r1] = ops.ce_fwd_bwd(lg, plan["shift_labels"][r0:r1], gscale, write_grad=compute_grads)
+            row_loss[r0:r1] = ops.ce_fwd_bwd(lg, lab_ce[r0:r1], gscale, write_grad=compute_grads)
             if compute_grads:
-                ops.gemm(lg, fz["lm_head_T"], out=d_hidden[r0:r1])
+                ops.gemm(lg, fz["lm_head_T"], out=d_hce[r0:r1])
                 if self.train_llm:                             # lm_head.weight.grad (+)= dlogits^T h, chunk by chunk
-                    self._wgrad(hidden[r0:r1], lg, ps.g("lm_head.weight"), accumulate=r0 > 0)
+                    self._wgrad(h_ce[r0:r1], lg, ps.g("lm_head.weight"), accumulate=r0 > 0)
+        d_hidden = d_hce
+        if compact and compute_grads:
+            d_hidden = torch.empty(M, H, device=dev, dtype=BF16)
+            ops.gather_rows([d_hce], plan["ce_inv_kind"], plan["ce_inv"], H, d_hidden)        # rows without a label: zeros
         text_loss = ops.sum_f32(row_loss, gscale)
         out["text_loss"] = text_loss
         if logits_keep is not None:

@@ -170,6 +170,14 @@ def host_plan(cfg, tasks, ids, am=None, lab=None):
     plan = dict(B=B, S=S, n_img=n_img, n_valid=int((shift != IGNORE_INDEX).sum()), lens_host=lens, n_tok_rows=n_tok_rows,
                 full=full, side=side, tok_cnt=max(n_img, 1), shift_labels=shift.reshape(-1))
     tables = dict(kind=fk, row=fr, lens=lens, img_dst=img_dst, tok_src=tok_src.reshape(-1), embed_idx=embed_idx)
+    # rows that carry a next-token label: the lm_head GEMMs and the cross-entropy only run on those (image / task-token / prompt /
+    # pad rows have label IGNORE_INDEX: zero loss and zero d_logits in the reference's CrossEntropyLoss, ola_llama.py:127-136)
+    ce_rows = np.flatnonzero(plan["shift_labels"] != IGNORE_INDEX).astype(np.int32)
+    ce_inv = np.full(M, -1, np.int32)
+    ce_inv[ce_rows] = np.arange(ce_rows.size, dtype=np.int32)
+    plan["ce_labels"] = plan["shift_labels"][ce_rows]
+    tables["ce_rows"], tables["ce_inv"] = ce_rows, ce_inv
+    tables["ce_kind"], tables["ce_inv_kind"] = np.zeros(ce_rows.size, np.int32), np.where(ce_inv >= 0, 0, -1).astype(np.int32)
     if side == "left" and not full:
         src = col - (S - lens)[:, None]                          # presented column c shows physical column c - (S - len)
         ok = src >= 0
