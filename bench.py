@@ -133,6 +133,38 @@ def cpu_baseline(cfg, dev):
                        f"(loss {loss4:.4f}); scaled in layer count only: T(32) = {t4:.2f} + 28 x {per_layer:.3f} = {step:.1f}s/step")}
 
 
+def clock_probe(dev, n=24):
+    """Sustained shader clock of the dominant kernel: `n` back-to-back launches of its longest decoder shape (the package sits at its power
+    cap, like inside the step), the last one with in-kernel stamps (s_memtime wall clock + shader-cycle counter around the first output tile's
+    K loop of every block, vp_debug_gemm_flags).  Returns MHz, K-loop cycles per 64-wide K-tile (2048 = pure MFMA issue for a 256x256 tile on
+    4 SIMDs), and the per-XCD clocks (each XCD is its own DVFS domain; the slowest one sets the kernel time)."""
+    import ctypes as C
+    import numpy as np
+    from visper_lm_amd import ops, _lib
+    M, N, K = 16384, 4096, 14336
+    a = torch.randn(M, K, device=dev, dtype=torch.bfloat16)
+    w = torch.randn(N, K, device=dev, dtype=torch.bfloat16) * 0.02
+    o = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+    for _ in range(n - 1):
+        ops.gemm(a, w, out=o)
+    _lib.call("vp_debug_gemm_flags", 0x10000)
+    try:
+        ops.gemm(a, w, out=o)
+        torch.cuda.synchronize()
+    finally:
+        _lib.call("vp_debug_gemm_flags", 0)
+    buf = (C.c_long * 2048)()
+    _lib.call("vp_debug_stamps", buf)
+    st = np.array(buf[:], dtype=np.int64).reshape(256, 8)
+    us = (st[:, 2] - st[:, 1]) / 100.0                          # wall clock ticks are 10 ns
+    cyc = (st[:, 7] - st[:, 6]).astype(np.float64)
+    mhz = cyc / us
+    return {"shape_MNK": [M, N, K], "shader_clock_mhz": round(float(mhz.mean()), 0), "nominal_mhz": 2400,
+            "per_xcd_mhz": [int(mhz[x::8].mean()) for x in range(8)],
+            "k_loop_cycles_per_k_tile": round(float(cyc.mean()) / (K // 64), 1), "mfma_issue_cycles_per_k_tile": 2048,
+            "mfma_issue_util_in_k_loop": round(2048.0 * (K // 64) / float(cyc.mean()), 4)}
+
+
 def k11_probe(cfg, B, world, dev, n=50):
     """The distillation-loss reduction (vp_emb_loss_fwd / _bwd; base_ola_vlm.py:289-320, ola_utils.py:108-125) timed alone with HIP events
     on its launch stream at this workload's shapes, against the 8 TB/s HBM roofline.  Algorithmic bytes: forward reads pred
@@ -359,6 +391,10 @@ def main():
         if args.workload in ("llama3_8b", "convnext", "phi3"):
             roof["k11"] = {"what": "distillation-loss reduction vp_emb_loss_fwd/bwd alone, HIP events, per call (launch included)",
                            "peak_GBps": 8000.0, "world1": k11_probe(cfg, args.batch, 1, dev), "world8_shaped": k11_probe(cfg, args.batch, 8, dev)}
+        # the chip clocks to its 1400 W package cap: the 2.5 PFLOP/s peak assumes 2.4 GHz; report the clock the kernel actually sustains
+        ck = clock_probe(dev)
+        roof["clock"] = ck
+        roof["frac_at_sustained_clock"] = round(achieved / (PEAK_BF16_TF * ck["shader_clock_mhz"] / ck["nominal_mhz"]), 4)
         if world == 1 and not args.no_cpu_baseline and args.workload == "llama3_8b":
             del eng, fresh, pool
             torch.cuda.empty_cache()

@@ -73,7 +73,11 @@ int vp_gemm_set_dynamic(int on);
 int vp_debug_occupy(int blocks, long cycles, vp_stream_t stream);
 
 /* dev aid (tools/gemm_stamps.py): per-block timestamps written by gemm_nt_256p8 when VP_GEMM_DBG=65536; 256*8 longs. */
+/* relative speeds of the 8 XCDs (each its own DVFS domain), or NULL = off: the persistent GEMM moves K prefixes of output tiles from slow
+   XCDs to fast ones; bit-identical results.  Experimental, off until called (visper_lm_amd.ops.calibrate_xcd_balance, VP_GEMM_BALANCE=1) */
+int vp_gemm_set_xcd_speeds(const float* speeds8);
 int vp_debug_stamps(long* host);
+int vp_debug_gemm_flags(int flags);   /* measurement aid: 0x10000 = in-kernel wall-clock / shader-cycle stamps of the first tile */
 
 int vp_transpose_bf16(int rows, int cols, const void* in, long ld_in, void* out, long ld_out, vp_stream_t stream);
 

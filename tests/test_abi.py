@@ -28,8 +28,7 @@ def test_ctypes_binding_covers_the_header():
     from visper_lm_amd import _lib
     declared, bound = set(_declared()), set(_lib.EXPORTS)
     assert bound <= declared, sorted(bound - declared)
-    dev_only = {"vp_debug_stamps"}                                        # profiling aid, bound ad hoc by tools/gemm_stamps.py
-    assert declared - bound <= dev_only, sorted(declared - bound)
+    assert declared == bound, sorted(declared ^ bound)
 
 
 def test_bad_arguments_return_codes_not_crashes():

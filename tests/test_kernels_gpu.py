@@ -684,3 +684,39 @@ def test_attention_with_additive_biases(ops):
     got = ops.attn_fwd_bias(dev(q), dev(k), dev(v), bias_h=dev(bh).contiguous(), bias_b=dev(mask).contiguous())
     close(got, ref, what="attn bias_h + bias_b")
     close(ops.attn_fwd_bias(dev(q), dev(k), dev(v), bias_h=dev(bh).contiguous()), (torch.softmax(s - mask.repeat(imgs, 1, 1)[:, None], -1) @ v.float().transpose(1, 2)).transpose(1, 2), what="attn bias_h only")
+
+
+@pytest.mark.gpu
+def test_gemm_xcd_balancing_is_bit_identical(ops):
+    """The persistent GEMM's XCD load balancing hands the fp32 accumulators of a K prefix from one block to another: every output
+    element still accumulates its K-tiles in the same order, so results must not depend on the speeds (vp_gemm_set_xcd_speeds)."""
+    torch.manual_seed(11)
+    cases = [(8192, 4096, 1024), (8192, 4096, 4096), (4096 + 256, 8192, 2048)]          # >= 2 rounds of 256 tiles; the last one ragged in rounds
+    speed_sets = [[1.0, 1.05, 0.97, 1.02, 1.08, 0.95, 1.0, 1.03], [2.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 0.5], [1.0] * 8]
+    try:
+        for M, N, K in cases:
+            a = torch.randn(M, K, device="cuda", dtype=BF)
+            w = torch.randn(N, K, device="cuda", dtype=BF) * 0.05
+            r = torch.randn(M, N, device="cuda", dtype=BF)
+            ops.set_xcd_speeds(None)
+            ref = ops.gemm(a, w, residual=r)
+            for sp in speed_sets:
+                ops.set_xcd_speeds(sp)
+                for _ in range(3):                              # repeated launches reuse the workspace slots (flag sequence numbers)
+                    out = ops.gemm(a, w, residual=r)
+                    assert torch.equal(out, ref), (M, N, K, sp)
+        # fused SwiGLU epilogues ride the same kernel
+        M, F, H = 8192, 4096, 1024
+        x = torch.randn(M, H, device="cuda", dtype=BF)
+        wgu = torch.randn(2 * F, H, device="cuda", dtype=BF) * 0.05
+        dy = torch.randn(M, H, device="cuda", dtype=BF)
+        wdT = torch.randn(F, H, device="cuda", dtype=BF) * 0.05
+        ops.set_xcd_speeds(None)
+        gu0, act0 = ops.gemm_swiglu_fwd(x, wgu)
+        dgu0 = ops.gemm_swiglu_bwd(dy, wdT, gu0)
+        ops.set_xcd_speeds(speed_sets[0])
+        gu1, act1 = ops.gemm_swiglu_fwd(x, wgu)
+        dgu1 = ops.gemm_swiglu_bwd(dy, wdT, gu1)
+        assert torch.equal(gu0, gu1) and torch.equal(act0, act1) and torch.equal(dgu0, dgu1)
+    finally:
+        ops.set_xcd_speeds(None)

@@ -4,7 +4,8 @@ os.environ["VP_GEMM_DBG"] = str(0x10000 + int(sys.argv[1]) if len(sys.argv) > 1 
 import torch, numpy as np
 from visper_lm_amd import ops, _lib
 lib = _lib.load()
-for (M, N, K) in [(16384, 28672, 4096)]:
+SH = [tuple(int(x) for x in a.split("x")) for a in os.environ.get("STAMP_SHAPES", "16384x28672x4096").split(",")]
+for (M, N, K) in SH:
     a = torch.randn(M, K, device="cuda", dtype=torch.bfloat16); w = torch.randn(N, K, device="cuda", dtype=torch.bfloat16) * 0.05
     out = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
     for _ in range(3):
@@ -26,4 +27,7 @@ for (M, N, K) in [(16384, 28672, 4096)]:
     print(" epilogue by xcd:", [round(float(ep[x::8].mean()), 1) for x in range(8)])
     cyc = (st[:, 7] - st[:, 6]).astype(float); us = (st[:, 2] - st[:, 1]) / 100.0
     print(" shader clock during first K loop: %.0f MHz (cycles %.0f / %.1f us)" % ((cyc / us).mean(), cyc.mean(), us.mean()))
+    print(" shader clock by xcd (MHz):", [int((cyc[x::8] / us[x::8]).mean()) for x in range(8)], " first K loop us by xcd:", [round(float(us[x::8].mean()), 1) for x in range(8)])
+    e = np.sort(d[:, 5])
+    print(" block end times (us) pct 0/10/50/90/100: %.1f %.1f %.1f %.1f %.1f ; by xcd mean:" % (e[0], e[25], e[128], e[230], e[255]), [round(float(d[x::8, 5].mean()), 1) for x in range(8)])
     print(" end: mean %.1f max %.1f ; loopend spread %.1f..%.1f" % (d[:, 5].mean(), d[:, 5].max(), d[:, 2].min(), d[:, 2].max()))

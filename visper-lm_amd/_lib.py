@@ -23,6 +23,9 @@ _SIGS = {
     "vp_gemm_bf16_swiglu": [i, i, i, i, p, l, p, l, p, l, p, l, p, l, p],
     "vp_gemm_set_dynamic": [i],
     "vp_debug_occupy": [i, l, p],
+    "vp_debug_gemm_flags": [i],
+    "vp_gemm_set_xcd_speeds": [p],
+    "vp_debug_stamps": [p],
     "vp_gemm_tn_bf16": [i, i, i, p, l, p, l, p, l, i, i, p],
     "vp_transpose_bf16": [i, i, p, l, p, l, p],
     "vp_rmsnorm_fwd": [i, i, p, l, p, f, p, l, p, p],
