@@ -133,7 +133,7 @@ def cpu_baseline(cfg, dev):
                        f"(loss {loss4:.4f}); scaled in layer count only: T(32) = {t4:.2f} + 28 x {per_layer:.3f} = {step:.1f}s/step")}
 
 
-def clock_probe(dev, n=24):
+def clock_probe(dev, n=120):
     """Sustained shader clock of the dominant kernel: `n` back-to-back launches of its longest decoder shape (the package sits at its power
     cap, like inside the step), the last one with in-kernel stamps (s_memtime wall clock + shader-cycle counter around the first output tile's
     K loop of every block, vp_debug_gemm_flags).  Returns MHz, K-loop cycles per 64-wide K-tile (2048 = pure MFMA issue for a 256x256 tile on
