@@ -6,10 +6,10 @@ root=$(pwd)
 out=$root/gpurun_out/prof_$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -- python $root/bench.py --steps 3 --warmup 1 > $out/bench_stats.log 2>&1
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -- python $root/bench.py --steps 3 --warmup 1 --no-probes --no-cpu-baseline > $out/bench_stats.log 2>&1
 f=$(find /tmp/prof_stats -name "*kernel_stats.csv" | head -1); if [ -n "$f" ]; then cp "$f" $out/kernel_stats.csv; fi
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout 900 rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/prof_$c -- python $root/bench.py --steps 1 --warmup 1 --no-cpu-baseline > $out/bench_$c.log 2>&1
+  timeout 900 rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/prof_$c -- python $root/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-probes > $out/bench_$c.log 2>&1
   f=$(find /tmp/prof_$c -name "*counter_collection.csv" | head -1); if [ -n "$f" ]; then python $root/tools/pmc_summarize.py "$f" $c > $out/pmc_$c.txt; fi
 done
 tail -1 $out/bench_stats.log | cut -c1-400
