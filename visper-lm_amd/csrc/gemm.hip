@@ -552,8 +552,9 @@ __global__ __launch_bounds__(512) void gemm_nt_256(GemmArgs p) {
 //     every barrier (the wait at the end of phase k's R retires exactly the piece phase k+1 reads first).
 // ------------------------------------------------------------------------------------------------
 #define STAMP(I) if ((p.dbg & 0x10000) && threadIdx.x == 0 && first_tile) vp_dbg_stamps[blockIdx.x * 8 + (I)] = wall_clock64();
-template <bool OUT_F32, bool PH4 = false>      // PH4: 4 phases per K-tile (32 MFMAs each, half the barriers), see the loop
-__global__ __launch_bounds__(512) void gemm_nt_256p8(GemmArgs p) {
+template <bool OUT_F32, bool PH4 = false, bool BAL = false>      // PH4: 4 phases per K-tile (32 MFMAs each, half the barriers), see the loop;
+__global__ __launch_bounds__(512) void gemm_nt_256p8(GemmArgs p) {    // BAL: the experimental XCD speed balancing (its own instantiation: the
+                                                                       // seam code costs the default kernel 0.5-0.7 % when merely compiled in)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   bf16_t* smem = (bf16_t*)smem_raw;                    // [buf][A 256x64 | B 256x64]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -646,7 +647,7 @@ __global__ __launch_bounds__(512) void gemm_nt_256p8(GemmArgs p) {
     Bal r{0, -1, 0, false};
     int me = blockIdx.x;
     asm volatile("" : "+s"(me));                         // opaque: no common-subexpression reuse across the K loop
-    if (p.bal_ws && gridDim.x == 256 && p.sched == nullptr && !OUT_F32) {
+    if (BAL && p.bal_ws && gridDim.x == 256 && p.sched == nullptr && !OUT_F32) {
       const int xme = me & 7, xp = (int)((p.bal_partner >> (4 * xme)) & 15u) - 1;
       if (xp >= 0) {
         const int pb = (me & ~7) | xp;
@@ -670,8 +671,8 @@ __global__ __launch_bounds__(512) void gemm_nt_256p8(GemmArgs p) {
   bool partial;                                          // the current segment is a donated K prefix (accumulators go to the workspace)
   int v, kn;                                             // current output tile; K-tiles of the current segment (even)
   {
-    const Bal b0 = bal_eval();
-    partial = b0.ks > 0 && b0.donor;
+    const Bal b0 = BAL ? bal_eval() : Bal{0, -1, 0, false};
+    partial = BAL && b0.ks > 0 && b0.donor;
     v = partial ? b0.vlast : (int)blockIdx.x;
     kn = partial ? b0.ks : nt;
   }
@@ -707,8 +708,8 @@ __global__ __launch_bounds__(512) void gemm_nt_256p8(GemmArgs p) {
     STAMP(1);
     if ((p.dbg & 0x10000) && threadIdx.x == 0 && first_tile) vp_dbg_stamps[blockIdx.x * 8 + 6] = clock64();   // shader cycles
     f32x4 acc[8][4];
-    const Bal bt = bal_eval();
-    if (bt.ks > 0 && !bt.donor && v == bt.vlast) {
+    const Bal bt = BAL ? bal_eval() : Bal{0, -1, 0, false};
+    if (BAL && bt.ks > 0 && !bt.donor && v == bt.vlast) {
       // the donor parked this tile's accumulators after its first bal_ks K-tiles (long ago: it did that before its own tiles): take them over
       if (tid == 0) {                                    // (bounded: a lost donor must not hang the GPU; the tile would then be wrong)
         for (int spin = 0; spin < (1 << 22) && __hip_atomic_load(p.bal_flags + bt.slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != p.bal_seq; ++spin)
@@ -735,7 +736,7 @@ __global__ __launch_bounds__(512) void gemm_nt_256p8(GemmArgs p) {
     const TileCoord tcur = tc;
     const bool partial_cur = partial;
     const int kn_cur = kn;
-    int vnext = partial ? (int)blockIdx.x : v + (int)gridDim.x;      // after the donated prefix: the block's own first tile
+    int vnext = (BAL && partial) ? (int)blockIdx.x : v + (int)gridDim.x;      // after the donated prefix: the block's own first tile
     // Dynamic scheduling (used when another kernel, e.g. an RCCL collective, may hold some CUs: a block that starts late would otherwise
     // do its whole static share after everyone else has finished).  Each XCD's 32 resident blocks claim the XCD's tiles in order from a
     // per-XCD counter, so tile v still runs on XCD v & 7 and the super-block walk keeps its L2 residency.  The claim for the NEXT tile is made
@@ -747,7 +748,7 @@ __global__ __launch_bounds__(512) void gemm_nt_256p8(GemmArgs p) {
     // Everything the COMPILER has in flight (spill reloads of the seam code, the accumulator loads) is retired here, once per output tile and
     // while the epilogue's stores drain anyway: otherwise hipcc places that vmcnt(0) at the first use INSIDE the K loop, where it empties the
     // DMA ring on every K-tile (measured 1330 -> 1000 TFLOP/s)
-    __builtin_amdgcn_s_waitcnt(0x0F70);
+    if (BAL) __builtin_amdgcn_s_waitcnt(0x0F70);
     for (int t = 0; t < kn_cur; ++t) {
       const int cur = t & 1;
       const bf16_t* As = smem + cur * 32768;
@@ -759,8 +760,8 @@ __global__ __launch_bounds__(512) void gemm_nt_256p8(GemmArgs p) {
       } else {
         if (dyn) vnext = __builtin_amdgcn_readfirstlane(*(volatile int*)&s_next);
         if (vnext < ntiles) tc = TILE_OF(vnext);
-        const Bal bn = bal_eval();
-        const int k0n = (bn.ks > 0 && !bn.donor && vnext == bn.vlast) ? bn.ks : 0;     // the receiver's last tile starts where its donor stopped
+        const Bal bn = BAL ? bal_eval() : Bal{0, -1, 0, false};
+        const int k0n = (BAL && bn.ks > 0 && !bn.donor && vnext == bn.vlast) ? bn.ks : 0;     // the receiver's last tile starts where its donor stopped
         SET_SRC(tc, k0n);
         kn = nt - k0n;
       }
@@ -833,7 +834,7 @@ __global__ __launch_bounds__(512) void gemm_nt_256p8(GemmArgs p) {
     if ((p.dbg & 0x10000) && threadIdx.x == 0 && first_tile) vp_dbg_stamps[blockIdx.x * 8 + 7] = clock64();
     // buffer 1 (the last K-tile's, nt is even) is free for C staging; buffer 0 is receiving the next tile's first K-tile
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    if (partial_cur) {
+    if (BAL && partial_cur) {
       // donated K prefix: park the accumulators (write-through 16-byte stores, 8 KB contiguous per instruction across the block), then the flag
       const Bal be = bal_eval();
       // plain 16-byte stores through ONE advancing pointer (32 hoisted addresses would spill; buffer stores make hipcc treat the LDS-DMA ring as
@@ -1617,8 +1618,13 @@ int vp_gemm_bf16(int M, int N, int K, const void* A, long lda, const void* B, lo
     if (out_f32) hipLaunchKernelGGL(gemm_nt_256p8<true>, dim3(g8), dim3(512), 131072, stream, p);
     else if (vp_ph4_enabled() && force_generic == 0) {
       static bool attr_p4 = false;
-      if (!attr_p4) { (void)hipFuncSetAttribute((const void*)gemm_nt_256p8<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072); attr_p4 = true; }
-      hipLaunchKernelGGL((gemm_nt_256p8<false, true>), dim3(g8), dim3(512), 131072, stream, p);
+      if (!attr_p4) {
+        (void)hipFuncSetAttribute((const void*)gemm_nt_256p8<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+        (void)hipFuncSetAttribute((const void*)gemm_nt_256p8<false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+        attr_p4 = true;
+      }
+      if (p.bal_ws) hipLaunchKernelGGL((gemm_nt_256p8<false, true, true>), dim3(g8), dim3(512), 131072, stream, p);
+      else hipLaunchKernelGGL((gemm_nt_256p8<false, true>), dim3(g8), dim3(512), 131072, stream, p);
     } else hipLaunchKernelGGL(gemm_nt_256p8<false>, dim3(g8), dim3(512), 131072, stream, p);
   } else if (fast && force_generic == 13 && !out_f32) {       // 4-phase variant of the 8-phase kernel (A/B testing)
     (void)hipFuncSetAttribute((const void*)gemm_nt_256p8<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
@@ -1679,8 +1685,13 @@ int vp_gemm_bf16_swiglu(int mode, int M, int N, int K, const void* A, long lda, 
   vp_setup_balance(p, g8, stream);
   if (vp_ph4_enabled()) {
     static bool attr_p4 = false;
-    if (!attr_p4) { (void)hipFuncSetAttribute((const void*)gemm_nt_256p8<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072); attr_p4 = true; }
-    hipLaunchKernelGGL((gemm_nt_256p8<false, true>), dim3(g8), dim3(512), 131072, stream, p);
+    if (!attr_p4) {
+      (void)hipFuncSetAttribute((const void*)gemm_nt_256p8<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+      (void)hipFuncSetAttribute((const void*)gemm_nt_256p8<false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+      attr_p4 = true;
+    }
+    if (p.bal_ws) hipLaunchKernelGGL((gemm_nt_256p8<false, true, true>), dim3(g8), dim3(512), 131072, stream, p);
+    else hipLaunchKernelGGL((gemm_nt_256p8<false, true>), dim3(g8), dim3(512), 131072, stream, p);
   } else hipLaunchKernelGGL(gemm_nt_256p8<false>, dim3(g8), dim3(512), 131072, stream, p);
   return vp_check_launch("vp_gemm_bf16_swiglu");
 }
