@@ -720,3 +720,17 @@ def test_gemm_xcd_balancing_is_bit_identical(ops):
         assert torch.equal(gu0, gu1) and torch.equal(act0, act1) and torch.equal(dgu0, dgu1)
     finally:
         ops.set_xcd_speeds(None)
+
+
+@pytest.mark.gpu
+def test_xcd_speed_calibration_and_clock_probe(ops):
+    """The measurement aids behind roofline.clock and the (opt-in) XCD balancing: in-kernel stamps give plausible per-XCD numbers."""
+    import bench
+    try:
+        sp = ops.calibrate_xcd_balance(launches=8, force=True)
+        assert sp is None or (len(sp) == 8 and 0.8 < min(sp) <= 1.0 <= max(sp) < 1.25), sp
+    finally:
+        ops.set_xcd_speeds(None)
+    ck = bench.clock_probe(torch.device("cuda"), n=6)
+    assert 800 < ck["shader_clock_mhz"] <= 2500 and len(ck["per_xcd_mhz"]) == 8, ck
+    assert 0.5 < ck["mfma_issue_util_in_k_loop"] <= 1.0, ck
