@@ -36,6 +36,9 @@ for (B, world, rank, D) in ((2, 4, 2, 2304), (8, 1, 0, 1024), (3, 1, 0, 40960), 
         _lib.call("vp_emb_loss_fwd", B, Bw, D, rank, ops._p(pred), ops._p(tgt), ops._p(mask), ops._p(ls), 0.3, ops._p(out3), ops._p(coef), ops._p(ws), ops._stream())
         torch.cuda.synchronize()
         fin = ws[njc * nblk * ns + njc * ngrp * ns:]
+        if fin.numel() < B * Bw + Bw + 2 * B:          # LDS-resident finalize: the sums never reach the workspace
+            print(f"B={B} Bw={Bw} D={D} plan={plan(B, Bw, D)}: sums stay in LDS; out3 {out3.tolist()}")
+            continue
         PT = fin[:B * Bw].view(B, Bw).double()
         TT = fin[B * Bw:B * Bw + Bw].double()
         PP = fin[B * Bw + Bw:B * Bw + Bw + B].double()
