@@ -627,8 +627,18 @@ class Engine:
             ops.gemm_tn(dy2d, x2d, out=g2, accumulate=accumulate)
             return
         Mp = (M + 63) // 64 * 64
-        dyT = torch.zeros(N, Mp, device=self.dev, dtype=BF16) if Mp != M else torch.empty(N, Mp, device=self.dev, dtype=BF16)
-        xT = torch.zeros(K, Mp, device=self.dev, dtype=BF16) if Mp != M else torch.empty(K, Mp, device=self.dev, dtype=BF16)
+        # zero-padded transposed operands live in a small pool keyed by (role, rows, M): the pad columns are zeroed once, the transposes only
+        # ever rewrite columns < M, and every use is ordered on the one stream (was: two fill kernels per call, ~230 launches per step)
+        pool = self.__dict__.setdefault("_wgrad_pool", {})
+
+        def padded(role, rows):
+            key = (role, rows, M)
+            if key not in pool:
+                if len(pool) >= 64:
+                    pool.clear()
+                pool[key] = torch.zeros(rows, Mp, device=self.dev, dtype=BF16)
+            return pool[key]
+        dyT, xT = padded(0, N), padded(1, K)
         ops.transpose(dy2d, out=dyT)
         ops.transpose(x2d, out=xT)
         if accumulate:
