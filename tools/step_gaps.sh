@@ -27,7 +27,7 @@ for s_, e_, n in seg:
     k = n[:60]
     t = tot.setdefault(k, [0, 0]); t[0] += e_ - s_; t[1] += 1
 print("per-kernel totals inside the step (ms, calls):")
-for k, (t, c) in sorted(tot.items(), key=lambda kv: -kv[1][0])[:45]:
+for k, (t, c) in sorted(tot.items(), key=lambda kv: -kv[1][0])[:90]:
     print(f"  {t / 1e6:8.3f} {c:5d}  {k}")
 PY
 fi
