@@ -17,6 +17,7 @@
 // BACKWARD = one streaming launch: dpred[b,:] = g * ( a_b * clamp(p_b - t_own(b), -1, 1) + sum_j c_bj * t_j - e_b * p_b ).
 // Any local batch B <= 64 and any gathered batch Bw <= 1024 (the reference's pretrain.sh runs 32 per device on 8 devices: Bw = 256).
 #include "common.h"
+#include <type_traits>
 #include <stdlib.h>
 
 namespace {
@@ -45,6 +46,18 @@ struct ElArgs {
 // device-coherent (agent-scope, sc1) accesses for data that crosses workgroups on different XCDs
 __device__ __forceinline__ void cstore(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ float cload(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// 16-byte forms of the same device-coherent accesses (buffer ops with cache policy sc0 sc1 = aux 17): a quarter of the instructions and of
+// the dependent round trips of the reduction tree.  The descriptor is built from a WAVE-UNIFORM, 16-byte aligned base; `elem` (multiple of 4
+// floats, < 2^29) is the lane's element offset from it.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t crsrc(const float* uniform_base) {
+  return __builtin_amdgcn_make_buffer_rsrc((void*)uniform_base, 0, 0x7fffffff, 0x00020000);
+}
+__device__ __forceinline__ f32x4 cload4(__amdgpu_buffer_rsrc_t rs, int elem) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, elem * 4, 0, 17));
+}
+__device__ __forceinline__ void cstore4(__amdgpu_buffer_rsrc_t rs, int elem, f32x4 v) {
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs, elem * 4, 0, 17);
+}
 
 // sum of the 8 products of two bf16x8 vectors, fp32 FMAs.  (v_dot2_f32_bf16 is NOT used: on gfx950 its sums of squares came out up
 // to 13 % off in tools/emb_loss_debug.py, while the MFMA dot products from the same registers were exact to 1e-7.)
@@ -77,27 +90,54 @@ __device__ __forceinline__ float smooth_l1_8(bf16x8 p, bf16x8 t, float c) {
 //   coef[2B+B*Bw]         d loss / d logit_scale parameter
 // mask semantics: sl1 = mean_all(sl1_elem * mask_b); con = w * mean_b(CE_b) * mean_b(mask_b)  (the outer-product broadcast of
 // base_ola_vlm.py:312-316).
+// Wave reductions for the finalize: the __shfl_xor butterflies of common.h compile to six dependent ds_bpermute round trips through the LDS
+// crossbar (~0.35 us per reduction; the finalize chains 11 of them = most of its 4 us).  Here the 16-lane rows are folded with four DPP moves
+// (xor 1, xor 2, half-row mirror, row mirror: register-to-register) and the four row totals are combined through v_readlane.
+template <bool MAX>
+__device__ __forceinline__ float el_wave_reduce(float v) {
+  auto comb = [](float a, float b) { return MAX ? fmaxf(a, b) : a + b; };
+  auto dpp = [](float x, auto ctrl) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), decltype(ctrl)::value, 0xf, 0xf, false));
+  };
+  v = comb(v, dpp(v, std::integral_constant<int, 0xB1>{}));     // quad_perm [1,0,3,2]
+  v = comb(v, dpp(v, std::integral_constant<int, 0x4E>{}));     // quad_perm [2,3,0,1]
+  v = comb(v, dpp(v, std::integral_constant<int, 0x141>{}));    // row_half_mirror
+  v = comb(v, dpp(v, std::integral_constant<int, 0x140>{}));    // row_mirror: every lane holds its 16-lane row total
+  const int vi = __builtin_bit_cast(int, v);
+  const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(vi, 0)), r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(vi, 16)),
+              r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(vi, 32)), r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(vi, 48));
+  return comb(comb(r0, r1), comb(r2, r3));
+}
+__device__ __forceinline__ float el_wave_sum(float v) { return el_wave_reduce<false>(v); }
+__device__ __forceinline__ float el_wave_max(float v) { return el_wave_reduce<true>(v); }
+
 __device__ void el_finalize(const ElArgs& a, float* PT, int ldpt, const float* TT, const float* PP, const float* SL, float* ce,
-                            float* dce) {
+                            float* dce, float mask_pre, float ls_pre, bool pt_in_lds) {
+  // Block-level sync points of this function.  With the statistics in LDS a barrier only has to cover LDS traffic: __syncthreads() would also
+  // wait (vmcnt(0)) for the coefficient STORES issued just before it, a 1-2 us global round trip each time, on the critical path of the launch.
+  auto sync = [&]() {
+    if (pt_in_lds) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); }
+    else { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __syncthreads(); }
+  };
   // 256 threads.  Phase A: every (b, j) logit in parallel, written IN PLACE of its dot product (PT is LDS when all gathered targets
   // fit one chunk, else the global workspace).  Phase B: one wave per local row, lane-strided over the gathered targets with shuffle
   // reductions.  (A serial loop per row cost ~170 ns per target: 30 us at Bw = 64.)
   const int t = threadIdx.x, lane = t & 63, wv = t >> 6, B = a.B, Bw = a.Bw;
   const bool has_con = a.logit_scale != nullptr;
   float scale = 0.f, dscale_dls = 0.f;
-  if (has_con) {
-    const float e = __expf(a.logit_scale[0]);
+  if (has_con) {                                                  // (mask / logit_scale were loaded at kernel entry: no memory round trip here)
+    const float e = __expf(ls_pre);
     scale = fminf(e, 100.f);
     dscale_dls = e < 100.f ? e : 0.f;
   }
   // mask -> LDS once (ce / dce double as scratch until phase B): a serial loop of dependent global loads per thread cost 4 us
-  if (t < 64) { ce[t] = t < B ? a.mask[t] : 0.f; dce[t] = 0.f; }
-  __syncthreads();
+  if (t < 64) { ce[t] = mask_pre; dce[t] = 0.f; }
+  sync();
   float msum = 0.f;
   for (int b = 0; b < B; ++b) msum += ce[b];
   const float mmean = msum / (float)B;
   const float mymask = t < 64 ? ce[t] : 0.f;
-  __syncthreads();
+  sync();
   for (int idx = t; idx < B * Bw; idx += 256) {
     const int b = idx / Bw, j = idx - b * Bw;
     float* z = PT + (long)b * ldpt + j;
@@ -107,8 +147,7 @@ __device__ void el_finalize(const ElArgs& a, float* PT, int ldpt, const float* T
     a.coef[t] = mymask / ((float)B * (float)a.D);
     if (!has_con) a.coef[B + t] = 0.f;
   }
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-  __syncthreads();
+  sync();
   for (int b = wv; b < B; b += 4) {
     const float* z = PT + (long)b * ldpt;
     float* cb = a.coef + 2 * B + (long)b * Bw;
@@ -121,10 +160,10 @@ __device__ void el_finalize(const ElArgs& a, float* PT, int ldpt, const float* T
     const int own = a.rank * B + b;
     float mx = -1e30f;
     for (int j = lane; j < Bw; j += 64) mx = fmaxf(mx, z[j]);
-    mx = wave_max(mx);
+    mx = el_wave_max(mx);
     float se = 0.f;
     for (int j = lane; j < Bw; j += 64) se += __expf(z[j] - mx);
-    se = wave_sum(se);
+    se = el_wave_sum(se);
     const float lse = mx + __logf(se);
     float e_b = 0.f, dls = 0.f;
     for (int j = lane; j < Bw; j += 64) {
@@ -137,21 +176,21 @@ __device__ void el_finalize(const ElArgs& a, float* PT, int ldpt, const float* T
       e_b += cbj * (zj * nt / (scale * np));                        // = c_bj * (p_b . t_j) / |p_b|^2
       dls += dz * (zj / scale) * dscale_dls;
     }
-    e_b = wave_sum(e_b);
-    dls = wave_sum(dls);
+    e_b = el_wave_sum(e_b);
+    dls = el_wave_sum(dls);
     if (lane == 0) {
       ce[b] = lse - z[own];
       dce[b] = dls;
       a.coef[B + b] = e_b;
     }
   }
-  __syncthreads();
+  sync();
   // masked smooth-L1 sum, CE sum, d/dlogit_scale sum: wave 0, fixed shuffle order
   if (wv == 0) {
     float s1 = lane < B ? SL[lane] * mymask : 0.f;
     float cm = (has_con && lane < B) ? ce[lane] : 0.f;
     float dl = (has_con && lane < B) ? dce[lane] : 0.f;
-    s1 = wave_sum(s1); cm = wave_sum(cm); dl = wave_sum(dl);
+    s1 = el_wave_sum(s1); cm = el_wave_sum(cm); dl = el_wave_sum(dl);
     if (lane == 0) {
       s1 /= ((float)B * (float)a.D);
       const float con = has_con ? a.w_con * (cm / (float)B) * mmean : 0.f;
@@ -168,7 +207,7 @@ __device__ void el_finalize(const ElArgs& a, float* PT, int ldpt, const float* T
 template <int NPB, int NG>
 __global__ __launch_bounds__(256) void emb_loss_fwd_kernel(const ElArgs a) {
   constexpr int PB = NPB * 16, TC = NG * 16, NS = PB * TC + TC + 2 * PB;
-  __shared__ float red[NS];
+  __shared__ __attribute__((aligned(16))) float red[NS];
   __shared__ float ce[64], dce[64];
   __shared__ unsigned ticket;
   const int jc = blockIdx.y, bx = blockIdx.x, tid = threadIdx.x;
@@ -176,6 +215,10 @@ __global__ __launch_bounds__(256) void emb_loss_fwd_kernel(const ElArgs a) {
   const bool first = jc == 0;
   const long long t_start = a.dbg ? wall_clock64() : 0;
   if (a.dbg && bx == 0 && jc == 0 && tid == 0) a.dbg[0] = t_start;
+  // the finishing block's two scalar inputs, fetched by every block under the stream (two loads) instead of as a dependent round trip at the end
+  float mask_pre = (tid < 64 && tid < a.B) ? a.mask[tid] : 0.f;
+  float ls_pre = a.logit_scale ? a.logit_scale[0] : 0.f;
+  asm volatile("" : "+v"(mask_pre), "+v"(ls_pre));
   const long D = a.D;
   const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
   f32x4 acc[NPB][NG];
@@ -292,8 +335,10 @@ __global__ __launch_bounds__(256) void emb_loss_fwd_kernel(const ElArgs a) {
   // Cross-block traffic (partials, tickets) goes through DEVICE-COHERENT accesses (agent-scope relaxed atomics = sc1 loads / stores
   // that bypass the per-XCD L2's non-coherent lines), ordered by vmcnt(0) + the workgroup barrier.  A __threadfence() here would
   // write back and invalidate the whole 4 MB L2 of the XCD once per wave: measured 118 us instead of ~10 for the depth loss.
-  float* mine = a.part + ((long)jc * a.nblk + bx) * NS;
-  for (int i = tid; i < NS; i += 256) cstore(mine + i, red[i]);
+  {
+    const __amdgpu_buffer_rsrc_t rs = crsrc(a.part + ((long)jc * a.nblk + bx) * NS);
+    for (int i = tid; i < NS / 4; i += 256) cstore4(rs, 4 * i, *(const f32x4*)(red + 4 * i));
+  }
   // ---- level 1: the last block of each group of G1 sums the group's partials (fixed order)
   unsigned* cnt = g_counters[a.slot];
   const int grp = bx / G1, gsz = min(G1, a.nblk - grp * G1);
@@ -327,17 +372,19 @@ __global__ __launch_bounds__(256) void emb_loss_fwd_kernel(const ElArgs a) {
   };
   const bool single = a.njc * a.ngrp == 1;                       // one group in total: its reducer is the finisher
   {
-    const float* src = a.part + ((long)jc * a.nblk + (long)grp * G1) * NS;
-    float* dst = a.part2 + ((long)jc * a.ngrp + grp) * NS;
-    for (int i = tid; i < NS; i += 256) {
-      float v[G1];
+    const __amdgpu_buffer_rsrc_t src = crsrc(a.part + ((long)jc * a.nblk + (long)grp * G1) * NS);
+    const __amdgpu_buffer_rsrc_t dst = crsrc(a.part2 + ((long)jc * a.ngrp + grp) * NS);
+    for (int i = tid; i < NS / 4; i += 256) {
+      f32x4 v[G1];
 #pragma unroll
-      for (int q = 0; q < G1; ++q) v[q] = q < gsz ? cload(src + (long)q * NS + i) : 0.f;
-      float sum = 0.f;
+      for (int q = 0; q < G1; ++q) v[q] = q < gsz ? cload4(src, q * NS + 4 * i) : f32x4{0.f, 0.f, 0.f, 0.f};
+      f32x4 sum = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int q = 0; q < G1; ++q) sum += v[q];
-      if (single) scatter(0, i, sum);
-      else cstore(dst + i, sum);
+      for (int q = 0; q < G1; ++q) sum += v[q];                  // same order per element as ever: q = 0, 1, 2, ...
+      if (single) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) scatter(0, 4 * i + e, sum[e]);
+      } else cstore4(dst, 4 * i, sum);
     }
   }
   if (tid == 0) __hip_atomic_store(&cnt[1 + jc * a.ngrp + grp], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm
@@ -350,22 +397,28 @@ __global__ __launch_bounds__(256) void emb_loss_fwd_kernel(const ElArgs a) {
     if (ticket != (unsigned)(a.njc * a.ngrp - 1)) return;
     if (tid == 0) __hip_atomic_store(&cnt[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     for (int c = 0; c < a.njc; ++c) {
-      const float* src = a.part2 + (long)c * a.ngrp * NS;
-      for (int i = tid; i < NS; i += 256) {
-        float v[G1];
+      const __amdgpu_buffer_rsrc_t src = crsrc(a.part2 + (long)c * a.ngrp * NS);
+      for (int i = tid; i < NS / 4; i += 256) {
+        f32x4 v[G1];
 #pragma unroll
-        for (int q = 0; q < G1; ++q) v[q] = q < a.ngrp ? cload(src + (long)q * NS + i) : 0.f;       // ngrp <= 32 (nblk <= 1024)
-        float sum = 0.f;
+        for (int q = 0; q < G1; ++q) v[q] = q < a.ngrp ? cload4(src, q * NS + 4 * i) : f32x4{0.f, 0.f, 0.f, 0.f};       // ngrp <= 32 (nblk <= 1024)
+        f32x4 sum = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int q = 0; q < G1; ++q) sum += v[q];
-        scatter(c, i, sum);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) scatter(c, 4 * i + e, sum[e]);
       }
     }
   }
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");       // the statistics were written by this very block
-  __syncthreads();
+  if (in_lds) {                                                 // the statistics were written by this very block: LDS-only barrier (a full
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // __syncthreads would wait for the counter re-arm stores: a global round trip)
+    __builtin_amdgcn_s_barrier();
+  } else {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __syncthreads();
+  }
   const long long t_reduced = a.dbg ? wall_clock64() : 0;
-  el_finalize(a, PT, ldpt, TT, PP, SL, ce, dce);
+  el_finalize(a, PT, ldpt, TT, PP, SL, ce, dce, mask_pre, ls_pre, in_lds);
   if (a.dbg && tid == 0) {
     a.dbg[1] = t_start; a.dbg[2] = t_stream; a.dbg[3] = t_ticket1; a.dbg[4] = t_reduced; a.dbg[5] = wall_clock64();
   }
@@ -479,7 +532,8 @@ int vp_emb_loss_fwd(int B, int Bw, long D, int rank, const void* pred, const voi
              "vp_emb_loss_fwd: need 0<B<=64, B<=Bw<=1024, D%%8==0 (got B=%d Bw=%d D=%ld)", B, Bw, D);
   VP_REQUIRE(rank >= 0 && (long)(rank + 1) * B <= Bw, VP_ERR_BAD_ARG, "vp_emb_loss_fwd: rank/B/Bw mismatch");
   VP_REQUIRE(pred && tgt_all && mask && out3 && coef && workspace, VP_ERR_BAD_ARG, "vp_emb_loss_fwd: null pointer");
-  VP_REQUIRE(((uintptr_t)pred | (uintptr_t)tgt_all) % 16 == 0, VP_ERR_BAD_ARG, "vp_emb_loss_fwd: pred / tgt_all must be 16-byte aligned");
+  VP_REQUIRE(((uintptr_t)pred | (uintptr_t)tgt_all | (uintptr_t)workspace) % 16 == 0, VP_ERR_BAD_ARG,
+             "vp_emb_loss_fwd: pred / tgt_all / workspace must be 16-byte aligned");
   const ElPlan p = el_plan(B, Bw, D);
   ElArgs a;
   a.pred = (const bf16_t*)pred; a.tgt = (const bf16_t*)tgt_all; a.mask = mask; a.logit_scale = logit_scale;
