@@ -11,7 +11,7 @@ import os
 import torch  # noqa: F401  (must be loaded before the library: shares its HIP runtime)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libvisper_hip.so")
+LIB_PATH = os.environ.get("VP_LIB_PATH") or os.path.join(_HERE, "libvisper_hip.so")     # VP_LIB_PATH: dev aid (A/B of build variants)
 
 i, l, f, p = C.c_int, C.c_long, C.c_float, C.c_void_p
 

@@ -47,6 +47,9 @@ struct GemmArgs {
   int bal_seq;
   unsigned long bal_speed_lo, bal_speed_hi;             // relative XCD speeds in 1/16384ths, 16 bits each (XCDs 0-3 | 4-7)
   unsigned int bal_partner;                             // 4 bits per XCD: partner XCD + 1, 0 = none  (scalars: no dynamic kernarg indexing)
+  // bf16 C tiles leave with non-temporal stores (set by the launcher for N <= 8192, the shapes where it measures +1...2 %: the output does not
+  // evict the operand panels from the XCD's L2; hipBLASLt's kernels store C the same way.  Wider outputs measured -0.7 %.)
+  int c_nt;
 };
 
 __device__ __forceinline__ float apply_epi(float v, int epi) {
@@ -347,7 +350,14 @@ __device__ __forceinline__ void epilogue_swz(const GemmArgs& p, bf16_t* wave_lds
             v[e] = pack_bf16x2(lo, hi);
           }
         }
-        *(u32x4*)(cptr + (long)(half * 64 + it * 8) * p.ldc) = v;
+        if (p.c_nt) {
+          // non-temporal store (cache policy nt = aux 2): the C tile does not linger in the XCD's L2, which the operand panels re-use
+          const __amdgpu_buffer_rsrc_t crs = __builtin_amdgcn_make_buffer_rsrc((void*)p.C, 0, 0x7fffffff, 0x00020000);
+          __builtin_amdgcn_raw_buffer_store_b128(v, crs, (int)((const char*)cptr - (const char*)p.C),
+                                                 (int)((long)(half * 64 + it * 8) * p.ldc * 2), 2);
+        } else {
+          *(u32x4*)(cptr + (long)(half * 64 + it * 8) * p.ldc) = v;
+        }
       }
       if (p.mode == 1) {
         // act = silu(gate) * up from the staged gate_up tile: lane (row rl + 16 it, chunk pair pr) -> 8 act columns
@@ -1496,6 +1506,12 @@ static void vp_setup_balance(GemmArgs& p, unsigned grid, hipStream_t s) {
   }
 }
 
+static bool vp_c_nt_enabled() {                        // VP_GEMM_C_NT=0 switches the non-temporal C stores off (A/B)
+  static int e = -1;
+  if (e < 0) { const char* v = getenv("VP_GEMM_C_NT"); e = v ? atoi(v) : 1; }
+  return e != 0;
+}
+
 static bool vp_ph4_enabled() {
   static int e = -1;
   // default ON since round 2: in-step A/B on one box, alternating runs: 458.1 / 459.0 ms per step against 461.7 / 462.5 with the 8-phase loop
@@ -1615,6 +1631,7 @@ int vp_gemm_bf16(int M, int N, int K, const void* A, long lda, const void* B, lo
     const unsigned g8 = (unsigned)(((K / 64) % 2 == 0 && big_tiles > 256 && !(p.dbg & 0x20000)) ? 256 : big_tiles);
     if (g8 == 256) p.sched = vp_sched_for(stream);
     if (!out_f32) vp_setup_balance(p, g8, stream);
+    p.c_nt = (!out_f32 && N <= 8192 && (long)M * ldc * 2 < 0x7fffffffL && vp_c_nt_enabled()) ? 1 : 0;
     if (out_f32) hipLaunchKernelGGL(gemm_nt_256p8<true>, dim3(g8), dim3(512), 131072, stream, p);
     else if (vp_ph4_enabled() && force_generic == 0) {
       static bool attr_p4 = false;
