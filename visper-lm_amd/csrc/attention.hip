@@ -54,6 +54,13 @@ struct AttnParams {
 #define RESCALE_THR 8.0f     // log2 units: skip the O/l rescale while the running max grows by < 2^8 (wave-uniform)
 static __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }   // raw v_exp_f32
 typedef __attribute__((ext_vector_type(4))) short s16x4;
+// 3-input max as ONE instruction: through fmaxf hipcc first canonicalises every MFMA output with a v_max_f32 x, x (NaN semantics are on:
+// -fno-finite-math-only), 16 extra VALU instructions per 16-score tile; scores are finite or -inf here, so the raw instruction is exact
+static __device__ __forceinline__ float vmax3(float a, float b, float c) {
+  float r;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
 static __device__ __forceinline__ bf16x8 zero8() { return bf16x8{0, 0, 0, 0, 0, 0, 0, 0}; }
 
 // 8 fp32 (two C tiles' registers) -> one bf16x8 MFMA operand
@@ -92,6 +99,26 @@ struct TileRegs {
       const int r = itc / CH, c = itc % CH;
       v[i] = *(const bf16x8*)(gbase + (long)min(row0 + r, limit - 1) * ts + c * 8);
     }
+  }
+  // Same tile through buffer loads: wave-uniform descriptor (base of this batch / head, num_records = bytes up to the end of row limit-1)
+  // + a per-lane byte offset that never changes (voff(ts)) + the tile's row offset as the scalar offset: NO address arithmetic per tile
+  // (the 64-bit multiply-adds and row clamps of load() were ~25 of the forward's ~144 VALU instructions per tile), and rows >= limit come
+  // back as zeros from the range check instead of a clamped copy (every consumer masks them anyway).
+  static __device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc(const bf16_t* gbase, long ts, int limit) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)gbase, 0, (int)(((long)(limit - 1) * ts + D) * 2), 0x00020000);
+  }
+  __device__ __forceinline__ void voff(int ts_elems, int (&off)[N]) const {
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      const int it = threadIdx.x + i * NT;
+      const int itc = (R * CH) % NT == 0 ? it : min(it, R * CH - 1);
+      off[i] = ((itc / CH) * ts_elems + (itc % CH) * 8) * 2;
+    }
+  }
+  __device__ __forceinline__ void load_buf(__amdgpu_buffer_rsrc_t rs, const int (&off)[N], int row0, int ts_elems) {
+    const int soff = row0 * ts_elems * 2;
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs, off[i], soff, 0));
   }
   __device__ __forceinline__ void store(bf16_t* lds, int ld) const {
 #pragma unroll
@@ -144,9 +171,13 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(AttnParams p) {
   const bf16_t* vbase = p.v + (long)b * p.v_bs + (long)hk * D;
 
   TileRegs<D, 64> kr, vr;
+  const __amdgpu_buffer_rsrc_t krs = TileRegs<D, 64>::rsrc(kbase, p.k_ts, p.Skv), vrs = TileRegs<D, 64>::rsrc(vbase, p.v_ts, p.Skv);
+  int koff[TileRegs<D, 64>::N], vofs[TileRegs<D, 64>::N];
+  kr.voff((int)p.k_ts, koff);
+  vr.voff((int)p.v_ts, vofs);
   if (kstart < kend) {
-    kr.load(kbase, p.k_ts, kstart, p.Skv);
-    vr.load(vbase, p.v_ts, kstart, p.Skv);
+    kr.load_buf(krs, koff, kstart, (int)p.k_ts);
+    vr.load_buf(vrs, vofs, kstart, (int)p.v_ts);
     kr.store(Kbuf, LD);
     vr.store(Vbuf, LD);
   }
@@ -155,8 +186,8 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(AttnParams p) {
   for (int k0 = kstart; k0 < kend; k0 += 64, cur ^= 1) {
     const bool more = k0 + 64 < kend;
     if (more) {
-      kr.load(kbase, p.k_ts, k0 + 64, p.Skv);
-      vr.load(vbase, p.v_ts, k0 + 64, p.Skv);
+      kr.load_buf(krs, koff, k0 + 64, (int)p.k_ts);
+      vr.load_buf(vrs, vofs, k0 + 64, (int)p.v_ts);
     }
     const bf16_t* Ks = Kbuf + cur * TILE;
     const bf16_t* Vs = Vbuf + cur * TILE;
@@ -205,9 +236,12 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(AttnParams p) {
       // LANE-LOCAL max of this lane's 16 scores; the cross-lane row max (two LDS-crossbar shuffles, ~100 cycles of latency each) is only
       // formed when some lane sees a score above m + 2^8: with every score <= m + RESCALE_THR the exponentials stay <= 2^8, so m may lag the
       // true running max (O / l does not depend on m).  The row sum l is kept per lane and folded across lanes once, after the loop.
-      float mx = fmaxf(fmaxf(st[0][0], st[0][1]), fmaxf(st[0][2], st[0][3]));
-#pragma unroll
-      for (int kt = 1; kt < 4; ++kt) mx = fmaxf(mx, fmaxf(fmaxf(st[kt][0], st[kt][1]), fmaxf(st[kt][2], st[kt][3])));
+      float mx;
+      {
+        const float m0 = vmax3(st[0][0], st[0][1], st[0][2]), m1 = vmax3(st[0][3], st[1][0], st[1][1]), m2 = vmax3(st[1][2], st[1][3], st[2][0]);
+        const float m3 = vmax3(st[2][1], st[2][2], st[2][3]), m4 = vmax3(st[3][0], st[3][1], st[3][2]);
+        mx = vmax3(vmax3(m0, m1, st[3][3]), vmax3(m2, m3, m4), -INFINITY);
+      }
       mx *= c;
       if (!__all(mx <= m + RESCALE_THR)) {            // rare after the first tiles: rescale everything held at the old max
         mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
