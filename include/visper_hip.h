@@ -77,6 +77,7 @@ int vp_debug_occupy(int blocks, long cycles, vp_stream_t stream);
    XCDs to fast ones; bit-identical results.  Experimental, off until called (visper_lm_amd.ops.calibrate_xcd_balance, VP_GEMM_BALANCE=1) */
 int vp_gemm_set_xcd_speeds(const float* speeds8);
 int vp_debug_stamps(long* host);
+int vp_debug_attn_stamps(long* host);   /* dev aid: phase cycle sums of the D = 128 forward (VP_ATTN_DBG=1 launches) */
 int vp_debug_gemm_flags(int flags);   /* measurement aid: 0x10000 = in-kernel wall-clock / shader-cycle stamps of the first tile */
 
 int vp_transpose_bf16(int rows, int cols, const void* in, long ld_in, void* out, long ld_out, vp_stream_t stream);

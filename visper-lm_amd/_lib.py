@@ -26,6 +26,7 @@ _SIGS = {
     "vp_debug_gemm_flags": [i],
     "vp_gemm_set_xcd_speeds": [p],
     "vp_debug_stamps": [p],
+    "vp_debug_attn_stamps": [p],
     "vp_gemm_tn_bf16": [i, i, i, p, l, p, l, p, l, i, i, p],
     "vp_transpose_bf16": [i, i, p, l, p, l, p],
     "vp_rmsnorm_fwd": [i, i, p, l, p, f, p, l, p, p],

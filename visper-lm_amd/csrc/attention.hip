@@ -133,7 +133,10 @@ struct TileRegs {
 // ================================================================================================
 // forward: block = 128 queries (8 waves x 16), loops 64-key tiles
 // ================================================================================================
-template <int D, bool CAUSAL, bool BIAS = false>        // BIAS: separate instantiation (the extra live pointers cost the plain path 40 %)
+// dev aid (tools/attn_phase_stamps.py, VP_ATTN_DBG=1): per-phase shader-cycle sums of waves 0 and 7 of the heaviest block, [wave][phase]
+__device__ long vp_attn_dbg[2 * 8];
+#define ATTN_STAMP(I) if (DBG && dbg_on) { const long t_ = clock64(); dbg_acc[I] += t_ - dbg_t; dbg_t = t_; }
+template <int D, bool CAUSAL, bool BIAS = false, bool DBG = false>   // BIAS: separate instantiation (the extra live pointers cost the plain path 40 %)
 __global__ __launch_bounds__(512) void attn_fwd_kernel(AttnParams p) {
   constexpr int LD = D + 16, NKS = D / 32, NDB = D / 16, TILE = 64 * LD;
   extern __shared__ __attribute__((aligned(16))) unsigned char attn_smem[];
@@ -182,6 +185,8 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(AttnParams p) {
     vr.store(Vbuf, LD);
   }
   __syncthreads();
+  const bool dbg_on = DBG && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && (wave == 0 || wave == 7) && lane == 0;
+  long dbg_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dbg_t = DBG ? clock64() : 0;
   int cur = 0;
   for (int k0 = kstart; k0 < kend; k0 += 64, cur ^= 1) {
     const bool more = k0 + 64 < kend;
@@ -189,6 +194,7 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(AttnParams p) {
       kr.load_buf(krs, koff, k0 + 64, (int)p.k_ts);
       vr.load_buf(vrs, vofs, k0 + 64, (int)p.v_ts);
     }
+    ATTN_STAMP(0)                                      // issue of the next tile's loads
     const bf16_t* Ks = Kbuf + cur * TILE;
     const bf16_t* Vs = Vbuf + cur * TILE;
     // wave-uniform skip of tiles that are entirely above this wave's causal diagonal
@@ -206,6 +212,8 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(AttnParams p) {
         }
       }
       __builtin_amdgcn_s_setprio(0);
+      if (DBG) { asm volatile("" :: "v"(st[0]), "v"(st[1]), "v"(st[2]), "v"(st[3])); asm volatile("s_nop 0" ::: "memory"); }
+      ATTN_STAMP(1)                                    // S = K Q^T done (results consumed)
       // st[kt][r]: raw score of key k0 + 16kt + 4g + r against query qrow
       if (BIAS) {                                      // scores are scaled later by c = scale * log2(e): add bias / scale here
         const float inv_scale = 1.f / p.scale;
@@ -263,6 +271,7 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(AttnParams p) {
           rs += e;
         }
       l += rs;
+      ATTN_STAMP(2)                                    // mask + softmax
       __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) {
@@ -274,12 +283,26 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(AttnParams p) {
         }
       }
       __builtin_amdgcn_s_setprio(0);
+      if (DBG) {
+#pragma unroll
+        for (int d = 0; d < NDB; ++d) asm volatile("" :: "v"(oacc[d]));
+        asm volatile("s_nop 0" ::: "memory");
+      }
+      ATTN_STAMP(3)                                    // O += V^T P done
     }
     if (more) {                       // other buffer: last read one iteration ago, i.e. before the previous barrier
       kr.store(Kbuf + (cur ^ 1) * TILE, LD);
       vr.store(Vbuf + (cur ^ 1) * TILE, LD);
     }
+    if (DBG) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    ATTN_STAMP(4)                                      // wait for the loaded tile + LDS stores
     __syncthreads();
+    ATTN_STAMP(5)                                      // barrier
+    if (DBG && dbg_on) dbg_acc[7] += 1;
+  }
+  if (DBG && dbg_on) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) vp_attn_dbg[(wave == 7) * 8 + i] = dbg_acc[i];
   }
   l += __shfl_xor(l, 16, 64);
   l += __shfl_xor(l, 32, 64);
@@ -1310,6 +1333,11 @@ static int launch_fwd(const AttnParams& p_in, int causal, hipStream_t s) {
     else hipLaunchKernelGGL((attn_fwd128_kernel<false>), grid, dim3(256), FWD128_LDS, s, p);
     return vp_check_launch("vp_attn_fwd");
   }
+  if (D == 128 && causal && !p.bias_h && !p.bias_b && getenv("VP_ATTN_DBG")) {       // dev aid: phase stamps
+    (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<D, true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kv_lds_bytes<D>());
+    hipLaunchKernelGGL((attn_fwd_kernel<D, true, false, true>), grid, dim3(512), kv_lds_bytes<D>(), s, p);
+    return vp_check_launch("vp_attn_fwd");
+  }
   if (p.bias_h || p.bias_b) {
     if (causal) hipLaunchKernelGGL((attn_fwd_kernel<D, true, true>), grid, dim3(512), kv_lds_bytes<D>(), s, p);
     else hipLaunchKernelGGL((attn_fwd_kernel<D, false, true>), grid, dim3(512), kv_lds_bytes<D>(), s, p);
@@ -1397,6 +1425,9 @@ int vp_attn_fwd(int B, int Hq, int Hkv, int Sq, int Skv, int D, const void* q, l
     default: return launch_fwd<128>(p, causal, s);
   }
 }
+
+// dev aid: the forward kernel's phase stamps of the last VP_ATTN_DBG launch (16 longs: waves 0 and 7 of block (0,0,0))
+int vp_debug_attn_stamps(long* host) { return hipMemcpyFromSymbol(host, HIP_SYMBOL(vp_attn_dbg), sizeof(long) * 16) == hipSuccess ? 0 : 1; }
 
 // Same, with additive fp32 score biases (Swin window attention, HF modeling_swin.py SwinAttention.forward: relative position bias per
 // head [Hq,Sq,Skv] + shifted-window mask [bias_nb,Sq,Skv] indexed by batch % bias_nb).  Forward only (frozen teacher).
