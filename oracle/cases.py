@@ -74,6 +74,34 @@ def tiny_ift_case():
     return cfg, W, batch, g
 
 
+def tiny_ift_tok_case():
+    """(cfg, W, batch, golden) for tests/golden/tiny_llama_ift_tok.npz: the reference's LlavaLlamaForCausalLM built from a PT-stage
+    config (num_task_tokens 8, aux_mode gen-depth-seg, task_token_format "emb"): raw (576, H) depth / seg rows + 8 gen rows behind the
+    image (llava_arch.py:250-293), NTP loss only, everything but the vision tower trainable."""
+    g = load_golden("tiny_llama_ift_tok.npz")
+    base, _, _, _ = tiny_llama_case()
+    t = json.loads(str(g["cfg"]))
+    cfg = O.make_config(**{**vars(base), "aux_mode": t["aux_mode"], "num_task_tokens": t["num_task_tokens"], "image_depth": t["image_depth"],
+                           "image_seg": t["image_seg"], "image_gen": t["image_gen"], "task_token_layout": "raw", "aux_heads": False})
+    W = {k: WT.param(k, s) for k, s in json.loads(str(g["manifest"])).items()}
+    B, T, col = json.loads(str(g["batch"]))
+    batch = {k: v for k, v in make_batch(B, T, col).items() if k in ("input_ids", "labels", "attention_mask", "images")}
+    assert np.array_equal(batch["input_ids"].numpy(), g["input_ids"])
+    return cfg, W, batch, g
+
+
+def tiny_nt0_case():
+    """(cfg, W, batch, golden) for tests/golden/tiny_llama_nt0.npz: the PT step with num_task_tokens == 0 (plain Resampler heads)."""
+    g = load_golden("tiny_llama_nt0.npz")
+    base, _, _, _ = tiny_llama_case()
+    cfg = O.make_config(**{**vars(base), "num_task_tokens": 0})
+    W = {k: WT.param(k, s) for k, s in json.loads(str(g["manifest"])).items()}
+    B, T, col = json.loads(str(g["batch"]))
+    batch = make_batch(B, T, col)
+    assert np.array_equal(batch["input_ids"].numpy(), g["input_ids"])
+    return cfg, W, batch, g
+
+
 def dinov2_weights(manifest):
     """Closed-form weights of the DINOv2 teacher fixture (same overrides as gen_golden.run_dinov2_teacher)."""
     W = {}

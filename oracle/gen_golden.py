@@ -114,7 +114,7 @@ def build_llama(tiny, arch="llama"):
     cfg.rope_theta = theta
     cfg._attn_implementation = "eager"
     cfg.aux_mode = tiny["aux_mode"]
-    cfg.num_task_tokens = 8
+    cfg.num_task_tokens = tiny.get("num_task_tokens", 8)
     cfg.contrastive_loss_weight = 0.3
     cfg.image_gen = dict(tiny["image_gen"])
     cfg.image_seg = dict(tiny["image_seg"])
@@ -137,7 +137,11 @@ def build_llama(tiny, arch="llama"):
     model.model.vision_tower = tower
     cfg.mm_projector_type, cfg.mm_hidden_size = "mlp2x_gelu", tiny["vit_hidden"]
     model.model.mm_projector = build_vision_projector(cfg)
-    model.model.initialize_special_tokens(cfg)
+    if cfg.num_task_tokens > 0:                         # ola_vlm_train.py:1239-1240
+        model.model.initialize_special_tokens(cfg)
+    else:
+        model.model.num_task_tokens, model.model.task_token_format = 0, "emb"          # what initialize_special_tokens would record
+        model.model.aux_tokens, model.model.token_order = cfg.aux_mode, cfg.aux_mode.split("-")
     return model, cfg
 
 
@@ -262,10 +266,13 @@ def run_tiny_llama(arch="llama"):
     return model
 
 
-def run_tiny_ift():
-    """IFT-stage golden: the reference's LlavaLlamaForCausalLM (llava_llama.py:50-119 + llava_arch.py:300-486, no
-    task tokens, NTP loss only) with everything but the vision tower trainable (scripts/train/finetune.sh) -> loss + the norm and
-    a subsample of EVERY parameter gradient."""
+def run_tiny_ift(task_tokens=None):
+    """IFT-stage golden: the reference's LlavaLlamaForCausalLM (llava_llama.py:50-119 + llava_arch.py:300-486, NTP loss
+    only) with everything but the vision tower trainable (scripts/train/finetune.sh) -> loss + the norm and a subsample of EVERY
+    parameter gradient.  task_tokens=None: no task tokens (a plain LLaVA checkpoint) -> tiny_llama_ift.npz.  task_tokens="emb": the
+    reference's own PT -> IFT hand-off (a PT checkpoint's config: num_task_tokens=8, aux_mode gen-depth-seg, task_token_format "emb"):
+    append_special_tokens splices the raw (576, H) depth / seg parameters + the 8 gen rows behind the image (llava_arch.py:250-293)
+    -> tiny_llama_ift_tok.npz; the same call with task_token_format "text" is recorded as raising (embed_tokens on float parameters)."""
     from ola_vlm.model.multimodal_encoder.clip_encoder import CLIPVisionTower
     from ola_vlm.model.multimodal_projector.builder import build_vision_projector
     from ola_vlm.model.language_model.llava_llama import LlavaLlamaForCausalLM, LlavaConfig
@@ -282,26 +289,48 @@ def run_tiny_ift():
     cfg.tokenizer_model_max_length, cfg.tokenizer_padding_side = 4096, "right"
     if not hasattr(cfg, "pretraining_tp"):
         cfg.pretraining_tp = 1
-    model = LlavaLlamaForCausalLM(cfg)
-    tower = CLIPVisionTower.__new__(CLIPVisionTower)
-    torch.nn.Module.__init__(tower)
-    tower.is_loaded, tower.select_layer, tower.select_feature = True, -2, "patch"
-    vcfg = CLIPVisionConfig(hidden_size=tiny["vit_hidden"], intermediate_size=tiny["vit_inter"], num_hidden_layers=tiny["vit_layers"],
-                            num_attention_heads=tiny["vit_heads"], image_size=336, patch_size=14)
-    vcfg._attn_implementation = "eager"
-    tower.vision_tower = CLIPVisionModel(vcfg).requires_grad_(False)
-    model.model.vision_tower = tower
-    cfg.mm_projector_type, cfg.mm_hidden_size = "mlp2x_gelu", tiny["vit_hidden"]
-    model.model.mm_projector = build_vision_projector(cfg)
-    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
-    model.load_state_dict({k: WT.param(k, s) for k, s in shapes.items()}, strict=True)
-    model.requires_grad_(True)
-    model.model.vision_tower.requires_grad_(False)
+    if task_tokens is not None:                         # what a PT-stage config.json carries (ola_vlm_train.py:1149-1157, 1237-1240)
+        cfg.num_task_tokens, cfg.aux_mode, cfg.task_token_format = 8, tiny["aux_mode"], task_tokens
+        cfg.image_depth, cfg.image_seg, cfg.image_gen = dict(tiny["image_depth"]), dict(tiny["image_seg"]), dict(tiny["image_gen"])
+
+    def build(c):
+        model = LlavaLlamaForCausalLM(c)
+        tower = CLIPVisionTower.__new__(CLIPVisionTower)
+        torch.nn.Module.__init__(tower)
+        tower.is_loaded, tower.select_layer, tower.select_feature = True, -2, "patch"
+        vcfg = CLIPVisionConfig(hidden_size=tiny["vit_hidden"], intermediate_size=tiny["vit_inter"], num_hidden_layers=tiny["vit_layers"],
+                                num_attention_heads=tiny["vit_heads"], image_size=336, patch_size=14)
+        vcfg._attn_implementation = "eager"
+        tower.vision_tower = CLIPVisionModel(vcfg).requires_grad_(False)
+        model.model.vision_tower = tower
+        c.mm_projector_type, c.mm_hidden_size = "mlp2x_gelu", tiny["vit_hidden"]
+        model.model.mm_projector = build_vision_projector(c)
+        shapes_ = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+        model.load_state_dict({k: WT.param(k, s_) for k, s_ in shapes_.items()}, strict=True)
+        model.requires_grad_(True)
+        model.model.vision_tower.requires_grad_(False)
+        return model, shapes_
+    model, shapes = build(cfg)
     B, T, col = 2, 59, 38
     ids, labels, images, *_ = make_batch(B, T, col)
     out = model(input_ids=ids, attention_mask=torch.ones_like(ids, dtype=torch.bool), labels=labels, images=images)
     out.loss.backward()
-    res = {"loss": np.float64(out.loss.item()), "logits_shape": np.array(out.logits.shape),
+    extra = {}
+    if task_tokens is not None:
+        import copy
+        c2 = copy.deepcopy(cfg)
+        c2.task_token_format = "text"
+        m2, _ = build(c2)
+        try:
+            m2(input_ids=ids, attention_mask=torch.ones_like(ids, dtype=torch.bool), labels=labels, images=images)
+            extra["text_format_error"] = ""
+        except Exception as e:                          # noqa: BLE001
+            extra["text_format_error"] = f"{type(e).__name__}: {str(e)[:160]}"
+        print("task_token_format='text' in the reference ->", extra["text_format_error"] or "ran")
+        extra["task_token_format"] = task_tokens
+        extra["cfg"] = json.dumps(dict(aux_mode=cfg.aux_mode, num_task_tokens=8, image_depth=cfg.image_depth, image_seg=cfg.image_seg,
+                                       image_gen=cfg.image_gen))
+    res = {**extra, "loss": np.float64(out.loss.item()), "logits_shape": np.array(out.logits.shape),
            "logits_sub": out.logits[:, ::41, ::997].detach().numpy().copy(),
            "manifest": json.dumps({k: list(s) for k, s in shapes.items()}),
            "trainable": json.dumps(sorted(n for n, p in model.named_parameters() if p.requires_grad)),
@@ -310,8 +339,58 @@ def run_tiny_ift():
         if p.requires_grad:
             res[f"gradnorm::{n}"] = np.float64(p.grad.double().norm().item())
             res[f"gradsub::{n}"] = sub(p.grad, 128)
-    np.savez_compressed(os.path.join(OUT, "tiny_llama_ift.npz"), **res)
-    print("tiny_llama_ift: loss", res["loss"], "params with grad", len(json.loads(res["trainable"])))
+    name = "tiny_llama_ift.npz" if task_tokens is None else "tiny_llama_ift_tok.npz"
+    np.savez_compressed(os.path.join(OUT, name), **res)
+    print(name, ": loss", res["loss"], "logits", res["logits_shape"], "params with grad", len(json.loads(res["trainable"])))
+
+
+def run_tiny_nt0():
+    """num_task_tokens == 0 with distillation heads (VERDICT r2 missing-5): init_heads builds GenHead / DepthHead / OneFormerSegHead around
+    the plain `Resampler` with its own `latents` parameter (base_ola_vlm.py:120-123,137-140,166-169; resampler.py:120-165), no
+    special_*_tokens exist, and forward_emb_predictor hands the WHOLE layer state to the head (:420-422, :429-430).  The reference's own
+    OlaLlavaLlamaForCausalLM -> tiny_llama_nt0.npz (loss, layer-loss triples, gradient norms of every trainable parameter)."""
+    B, T, col = 2, 59, 38
+    ids, labels, images, tg, td, ts = make_batch(B, T, col)
+    tiny = dict(TINY_LLAMA, num_task_tokens=0)
+    model, cfg = build_llama(tiny)
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    model.load_state_dict({k: WT.param(k, s) for k, s in shapes.items()}, strict=True)
+    model.requires_grad_(False)
+    for n, p in model.named_parameters():
+        if ("mm_projector" in n or "_heads." in n or "special_" in n or "logit_scale" in n):
+            p.requires_grad_(True)
+    model._get_gen_feats = lambda pil, dev: tg
+    model._get_seg_targets = lambda pil, h: ts
+    model._get_dav2_feats = lambda pil, dev: ([(td, None)], torch.zeros(B, 336, 336))
+    captured = []
+    orig = model._emb_loss
+
+    def spy(preds, mask, tgt, scale):
+        r = orig(preds, mask, tgt, scale)
+        captured.append((tuple(preds.shape), [float(x) for x in r]))
+        return r
+    model._emb_loss = spy
+    mk = lambda: torch.ones(B).as_subclass(KeepMask)
+    out = model(input_ids=ids, attention_mask=torch.ones_like(ids, dtype=torch.bool), labels=labels, images=images,
+                pil_images=[None] * B, gen_mask=mk(), seg_mask=mk(), depth_mask=mk())
+    out.loss.backward()
+    res = {"loss": np.float64(out.loss.item()), "layer_losses": np.array([c[1] for c in captured], dtype=np.float64),
+           "layer_shapes": json.dumps([c[0] for c in captured]), "logits_shape": np.array(out.logits.shape),
+           "manifest": json.dumps({k: list(s) for k, s in shapes.items()}),
+           "trainable": json.dumps(sorted(n for n, p in model.named_parameters() if p.requires_grad)),
+           "input_ids": ids.numpy(), "batch": json.dumps([B, T, col]), "cfg": json.dumps(tiny),
+           "seg_emb_sub": sub(out.seg_embs[0], 2048), "gen_emb_sub": sub(out.image_embs[0], 1024)}
+    none = []
+    for n, p in model.named_parameters():
+        if p.requires_grad:
+            if p.grad is None:
+                none.append(n)
+            else:
+                res[f"gradnorm::{n}"] = np.float64(p.grad.double().norm().item())
+                res[f"gradsub::{n}"] = sub(p.grad, 128)
+    res["grad_none"] = json.dumps(sorted(none))
+    np.savez_compressed(os.path.join(OUT, "tiny_llama_nt0.npz"), **res)
+    print("tiny_llama_nt0: loss", res["loss"], "logits", res["logits_shape"], "layer losses\n", res["layer_losses"], res["layer_shapes"])
 
 
 def run_data_path():
@@ -495,6 +574,30 @@ def run_units():
         lat = WT.tensor(f"{name}.lat", (2, nlat, emb))
         res[f"{name}_out"] = m(x, lat).detach().numpy().copy()
         res[f"{name}_manifest"] = json.dumps({k: list(s) for k, s in shapes.items()})
+    # plain Resampler (num_task_tokens == 0 heads; resampler.py:120-165): own latents, proj_in on x only; depth 1 and 2
+    from ola_vlm.model.multimodal_projector.resampler import Resampler
+    for name, (dim, nq, emb, out_dim, depth) in {"rs_plain": (32, 12, 48, 40, 1), "rs_plain_deep": (64, 5, 48, 24, 2)}.items():
+        m = Resampler(dim=dim, depth=depth, dim_head=32, heads=4, num_queries=nq, embedding_dim=emb, output_dim=out_dim, ff_mult=1)
+        shapes = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+        m.load_state_dict({k: WT.param(f"{name}.{k}", s) for k, s in shapes.items()})
+        x = WT.tensor(f"{name}.x", (2, 50, emb))
+        res[f"{name}_out"] = m(x).detach().numpy().copy()
+        res[f"{name}_manifest"] = json.dumps({k: list(s) for k, s in shapes.items()})
+    # _emb_loss's batch-repeat branch (base_ola_vlm.py:292-299): 4 predictions against 2 targets / 2 mask entries (rank-3 targets)
+    for name, shp in {"rep_gen": (1, 1024), "rep_depth": (40, 256)}.items():
+        p = WT.tensor(f"unit_pred_{name}", (4, *shp), 1.3).requires_grad_(True)
+        t = WT.tensor(f"unit_tgt_{name}", (2, *shp), 1.0)
+        s = torch.tensor(2.0, requires_grad=True)
+        e, l1, c = BaseOLA_VLM._emb_loss(fake, p, torch.tensor([1.0, 0.5]), t, s)
+        e.backward()
+        res[f"{name}_out"] = np.array([e.item(), l1.item(), c.item()], dtype=np.float64)
+        res[f"{name}_dpred"] = p.grad.numpy().copy()
+        res[f"{name}_dscale"] = np.float64(s.grad.item())
+    try:                                                # the same branch on a rank-4 (seg) target: the reference's 3-argument repeat raises
+        BaseOLA_VLM._emb_loss(fake, WT.tensor("unit_pred_rep4", (4, 8, 3, 3)), torch.ones(2), WT.tensor("unit_tgt_rep4", (2, 8, 3, 3)), None)
+        res["rep_rank4_error"] = ""
+    except Exception as e:                              # noqa: BLE001
+        res["rep_rank4_error"] = f"{type(e).__name__}: {str(e)[:120]}"
     np.savez_compressed(os.path.join(OUT, "units.npz"), **res)
     print("units written:", sorted(res)[:8], "...")
 
@@ -503,7 +606,7 @@ if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
     setup_reference()
-    which = sys.argv[1:] or ["units", "llama", "phi3", "ift", "data", "dino", "clipemb", "swin"]
+    which = sys.argv[1:] or ["units", "llama", "phi3", "ift", "ift_tok", "nt0", "data", "dino", "clipemb", "swin"]
     if "units" in which:
         run_units()
     if "llama" in which:
@@ -512,6 +615,10 @@ if __name__ == "__main__":
         run_tiny_llama("phi3")
     if "ift" in which:
         run_tiny_ift()
+    if "ift_tok" in which:
+        run_tiny_ift("emb")
+    if "nt0" in which:
+        run_tiny_nt0()
     if "data" in which:
         run_data_path()
     if "dino" in which:

@@ -52,6 +52,8 @@ def make_config(**kw) -> SimpleNamespace:
         # distillation
         aux_mode="gen-depth-seg", num_task_tokens=8, contrastive_loss_weight=0.3,
         use_contrastive=True, pass_text_to_aux=True,
+        aux_heads=True,                   # False: the IFT-stage LlavaLlamaForCausalLM (task tokens may be spliced, no distillation heads)
+        task_token_layout="pooled",       # "pooled": ola_arch.py:224-254 (PT) / llava_arch.py "expand_emb"; "raw": llava_arch.py:259-260 "emb" (IFT)
         image_gen=dict(depth=1, dim_head=32, num_heads=4, num_tokens=1, output_dim=1024, ff_mult=1,
                        img_layer_indices="20", img_loss_weight=0.5),
         image_depth=dict(depth=1, dim_head=32, num_heads=4, num_tokens=576, output_dim=1024, ff_mult=1,
@@ -186,15 +188,18 @@ def encode_images(images, W, cfg):
 # sequence splice  (ola_arch.py:224-254, 256-444)
 # ----------------------------------------------------------------------------------------------
 def task_token_rows(W, cfg) -> List[torch.Tensor]:
-    """append_special_tokens (ola_arch.py:224-254): per task in token_order, 8 rows:
-    depth/seg = mean over (num_tokens/8)-row groups of the (num_tokens,H) parameter; gen = raw."""
+    """append_special_tokens.  PT stage (ola_arch.py:224-254): per task in token_order, 8 rows: depth/seg = mean over (num_tokens/8)-row
+    groups of the (num_tokens,H) parameter; gen = raw.  IFT stage (llava_arch.py:250-293): task_token_format "expand_emb" = the same
+    pooling, "emb" (the default, :259-260) = every row of the depth / seg parameters as it is (layout "raw"); "text" calls embed_tokens on
+    the FLOAT parameters (:257-258, :284-285), which raises in F.embedding — the reference has no working "text" path."""
     rows = []
     n = cfg.num_task_tokens
-    for t in cfg.aux_mode.split("-"):
+    raw = getattr(cfg, "task_token_layout", "pooled") == "raw"
+    for t in (cfg.aux_mode.split("-") if cfg.aux_mode else []):
         name = f"model.special_{t}_tokens"
         if n > 0 and name in W:
             tk = W[name]
-            if t in ("depth", "seg"):
+            if t in ("depth", "seg") and not raw:
                 tk = tk.view(n, tk.shape[0] // n, tk.shape[1]).mean(dim=1)
             rows.append(tk)
     return rows
@@ -401,8 +406,34 @@ def task_token_resampler(x, latents, W, pfx, hcfg):
     return F.layer_norm(out, (Do,), W[pfx + "norm_out.weight"], W[pfx + "norm_out.bias"])
 
 
+def resampler(x, W, pfx, hcfg):
+    """Resampler.forward (resampler.py:150-165), the num_task_tokens == 0 heads' projector: the queries are the module's own `latents`
+    parameter (1, num_queries, dim), tiled over the batch and NOT passed through proj_in; x is."""
+    heads, dh = hcfg["num_heads"], hcfg["dim_head"]
+    lat = W[pfx + "latents"].repeat(x.shape[0], 1, 1).to(x.dtype)
+    x = F.linear(x, W[pfx + "proj_in.weight"], W[pfx + "proj_in.bias"])
+    D = lat.shape[-1]
+    for d in range(hcfg["depth"]):
+        a, f = f"{pfx}layers.{d}.0.", f"{pfx}layers.{d}.1."
+        xn = F.layer_norm(x, (D,), W[a + "norm1.weight"], W[a + "norm1.bias"])                  # PerceiverAttention.forward :46-75
+        ln = F.layer_norm(lat, (D,), W[a + "norm2.weight"], W[a + "norm2.bias"])
+        b, l, _ = ln.shape
+        q = F.linear(ln, W[a + "to_q.weight"])
+        k, v = F.linear(torch.cat([xn, ln], dim=-2), W[a + "to_kv.weight"]).chunk(2, dim=-1)
+        sp = lambda t: t.view(b, t.shape[1], heads, -1).transpose(1, 2)
+        q, k, v = sp(q), sp(k), sp(v)
+        sc = 1.0 / math.sqrt(math.sqrt(dh))
+        w = (q * sc) @ (k * sc).transpose(-2, -1)
+        w = torch.softmax(w.float(), dim=-1).type(w.dtype)
+        lat = F.linear((w @ v).permute(0, 2, 1, 3).reshape(b, l, -1), W[a + "to_out.weight"]) + lat
+        y = F.layer_norm(lat, (D,), W[f + "0.weight"], W[f + "0.bias"])                          # FeedForward :9-16
+        lat = F.linear(F.gelu(F.linear(y, W[f + "1.weight"])), W[f + "3.weight"]) + lat
+    out = F.linear(lat, W[pfx + "proj_out.weight"], W[pfx + "proj_out.bias"])
+    return F.layer_norm(out, (out.shape[-1],), W[pfx + "norm_out.weight"], W[pfx + "norm_out.bias"])
+
+
 def head_inputs(state, task, W, cfg):
-    """forward_emb_predictor token selection (base_ola_vlm.py:413-441)."""
+    """forward_emb_predictor token selection (base_ola_vlm.py:413-441); latents None when num_task_tokens == 0 (:429-430)."""
     order = cfg.aux_mode.split("-")
     ns = num_sys_tokens(cfg)
     nt = cfg.num_task_tokens
@@ -417,6 +448,8 @@ def head_inputs(state, task, W, cfg):
         x = torch.cat([x, state[:, s0:s0 + nt]], dim=1)
         if cfg.pass_text_to_aux:
             x = torch.cat([x, state[:, end:]], dim=1)
+    if nt == 0:
+        return x, None
     if task != "gen":
         lat = W[f"model.special_{task}_tokens"][None].repeat(x.shape[0], 1, 1)
     else:
@@ -434,7 +467,10 @@ def head_forward(state, task, i, W, cfg):
     x, lat = head_inputs(state, task, W, cfg)
     name = {"gen": "image_gen_heads", "seg": "image_seg_heads", "depth": "image_depth_heads"}[task]
     hcfg = {"gen": cfg.image_gen, "seg": cfg.image_seg, "depth": cfg.image_depth}[task]
-    v = task_token_resampler(x, lat.to(x.dtype), W, f"{name}.{i}.projector.", hcfg)
+    if lat is None:                                                   # GenHead / DepthHead / OneFormerSegHead (num_task_tokens == 0)
+        v = resampler(x, W, f"{name}.{i}.projector.", hcfg)
+    else:
+        v = task_token_resampler(x, lat.to(x.dtype), W, f"{name}.{i}.projector.", hcfg)
     if task == "gen":
         return v, None
     if task == "seg":
@@ -693,6 +729,13 @@ def contrastive_loss(preds, targets, logit_scale, rank=0, gathered_targets=None)
 def emb_loss(preds, mask, targets, logit_scale, w_contrastive, rank=0, gathered_targets=None):
     """_emb_loss (base_ola_vlm.py:289-320) incl. the outer-product mask broadcast."""
     targets = targets.to(preds.dtype)
+    if targets.shape[0] != preds.shape[0]:                            # :292-299 (3-argument repeat: rank-3 targets only, like the reference)
+        r = preds.shape[0] // targets.shape[0]
+        targets = targets.repeat(r, 1, 1)
+        mask = mask.repeat(r, 1, 1)
+        if targets.shape[0] != preds.shape[0]:
+            targets = targets[:preds.shape[0]]
+            mask = mask[:preds.shape[0]]
     m = mask.view(preds.shape[0], *([1] * (preds.ndim - 1))).float()
     sl1 = F.smooth_l1_loss(preds.float(), targets.float(), reduction="none")
     con = contrastive_loss(preds, targets, logit_scale, rank, gathered_targets) if logit_scale is not None else 0
@@ -722,7 +765,7 @@ def forward(W, batch, cfg, rank=0, gathered=None, need_logits=True):
             "seg": ("image_seg", "seg_layer_indices", "seg_loss_weight", "seg_logit_scale"),
             "gen": ("image_gen", "img_layer_indices", "img_loss_weight", "gen_logit_scale")}
     for task in ("depth", "seg", "gen"):                      # call order: ola_llama.py:139-141
-        if task not in modes or states[0].shape[1] <= ns:
+        if task not in modes or states[0].shape[1] <= ns or not getattr(cfg, "aux_heads", True):
             continue
         cname, ikey, wkey, sname = spec[task]
         hcfg = getattr(cfg, cname)

@@ -586,3 +586,106 @@ def test_resampler_depth_two_heads_match_oracle():
         c, n = grad_err(got, want)
         check(f"depth2/grad/{k}/one_minus_cos", c, 3e-2)
         check(f"depth2/grad/{k}/norm_dev", n, 6e-2)
+
+
+# ------------------------------------------------------------------------------------------------ round 3: VERDICT r2 missing-2 / -5 / -6 / -7
+def test_ift_stage_with_pt_task_tokens_matches_reference_golden():
+    """The reference's own PT -> IFT hand-off (scripts/train/finetune.sh on a PT checkpoint): LlavaLlamaForCausalLM with num_task_tokens 8 and
+    task_token_format "emb" splices the RAW (576, H) depth / seg parameters + 8 gen rows behind the image (llava_arch.py:250-293).  Engine
+    (task_token_layout "raw") against tests/golden/tiny_llama_ift_tok.npz from the reference itself, and against the fp32 oracle."""
+    from oracle import cases, visper_oracle as O
+    from visper_lm_amd.config import VisperConfig
+    from visper_lm_amd.engine import Engine
+    ocfg, W, batch, g = cases.tiny_ift_tok_case()
+    eng = Engine(VisperConfig(**vars(ocfg), train_llm=True))
+    eng.load_weights(W)
+    out = eng.train_step(_to_gpu_batch(batch))
+    assert out["plan"]["S"] == 58 + 576 * 3 + 8 == int(g["logits_shape"][1])
+    check("ift_tok/loss_rel_vs_reference_golden", rel(out["loss"], g["loss"]), 1e-3)
+    tr = json.loads(str(g["trainable"]))
+    assert sorted(eng.ps.index) == tr and len(tr) == 46
+    for k in tr:
+        got = eng.ps.g(k).detach().float().cpu()
+        ref_norm = float(g[f"gradnorm::{k}"])
+        check(f"ift_tok/gradnorm/{k}_rel", abs(float(got.norm()) - ref_norm) / ref_norm, 2.5e-2)
+        mine, theirs = torch.from_numpy(cases.sub(got, 128)), torch.from_numpy(g[f"gradsub::{k}"])
+        if float(theirs.norm()) > 0:
+            c, _ = grad_err(mine, theirs)
+            check(f"ift_tok/gradsub/{k}/one_minus_cos", c, 2e-3 if "special_" not in k else 5e-3)
+    # full token-parameter gradients (not just a subsample) against the fp32 oracle on the same bf16-rounded weights
+    Wq = {k: v.to(BF).float() for k, v in W.items()}
+    for k in tr:
+        Wq[k] = Wq[k].clone().requires_grad_(True)
+    bq = {k: (v.to(BF).float() if (torch.is_tensor(v) and v.is_floating_point()) else v) for k, v in batch.items()}
+    ref = O.forward(Wq, bq, ocfg)
+    ref["loss"].backward()
+    for t in ("depth", "seg", "gen"):
+        k = f"model.special_{t}_tokens"
+        c, n = grad_err(eng.ps.g(k).detach().float().cpu().reshape(-1), Wq[k].grad.reshape(-1))
+        check(f"ift_tok/oracle/{k}/one_minus_cos", c, 2e-3)
+        check(f"ift_tok/oracle/{k}/norm_dev", n, 2e-2)
+    # the pooled layout ("expand_emb", llava_arch.py:261-263) on the same weights gives the PT-stage sequence length
+    import copy
+    oc2 = copy.copy(ocfg); oc2.task_token_layout = "pooled"
+    eng2 = Engine(VisperConfig(**vars(oc2), train_llm=True))
+    eng2.load_weights(W)
+    out2 = eng2.train_step(_to_gpu_batch(batch))
+    ref2 = O.forward({k: v.to(BF).float() for k, v in W.items()}, bq, oc2)
+    assert out2["plan"]["S"] == 58 + 576 + 24
+    check("ift_tok/expand_emb/loss_rel", rel(out2["loss"], ref2["loss"]), 1e-3)
+
+
+def test_pt_step_without_task_tokens_matches_oracle_and_reference_golden():
+    """num_task_tokens == 0: GenHead / DepthHead / OneFormerSegHead around the plain Resampler with its own `latents` parameter, whole layer
+    state as head input (base_ola_vlm.py:120-169, 420-422, 429-430; resampler.py:120-165).  Engine vs tests/golden/tiny_llama_nt0.npz
+    (the reference itself, fp32) and vs the fp32 oracle on the same bf16-rounded weights (every trainable gradient)."""
+    from oracle import cases, visper_oracle as O
+    from visper_lm_amd.config import VisperConfig
+    from visper_lm_amd.engine import Engine
+    ocfg, W, batch, g = cases.tiny_nt0_case()
+    eng = Engine(VisperConfig(**vars(ocfg)))
+    eng.load_weights(W)
+    out = eng.train_step(_to_gpu_batch(batch))
+    assert out["plan"]["S"] == 58 + 576 and out["plan"]["n_tok_rows"] == 0
+    check("nt0/loss_rel_vs_reference_golden", rel(out["loss"], g["loss"]), 1e-3)
+    order = [("depth", 2), ("seg", 1), ("seg", 2), ("gen", 3)]
+    for i, key in enumerate(order):
+        check(f"nt0/layer_loss_vs_golden/{key[0]}@{key[1]}", _trip_err(out["layer_losses"][key].float().cpu().numpy(), g["layer_losses"][i]), 1.2e-2)
+    tr = json.loads(str(g["trainable"]))
+    assert sorted(eng.ps.index) == tr and sum(k.endswith("projector.latents") for k in tr) == 4
+    Wq = {k: v.to(BF).float() for k, v in W.items()}
+    for k in tr:
+        Wq[k] = Wq[k].clone().requires_grad_(True)
+    bq = {k: (v.to(BF).float() if (torch.is_tensor(v) and v.is_floating_point() and not k.endswith("_mask")) else v) for k, v in batch.items()}
+    ref = O.forward(Wq, bq, ocfg)
+    ref["loss"].backward()
+    check("nt0/loss_rel_vs_oracle", rel(out["loss"], ref["loss"]), 1e-3)
+    for k in tr:
+        got, want = eng.ps.g(k).detach().float().cpu().reshape(-1), Wq[k].grad
+        if want is None:
+            assert float(got.abs().max()) == 0.0, k
+            continue
+        if got.numel() == 1:
+            check(f"nt0/grad/{k}_abs", abs(float(got) - float(want)), 0.05 * abs(float(want)) + 1e-3)
+            continue
+        c, n = grad_err(got, want.reshape(-1))
+        check(f"nt0/grad/{k}/one_minus_cos", c, 1.5e-2)
+        check(f"nt0/grad/{k}/norm_dev", n, 3e-2)
+
+
+def test_emb_loss_batch_repeat_branch_in_the_step():
+    """_emb_loss's repeat branch (base_ola_vlm.py:292-299): ONE gen / depth target row for the batch of two predictions -> targets and
+    masks tiled.  The rank-4 seg target cannot take that branch (the reference's 3-argument repeat raises): ValueError here."""
+    def mutate(b):
+        b["gen_target"], b["gen_mask"] = b["gen_target"][:1].clone(), torch.tensor([0.5])
+        b["depth_target"], b["depth_mask"] = b["depth_target"][:1].clone(), torch.tensor([1.0])
+    out, ref = _edge_case({}, mutate, tag="edge_repeat")
+    from oracle import cases
+    from visper_lm_amd.config import VisperConfig
+    from visper_lm_amd.engine import Engine
+    ocfg, W, batch, g = cases.tiny_llama_case()
+    batch = dict(batch, seg_target=batch["seg_target"][:1].clone())
+    eng = Engine(VisperConfig(**vars(ocfg)))
+    eng.load_weights(W)
+    with pytest.raises(ValueError):
+        eng.train_step(_to_gpu_batch(batch))

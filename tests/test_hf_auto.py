@@ -24,3 +24,21 @@ def test_auto_classes_resolve_all_four_model_types(tmp_path):
     assert type(c2) is reg["ola_llama"][0] and c2.num_hidden_layers == 3 and c2.image_seg["seg_layer_indices"] == "18"
     assert AutoModelForCausalLM._model_mapping[type(c2)] is reg["ola_llama"][1]
     assert issubclass(reg["llava_llama"][1], __import__("visper_lm_amd.model", fromlist=["x"]).LlavaMetaForCausalLM)
+
+
+def test_ift_config_ignores_a_stored_pt_trainability_and_model_type():
+    """a PT-stage config.json carries train_llm=False / aux_heads=True / model_type "ola_*" (save_pretrained dumps
+    config.to_dict()); the IFT classes are trainable whatever the stored config says (train.py:1045-1068), and stay llava_* models."""
+    from visper_lm_amd.model import LlavaPhi3Config, OlaLlavaPhi3Config
+    pt = OlaLlavaLlamaConfig(num_hidden_layers=2)
+    assert pt.train_llm is False and pt.aux_heads is True
+    c = LlavaConfig(**pt.to_dict())
+    assert c.train_llm is True and c.aux_heads is False and c.model_type == "llava_llama"
+    assert c.num_task_tokens == 8 and c.aux_mode == "gen-depth-seg" and c.task_token_format == "emb"      # the PT recipe's tokens are kept
+    assert LlavaConfig(**{**pt.to_dict(), "freeze_llm": True}).train_llm is False                     # the only way to freeze: explicit
+    p = LlavaPhi3Config()
+    assert p.model_type == "llava_phi3" and "model_type" not in p.to_dict() and p.arch == "phi3" and p.train_llm
+    p2 = LlavaPhi3Config(**OlaLlavaPhi3Config().to_dict())
+    assert p2.model_type == "llava_phi3" and p2.train_llm and p2.hidden_size == 3072
+    reg = register_auto_classes()
+    assert reg["llava_phi3"][0]().to_visper().model_type == "llava_phi3"

@@ -506,6 +506,32 @@ def test_emb_loss_full_size_world8(ops):
         ops.emb_loss_fwd(pred, tgt[:4], mask, None, 0.3)                                               # Bw < B
 
 
+def test_emb_loss_concurrent_streams(ops):
+    """the loss forward's ticket counters are per DISTINCT stream (a registry, not a hash of the stream pointer), so launches
+    that overlap on several streams never share tickets.  12 streams (more than the old 8 hash slots) run the single-launch forward
+    concurrently, 6 rounds each on its own data; every result must equal the bits of the same call made alone on the default stream, and
+    a later default-stream call must still be exact (no counter left armed)."""
+    B, Bw, D = 8, 16, 576 * 256
+    g = torch.Generator(device="cuda").manual_seed(9)
+    preds = [(torch.randn(B, D, device="cuda", generator=g) * 1.3).to(torch.bfloat16) for _ in range(12)]
+    tgts = [torch.randn(Bw, D, device="cuda", generator=g).to(torch.bfloat16) for _ in range(12)]
+    mask, ls = torch.ones(B, device="cuda"), torch.tensor([2.0], device="cuda")
+    alone = [ops.emb_loss_fwd(p, t, mask, ls, 0.3, rank=1) for p, t in zip(preds, tgts)]
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream() for _ in range(12)]
+    got = [[] for _ in range(12)]
+    for _ in range(6):
+        for i, st in enumerate(streams):
+            with torch.cuda.stream(st):
+                got[i].append(ops.emb_loss_fwd(preds[i], tgts[i], mask, ls, 0.3, rank=1))
+    torch.cuda.synchronize()
+    for i in range(12):
+        for out3, coef in got[i]:
+            assert torch.equal(out3, alone[i][0]) and torch.equal(coef, alone[i][1]), i
+    again = ops.emb_loss_fwd(preds[0], tgts[0], mask, ls, 0.3, rank=1)
+    assert torch.equal(again[0], alone[0][0]) and torch.equal(again[1], alone[0][1])
+
+
 def test_dpt_conv_helpers(ops):
     """conv.hip (frozen DPT decoder, da_v2_head.py:182-321): im2col3x3 + GEMM == F.conv2d, GEMM + pixel shuffle ==
     F.conv_transpose2d(k = stride), bilinear align_corners=True, per-image min-max normalisation."""

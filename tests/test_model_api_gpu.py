@@ -364,3 +364,62 @@ def test_hf_trainer_drives_the_pt_mirror():
     assert p.data_ptr() == eng.ps.w("model.mm_projector.0.weight").data_ptr()
     model._sync_trainable()                                           # fold the Trainer's in-place steps on the bf16 Parameters into the fp32 master
     assert torch.equal(eng.ps.p("model.mm_projector.0.weight").to(torch.bfloat16).view(p.shape), p.detach())
+
+
+def test_pt_checkpoint_hands_off_to_the_ift_class():
+    """ADVICE r2 + VERDICT r2 missing-2/-7: the reference's PT -> IFT hand-off.  A PT-stage save_pretrained directory (config.json carries
+    train_llm=false, aux_heads=true, model_type ola_llama, num_task_tokens 8, task_token_format "emb") loaded into LlavaLlamaForCausalLM:
+    the whole LLM is trainable (train.py makes it so whatever the config stores), the heads are skipped, the three special_*_tokens come
+    along and are spliced raw (llava_arch.py:259-260), the loss equals the IFT golden's reference loss when the weights are the golden's,
+    a text-only batch (no `images`) runs (the reference's dataset attaches a zero image), and "text" is refused like the reference does."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import tempfile
+    from oracle import cases
+    from visper_lm_amd.model import OlaLlavaLlamaForCausalLM, OlaLlavaLlamaConfig, LlavaLlamaForCausalLM, LlavaConfig
+    ocfg, W, batch, g = cases.tiny_ift_tok_case()
+    pt_cfg = OlaLlavaLlamaConfig(**{k: v for k, v in vars(ocfg).items() if k not in ("aux_heads", "task_token_layout")})
+    assert pt_cfg.train_llm is False and pt_cfg.aux_heads is True and pt_cfg.task_token_format == "emb"
+    pt = OlaLlavaLlamaForCausalLM(pt_cfg, init="random", seed=3)
+    own = dict(pt.named_parameters())
+    nest = lambda k: (k.replace("model.vision_tower.vision_tower.", "model.vision_tower.vision_tower.vision_model.")
+                      if k.startswith("model.vision_tower.vision_tower.") else k)
+    with torch.no_grad():
+        for k, v in W.items():                                       # the golden's LLM / tower / projector / token weights into the PT model
+            own[nest(k)].copy_(v.to(own[nest(k)].dtype))
+    with tempfile.TemporaryDirectory() as d:
+        pt.save_pretrained(d)
+        stored = json.load(open(f"{d}/config.json"))
+        assert stored["train_llm"] is False and stored["model_type"] == "ola_llama" and stored["num_task_tokens"] == 8
+        ift = LlavaLlamaForCausalLM.from_pretrained(d, strict=False)
+        frozen = LlavaLlamaForCausalLM.from_pretrained(d, strict=False, freeze_llm=True)
+    cfg = ift.config
+    assert isinstance(cfg, LlavaConfig) and cfg.train_llm and not cfg.aux_heads and cfg.model_type == "llava_llama" and cfg.task_token_layout == "raw"
+    named = dict(ift.named_parameters())
+    assert not any("_heads." in k or k.endswith("logit_scale") for k in named)
+    for k in ("model.layers.0.self_attn.q_proj.weight", "model.layers.3.mlp.down_proj.weight", "lm_head.weight", "model.embed_tokens.weight",
+              "model.norm.weight", "model.mm_projector.2.weight", "model.special_depth_tokens", "model.special_seg_tokens", "model.special_gen_tokens"):
+        assert named[k].requires_grad, k
+    assert not any(p.requires_grad for k, p in named.items() if "vision_tower" in k)
+    assert not dict(frozen.named_parameters())["model.layers.0.self_attn.q_proj.weight"].requires_grad          # explicit freeze only
+    assert torch.equal(named["model.special_seg_tokens"].detach().float().cpu(), W["model.special_seg_tokens"].to(torch.bfloat16).float())
+    kw = dict(input_ids=batch["input_ids"], attention_mask=batch["attention_mask"], labels=batch["labels"], images=batch["images"].cuda())
+    out = ift(**kw)
+    assert out.hidden_states[0].shape[1] == 58 + 576 * 3 + 8
+    check("pt_to_ift/loss_rel_vs_reference_golden", abs(float(out.loss) - float(g["loss"])) / float(g["loss"]), 1e-3)
+    out.loss.backward()
+    for k in ("model.special_depth_tokens", "model.special_seg_tokens", "model.special_gen_tokens", "model.layers.1.mlp.up_proj.weight"):
+        ref = float(g[f"gradnorm::{k}"])
+        check(f"pt_to_ift/gradnorm/{k}_rel_vs_reference_golden", abs(float(named[k].grad.float().norm()) - ref) / ref, 2.5e-2)
+    # text-only batch: no images, no <image> token -> a zero image per sample whose features are never read (llava_arch.py:347-354)
+    ids = batch["input_ids"].clone(); ids[:, 38] = 7
+    lab = ids.clone(); lab[:, :45] = -100
+    ift.zero_grad(set_to_none=True)
+    o2 = ift(input_ids=ids, attention_mask=batch["attention_mask"], labels=lab)
+    assert o2.hidden_states[0].shape[1] == 59 and float(o2.loss) == float(o2.loss)
+    o2.loss.backward()
+    assert float(named["model.mm_projector.0.weight"].grad.float().abs().max()) == 0.0          # the dummy image feeds nothing
+    with pytest.raises(ValueError):
+        ift(input_ids=batch["input_ids"], attention_mask=batch["attention_mask"], labels=batch["labels"])     # <image> token without images
+    with pytest.raises(ValueError, match="text"):
+        LlavaLlamaForCausalLM(LlavaConfig(**{**pt_cfg.to_dict(), "task_token_format": "text"}), init="empty")

@@ -184,6 +184,78 @@ def test_ift_stage_matches_reference_llava_llama():
         _close(cases.sub(W[k].grad, 128), g[f"gradsub::{k}"], 2e-3, 1e-7 + 1e-4 * float(np.abs(g[f"gradsub::{k}"]).max()))
 
 
+def test_ift_stage_with_pt_task_tokens_matches_reference_llava_llama():
+    """VERDICT r2 missing-2: the reference's own PT -> IFT hand-off.  LlavaLlamaForCausalLM built from a PT-stage config
+    (num_task_tokens 8, task_token_format "emb") splices the RAW (576, H) depth / seg parameters and the 8 gen rows behind the image
+    (llava_arch.py:250-293): S = 58 + 576 + 576 + 576 + 8.  Loss, logits and every parameter gradient incl. the three token tensors."""
+    cfg, W, batch, g = cases.tiny_ift_tok_case()
+    tr = json.loads(str(g["trainable"]))
+    W = {k: (v.clone().requires_grad_(True) if k in tr else v) for k, v in W.items()}
+    out = O.forward(W, batch, cfg)
+    out["loss"].backward()
+    assert tuple(out["logits"].shape) == tuple(g["logits_shape"]) and out["logits"].shape[1] == 58 + 576 * 3 + 8
+    _close(out["loss"].item(), g["loss"], 1e-5, 1e-6)
+    _close(out["logits"][:, ::41, ::997].detach().numpy(), g["logits_sub"], 1e-3, 2e-5)
+    assert len(tr) == 46 and all(f"model.special_{t}_tokens" in tr for t in ("depth", "seg", "gen"))
+    for k in tr:
+        ref_norm = float(g[f"gradnorm::{k}"])
+        assert abs(float(W[k].grad.double().norm()) - ref_norm) <= 2e-4 * ref_norm + 1e-9, k
+        _close(cases.sub(W[k].grad, 128), g[f"gradsub::{k}"], 2e-3, 1e-7 + 1e-4 * float(np.abs(g[f"gradsub::{k}"]).max()))
+    # "text": the reference calls embed_tokens on the float parameters -> F.embedding raises; recorded by the generator
+    assert str(g["text_format_error"]).startswith("RuntimeError")
+
+
+def test_pt_step_without_task_tokens_matches_reference():
+    """VERDICT r2 missing-5: num_task_tokens == 0 -> GenHead / DepthHead / OneFormerSegHead around the plain Resampler with its own
+    latents (base_ola_vlm.py:120-169, 429-430; resampler.py:120-165), whole layer state as head input."""
+    cfg, W, batch, g = cases.tiny_nt0_case()
+    tr = json.loads(str(g["trainable"]))
+    assert not any("special_" in k for k in W) and sum(k.endswith("projector.latents") for k in tr) == 4
+    W = {k: (v.clone().requires_grad_(True) if k in tr else v) for k, v in W.items()}
+    out = O.forward(W, batch, cfg)
+    out["loss"].backward()
+    assert tuple(out["logits"].shape) == tuple(g["logits_shape"]) and out["logits"].shape[1] == 58 + 576
+    _close(out["loss"].item(), g["loss"], 1e-5, 1e-6)
+    mine = [out["layer_losses"][("depth", 2)], out["layer_losses"][("seg", 1)], out["layer_losses"][("seg", 2)], out["layer_losses"][("gen", 3)]]
+    for i, trip in enumerate(mine):
+        _close([float(x.detach()) for x in trip], g["layer_losses"][i], 2e-5, 1e-6)
+    _close(cases.sub(out["seg_embs"][0], 2048), g["seg_emb_sub"], 1e-3, 2e-5)
+    none_ref = set(json.loads(str(g["grad_none"])))
+    for k in tr:
+        if k in none_ref:
+            continue
+        ref_norm = float(g[f"gradnorm::{k}"])
+        assert abs(float(W[k].grad.double().norm()) - ref_norm) <= 2e-4 * ref_norm + 1e-9, k
+
+
+@pytest.mark.parametrize("name,dims", [("rs_plain", (32, 12, 48, 40, 1)), ("rs_plain_deep", (64, 5, 48, 24, 2))])
+def test_plain_resampler(name, dims):
+    g = cases.load_golden("units.npz")
+    dim, nq, emb, out_dim, depth = dims
+    man = json.loads(str(g[f"{name}_manifest"]))
+    W = {f"h.{k}": WT.param(f"{name}.{k}", s) for k, s in man.items()}
+    assert tuple(man["latents"]) == (1, nq, dim)
+    out = O.resampler(WT.tensor(f"{name}.x", (2, 50, emb)), W, "h.", dict(num_tokens=nq, num_heads=4, dim_head=32, depth=depth))
+    _close(out.numpy(), g[f"{name}_out"], 1e-4, 1e-5)
+
+
+@pytest.mark.parametrize("name,shp", [("rep_gen", (1, 1024)), ("rep_depth", (40, 256))])
+def test_emb_loss_batch_repeat_branch(name, shp):
+    """base_ola_vlm.py:292-299: 4 predictions against 2 targets -> targets.repeat(2, 1, 1), mask.repeat(2, 1, 1)."""
+    g = cases.load_golden("units.npz")
+    p = WT.tensor(f"unit_pred_{name}", (4, *shp), 1.3).requires_grad_(True)
+    t = WT.tensor(f"unit_tgt_{name}", (2, *shp), 1.0)
+    s = torch.tensor(2.0, requires_grad=True)
+    e, l1, c = O.emb_loss(p, torch.tensor([1.0, 0.5]), t, s, 0.3)
+    e.backward()
+    _close([e.item(), l1.item(), c.item()], g[f"{name}_out"], 1e-5, 1e-7)
+    _close(p.grad.numpy(), g[f"{name}_dpred"], 1e-4, 1e-9)
+    _close(s.grad.item(), g[f"{name}_dscale"], 1e-4, 1e-8)
+    assert str(g["rep_rank4_error"]).startswith("RuntimeError")          # the reference's 3-argument repeat on a rank-4 (seg) target
+    with pytest.raises(RuntimeError):
+        O.emb_loss(WT.tensor("unit_pred_rep4", (4, 8, 3, 3)), torch.ones(2), WT.tensor("unit_tgt_rep4", (2, 8, 3, 3)), None, 0.3)
+
+
 def test_dinov2_depth_teacher_matches_reference():
     """the DINOv2 depth-teacher target (mean of 4 normed intermediate patch-token maps; base_ola_vlm.py:347-365 ->
     depth_anything_v2/dinov2.py) against the reference's own DinoVisionTransformer, incl. the bicubic 37x37 -> 24x24 position grid."""

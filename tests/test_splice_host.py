@@ -13,11 +13,11 @@ from visper_lm_amd.config import VisperConfig
 H = 16
 
 
-def _case(side="right", ragged=False, no_image=False, two_images=False, max_len=4096, aux="gen-depth-seg", nt=8):
+def _case(side="right", ragged=False, no_image=False, two_images=False, max_len=4096, aux="gen-depth-seg", nt=8, layout="pooled"):
     cfg = VisperConfig(vocab_size=500, hidden_size=H, num_hidden_layers=2, aux_mode=aux, num_task_tokens=nt,
-                       tokenizer_padding_side=side, tokenizer_model_max_length=max_len)
+                       tokenizer_padding_side=side, tokenizer_model_max_length=max_len, task_token_layout=layout)
     ocfg = O.make_config(vocab_size=500, hidden_size=H, num_hidden_layers=2, aux_mode=aux, num_task_tokens=nt,
-                         tokenizer_padding_side=side, tokenizer_model_max_length=max_len)
+                         tokenizer_padding_side=side, tokenizer_model_max_length=max_len, task_token_layout=layout)
     g = torch.Generator().manual_seed(3)
     B, T = 3, 61
     ids = torch.randint(0, 500, (B, T), generator=g)
@@ -57,7 +57,10 @@ def _apply(plan, W, feats, ocfg):
 
 @pytest.mark.parametrize("side", ["right", "left"])
 @pytest.mark.parametrize("kw", [dict(), dict(ragged=True), dict(ragged=True, no_image=True), dict(two_images=True, ragged=True),
-                                dict(max_len=640), dict(aux="", nt=0, ragged=True)])
+                                dict(max_len=640), dict(aux="", nt=0, ragged=True),
+                                # IFT-stage "emb" layout (llava_arch.py:259-260): raw 576 + 576 + 8 task-token rows behind every image
+                                dict(layout="raw", ragged=True), dict(layout="raw", two_images=True, ragged=True, no_image=True),
+                                dict(layout="raw", aux="seg-gen", max_len=1300)])
 def test_plan_reproduces_oracle_splice(side, kw):
     cfg, ocfg, ids, am, labels, W, feats = _case(side=side, **kw)
     plan = splice.host_plan(cfg, [], ids.numpy(), am.numpy(), labels.numpy())
@@ -119,6 +122,39 @@ def test_head_tables_match_forward_emb_predictor_selection():
         assert np.array_equal(inv[rows, j], off + np.arange(rows.size))
         assert (inv[:, j] >= 0).sum() == rows.size
         off += rows.size
+
+
+def test_task_token_rows_per_layout():
+    from visper_lm_amd.config import task_token_rows
+    cfg, *_ = _case()
+    assert task_token_rows(cfg) == [("gen", 8, False), ("depth", 8, True), ("seg", 8, True)]
+    cfg, ocfg, ids, am, labels, W, feats = _case(layout="raw")
+    assert task_token_rows(cfg) == [("gen", 8, False), ("depth", 576, False), ("seg", 576, False)]
+    plan = splice.host_plan(cfg, [], ids.numpy(), am.numpy(), labels.numpy())
+    assert plan["n_tok_rows"] == 8 + 576 + 576 and plan["S"] == 61 - 1 + 576 + plan["n_tok_rows"]
+    assert task_token_rows(_case(aux="", nt=0)[0]) == []
+    with pytest.raises(NotImplementedError):                         # heads slice by num_task_tokens-row blocks: pooled layout only
+        splice.host_plan(cfg, [("seg", 0, 1)], ids.numpy(), am.numpy(), labels.numpy())
+
+
+def test_head_tables_without_task_tokens_select_the_whole_state():
+    """num_task_tokens == 0 (base_ola_vlm.py:420-422, 429-430): every head reads the whole layer state (pass_text_to_aux) and brings its
+    own latents: lat_rep tiles the (num_queries, dim) parameter over the batch, lat_bwd is the transpose of that tiling."""
+    cfg, ocfg, ids, am, labels, W, feats = _case(aux="gen-depth-seg", nt=0)
+    tasks = [("depth", 0, 1), ("seg", 0, 0), ("gen", 0, 1)]
+    plan = splice.host_plan(cfg, tasks, ids.numpy(), am.numpy(), labels.numpy())
+    B, S = plan["B"], plan["S"]
+    assert S == 61 - 1 + 576 and plan["n_tok_rows"] == 0
+    state = torch.arange(B * S, dtype=torch.float32).view(B, S, 1).expand(B, S, 2).contiguous()
+    for task, nq in (("depth", 576), ("seg", 576), ("gen", 1)):
+        x, lat = O.head_inputs(state, task, {}, ocfg)
+        h = plan["heads"][task]
+        assert lat is None and h["mode"] == "own" and h["nq"] == nq and h["n_x"] == S
+        assert np.array_equal(x[..., 0].reshape(-1).numpy().astype(np.int64), h["rows_host"].astype(np.int64))
+        assert np.array_equal(h["xin_row"], h["rows_host"]) and not h["xin_kind"].any()
+        assert np.array_equal(h["lat_rep"], np.tile(np.arange(nq), B))
+        lb = h["lat_bwd"].reshape(nq, B)
+        assert h["lat_cnt"] == B and np.array_equal(lb, np.arange(B)[None, :] * nq + np.arange(nq)[:, None])
 
 
 def test_ragged_left_padding_with_heads_is_refused():

@@ -33,6 +33,10 @@ class VisperConfig:
             # distillation (ola_vlm_train.py:1149-1229)
             aux_mode="gen-depth-seg", num_task_tokens=8, contrastive_loss_weight=0.3, use_contrastive=True,
             pass_text_to_aux=True, task_token_format="emb",
+            # how append_special_tokens lays the task tokens into the sequence: "pooled" = PT stage, ola_arch.py:224-254 (depth / seg parameters
+            # mean-pooled to num_task_tokens rows whatever task_token_format says); "raw" = IFT stage with task_token_format "emb",
+            # llava_arch.py:259-260 (every row of the (num_tokens, H) depth / seg parameters).  Set by the model classes, not by users.
+            task_token_layout="pooled",
             aux_heads=True,        # False: task tokens are spliced but no distillation heads exist (the IFT-stage LlavaLlamaForCausalLM)
             image_gen=dict(depth=1, dim_head=32, num_heads=4, num_tokens=1, output_dim=1024, ff_mult=1,
                            img_layer_indices="20", img_loss_weight=0.5),
@@ -98,6 +102,24 @@ def phi3_mini(**kw) -> VisperConfig:
     c = VisperConfig(**d)
     c.model_type = "ola_phi3"
     return c
+
+
+def task_token_rows(cfg) -> list:
+    """[(task, rows, pooled)] in token_order: how many sequence rows each task's tokens take behind an image (append_special_tokens,
+    ola_arch.py:224-254 / llava_arch.py:250-293).  gen: always its num_task_tokens raw rows; depth / seg: num_task_tokens pooled rows
+    (PT stage, and the IFT stage's "expand_emb") or all num_tokens raw rows (IFT stage, "emb")."""
+    nt = int(cfg.num_task_tokens)
+    if nt <= 0:
+        return []
+    raw = getattr(cfg, "task_token_layout", "pooled") == "raw"
+    out = []
+    for task in cfg.token_order:
+        if task == "gen":
+            out.append((task, nt, False))
+        else:
+            hc = {"depth": getattr(cfg, "image_depth", None), "seg": getattr(cfg, "image_seg", None)}[task]
+            out.append((task, int(hc["num_tokens"]) if raw else nt, not raw))
+    return out
 
 
 def layer_indices(spec) -> list:

@@ -19,12 +19,15 @@
 #include "common.h"
 #include <type_traits>
 #include <stdlib.h>
+#include <mutex>
+#include <unordered_map>
 
 namespace {
 
 constexpr int G1 = 32;                 // blocks per first-level reduction group
 constexpr int MAX_GROUPS = 1024;       // njc * ngrp
-constexpr int N_SLOTS = 8;             // independent counter sets (one per stream hash) so that calls on different streams do not collide
+constexpr int N_SLOTS = 32;            // independent counter sets, one per DISTINCT stream (el_slot_for: a registry, not a hash, so two streams
+                                       // can never share tickets); calls on one stream are ordered by the stream itself
 __device__ unsigned g_counters[N_SLOTS][1 + MAX_GROUPS];   // zero at module load; every launch leaves its slot zeroed again
 
 struct ElArgs {
@@ -340,8 +343,13 @@ __global__ __launch_bounds__(256) void emb_loss_fwd_kernel(const ElArgs a) {
     for (int i = tid; i < NS / 4; i += 256) cstore4(rs, 4 * i, *(const f32x4*)(red + 4 * i));
   }
   // ---- level 1: the last block of each group of G1 sums the group's partials (fixed order)
+  // Memory-model note (MI355X_MICROARCH.md, "Valid forms": {sc0 sc1 stores and loads on both sides} + a drained flag): the partials leave as
+  // write-through `sc0 sc1` stores, every wave drains its own stores with an EXPLICIT s_waitcnt vmcnt(0) (inline asm: not left to what the
+  // compiler happens to emit for __syncthreads), the workgroup barrier collects the waves, and only then one lane takes the agent-scope
+  // ticket; the reducer reads the partials with `sc0 sc1` loads that bypass its L1 and the (non-coherent) L2 lines.
   unsigned* cnt = g_counters[a.slot];
   const int grp = bx / G1, gsz = min(G1, a.nblk - grp * G1);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   __syncthreads();
   if (tid == 0) ticket = __hip_atomic_fetch_add(&cnt[1 + jc * a.ngrp + grp], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -390,6 +398,7 @@ __global__ __launch_bounds__(256) void emb_loss_fwd_kernel(const ElArgs a) {
   if (tid == 0) __hip_atomic_store(&cnt[1 + jc * a.ngrp + grp], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm
   if (!single) {
     // ---- level 2: the last group reducer sums the group partials of every chunk and finishes
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // this wave's group-partial stores (sc0 sc1) have left before the ticket
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __syncthreads();
     if (tid == 0) ticket = __hip_atomic_fetch_add(&cnt[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -481,6 +490,20 @@ struct ElPlan {
   int npb, ng, njc, nblk, ngrp, ns;
 };
 
+// One ticket-counter set per distinct stream, handed out in order of first use (a hash of the stream pointer let two streams
+// share a set).  Returns -1 when more than N_SLOTS different streams have called the loss (the caller reports VP_ERR_UNSUPPORTED_SHAPE).
+int el_slot_for(hipStream_t s) {
+  static std::mutex mu;
+  static std::unordered_map<hipStream_t, int> slots;
+  std::lock_guard<std::mutex> lk(mu);
+  auto it = slots.find(s);
+  if (it != slots.end()) return it->second;
+  if ((int)slots.size() >= N_SLOTS) return -1;
+  const int id = (int)slots.size();
+  slots.emplace(s, id);
+  return id;
+}
+
 ElPlan el_plan(int B, int Bw, long D) {
   ElPlan p;
   p.npb = B <= 16 ? 1 : (B <= 32 ? 2 : 4);
@@ -542,7 +565,8 @@ int vp_emb_loss_fwd(int B, int Bw, long D, int rank, const void* pred, const voi
   a.part2 = a.part + (long)p.njc * p.nblk * p.ns;
   a.fin = a.part2 + (long)p.njc * p.ngrp * p.ns;
   a.D = D; a.B = B; a.Bw = Bw; a.rank = rank; a.nblk = p.nblk; a.njc = p.njc; a.ngrp = p.ngrp;
-  a.slot = (int)((((uintptr_t)s) >> 6) % N_SLOTS);
+  a.slot = el_slot_for(s);
+  VP_REQUIRE(a.slot >= 0, VP_ERR_UNSUPPORTED_SHAPE, "vp_emb_loss_fwd: more than %d distinct streams have used the loss", N_SLOTS);
   a.w_con = w_contrastive;
   a.dbg = g_dbg;
   const dim3 grid(p.nblk, p.njc);

@@ -29,7 +29,7 @@ import numpy as np
 import torch
 
 from . import ops
-from .config import IGNORE_INDEX, IMAGE_TOKEN_INDEX, layer_indices
+from .config import IGNORE_INDEX, IMAGE_TOKEN_INDEX, layer_indices, task_token_rows
 
 BF16 = torch.bfloat16
 F32 = torch.float32
@@ -404,6 +404,7 @@ class Engine:
         if self._red is None or self._red.g is not self.ps.grad:
             wire = torch.float32 if str(getattr(self.cfg, "grad_reduce_dtype", "bf16")) in ("fp32", "float32") else BF16
             self._red = GradReducer(self.ps.grad, self.ps.split, comm=getattr(self, "comm", None), reduce_dtype=wire)
+        self._red.dry = bool(getattr(self, "comm_dry", False))
         return self._red
 
     def finish_grads(self):
@@ -481,6 +482,18 @@ class Engine:
                 for i, idx in enumerate(layer_indices(hc[TASK_SPEC[task][1]])):
                     self.tasks.append((task, i, idx))
         self.tapped = sorted({idx for _, _, idx in self.tasks})
+
+    def _zeros_i32(self, n):
+        key = ("zeros_i32", n)
+        if key not in self._static:
+            self._static[key] = torch.zeros(n, device=self.dev, dtype=torch.int32)
+        return self._static[key]
+
+    def _arange(self, n):
+        key = ("arange", n)
+        if key not in self._static:
+            self._static[key] = torch.arange(n, device=self.dev, dtype=torch.int32)
+        return self._static[key]
 
     def rope(self, S):
         if S not in self._rope:
@@ -713,7 +726,8 @@ class Engine:
             h["rows"] = view("rows:" + task)
             h["xin"] = dict(kind=view("xin_kind:" + task), row=view("xin_row:" + task),
                             mean_idx=view("mean_idx:" + task) if ("mean_idx:" + task) in offs else None,
-                            lat_bwd=view("lat_bwd:" + task) if ("lat_bwd:" + task) in offs else None, lat_cnt=h.get("lat_cnt", 0))
+                            lat_bwd=view("lat_bwd:" + task) if ("lat_bwd:" + task) in offs else None, lat_cnt=h.get("lat_cnt", 0),
+                            lat_rep=view("lat_rep:" + task) if ("lat_rep:" + task) in offs else None)
         plan["heads"] = heads
         plan["inv"] = {l: view(f"inv:{l}") for l in self.tapped if f"inv:{l}" in offs}
         if len(self._plan_cache) > 8:
@@ -731,19 +745,20 @@ class Engine:
         z1 = ops.gemm(feats, ps.w("model.mm_projector.0.weight"), bias=ps.w("model.mm_projector.0.bias"))
         a1 = ops.act_fwd(z1, ops.EPI_GELU)
         img = ops.gemm(a1, ps.w("model.mm_projector.2.weight"), bias=ps.w("model.mm_projector.2.bias"))
-        # task-token rows (a4): depth/seg = group means of the (576,H) parameter, gen = raw rows
-        nt = cfg.num_task_tokens
+        # task-token rows (a4).  PT stage (ola_arch.py:224-254) and the IFT stage's "expand_emb": depth / seg = group means of the (576, H)
+        # parameter, gen = its raw rows; IFT stage "emb" (llava_arch.py:259-260): every parameter row as it is
         tok_rows = None
         if plan["n_tok_rows"] > 0:
             tok_rows = torch.empty(plan["n_tok_rows"], H, device=dev, dtype=BF16)
-            for k, task in enumerate(cfg.token_order):
+            off = 0
+            for task, nr, pooled in task_token_rows(cfg):
                 src = ps.w(f"model.special_{task}_tokens")
-                if task == "gen":
-                    ops.copy2d_(tok_rows[k * nt:(k + 1) * nt], src)
+                if not pooled:
+                    ops.copy2d_(tok_rows[off:off + nr], src)
                 else:
-                    grp = src.shape[0] // nt
-                    idx = torch.arange(src.shape[0], device=dev, dtype=torch.int32)
-                    ops.gather_sum_rows(src, idx, grp, 1.0 / grp, tok_rows[k * nt:(k + 1) * nt])
+                    grp = src.shape[0] // nr
+                    ops.gather_sum_rows(src, self._arange(src.shape[0]), grp, 1.0 / grp, tok_rows[off:off + nr])
+                off += nr
         x = torch.empty(plan["B"] * plan["S"], H, device=dev, dtype=BF16)
         srcs = [fz["embed"], img] + ([tok_rows] if tok_rows is not None else [])
         ops.gather_rows(srcs, plan["kind"], plan["row"], H, x)
@@ -875,7 +890,7 @@ class Engine:
         ns = cfg.num_sys_tokens
         run_heads = len(self.tasks) > 0 and S > ns
         if run_heads:
-            targets = self._prepare_targets(batch)
+            targets = self._prepare_targets(batch, B)
             for task, i, idx in self.tasks:
                 res = self._head_fwd_bwd(task, i, idx, states[idx], plan, batch, targets, compute_grads)
                 if res["loss3"] is not None:
@@ -995,15 +1010,18 @@ class Engine:
         if plan["n_tok_rows"] > 0:
             d_tok = torch.empty(plan["n_tok_rows"], H, device=dev, dtype=F32)
             ops.gather_sum_rows(dx, plan["tok_src"], plan["tok_cnt"], 1.0, d_tok)
-            for k, task in enumerate(cfg.token_order):
-                name = f"model.special_{task}_tokens"
-                g = ps.g(name)
-                if task == "gen":
-                    self._acc(g, d_tok[k * nt:(k + 1) * nt].contiguous())
-                else:
-                    grp = g.shape[0] // nt
-                    idx = (torch.arange(g.shape[0], device=dev, dtype=torch.int32) // grp + k * nt).to(torch.int32)
-                    ops.gather_sum_rows(d_tok, idx, 1, 1.0 / grp, g, accumulate=True)
+            off = 0
+            for task, nr, pooled in task_token_rows(cfg):
+                g = ps.g(f"model.special_{task}_tokens")
+                if not pooled:                                   # raw rows: the parameter's gradient is the rows' own
+                    self._acc(g, d_tok[off:off + nr])
+                else:                                            # transpose of the group mean: every row of a group gets 1/grp of its pooled row's
+                    grp = g.shape[0] // nr
+                    key = ("tok_bwd", g.shape[0], grp, off)
+                    if key not in self._static:
+                        self._static[key] = (torch.arange(g.shape[0], device=dev, dtype=torch.int32) // grp + off).to(torch.int32)
+                    ops.gather_sum_rows(d_tok, self._static[key], 1, 1.0 / grp, g, accumulate=True)
+                off += nr
         # ---- projector backward
         d_a1 = self._lin_bwd(a1, d_img, "model.mm_projector.2.weight", "model.mm_projector.2.bias", need_dx=True)
         d_z1 = ops.act_bwd(d_a1, z1, ops.EPI_GELU)
@@ -1011,7 +1029,7 @@ class Engine:
         return out
 
     # ------------------------------------------------------------------------------------------ targets
-    def _prepare_targets(self, batch):
+    def _prepare_targets(self, batch, B=None):
         """Frozen-teacher features are inputs.  Flatten to [B, D] in the PREDICTION's memory order
         (seg targets (B,C,24,24) are re-laid out to (B,576,C) once so the loss kernel streams both linearly), then
         all-gather across DP ranks for the contrastive negatives (ola_utils.py:96-106), once per task per step."""
@@ -1033,9 +1051,25 @@ class Engine:
             else:
                 flat = tg.reshape(Bn, -1).contiguous()
             from .parallel import all_gather_rows
-            allt = all_gather_rows(flat, getattr(self, "comm", None)) if self.world > 1 else flat
             mask = batch.get(f"{task}_mask")
-            mask = torch.ones(Bn, device=self.dev, dtype=F32) if mask is None else mask.to(device=self.dev, dtype=F32)
+            mask = torch.ones(Bn, device=self.dev, dtype=F32) if mask is None else mask.to(device=self.dev, dtype=F32).reshape(-1)
+            if B is not None and Bn != B:
+                # _emb_loss's batch-repeat branch (base_ola_vlm.py:292-299): fewer target rows than predictions -> targets.repeat(r, 1, 1) and
+                # mask.repeat(r, 1, 1) with r = B // Bn.  Like the reference this only works for rank-3 targets (its 3-argument repeat raises on
+                # the (B, C, 24, 24) seg targets) and when B is a multiple of Bn (otherwise its smooth_l1_loss raises on the shapes)
+                if tg.dim() != 3 or Bn == 0 or B % Bn != 0 or B < Bn:
+                    raise ValueError(f"{task}_target has batch {Bn} for {B} predictions: the reference's repeat branch needs rank-3 targets "
+                                     f"and B % Bn == 0 (base_ola_vlm.py:292-299)")
+                rep = torch.empty(B, flat.shape[1], device=self.dev, dtype=BF16)
+                key = ("tile_rows", Bn, B)
+                if key not in self._static:
+                    self._static[key] = torch.arange(B, device=self.dev, dtype=torch.int32) % Bn
+                ops.gather_rows([flat], self._zeros_i32(B), self._static[key], flat.shape[1], rep)
+                flat = rep
+                mask = mask.repeat(B // Bn)
+                Bn = B
+            allt = all_gather_rows(flat, getattr(self, "comm", None),
+                                   dry_world=self.world if getattr(self, "comm_dry", False) else 0) if self.world > 1 else flat
             if self.cfg.zero_masks:
                 mask = torch.zeros_like(mask)
             out[task] = (allt, mask)
@@ -1059,23 +1093,34 @@ class Engine:
         #    task-token rows of the state itself, or their per-sample mean when num_queries is not a multiple of 8: resampler.py:207-212)
         # kind / row tables of the [B*T] gather come with the splice plan (splice.head_tables: one pinned upload per batch, no sync)
         nl, mode, xt = tb["nl"], tb["mode"], tb["xin"]
+        own = mode == "own"               # num_task_tokens == 0: plain Resampler with its own `latents` parameter (resampler.py:120-165)
         state2 = state.view(-1, H)
-        if task != "gen":
-            lat_src = ps.w(f"model.special_{task}_tokens")
-            if mode == "mean":                                                          # mean over the parameter rows (resampler.py:212)
-                lat_src = lat_src.float().mean(0, keepdim=True).to(BF16)
-        elif mode == "mean":
-            lat_src = torch.empty(B, H, device=dev, dtype=BF16)
-            ops.gather_sum_rows(state2, xt["mean_idx"], nl, 1.0 / nl, lat_src)
-        else:
-            lat_src = state2
-        xin = torch.empty(B, T, H, device=dev, dtype=BF16)
-        ops.gather_rows([state2, lat_src], xt["kind"], xt["row"], H, xin)
-        xin2 = xin.view(B * T, H)
         Dm = ps.w(pf + "proj_in.weight").shape[0]
-        P = ops.gemm(xin2, ps.w(pf + "proj_in.weight"), bias=ps.w(pf + "proj_in.bias")).view(B, T, Dm)
-        Px = P[:, :n].contiguous().view(B * n, Dm)
-        lat = P[:, n:].contiguous().view(B * nq, Dm)
+        if own:
+            xin = torch.empty(B, n, H, device=dev, dtype=BF16)
+            ops.gather_rows([state2], xt["kind"], xt["row"], H, xin)
+            xin2 = xin.view(B * n, H)
+            Px = ops.gemm(xin2, ps.w(pf + "proj_in.weight"), bias=ps.w(pf + "proj_in.bias"))            # proj_in on x only (:154)
+            lat = torch.empty(B * nq, Dm, device=dev, dtype=BF16)                                        # latents.repeat(B, 1, 1) (:152)
+            ops.gather_rows([ps.w(pf + "latents").view(nq, Dm)], self._zeros_i32(B * nq), xt["lat_rep"], Dm, lat)
+        else:
+            if task != "gen":
+                lat_src = ps.w(f"model.special_{task}_tokens")
+                if mode == "mean":                                                          # mean over the parameter rows (resampler.py:212)
+                    lat_src = lat_src.float().mean(0, keepdim=True).to(BF16)
+            elif mode == "mean":
+                lat_src = torch.empty(B, H, device=dev, dtype=BF16)
+                ops.gather_sum_rows(state2, xt["mean_idx"], nl, 1.0 / nl, lat_src)
+            else:
+                lat_src = state2
+            xin = torch.empty(B, T, H, device=dev, dtype=BF16)
+            ops.gather_rows([state2, lat_src], xt["kind"], xt["row"], H, xin)
+            xin2 = xin.view(B * T, H)
+            P = ops.gemm(xin2, ps.w(pf + "proj_in.weight"), bias=ps.w(pf + "proj_in.bias")).view(B, T, Dm)
+            Px = torch.empty(B * n, Dm, device=dev, dtype=BF16)
+            lat = torch.empty(B * nq, Dm, device=dev, dtype=BF16)
+            ops.copy2d_(Px.view(B, n * Dm), P.view(B, T * Dm)[:, :n * Dm])
+            ops.copy2d_(lat.view(B, nq * Dm), P.view(B, T * Dm)[:, n * Dm:])
         # -- `depth` Perceiver blocks (resampler.py:217-219): latents = attn(x, latents) + latents; latents = ff(latents) + latents.
         #    x (the projected token rows) is the same for every block; each block has its own norm1 / norm2 / projections.
         blocks = []
@@ -1169,9 +1214,15 @@ class Engine:
                                               dres=d_lat1)        # + residual path lat1 = to_out(.) + latents
             ps.g(a + "norm2.weight").copy_(dw); ps.g(a + "norm2.bias").copy_(db)
         dPl = d_lat
+        if own:
+            # the latents parameter was tiled over the batch: its gradient is the batch sum of the final latent gradients
+            ops.gather_sum_rows(dPl, xt["lat_bwd"], xt["lat_cnt"], 1.0, ps.g(pf + "latents").view(nq, Dm), accumulate=True)
+            dxg = self._lin_bwd(xin2, dPx, pf + "proj_in.weight", pf + "proj_in.bias").view(B, n, H)
+            res["dx"] = dxg.view(B * n, H)
+            return res
         dP = torch.empty(B, T, Dm, device=dev, dtype=BF16)
-        dP[:, :n] = dPx.view(B, n, Dm)
-        dP[:, n:] = dPl.view(B, nq, Dm)
+        ops.copy2d_(dP.view(B, T * Dm)[:, :n * Dm], dPx.view(B, n * Dm))
+        ops.copy2d_(dP.view(B, T * Dm)[:, n * Dm:], dPl.view(B, nq * Dm))
         dxin = self._lin_bwd(xin2, dP.view(B * T, Dm), pf + "proj_in.weight", pf + "proj_in.bias").view(B, T, H)
         dxg = dxin[:, :n].contiguous()                                                  # grads of the gathered state rows
         # latents' gradient: the transpose of the forward row gather -> the (576,H) parameter (depth / seg) or the 8 hidden rows (gen)

@@ -151,8 +151,12 @@ def _install_optimizer_hook():
         from torch.optim.optimizer import register_optimizer_step_post_hook
 
         def _mark(optimizer, args, kwargs):
+            # only modules whose OWN Parameters this optimizer steps: an unrelated optimizer (another model in the process) must not make
+            # _sync_trainable copy the bf16 shadow over the fp32 master the fused AdamW maintains (it would truncate the master to bf16)
+            stepped = {id(p) for g in optimizer.param_groups for p in g["params"]}
             for m in list(_LIVE_MODULES):
-                m.__dict__["_force_dirty"] = True
+                if any(id(p) in stepped for p in m.__dict__.get("_trainable_params", ())):
+                    m.__dict__["_force_dirty"] = True
         register_optimizer_step_post_hook(_mark)
     except ImportError:                                           # older torch: the version counters alone
         pass
@@ -319,11 +323,9 @@ class EngineModule(nn.Module):
         with open(os.path.join(directory, "config.json")) as fh:
             cfgd = json.load(fh)
         cfgd.pop("architectures", None)
-        mt = cfgd.pop("model_type", None)
-        cfgd.update(config_overrides)
+        cfgd.pop("model_type", None)                                 # the loading CLASS names the model type (a PT directory loaded into the
+        cfgd.update(config_overrides)                                # IFT class is a llava_* model from then on), not the stored string
         config = cls.config_class(**cfgd)
-        if mt is not None:
-            config.model_type = mt
         model = cls(config, device=device, dtype=dtype, init="empty")
         idx = os.path.join(directory, "model.safetensors.index.json")
         files = sorted(set(json.load(open(idx))["weight_map"].values())) if os.path.exists(idx) else ["model.safetensors"]

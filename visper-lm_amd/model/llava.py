@@ -33,20 +33,36 @@ class CausalLMOutputWithPast(_ModelOutput):
 _IFT_DEFAULTS = dict(aux_mode="", num_task_tokens=0, train_llm=True, aux_heads=False)
 
 
+def _ift_kwargs(kw):
+    """IFT-stage trainability is a property of the CLASS, not of a stored config: the reference's train.py makes the LLM trainable
+    whatever the checkpoint's config.json says (train.py:1045-1068; a PT-stage config.json always carries the PT run's
+    `train_llm: false` because save_pretrained dumps config.to_dict()).  So `train_llm` / `aux_heads` / `model_type` found in `kw`
+    are ignored; the only way to freeze the LLM in these classes is the explicit `freeze_llm=True` (constructor or from_pretrained
+    override; the analogue of train.py's `freeze_backbone`)."""
+    kw = dict(kw)
+    freeze = bool(kw.pop("freeze_llm", False))
+    for k in ("train_llm", "aux_heads", "model_type"):
+        kw.pop(k, None)
+    return {**_IFT_DEFAULTS, **kw, "train_llm": not freeze, "aux_heads": False, "freeze_llm": freeze}
+
+
 class LlavaConfig(VisperConfig):
     """llava_llama.py:39-40 (`model_type = "llava_llama"`).  Defaults = finetune.sh on a plain LLaVA checkpoint: no task tokens.
-    A PT-stage checkpoint's config carries aux_mode / num_task_tokens / task_token_format and is honoured (llava_arch.py:49-50)."""
+    A PT-stage checkpoint's config carries aux_mode / num_task_tokens / task_token_format and is honoured (llava_arch.py:49-50,
+    67-94): the task-token rows are spliced in the layout `task_token_format` names (LlavaMetaForCausalLM below)."""
     model_type = "llava_llama"
 
     def __init__(self, **kw):
-        super().__init__(**{**_IFT_DEFAULTS, **kw, "train_llm": kw.get("train_llm", True), "aux_heads": False})
+        super().__init__(**_ift_kwargs(kw))
 
 
 class LlavaPhi3Config(VisperConfig):
     model_type = "llava_phi3"
 
     def __init__(self, **kw):
-        super().__init__(**{**phi3_mini().to_dict(), **_IFT_DEFAULTS, **kw, "train_llm": kw.get("train_llm", True), "aux_heads": False})
+        base = phi3_mini().to_dict()
+        base.pop("model_type", None)                     # phi3_mini() tags its instance "ola_phi3": would shadow the class attribute
+        super().__init__(**_ift_kwargs({**base, **kw}))
 
 
 class LlavaMetaModel(OlaLlavaMetaModel):
@@ -56,17 +72,24 @@ class LlavaMetaModel(OlaLlavaMetaModel):
 class LlavaMetaForCausalLM(OlaLlavaMetaForCausalLM):
     """llava_arch.py:210-486: encode_images (:295-298), prepare_inputs_labels_for_multimodal (:300-486), the token properties.
 
-    append_special_tokens (:240-293) differs from the PT stage in ONE way: with task_token_format == "emb" it splices the raw
-    (576, H) depth / seg parameters (all rows), while "expand_emb" mean-pools them to num_task_tokens rows like ola_arch.py.  The
-    engine implements the pooled layout; the "emb" / "text" layouts with num_task_tokens > 0 are refused loudly."""
+    append_special_tokens (:250-293) differs from the PT stage: with task_token_format == "emb" (the default, and what every PT
+    checkpoint's config carries) it splices the RAW (num_tokens, H) depth / seg parameters — 576 + 576 + 8 rows behind each image —
+    while "expand_emb" mean-pools them to num_task_tokens rows like ola_arch.py.  Both run here (config.task_token_layout "raw" /
+    "pooled": splice.host_plan, Engine._embed and the token-gradient scatter; golden tests/golden/tiny_llama_ift_tok.npz from the
+    reference's own LlavaLlamaForCausalLM).  "text" calls embed_tokens on the float parameters (:257-258, :284-285): the reference
+    itself raises there (F.embedding wants integer indices; recorded by oracle/gen_golden.py), so it is refused with that message."""
 
-    def _check_task_token_format(self):
-        cfg = self.config
-        if cfg.num_task_tokens > 0 and cfg.token_order and getattr(cfg, "task_token_format", "emb") != "expand_emb":
-            raise NotImplementedError(
-                f"LlavaMetaForCausalLM with num_task_tokens={cfg.num_task_tokens} and task_token_format="
-                f"{cfg.task_token_format!r}: only 'expand_emb' (mean-pooled rows, llava_arch.py:252-254) or num_task_tokens == 0 "
-                "are implemented on the MI355X path")
+    @staticmethod
+    def _check_task_token_format(cfg):
+        fmt = getattr(cfg, "task_token_format", "emb")
+        if cfg.num_task_tokens > 0 and cfg.token_order:
+            if fmt == "text":
+                raise ValueError("task_token_format='text' embeds the FLOAT special_*_tokens parameters through embed_tokens "
+                                 "(llava_arch.py:257-258): the reference raises 'Expected tensor for argument #1 indices to have one of the "
+                                 "following scalar types: Long, Int' in F.embedding — there is no working 'text' layout to reproduce")
+            if fmt not in ("emb", "expand_emb"):
+                raise ValueError(f"Unexpected task_token_format: {fmt}")                     # llava_arch.py:265
+        cfg.task_token_layout = "pooled" if fmt == "expand_emb" else "raw"
 
 
 class LlavaLlamaModel(LlavaMetaModel, ParamTree):
@@ -82,8 +105,8 @@ class _LlavaCausalLMBase(LlavaMetaForCausalLM, EngineModule):
 
     def __init__(self, config, device="cuda", dtype=torch.bfloat16, init="random", seed=0):
         config.aux_heads = False
+        self._check_task_token_format(config)           # sets config.task_token_layout before the parameters / engine are laid out
         EngineModule.__init__(self, config, device=device, dtype=dtype, init=init, seed=seed)
-        self._check_task_token_format()
 
     def forward(self, input_ids=None, attention_mask=None, position_ids=None, past_key_values=None, inputs_embeds=None,
                 labels=None, use_cache=None, output_attentions=None, output_hidden_states=None, images=None, image_sizes=None,
@@ -92,10 +115,17 @@ class _LlavaCausalLMBase(LlavaMetaForCausalLM, EngineModule):
         (the reference always returns the full fp32 logits; the fused lm_head + CE path never builds them unless asked)."""
         if inputs_embeds is not None or past_key_values is not None or use_cache:
             raise NotImplementedError("the MI355X path covers the training forward (input_ids + images); generation is out of scope")
-        if images is None:
-            raise NotImplementedError("text-only batches without an `images` tensor are not wired (the reference feeds a dummy image)")
         self._sync_trainable()
         eng = self._get_engine()
+        if images is None:
+            # text-only batch: the reference's dataset attaches a zero image to samples without one (train.py LazySupervisedDataset:
+            # `data_dict['image'] = torch.zeros(3, crop, crop)` when the run is multimodal) and the splice consumes an empty feature slice
+            # for samples without an <image> token (llava_arch.py:347-354).  Same here: one zero image per sample, no <image> token allowed.
+            from ..config import IMAGE_TOKEN_INDEX
+            if bool((input_ids == IMAGE_TOKEN_INDEX).any()):
+                raise ValueError("input_ids carry an <image> token but no `images` tensor was given")
+            side = self.config.cnx_image if self.config.is_convnext else self.config.vit_image
+            images = torch.zeros(input_ids.shape[0], 3, side, side, device=eng.dev, dtype=torch.bfloat16)
         batch = dict(input_ids=input_ids, attention_mask=attention_mask, labels=labels, images=images.to(eng.dev))
         eng.keep_logits = bool(kwargs.get("output_logits", False))
         if labels is not None:

@@ -80,8 +80,11 @@ class NativeComm:
             self.h = C.c_void_p()
 
 
-def all_gather_rows(flat: torch.Tensor, comm: NativeComm = None) -> torch.Tensor:
-    """[B, D] on every rank -> [world*B, D], rank r's rows at r*B..(r+1)*B (dist_collect order, ola_utils.py:104-106)."""
+def all_gather_rows(flat: torch.Tensor, comm: NativeComm = None, dry_world: int = 0) -> torch.Tensor:
+    """[B, D] on every rank -> [world*B, D], rank r's rows at r*B..(r+1)*B (dist_collect order, ola_utils.py:104-106).
+    dry_world > 0 (bench.py's "no communication" leg): no collective, the local rows repeated dry_world times (same shapes downstream)."""
+    if dry_world > 0:
+        return flat.repeat(dry_world, 1) if dry_world > 1 else flat
     if comm is not None:
         return comm.allgather(flat) if comm.world > 1 else flat
     rank, world = world_info()
@@ -103,6 +106,7 @@ class GradReducer:
         self.done = []                                  # [lo, hi) ranges already launched this step
         self.reduce_dtype = reduce_dtype
         self._stage = None                              # bf16 wire copy of the gradient buffer (allocated on first use)
+        self.dry = False                                # bench.py's "no communication" leg: buckets are tracked but nothing goes on the wire
 
     def _world(self):
         return self.comm.world if self.comm is not None else world_info()[1]
@@ -125,7 +129,7 @@ class GradReducer:
         if hi <= lo:
             return
         self.done.append((lo, hi))
-        if self._world() <= 1:
+        if self._world() <= 1 or self.dry:
             return
         w = self._wire(lo, hi)
         if self.comm is not None:
@@ -156,9 +160,9 @@ class GradReducer:
             pos = max(pos, hi)
         for w in self.pending:
             w.wait()
-        if self.comm is not None and self._world() > 1:
+        if self.comm is not None and self._world() > 1 and not self.dry:
             self.comm.wait()
-        if self.reduce_dtype != torch.float32 and self._world() > 1:
+        if self.reduce_dtype != torch.float32 and self._world() > 1 and not self.dry:
             for lo, hi in self.done:
                 if self.g.is_cuda:
                     from . import ops

@@ -12,8 +12,10 @@ from collections import OrderedDict
 from .config import layer_indices
 
 
-def _resampler(pfx, dim, emb, out_dim, hc, sh):
+def _resampler(pfx, dim, emb, out_dim, hc, sh, own_latents=False):
     inner = hc["num_heads"] * hc["dim_head"]
+    if own_latents:                                   # Resampler (resampler.py:120-165): learned queries instead of task tokens
+        sh[pfx + "latents"] = (1, hc["num_tokens"], dim)
     sh[pfx + "proj_in.weight"] = (dim, emb); sh[pfx + "proj_in.bias"] = (dim,)
     sh[pfx + "proj_out.weight"] = (out_dim, dim); sh[pfx + "proj_out.bias"] = (out_dim,)
     sh[pfx + "norm_out.weight"] = (out_dim,); sh[pfx + "norm_out.bias"] = (out_dim,)
@@ -45,11 +47,12 @@ def param_shapes(cfg, vit_nested=True, with_vit=True) -> "OrderedDict[str, tuple
     if "gen" in heads and hasattr(cfg, "image_gen"):
         hc = cfg.image_gen
         for i in range(len(layer_indices(hc["img_layer_indices"]))):
-            _resampler(f"image_gen_heads.{i}.projector.", hc["output_dim"], H, hc["output_dim"], hc, sh)   # gen_head.py:48-57
+            _resampler(f"image_gen_heads.{i}.projector.", hc["output_dim"], H, hc["output_dim"], hc, sh, nt == 0)   # gen_head.py:20-29 / 48-57
     if "depth" in heads and hasattr(cfg, "image_depth"):
         hc = cfg.image_depth
         for i in range(len(layer_indices(hc["depth_layer_indices"]))):
-            _resampler(f"image_depth_heads.{i}.projector.", H, H, hc["output_dim"], hc, sh)                 # da_v2_head.py:427-436 (dim = llm hidden)
+            # TaskTokenDepthHead: dim = llm hidden (da_v2_head.py:427-436); the num_task_tokens == 0 DepthHead: dim = output_dim (:386-395)
+            _resampler(f"image_depth_heads.{i}.projector.", H if nt > 0 else hc["output_dim"], H, hc["output_dim"], hc, sh, nt == 0)
             for j in (1, 2, 3):
                 p = f"image_depth_heads.{i}.linear_{j}."
                 sh[p + "0.weight"] = (hc["output_dim"], hc["output_dim"]); sh[p + "0.bias"] = (hc["output_dim"],)
@@ -57,7 +60,7 @@ def param_shapes(cfg, vit_nested=True, with_vit=True) -> "OrderedDict[str, tuple
     if "seg" in heads and hasattr(cfg, "image_seg"):
         hc = cfg.image_seg
         for i in range(len(layer_indices(hc["seg_layer_indices"]))):
-            _resampler(f"image_seg_heads.{i}.projector.", hc["output_dim"], H, hc["output_dim"], hc, sh)    # oneformer_head.py:233-242
+            _resampler(f"image_seg_heads.{i}.projector.", hc["output_dim"], H, hc["output_dim"], hc, sh, nt == 0)    # oneformer_head.py:197-206 / 233-242
     if nt > 0:
         if "depth" in order:
             sh["model.special_depth_tokens"] = (cfg.image_depth["num_tokens"], H)
@@ -164,6 +167,8 @@ def init_value(name, shape, gen, device, dtype):
         return torch.full((), 2.0, device=device, dtype=dtype)
     if "special_" in name:
         return torch.randn(shape, device=device, dtype=dtype, generator=gen)
+    if name.endswith("projector.latents"):            # resampler.py:135: randn(1, num_queries, dim) / dim ** 0.5
+        return torch.randn(shape, device=device, dtype=dtype, generator=gen) / shape[-1] ** 0.5
     if name.startswith("da_v2_head.") and len(shape) == 4:
         fan = shape[0] if ("resize_layers.0." in name or "resize_layers.1." in name) else shape[1] * shape[2] * shape[3]
         return torch.randn(shape, device=device, dtype=dtype, generator=gen) * (1.4 / fan ** 0.5)

@@ -12,7 +12,7 @@ from __future__ import annotations
 
 import numpy as np
 
-from .config import IGNORE_INDEX, IMAGE_TOKEN_INDEX
+from .config import IGNORE_INDEX, IMAGE_TOKEN_INDEX, task_token_rows
 
 N_IMG_TOK = 576   # the reference hard-codes 576 image tokens in the head slicing (base_ola_vlm.py:415-418)
 
@@ -26,6 +26,9 @@ def head_tables(cfg, tasks, B, S):
     out = {}
     if not tasks or S <= ns:                                   # ola_llama.py:139: heads only run when the sequence carries an image
         return out
+    if nt > 0 and getattr(cfg, "task_token_layout", "pooled") != "pooled":
+        raise NotImplementedError("distillation heads slice the sequence by num_task_tokens-row blocks (base_ola_vlm.py:414-417): they only "
+                                  "exist with the PT stage's pooled task-token layout")
     for task in sorted({t for t, _, _ in tasks}):              # SORTED: every rank must issue the all-gathers in the same order
         k = order.index(task)
         s0 = ns + N_IMG_TOK + nt * k
@@ -47,6 +50,16 @@ def head_tables(cfg, tasks, B, S):
         # depth / seg; for gen the state rows of its 8 task tokens, or row b of their per-sample mean)
         hc = {"gen": cfg.image_gen, "seg": cfg.image_seg, "depth": cfg.image_depth}[task]
         n, nq = len(sel), int(hc["num_tokens"])
+        if nt == 0:
+            # num_task_tokens == 0: GenHead / DepthHead / OneFormerSegHead with a plain Resampler (base_ola_vlm.py:429-430, resampler.py:120-165):
+            # the queries are the head's own `latents` parameter (already in the resampler's width, NOT passed through proj_in), so the input
+            # gather holds the state rows only; `lat_rep` tiles the (num_queries, dim) parameter over the batch and `lat_bwd` is its transpose
+            bb = np.arange(B, dtype=np.int32)[:, None]
+            h.update(nq=nq, nl=nq, mode="own", xin_kind=np.zeros(B * n, np.int32), xin_row=(bb * S + sel[None, :]).reshape(-1).astype(np.int32),
+                     mean_idx=None, lat_rep=np.tile(np.arange(nq, dtype=np.int32), B),
+                     lat_bwd=np.ascontiguousarray((bb * nq + np.arange(nq, dtype=np.int32)[None, :]).T.reshape(-1)).astype(np.int32), lat_cnt=B)
+            out[task] = h
+            continue
         nl = nt if task == "gen" else nq                             # gen latents = its nt task-token rows of the state; depth / seg = the
                                                                      # (num_tokens, H) special_{task}_tokens parameter (ola_arch.py:80-90)
         mode = "same" if nl == nq else ("tile" if (nq > 1 and nl > 0 and nq % nl == 0) else "mean")
@@ -111,8 +124,7 @@ def host_plan(cfg, tasks, ids, am=None, lab=None):
         am = np.ones((B, T), bool)
     if lab is None:
         lab = np.full((B, T), IGNORE_INDEX, np.int64)
-    nt = cfg.num_task_tokens
-    n_tok_rows = nt * len(cfg.token_order) if nt > 0 else 0
+    n_tok_rows = sum(r for _, r, _ in task_token_rows(cfg))    # rows the task tokens take behind every image (pooled or raw layout)
     blk = N_IMG_TOK + n_tok_rows
     blk_kind = np.concatenate([np.full(N_IMG_TOK, 1, np.int32), np.full(n_tok_rows, 2, np.int32)])
     blk_lab = np.full(blk, IGNORE_INDEX, np.int64)
@@ -203,6 +215,8 @@ def host_plan(cfg, tasks, ids, am=None, lab=None):
             tables["mean_idx:" + task] = h["mean_idx"]
         if "lat_bwd" in h:
             tables["lat_bwd:" + task] = h["lat_bwd"]
+        if "lat_rep" in h:
+            tables["lat_rep:" + task] = h["lat_rep"]
     for l, inv in inverse_tables(tasks, heads, M).items():
         tables[f"inv:{l}"] = inv.reshape(-1)
     plan["tables"] = tables
