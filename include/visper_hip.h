@@ -111,6 +111,8 @@ int vp_act_bwd(int kind, long n, const void* dy, const void* x, void* dx, vp_str
 int vp_add_bf16(long n, const void* a, const void* b, void* out, vp_stream_t stream);
 int vp_add2d_bf16(long R, int C, void* dst, long ldd, const void* src, long lds, vp_stream_t stream);
 int vp_copy2d_bf16(long R, int C, void* dst, long ldd, const void* src, long lds, vp_stream_t stream);
+/* zero a device range on `stream` (replaces torch's `.zero_()` / `torch.zeros` of gradient buffers and scatter targets) */
+int vp_memset_zero(void* ptr, long bytes, vp_stream_t stream);
 /* depthwise 7x7 conv, NHWC, zero pad 3 — timm ConvNeXtBlock.conv_dw of the CLIP-ConvNeXt-XXL tower
  * (multimodal_encoder/clip_convnext_encoder.py:161-165).  w is tap-major [49, C]. */
 int vp_dwconv7x7_nhwc(int B, int H, int W, int C, const void* x, const void* w, const void* bias, void* y, vp_stream_t stream);

@@ -356,12 +356,22 @@ def decoder_forward(inputs_embeds, position_ids, attention_mask, W, cfg, prefix=
     return hidden, states
 
 
-def ntp_loss(hidden, labels, W, cfg):
-    """ola_llama.py:121-136: lm_head (no bias) -> .float() -> shifted CE, mean over labels != -100."""
-    logits = F.linear(hidden, W["lm_head.weight"]).float()
-    sl = logits[:, :-1].reshape(-1, logits.shape[-1])
+def ntp_loss(hidden, labels, W, cfg, keep_logits=True, chunk_rows=2048):
+    """ola_llama.py:121-136: lm_head (no bias) -> .float() -> shifted CE, mean over labels != -100.
+    keep_logits=False: the same arithmetic in row chunks (every row still goes through lm_head like in the reference; only the
+    8.4 GB fp32 logits tensor of configs[1] is not held at once): sum of the per-row losses / number of labelled rows."""
+    if keep_logits:
+        logits = F.linear(hidden, W["lm_head.weight"]).float()
+        sl = logits[:, :-1].reshape(-1, logits.shape[-1])
+        tl = labels[:, 1:].reshape(-1)
+        return logits, F.cross_entropy(sl, tl, ignore_index=IGNORE_INDEX)
+    h = hidden[:, :-1].reshape(-1, hidden.shape[-1])
     tl = labels[:, 1:].reshape(-1)
-    return logits, F.cross_entropy(sl, tl, ignore_index=IGNORE_INDEX)
+    tot = hidden.new_zeros((), dtype=torch.float32)
+    for r0 in range(0, h.shape[0], chunk_rows):
+        lg = F.linear(h[r0:r0 + chunk_rows], W["lm_head.weight"]).float()
+        tot = tot + F.cross_entropy(lg, tl[r0:r0 + chunk_rows], ignore_index=IGNORE_INDEX, reduction="sum")
+    return None, tot / (tl != IGNORE_INDEX).sum()
 
 
 # ----------------------------------------------------------------------------------------------
@@ -754,8 +764,8 @@ def forward(W, batch, cfg, rank=0, gathered=None, need_logits=True):
     pid, am, emb, labels = prepare_inputs_labels_for_multimodal(
         batch["input_ids"], batch.get("attention_mask"), batch.get("labels"), feats, W, cfg)
     hidden, states = decoder_forward(emb, pid, am, W, cfg)
-    logits, text_loss = ntp_loss(hidden, labels, W, cfg)
-    out = dict(text_loss=text_loss, logits=logits if need_logits else None, labels=labels,
+    logits, text_loss = ntp_loss(hidden, labels, W, cfg, keep_logits=need_logits)
+    out = dict(text_loss=text_loss, logits=logits, labels=labels,
                inputs_embeds=emb, image_features=feats, hidden=hidden, layer_states=states,
                layer_losses={})
     total = text_loss

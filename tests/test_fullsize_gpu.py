@@ -160,3 +160,60 @@ torch.save(outs, os.environ["VP_OUT"])
         valid = torch.isfinite(l0) & (l0 > -1e29)
         assert float((o0 - o1).abs().max()) <= 2e-2 * float(o0.abs().max())
         assert float((l0[valid] - l1[valid]).abs().max()) < 1e-3
+
+
+@pytest.mark.slow
+def test_config1_real_step_vs_reference_style_bf16_cpu_path():
+    """BASELINE.json configs[1] ITSELF — the step bench.py times: CLIP-ViT-L + Llama-3-8B, all 32 layers, B=8, T=1449 -> S=2048, three
+    distillation heads (depth@18, seg@18, gen@20) — on identical random-init weights and batch against the oracle executed like the
+    reference's CPU PyTorch path (bf16 weights and activations, PyTorch bf16 ops, eager attention, every row through lm_head; forward
+    only, torch.no_grad).  Asserted (north-star: "NTP logits and per-layer embedding losses match the reference CPU PyTorch path within
+    1e-3 bf16 relative"): total loss and NTP loss 1e-3; each layer's (emb, sl1, contrastive) triple — sl1 1e-3, emb / contrastive 1e-2
+    (the contrastive term is a softmax over 8 cosine logits x exp(2), the noisiest scalar of the step; configs[0] measured 1.9e-3).
+    ~3-6 min of host time on 64 threads: marked slow, inside the driver's GPU-test budget."""
+    import os
+    import time
+    from oracle import visper_oracle as O
+    from parity import check, rel
+    from visper_lm_amd.config import llama3_8b
+    from visper_lm_amd.engine import Engine
+    from visper_lm_amd.params import param_shapes, init_value
+    cfg = llama3_8b()
+    B, T = 8, 1449
+    gen = torch.Generator(device="cuda").manual_seed(0)
+    W = {k: init_value(k, s, gen, torch.device("cuda"), BF if len(s) else torch.float32) for k, s in param_shapes(cfg, vit_nested=True).items()
+         if not k.startswith("da_v2_head.")}
+    g = torch.Generator().manual_seed(11)
+    ns = cfg.num_sys_tokens
+    ids = torch.randint(0, 1000, (B, T), generator=g)
+    ids[:, ns] = -200
+    labels = ids.clone()
+    labels[:, :ns + 7] = -100
+    rn = lambda *s: torch.randn(*s, generator=g).to(BF)
+    batch = dict(input_ids=ids, labels=labels, attention_mask=torch.ones_like(ids, dtype=torch.bool), images=rn(B, 3, 336, 336),
+                 gen_target=rn(B, 1, 1024), gen_mask=torch.ones(B), depth_target=rn(B, 576, 1024), depth_mask=torch.ones(B),
+                 seg_target=rn(B, 1536, 24, 24), seg_mask=torch.ones(B))
+    eng = Engine(cfg)
+    eng.load_weights(W)
+    out = eng.train_step({k: (v.cuda() if (k == "images" or k.endswith("_target") or k.endswith("_mask")) else v) for k, v in batch.items()})
+    torch.cuda.synchronize()
+    assert out["plan"]["S"] == 2048 and out["plan"]["n_valid"] == B * (T - 1 - (ns + 6))
+    mine = dict(loss=float(out["loss"]), text=float(out["text_loss"]), layers={k: v.float().cpu().tolist() for k, v in out["layer_losses"].items()})
+    gn = float(eng.ps.grad.norm())
+    assert gn > 0 and gn == gn
+    Wc = {k: v.detach().cpu() for k, v in W.items()}
+    del eng, out, W
+    torch.cuda.empty_cache()
+    torch.set_num_threads(min(64, os.cpu_count() or 1))
+    ocfg = O.make_config(**{k: v for k, v in cfg.to_dict().items() if k in vars(O.make_config())})
+    t0 = time.time()
+    with torch.no_grad():
+        ref = O.forward(Wc, batch, ocfg, need_logits=False)
+    print(f"[parity] config1: bf16 CPU oracle forward {time.time() - t0:.1f} s on {torch.get_num_threads()} threads; "
+          f"HIP loss {mine['loss']:.5f} vs {float(ref['loss']):.5f}")
+    check("config1_vs_bf16_cpu_path/loss_rel", rel(mine["loss"], ref["loss"]), 1e-3)
+    check("config1_vs_bf16_cpu_path/text_loss_rel", rel(mine["text"], ref["text_loss"]), 1e-3)
+    assert sorted(ref["layer_losses"]) == sorted(mine["layers"]) == [("depth", 17), ("gen", 19), ("seg", 17)]
+    for key, trip in ref["layer_losses"].items():
+        for j, (nm, bound) in enumerate((("emb", 1e-2), ("sl1", 1e-3), ("con", 1e-2))):
+            check(f"config1_vs_bf16_cpu_path/layer_loss/{key[0]}@{key[1]}/{nm}_rel", rel(mine["layers"][key][j], trip[j]), bound)

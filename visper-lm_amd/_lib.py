@@ -48,6 +48,7 @@ _SIGS = {
     "vp_add_bf16": [l, p, p, p, p],
     "vp_add2d_bf16": [l, i, p, l, p, l, p],
     "vp_copy2d_bf16": [l, i, p, l, p, l, p],
+    "vp_memset_zero": [p, l, p],
     "vp_colsum_partial": [l, i, p, l, p, i, p],
     "vp_colsum_finish": [i, i, p, p, f, i, p],
     "vp_gather_rows": [l, i, p, p, i, p, p, p, l, p],

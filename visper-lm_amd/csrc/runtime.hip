@@ -25,6 +25,18 @@ int vp_check_launch(const char* what) {
 extern "C" {
 const char* vp_last_error_string(void) { return g_err; }
 int vp_version(void) { return 100; }   // 0.1.0
+// Zero `bytes` bytes of device memory on `stream` (gradient buffers, scatter targets): hipMemsetAsync, no kernel of ours and none of the
+// caller's tensor library on the hot path.
+int vp_memset_zero(void* ptr, long bytes, hipStream_t stream) {
+  VP_REQUIRE(ptr && bytes >= 0, VP_ERR_BAD_ARG, "vp_memset_zero: bad args");
+  if (bytes == 0) return VP_OK;
+  hipError_t e = hipMemsetAsync(ptr, 0, (size_t)bytes, stream);
+  if (e != hipSuccess) {
+    vp_set_error("vp_memset_zero: %s", hipGetErrorString(e));
+    return VP_ERR_HIP;
+  }
+  return VP_OK;
+}
 // Device facts the host side sizes grids / workspaces with.
 int vp_device_info(int* cu_count, int* wave_size, long* lds_bytes_per_cu) {
   hipDeviceProp_t prop;

@@ -104,7 +104,7 @@ class ParamStore:
         return (self.shadow if buf is None else buf)[off0:off].view(-1, cols)
 
     def zero_grad(self):
-        self.grad.zero_()
+        ops.zero_(self.grad)
 
     def grad_norm(self, grad_scale=1.0):
         """Global L2 norm of grad_scale * grad (host float; one small reduction kernel + a sync)."""
@@ -793,8 +793,8 @@ class Engine:
             if self.train_llm:
                 # every decoder / lm_head / norm gradient is overwritten by its wgrad GEMM below: clear only what accumulates
                 # (heads, projector, task tokens in front of the LLM block, and the scatter-added embedding table at its end)
-                ps.grad[:ps.index["lm_head.weight"][0]].zero_()
-                ps.g("model.embed_tokens.weight").zero_()
+                ops.zero_(ps.grad[:ps.index["lm_head.weight"][0]])
+                ops.zero_(ps.g("model.embed_tokens.weight"))
             else:
                 ps.zero_grad()
         out = {"plan": plan}
@@ -867,7 +867,7 @@ class Engine:
             lg = ops.gemm(h_ce[r0:r1], fz["lm_head"])
             if logits_keep is not None:
                 logits_keep.append(lg.clone())
-            row_loss[r0:r1] = ops.ce_fwd_bwd(lg, lab_ce[r0:r1], gscale, write_grad=compute_grads)
+            ops.ce_fwd_bwd(lg, lab_ce[r0:r1], gscale, write_grad=compute_grads, out=row_loss[r0:r1])
             if compute_grads:
                 ops.gemm(lg, fz["lm_head_T"], out=d_hce[r0:r1])
                 if self.train_llm:                             # lm_head.weight.grad (+)= dlogits^T h, chunk by chunk
@@ -922,7 +922,7 @@ class Engine:
             cat = torch.empty(tot, H, device=dev, dtype=BF16)
             off = 0
             for _, p in parts:
-                cat[off:off + p.shape[0]] = p
+                ops.copy2d_(cat[off:off + p.shape[0]], p)
                 off += p.shape[0]
             if len(parts) == len([1 for _, _, idx in self.tasks if idx == l]) and l in plan["inv"]:
                 inv_t = plan["inv"][l]                   # built on the host with the plan (no D2H sync in the step)
@@ -946,7 +946,7 @@ class Engine:
             ops.add(d_hidden, d_state[L - 1], out=d_hidden)
         train_llm = self.train_llm
         if train_llm:
-            ps.g("model.norm.weight").copy_(ops.rmsnorm_bwd_w(d_hidden, x, rstd_f))
+            ops.rmsnorm_bwd_w(d_hidden, x, rstd_f, out=ps.g("model.norm.weight"))
             i0 = ps.index["lm_head.weight"][0]
             i1 = ps.index["model.norm.weight"][0] + 64 * ((ps.index["model.norm.weight"][1] + 63) // 64)
             self._reduce_range(i0, i1 - i0)                   # lm_head + final norm gradients are final: reduce under the backward
@@ -972,7 +972,7 @@ class Engine:
             d_hn = ops.gemm(d_gu, fz[o + "wgu_T"])
             del d_gu
             if train_llm:
-                ps.g(pl + "post_attention_layernorm.weight").copy_(ops.rmsnorm_bwd_w(d_hn, h1, rstd2))
+                ops.rmsnorm_bwd_w(d_hn, h1, rstd2, out=ps.g(pl + "post_attention_layernorm.weight"))
             d_h1 = ops.rmsnorm_bwd(d_hn, h1, fz[o + "ln2"], rstd2, dres=dx)
             if train_llm:
                 self._wgrad(att.view(M, nh * hd), d_h1, ps.g(pl + "self_attn.o_proj.weight"))
@@ -996,7 +996,7 @@ class Engine:
                 xn, _ = ops.rmsnorm_fwd(x_in, fz[o + "ln1"], cfg.rms_norm_eps, save_rstd=False)
                 self._wgrad(xn, dqkv, self._gfused(o + "wqkv"))
                 del xn
-                ps.g(pl + "input_layernorm.weight").copy_(ops.rmsnorm_bwd_w(d_xn, x_in, rstd1))
+                ops.rmsnorm_bwd_w(d_xn, x_in, rstd1, out=ps.g(pl + "input_layernorm.weight"))
                 self._reduce_range(*self._llm_ranges[o])        # this layer's gradients are final
             dx = ops.rmsnorm_bwd(d_xn, x_in, fz[o + "ln1"], rstd1, dres=d_h1)
             saved[l] = None
@@ -1129,8 +1129,8 @@ class Engine:
             Nn = torch.empty(B, T, Dm, device=dev, dtype=BF16)
             nx, mx_, rx = ops.layernorm_fwd(Px, ps.w(a + "norm1.weight"), ps.w(a + "norm1.bias"))
             nlat, ml_, rl = ops.layernorm_fwd(lat, ps.w(a + "norm2.weight"), ps.w(a + "norm2.bias"))
-            Nn[:, :n] = nx.view(B, n, Dm)
-            Nn[:, n:] = nlat.view(B, nq, Dm)
+            ops.copy2d_(Nn.view(B, T * Dm)[:, :n * Dm], nx.view(B, n * Dm))
+            ops.copy2d_(Nn.view(B, T * Dm)[:, n * Dm:], nlat.view(B, nq * Dm))
             wqkv = ps.fused([a + "to_q.weight", a + "to_kv.weight"])                               # [3*inner, Dm]: adjacent in the flat store
             QKV = ops.gemm(Nn.view(B * T, Dm), wqkv).view(B, T, 3 * inner)
             q4 = QKV[:, n:, :inner].unflatten(-1, (heads, dh))
@@ -1189,30 +1189,33 @@ class Engine:
             dvout = self._lin_bwd(vout, d_zd, l1 + "0.weight", l1 + "0.bias")
         else:
             dvout = dpred
-        d_po, dw, db = ops.layernorm_bwd(dvout, po, ps.w(pf + "norm_out.weight"), mo, ro)
-        ps.g(pf + "norm_out.weight").copy_(dw); ps.g(pf + "norm_out.bias").copy_(db)
+        d_po, _, _ = ops.layernorm_bwd(dvout, po, ps.w(pf + "norm_out.weight"), mo, ro, dw_out=ps.g(pf + "norm_out.weight"),
+                                       db_out=ps.g(pf + "norm_out.bias"))
         d_lat = self._lin_bwd(lat2, d_po, pf + "proj_out.weight", pf + "proj_out.bias")       # gradient of the latents leaving the last block
         dPx = None
         for (a, f, Nn, mx_, rx, lat_in, ml_, rl, wqkv, q4, k4, v4, att, lse, att2, lat1, y, mf, rf, zf, af) in reversed(blocks):
             d_af = self._lin_bwd(af, d_lat, f + "3.weight")
             d_zf = ops.act_bwd(d_af, zf, ops.EPI_GELU)
             d_y = self._lin_bwd(y, d_zf, f + "1.weight")
-            d_lat1, dw, db = ops.layernorm_bwd(d_y, lat1, ps.w(f + "0.weight"), mf, rf, dres=d_lat)
-            ps.g(f + "0.weight").copy_(dw); ps.g(f + "0.bias").copy_(db)
+            d_lat1, _, _ = ops.layernorm_bwd(d_y, lat1, ps.w(f + "0.weight"), mf, rf, dres=d_lat, dw_out=ps.g(f + "0.weight"),
+                                             db_out=ps.g(f + "0.bias"))
             d_att = self._lin_bwd(att2, d_lat1, a + "to_out.weight")
-            dQKV = torch.zeros(B, T, 3 * inner, device=dev, dtype=BF16)
+            dQKV = ops.zero_(torch.empty(B, T, 3 * inner, device=dev, dtype=BF16))        # the x rows carry no queries: their dq stays 0
             ops.attn_bwd(q4, k4, v4, att, lse, d_att.view(B, nq, heads, dh), causal=False, scale=1.0 / math.sqrt(dh),
                          dq=dQKV[:, n:, :inner].unflatten(-1, (heads, dh)), dk=dQKV[:, :, inner:2 * inner].unflatten(-1, (heads, dh)),
                          dv=dQKV[:, :, 2 * inner:].unflatten(-1, (heads, dh)))
             dQKV2 = dQKV.view(B * T, 3 * inner)
             dNn = ops.gemm(dQKV2, self._wT(a + "to_q|to_kv", wqkv)).view(B, T, Dm)
             self._wgrad(Nn.view(B * T, Dm), dQKV2, ps.fused([a + "to_q.weight", a + "to_kv.weight"], ps.grad))
-            dpx, dw, db = ops.layernorm_bwd(dNn[:, :n].contiguous().view(B * n, Dm), Px, ps.w(a + "norm1.weight"), mx_, rx, dres=dPx)
-            ps.g(a + "norm1.weight").copy_(dw); ps.g(a + "norm1.bias").copy_(db)
+            dNx = torch.empty(B * n, Dm, device=dev, dtype=BF16)
+            dNl = torch.empty(B * nq, Dm, device=dev, dtype=BF16)
+            ops.copy2d_(dNx.view(B, n * Dm), dNn.view(B, T * Dm)[:, :n * Dm])
+            ops.copy2d_(dNl.view(B, nq * Dm), dNn.view(B, T * Dm)[:, n * Dm:])
+            dpx, _, _ = ops.layernorm_bwd(dNx, Px, ps.w(a + "norm1.weight"), mx_, rx, dres=dPx, dw_out=ps.g(a + "norm1.weight"),
+                                          db_out=ps.g(a + "norm1.bias"))
             dPx = dpx                                             # every block reads the same projected tokens: their gradients add up
-            d_lat, dw, db = ops.layernorm_bwd(dNn[:, n:].contiguous().view(B * nq, Dm), lat_in, ps.w(a + "norm2.weight"), ml_, rl,
-                                              dres=d_lat1)        # + residual path lat1 = to_out(.) + latents
-            ps.g(a + "norm2.weight").copy_(dw); ps.g(a + "norm2.bias").copy_(db)
+            d_lat, _, _ = ops.layernorm_bwd(dNl, lat_in, ps.w(a + "norm2.weight"), ml_, rl, dres=d_lat1,     # + residual path lat1 = to_out(.) + latents
+                                            dw_out=ps.g(a + "norm2.weight"), db_out=ps.g(a + "norm2.bias"))
         dPl = d_lat
         if own:
             # the latents parameter was tiled over the batch: its gradient is the batch sum of the final latent gradients

@@ -231,8 +231,8 @@ def layernorm_fwd(x, w, b, eps=1e-5, save_stats=True):
     return y, mean, rstd
 
 
-def layernorm_bwd(dy, x, w, mean, rstd, dres=None, want_wb=True):
-    """-> dx (bf16), dw (f32), db (f32)."""
+def layernorm_bwd(dy, x, w, mean, rstd, dres=None, want_wb=True, dw_out=None, db_out=None):
+    """-> dx (bf16), dw (f32), db (f32); dw_out / db_out: fp32 [H] destinations (e.g. views of the flat gradient buffer) written in place."""
     M, H, ld = _rows2d(x)
     assert dy.is_contiguous() and x.is_contiguous()
     dx = torch.empty_like(x)
@@ -244,14 +244,17 @@ def layernorm_bwd(dy, x, w, mean, rstd, dres=None, want_wb=True):
     pw = torch.empty(nslab, H, device=x.device, dtype=torch.float32)
     pb = torch.empty(nslab, H, device=x.device, dtype=torch.float32)
     _lib.call("vp_layernorm_bwd_wb_partial", M, H, _p(dy), _p(x), _p(mean), _p(rstd), _p(pw), _p(pb), ld, rpb, _stream())
-    dw = torch.empty(H, device=x.device, dtype=torch.float32)
-    db = torch.empty(H, device=x.device, dtype=torch.float32)
+    dw = torch.empty(H, device=x.device, dtype=torch.float32) if dw_out is None else dw_out
+    db = torch.empty(H, device=x.device, dtype=torch.float32) if db_out is None else db_out
     _lib.call("vp_colsum_finish", nslab, H, _p(pw), _p(dw), 1.0, 0, _stream())
     _lib.call("vp_colsum_finish", nslab, H, _p(pb), _p(db), 1.0, 0, _stream())
     return dx, dw, db
 
 
-def rmsnorm_bwd_w(dy, x, rstd):
+_ZEROS_F32 = {}
+
+
+def rmsnorm_bwd_w(dy, x, rstd, out=None):
     """RMSNorm weight gradient sum_rows dy * x * rstd -> f32 [H] (the LayerNorm partial kernel with mean = 0)."""
     M, H, ld = _rows2d(x)
     assert dy.is_contiguous() and x.is_contiguous()
@@ -259,9 +262,11 @@ def rmsnorm_bwd_w(dy, x, rstd):
     nslab = (M + rpb - 1) // rpb
     pw = torch.empty(nslab, H, device=x.device, dtype=torch.float32)
     pb = torch.empty(nslab, H, device=x.device, dtype=torch.float32)
-    zero = torch.zeros(M, device=x.device, dtype=torch.float32)
+    zero = _ZEROS_F32.get((M, x.device))
+    if zero is None:
+        zero = _ZEROS_F32[(M, x.device)] = torch.zeros(M, device=x.device, dtype=torch.float32)
     _lib.call("vp_layernorm_bwd_wb_partial", M, H, _p(dy), _p(x), _p(zero), _p(rstd), _p(pw), _p(pb), ld, rpb, _stream())
-    dw = torch.empty(H, device=x.device, dtype=torch.float32)
+    dw = torch.empty(H, device=x.device, dtype=torch.float32) if out is None else out
     _lib.call("vp_colsum_finish", nslab, H, _p(pw), _p(dw), 1.0, 0, _stream())
     return dw
 
@@ -379,6 +384,13 @@ def add2d_(dst, src):
     _, _, lds = _rows2d(src)
     _lib.call("vp_add2d_bf16", R, Cc, _p(dst), ldd, _p(src), lds, _stream())
     return dst
+
+
+def zero_(t):
+    """t[...] = 0 for a contiguous tensor (hipMemsetAsync on the current stream)."""
+    assert t.is_contiguous()
+    _lib.call("vp_memset_zero", _p(t), t.numel() * t.element_size(), _stream())
+    return t
 
 
 def copy2d_(dst, src):
@@ -519,10 +531,10 @@ def attn_bwd(q, k, v, o, lse, dout, causal, scale=None, window=0, kv_len=None, d
 
 
 # ------------------------------------------------------------------------------------------------
-def ce_fwd_bwd(logits, labels, grad_scale, write_grad=True):
-    """logits [rows, V] bf16 (overwritten with dlogits when write_grad), labels int64 [rows] -> row_loss f32 [rows]."""
+def ce_fwd_bwd(logits, labels, grad_scale, write_grad=True, out=None):
+    """logits [rows, V] bf16 (overwritten with dlogits when write_grad), labels int64 [rows] -> row_loss f32 [rows] (`out`: destination)."""
     rows, V, ld = _rows2d(logits)
-    row_loss = torch.empty(rows, device=logits.device, dtype=torch.float32)
+    row_loss = torch.empty(rows, device=logits.device, dtype=torch.float32) if out is None else out
     _lib.call("vp_ce_fwd_bwd", rows, V, _p(logits), ld, _p(labels), _p(row_loss), grad_scale, 1 if write_grad else 0, _stream())
     return row_loss
 
