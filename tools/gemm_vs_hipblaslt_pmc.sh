@@ -13,33 +13,35 @@ import csv, sys, glob, collections
 out = sys.argv[1]
 kt = glob.glob("/tmp/pmc_vs/**/*kernel_trace.csv", recursive=True)
 cc = glob.glob("/tmp/pmc_vs/**/*counter_collection.csv", recursive=True)
-dur = {}
+rows = {}
 for r in csv.DictReader(open(kt[0])):
-    dur[r["Dispatch_Id"]] = (r["Kernel_Name"], int(r["End_Timestamp"]) - int(r["Start_Timestamp"]), r.get("Grid_Size_X") or r.get("Grid_Size"))
-agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    rows[int(r["Dispatch_Id"])] = dict(name=r["Kernel_Name"], ns=int(r["End_Timestamp"]) - int(r["Start_Timestamp"]), c={})
 for r in csv.DictReader(open(cc[0])):
-    d = r["Dispatch_Id"]
-    if d not in dur:
+    d = int(r["Dispatch_Id"])
+    if d in rows:
+        rows[d]["c"][r["Counter_Name"]] = rows[d]["c"].get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
+groups, prev = [], None
+for d in sorted(rows):
+    r = rows[d]
+    if not ("gemm_nt" in r["name"] or "Cijk" in r["name"]):
         continue
-    name, ns, grid = dur[d]
-    if not ("gemm_nt" in name or "Cijk" in name):
-        continue
-    key = (name[:70], r.get("Grid_Size", grid))
-    agg[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
-    agg[key]["_ns_" + d] = [ns]
+    if prev != r["name"]:
+        groups.append((r["name"], []))
+        prev = r["name"]
+    groups[-1][1].append(r)
+CTR = ("GRBM_GUI_ACTIVE", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_WAIT_INST_ANY", "SQ_WAIT_ANY", "SQ_ACTIVE_INST_ANY", "SQ_INSTS_VALU")
 with open(out + "/summary.txt", "w") as fh:
-    for key, c in agg.items():
-        nss = [v[0] for k, v in c.items() if k.startswith("_ns_")]
-        nss = sorted(nss)[len(nss) // 4:]                       # drop the ramp-up quarter
-        ns = sum(nss) / len(nss)
-        line = f"{key[0]} grid={key[1]} n={len(nss)} avg_us={ns / 1e3:.1f}"
-        for k in ("GRBM_GUI_ACTIVE", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_WAIT_INST_ANY", "SQ_WAIT_ANY", "SQ_ACTIVE_INST_ANY", "SQ_INSTS_VALU"):
-            if k in c:
-                v = c[k]
-                v = sorted(v)[len(v) // 4:]
+    for name, rs in groups:
+        rs = rs[len(rs) // 4:]                                  # drop the ramp-up quarter of each run of back-to-back launches
+        ns = sum(r["ns"] for r in rs) / len(rs)
+        line = f"{name[:48]:48s} n={len(rs):3d} avg_us={ns / 1e3:8.1f}"
+        for k in CTR:
+            v = [r["c"][k] for r in rs if k in r["c"]]
+            if v:
                 m = sum(v) / len(v)
-                line += f" {k}={m:.0f}"
                 if k == "GRBM_GUI_ACTIVE":
-                    line += f" clock_MHz={m / ns * 1e3:.0f}"
+                    line += f" gui_cycles_per_xcd={m / 8:.0f} clock_MHz={m / 8 / ns * 1e3:.0f}"
+                else:
+                    line += f" {k}={m:.3e}"
         print(line); fh.write(line + "\n")
 PY

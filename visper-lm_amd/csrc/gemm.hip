@@ -17,6 +17,22 @@
 #include <mutex>
 #include <unordered_map>
 #include <cstdlib>
+#include <utility>
+#include <type_traits>
+
+// compile-time loop: f(std::integral_constant<int, 0>{}), ..., f(<N-1>) — the index is a constant expression inside f (asm "n" operands,
+// if constexpr), which a `#pragma unroll` loop variable is only after the optimiser ran (and only if it did unroll)
+template <class F, int... I>
+__device__ __forceinline__ void vp_static_for_impl(F&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
+// 4-wave GEMM kernel: gap (of K-step 1) -> which of the 16 fragment reads of the next K-tile's K-step 0 sits there (-1: none)
+constexpr int vp_w4_rd_slot(int g) {
+  constexpr int RG[16] = {13, 15, 18, 20, 22, 25, 27, 29, 32, 34, 36, 39, 41, 43, 46, 48};      // never a DMA (16 + 7k) / m0 (17 + 7k) / offset (19 + 7k) gap
+  for (int r = 0; r < 16; ++r)
+    if (RG[r] == g) return r;
+  return -1;
+}
+template <int N, class F>
+__device__ __forceinline__ void vp_static_for(F&& f) { vp_static_for_impl(static_cast<F&&>(f), std::make_integer_sequence<int, N>{}); }
 
 enum { EPI_NONE = 0, EPI_GELU = 1, EPI_QUICK_GELU = 2, EPI_RELU = 3 };
 
@@ -1165,25 +1181,31 @@ __global__ __launch_bounds__(512) void gemm_tn_256p8(GemmArgs p) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// EXPERIMENTAL (force code 8 / VP_GEMM_W4=1; not the default): 4-wave variant of the persistent 256x256x64 kernel, the structure of
-// hipBLASLt's hand-written MT256x256x64 kernel: ONE wave per SIMD, each owning a 128x128 quarter of the output tile with its 256
-// accumulator registers in AGPRs.  Against the 8-wave kernel every LDS fragment feeds 8 MFMAs instead of 4 (128 KB instead of 192 KB
-// of LDS reads per K-tile and CU) and there is one barrier per K-tile instead of eight; in exchange nothing hides a stall, so the
-// single wave software-pipelines itself and the loop body is hand-ordered inline asm (with 256 accumulators the compiler's own MFMAs
-// come out untied, dst != srcC, and it moves every accumulator through a VGPR once per K-tile: 500 v_accvgpr moves; "+a" ties them.
-// asm ds_reads need explicit waits and a register pin before the first consumer).
-//   step (kt,0): 64 MFMAs on f0 | the 16 reads of f1 = fragments(kt, ks 1), one per MFMA
-//   step (kt,1): 8 MFMAs on f1, vmcnt(0) + barrier (K-tile kt+1 landed everywhere, nobody reads buffer kt&1 any more), 56 MFMAs |
-//                the 16 reads of f0 = fragments(kt+1, ks 0) from the other buffer | the 16 DMA pieces of K-tile kt+2, one per 3.5 MFMAs
-// Measured (tools/gemm_stamps.py, force codes 9-12 = ablations): 64 K-tiles take 168 k shader cycles (8-phase kernel: 170 k; 131 k =
-// MFMA issue only); without the DMA instructions 137 k -- an LDS-DMA instruction costs the lone wave ~30 cycles of MFMA issue even when
-// they are spaced out (2 MFMAs apart: 50 cycles each, 190 k in total; buffer_load...lds and global_load_lds cost the same), which a
-// second wave per SIMD hides for free.  A k-half-major LDS image that spreads the 16 pieces over both steps (two barriers per K-tile,
-// 64-byte rows) was slower (184 k).  End to end it ties the 8-phase kernel (+9 % at N = 28672, -8 % at K = 14336), so the default stays.
+// 4-wave kernel (force code 8 / VP_GEMM_W4): ONE wave per SIMD, each owning a 128x128 quarter of the 256x256 output tile with its 256
+// accumulator registers in AGPRs, every LDS fragment feeding 8 MFMAs (128 KB instead of 192 KB of LDS reads per K-tile and CU).
+//
+// Round 3 rewrite of the K loop.  What the rocprofv3 counters say (profiles/r03_gemm_vs_hipblaslt_pmc.txt; GRBM_GUI_ACTIVE / kernel time =
+// the clock a kernel sustains): hipBLASLt's kernels for the decoder shapes win on CYCLES, not on clock — 2300-2520 GPU cycles per K-tile and
+// CU at 1.72-1.84 GHz against 2810-3030 cycles at 1.89-1.99 GHz for the 8-phase kernel, whose eight waves spend 31 % of their cycles parked
+// at its barriers (SQ_WAIT_ANY; theirs: 6 %).  A lone wave per SIMD never waits for a partner; what it must not do is put more than ONE
+// non-MFMA instruction between two MFMAs (a 16x16x32 MFMA leaves ~3 issue slots): round 2's version of this kernel issued its 16 LDS-DMA
+// pieces in bursts of [buffer_load, s_mov m0, s_add, s_add] inside one gap, all of them in the second half of the K-tile, behind a
+// vmcnt(0), and paid ~30 cycles per piece (168 k cycles per 64 K-tiles against 137 k without the DMA).  The loop below is scheduled by hand:
+//   * every gap between two MFMAs holds at most one other instruction: a ds_read_b128, an LDS-DMA piece, the m0 bump of the previous piece,
+//     a wait or a barrier — and nothing the compiler generates (the per-piece global offsets live in 16 loop-invariant VGPRs, the K advance
+//     in ONE SGPR bumped once per K-tile, the LDS destination in m0 bumped by asm);
+//   * the two LDS buffers release their A and B halves separately (the fragments of K-step 1 are in registers long before the K-tile's
+//     MFMAs are done), so the DMA of K-tile kt+2 starts a quarter into K-tile kt and is spread over ~50 gaps;
+//   * vmcnt is only ever counted (16 pieces stay in flight across the hand-over barrier), never drained.
+// Three barriers per K-tile (A half free | B half free | K-tile kt+1 landed), all four waves run the same stream, so they arrive together.
 // The K-tile stream runs on into the block's next output tile; C staging has its own 32 KB of LDS behind the two buffers.
 // Interior tiles only: M, N multiples of 256, K a multiple of 128 (the launcher checks).
 // ------------------------------------------------------------------------------------------------
-template <bool OUT_F32, int VAR = 0>     // VAR != 0: timing ablations (wrong results): 1 no DMA, 2 no fragment reads, 3 no barrier, 4 no DMA + no reads
+// Ablations run while building it (tools/gemm_w4_ablate.py, 60 back-to-back launches, 16384 x 4096 x 14336): whole kernel 1217-1236 us (8-phase
+// kernel 1323, hipBLASLt 1163-1187); without the fragment reads 1050; without the DMA 1013; unswizzled (perfectly coalesced) DMA source addresses
+// change nothing (1047 vs 1052) — the pieces cost what they cost because DMA and reads share the CU's LDS / texture-address ports, not because
+// of their address pattern.  The ablation instantiations are gone again (they tripled the build time).
+template <bool OUT_F32>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void gemm_nt_256w4(GemmArgs p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   bf16_t* smem = (bf16_t*)smem_raw;                    // [buf 0: A 256x64 | B 256x64][buf 1][C staging 4 x 8 KB]
@@ -1198,13 +1220,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   // LDS-DMA geometry: 16-byte chunk q = it * 256 + tid (it 0..7) of an operand lands at LDS chunk q (lane-linear) = row q >> 3, slot q & 7;
   // it is chunk (q & 7) ^ ((row >> 1) & 7) of that row on the source side, so the 128-byte LDS rows read conflict-free with ds_read_b128
   const int drow = tid >> 3, dsw = ((tid & 7) ^ ((drow >> 1) & 7)) << 3;
-  const uint32_t laneA = (uint32_t)(drow * p.lda + dsw) * 2u, laneB = (uint32_t)(drow * p.ldb + dsw) * 2u;     // byte offsets
-  const uint32_t stepA = (uint32_t)(32 * p.lda * 2), stepB = (uint32_t)(32 * p.ldb * 2);                       // 32 rows per `it`
-  // fragment read addresses (bytes, within a buffer): + i * 2048 per 16-row block
+  // one lane offset per operand (bytes into the 256-row panel); the piece (32 rows each) and the K-tile go into the scalar offset
+  const uint32_t vA = (uint32_t)(drow * p.lda + dsw) * 2u, vB = (uint32_t)(drow * p.ldb + dsw) * 2u;
+  const uint32_t stepA = __builtin_amdgcn_readfirstlane((uint32_t)(32 * p.lda * 2)), stepB = __builtin_amdgcn_readfirstlane((uint32_t)(32 * p.ldb * 2));
+  // fragment read addresses (bytes): + i * 2048 per 16-row block; one set per LDS buffer so the loop needs no address arithmetic
   const int fsw0 = (g ^ ((fr >> 1) & 7)) << 3, fsw1 = ((4 + g) ^ ((fr >> 1) & 7)) << 3;
   const uint32_t ldsb = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)smem;
   const uint32_t aad0 = ldsb + 2u * (uint32_t)((wr * 128 + fr) * 64 + fsw0), aad1 = ldsb + 2u * (uint32_t)((wr * 128 + fr) * 64 + fsw1);
   const uint32_t bad0 = ldsb + 32768u + 2u * (uint32_t)((wc * 128 + fr) * 64 + fsw0), bad1 = ldsb + 32768u + 2u * (uint32_t)((wc * 128 + fr) * 64 + fsw1);
+  uint32_t aad0x = aad0 + 65536u, aad1x = aad1 + 65536u, bad0x = bad0 + 65536u, bad1x = bad1 + 65536u;
+  asm volatile("" : "+v"(aad0x), "+v"(aad1x), "+v"(bad0x), "+v"(bad1x));     // keep them in registers (not re-derived inside the loop)
+  // LDS destination of this wave's first piece in buffer 0 / 1 (every piece is 1 KB per wave, 4 KB per workgroup; 16 pieces = one buffer)
+  const uint32_t m0b0 = __builtin_amdgcn_readfirstlane(ldsb + (uint32_t)wave * 1024u), m0b1 = m0b0 + 65536u;
 
   int sbm = 0, sbn = 0;
   if (gridDim.x == 256 && !(p.dbg & 0x40000)) {
@@ -1214,102 +1241,148 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #define TILE_OF(V) (sbm ? tile_coord_sb((V), tiles_m, tiles_n, sbm, sbn) : tile_coord_256((V), tiles_m, tiles_n))
   int v = blockIdx.x;
   TileCoord tc = TILE_OF(v);
-  // DMA stream state (wave-uniform): next K-tile to fetch = K-tile `kn` of tile `vn`.  buffer_load ... lds: one 32-bit lane offset per
-  // operand, everything else (panel base, K-tile, 32-row step) in the SGPR descriptor / soffset
+  // DMA stream state (wave-uniform): next K-tile to fetch = K-tile `kn` of tile `vn`; its byte offset along K is the soffset `kofs`
+  typedef uint32_t u32x4s __attribute__((ext_vector_type(4)));
+  auto make_rs = [&](const bf16_t* base, long rows_ld) -> u32x4s {
+    const uint64_t b = (uint64_t)(uintptr_t)base;
+    u32x4s r;
+    r[0] = __builtin_amdgcn_readfirstlane((uint32_t)b);
+    r[1] = __builtin_amdgcn_readfirstlane((uint32_t)(b >> 32) & 0xffffu);
+    r[2] = __builtin_amdgcn_readfirstlane((uint32_t)(256u * (uint32_t)rows_ld * 2u));
+    r[3] = 0x00020000u;
+    return r;
+  };
   int vn = v, kn = 0;
-  __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)(p.A + (long)tc.m0 * p.lda), 0, (int)(256u * (uint32_t)p.lda * 2u), 0x00020000);
-  __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)(p.B + (long)tc.n0 * p.ldb), 0, (int)(256u * (uint32_t)p.ldb * 2u), 0x00020000);
-#define W4_DMA_A(IT, DST) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)(DST), 16, (int)laneA, kn * 128 + (IT) * (int)stepA, 0, 0)
-#define W4_DMA_B(IT, DST) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (__attribute__((address_space(3))) void*)(DST), 16, (int)laneB, kn * 128 + (IT) * (int)stepB, 0, 0)
-  // piece d (0..15) of the K-tile going to buffer BP (element pointer): even A, odd B
-#define W4_PIECE(D, BP)                                                                                \
-  {                                                                                                    \
-    if ((D) & 1) W4_DMA_B((D) >> 1, (BP) + 16384 + ((D) >> 1) * 2048 + wave * 512);                    \
-    else W4_DMA_A((D) >> 1, (BP) + ((D) >> 1) * 2048 + wave * 512);                                    \
-  }
+  uint32_t kofs = 0, soff = 0;                         // kofs: byte offset of the stream's K-tile along K; soff: kofs + piece * step, walked by asm
+  u32x4s rsA = make_rs(p.A + (long)tc.m0 * p.lda, p.lda), rsB = make_rs(p.B + (long)tc.n0 * p.ldb, p.ldb);
+#define W4_DMA(VOFF, RS) asm volatile("buffer_load_dwordx4 %0, %1, %2 offen lds" ::"v"(VOFF), "s"(RS), "s"(soff) : "memory")
+#define W4_SOFF0() asm volatile("s_mov_b32 %0, %1" : "=s"(soff) : "s"(kofs))                  /* first piece of an operand */
+#define W4_SOFFBUMP(STEP) asm volatile("s_add_u32 %0, %0, %1" : "+s"(soff) : "s"(STEP) : "scc")
+#define W4_M0SET(X) asm volatile("s_mov_b32 m0, %0" ::"s"(X) : "memory")
+#define W4_M0BUMP() asm volatile("s_add_u32 m0, m0, 0x1000" ::: "memory", "scc")
+#define W4_KBUMP() asm volatile("s_add_u32 %0, %0, 0x80" : "+s"(kofs)::"scc")
 #define ADVANCE_STREAM()                                                                               \
   {                                                                                                    \
     if (++kn == nt) {                                                                                  \
       kn = 0;                                                                                          \
+      kofs = 0;                                                                                        \
       if (vn + (int)gridDim.x < ntiles) vn += gridDim.x;      /* else: harmless in-bounds re-fetch of the last tile */ \
       const TileCoord tn_ = TILE_OF(vn);                                                               \
-      rsA = __builtin_amdgcn_make_buffer_rsrc((void*)(p.A + (long)tn_.m0 * p.lda), 0, (int)(256u * (uint32_t)p.lda * 2u), 0x00020000); \
-      rsB = __builtin_amdgcn_make_buffer_rsrc((void*)(p.B + (long)tn_.n0 * p.ldb), 0, (int)(256u * (uint32_t)p.ldb * 2u), 0x00020000); \
+      rsA = make_rs(p.A + (long)tn_.m0 * p.lda, p.lda);                                                \
+      rsB = make_rs(p.B + (long)tn_.n0 * p.ldb, p.ldb);                                                \
     }                                                                                                  \
   }
 #define W4_MFMA(ACC, BF, AF) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(ACC) : "v"(BF), "v"(AF))
 #define W4_MFMA0(ACC, BF, AF) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=a"(ACC) : "v"(BF), "v"(AF))
-#define W4_LDS(DST, ADDR, OFF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(DST) : "v"(ADDR), "n"(OFF))
+#define W4_LDS(DST, ADDR, OFF) do { asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(DST) : "v"(ADDR), "n"(OFF)); } while (0)
 #define W4_PIN(F) asm volatile("" : "+v"(F))
-  // MFMA number m of a step (0..63): row i = m >> 3, column block c = m & 7
-#define W4_MF1(MF, FA, FB, M) { if (VAR != 7 && VAR != 8) MF(acc[((M) & 7) >> 2][(M) >> 3][(M) & 3], FB[(M) & 7], FA[(M) >> 3]); }
-  // read slot r (0..15) -> fragment: fa[0..6], fb[0..7], fa[7]  (a register's last consumer is >= 8 MFMAs behind its reload)
-#define W4_RD(FA, FB, AAD, BAD, R)                                                                     \
-  {                                                                                                    \
-    if ((R) < 7) W4_LDS(FA[(R) < 7 ? (R) : 0], AAD, ((R) < 7 ? (R) : 0) * 2048);                       \
-    else if ((R) < 15) W4_LDS(FB[(R) >= 7 && (R) < 15 ? (R) - 7 : 0], BAD, ((R) >= 7 && (R) < 15 ? (R) - 7 : 0) * 2048); \
-    else W4_LDS(FA[7], AAD, 7 * 2048);                                                                 \
+#define W4_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#define W4_BAR() asm volatile("s_barrier" ::: "memory")
+  // MFMA number m of a K-step (0..63): B fragment (m >> 3), A fragment (m & 7): consecutive MFMAs never share an accumulator
+#define W4_MF1(MF, FA, FB, M) MF(acc[(M) >> 5][(M) & 7][((M) >> 3) & 3], FB[(M) >> 3], FA[(M) & 7])
+
+  // ---- prologue: K-tiles 0 and 1 of the first output tile
+  W4_M0SET(m0b0);
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {                        // (m0 runs on from buffer 0 into buffer 1)
+#pragma unroll
+    for (int d = 0; d < 16; ++d) {
+      if (d == 0 || d == 8) W4_SOFF0();
+      if (d < 8) { W4_DMA(vA, rsA); W4_SOFFBUMP(stepA); } else { W4_DMA(vB, rsB); W4_SOFFBUMP(stepB); }
+      W4_M0BUMP();
+    }
+    W4_KBUMP();
+    ADVANCE_STREAM();
   }
-#pragma unroll
-  for (int d = 0; d < 16; ++d) W4_PIECE(d, smem);
-  ADVANCE_STREAM();
-#pragma unroll
-  for (int d = 0; d < 16; ++d) W4_PIECE(d, smem + 32768);
-  ADVANCE_STREAM();
   asm volatile("s_waitcnt vmcnt(16)" ::: "memory");    // K-tile 0 landed (this wave's part)
-  VP_BAR();
+  W4_BAR();
   bf16x8 fa0[8], fb0[8], fa1[8], fb1[8];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) W4_RD(fa0, fb0, aad0, bad0, r);
+  for (int r = 0; r < 8; ++r) { W4_LDS(fa0[r], aad0, r * 2048); W4_LDS(fb0[r], bad0, r * 2048); }
+  // asm ds_reads are invisible to the compiler's wait-count bookkeeping: if it moves or spills one of these registers before the data has
+  // landed it saves garbage (seen: a scratch_store of fa0[7] right behind its ds_read, in front of the per-wave dispatch below).  Every point
+  // where compiler-generated code follows in-flight fragment reads therefore waits for them first.
+  W4_LGKM0();
+
+  // One K-tile.  CUR = its LDS buffer (0 / 1: literal, the loop is unrolled by two), MF0 = the MFMA form of its K-step 0 (zero-init on the
+  // first K-tile of an output tile), PH = this wave's phase.  Gap g = the slot behind MFMA g of the K-step; every memory instruction of the
+  // schedule sits PH gaps later in wave PH.  Why: the four waves of the block run the same stream in lock-step behind the barriers, so without
+  // the phase all four hand the SAME instruction to the CU's one texture-address unit / one LDS in the same cycle, and the last of them waits
+  // three instruction times before its next MFMA can issue (rocprofv3: SQ_VMEM_TA_ADDR_FIFO_FULL 34x hipBLASLt's; an LDS-DMA piece cost ~27
+  // cycles of MFMA issue, DMA and fragment reads together +24 % over either alone).  hipBLASLt's hand-written kernel does the same with two
+  // copies of its loop chosen by the SIMD id; here every wave has its own slot.
+#define W4_AT(M, G) ((M) - (PH_) == (G))
+#define W4_KTILE(CUR, MF0, PH)                                                                         \
+  {                                                                                                    \
+    constexpr int PH_ = (PH);                                                                          \
+    const uint32_t ra1_ = (CUR) ? aad1x : aad1, rb1_ = (CUR) ? bad1x : bad1;      /* K-step 1 of this K-tile  */ \
+    const uint32_t ra0n_ = (CUR) ? aad0 : aad0x, rb0n_ = (CUR) ? bad0 : bad0x;    /* K-step 0 of the next one */ \
+    W4_LGKM0();                                                                                        \
+    _Pragma("unroll") for (int i = 0; i < 8; ++i) { W4_PIN(fa0[i]); W4_PIN(fb0[i]); }                  \
+    /* ---- K-step 0: 64 MFMAs on f0 */                                                                \
+    vp_static_for<64>([&](auto mc_) __attribute__((always_inline)) {                                   \
+      constexpr int m = decltype(mc_)::value;                                                          \
+      W4_MF1(MF0, fa0, fb0, m);                                                                        \
+      constexpr int g_ = m - PH_;                                                                      \
+      if constexpr (g_ >= 0 && g_ < 16 && !(g_ & 1)) W4_LDS(fa1[(g_ >> 1) & 7], ra1_, ((g_ >> 1) & 7) * 2048);   /* A fragments of K-step 1: gaps 0,2..14 */ \
+      if (g_ == 18) W4_LGKM0();                                                                        \
+      if (g_ == 19) W4_BAR();                                                      /* the A half of this buffer is free */ \
+      if (g_ == 17) W4_SOFF0();                                                                        \
+      if (g_ == 20) W4_M0SET((CUR) ? m0b1 : m0b0);                                                     \
+      if (g_ >= 21 && g_ <= 56 && (g_ - 21) % 5 == 0) W4_DMA(vA, rsA);             /* A pieces of K-tile kt+2: gaps 21,26..56 */ \
+      if (g_ >= 22 && g_ <= 57 && (g_ - 22) % 5 == 0) W4_M0BUMP();                                     \
+      if (g_ >= 23 && g_ <= 53 && (g_ - 23) % 5 == 0) W4_SOFFBUMP(stepA);          /* 23,28..53: 7 bumps between the 8 pieces */ \
+      if constexpr (g_ >= 24 && g_ <= 40 && ((g_ - 24) % 5 == 0 || (g_ - 24) % 5 == 1))    /* B fragments: gaps 24,25,29,30,..,39,40 */ \
+        W4_LDS(fb1[(((g_ - 24) / 5) * 2 + (g_ - 24) % 5) & 7], rb1_, ((((g_ - 24) / 5) * 2 + (g_ - 24) % 5) & 7) * 2048); \
+      if (g_ == 58) W4_SOFF0();                                                    /* B operand starts at the K-tile's offset again */ \
+      if (g_ == 44) W4_LGKM0();                                                                        \
+      if (g_ == 45) W4_BAR();                                                      /* the B half is free */ \
+    });                                                                                                \
+    _Pragma("unroll") for (int i = 0; i < 8; ++i) { W4_PIN(fa1[i]); W4_PIN(fb1[i]); }                  \
+    /* ---- K-step 1: 64 MFMAs on f1 */                                                                \
+    vp_static_for<64>([&](auto mc_) __attribute__((always_inline)) {                                   \
+      constexpr int m = decltype(mc_)::value;                                                          \
+      W4_MF1(W4_MFMA, fa1, fb1, m);                                                                    \
+      constexpr int g_ = m - PH_;                                                                      \
+      if (g_ == 1 || g_ == 5) W4_DMA(vB, rsB);                                     /* B pieces 0,1 */  \
+      if (g_ == 2 || g_ == 6) W4_M0BUMP();                                                             \
+      if (g_ == 3 || g_ == 7) W4_SOFFBUMP(stepB);                                                      \
+      if (g_ == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");              /* K-tile kt+1 landed (this wave's part): 10 pieces of kt+2 newer */ \
+      if (g_ == 11) W4_BAR();                                                      /* ... and everybody's */ \
+      if (g_ >= 16 && g_ <= 51 && (g_ - 16) % 7 == 0) W4_DMA(vB, rsB);             /* B pieces 2..7: gaps 16,23,..,51 */ \
+      if (g_ >= 17 && g_ <= 45 && (g_ - 17) % 7 == 0) W4_M0BUMP();                                     \
+      if (g_ >= 19 && g_ <= 47 && (g_ - 19) % 7 == 0) W4_SOFFBUMP(stepB);                              \
+      if (g_ == 53) W4_KBUMP();                                                                        \
+      constexpr int r_ = vp_w4_rd_slot(g_);                                        /* the 16 fragments of K-step 0 of K-tile kt+1 */ \
+      if constexpr (r_ >= 0 && r_ < 8) W4_LDS(fa0[r_ & 7], ra0n_, (r_ & 7) * 2048);                    \
+      if constexpr (r_ >= 8) W4_LDS(fb0[r_ & 7], rb0n_, (r_ & 7) * 2048);                              \
+    });                                                                                                \
+    ADVANCE_STREAM();                                                                                  \
+  }
+#define W4_MAINLOOP(PH)                                                                                \
+  {                                                                                                    \
+    W4_KTILE(0, W4_MFMA0, PH);                                                                         \
+    W4_KTILE(1, W4_MFMA, PH);                                                                          \
+    for (int kt = 2; kt < nt; kt += 2) {                                                               \
+      W4_KTILE(0, W4_MFMA, PH);                                                                        \
+      W4_KTILE(1, W4_MFMA, PH);                                                                        \
+    }                                                                                                  \
+  }
+
   while (true) {
-    f32x4 acc[2][8][4];
+    f32x4 acc[2][8][4];                                // [B fragment >> 2][A fragment][B fragment & 3]
     const TileCoord tcur = tc;
     if ((p.dbg & 0x10000) && threadIdx.x == 0 && v == (int)blockIdx.x) {
       vp_dbg_stamps[blockIdx.x * 8 + 1] = wall_clock64();
       vp_dbg_stamps[blockIdx.x * 8 + 6] = clock64();
     }
-    for (int kt = 0; kt < nt; ++kt) {
-      const uint32_t co = (uint32_t)(kt & 1) << 16, cn = co ^ 65536u;     // byte offsets of this / the other buffer
-      // ---- step 0: 64 MFMAs on f0; the 16 reads of f1 (ks 1 of this K-tile), one per MFMA
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-      for (int i = 0; i < 8; ++i) { W4_PIN(fa0[i]); W4_PIN(fb0[i]); }
-#define W4_STEP0(MF)                                                                                   \
-  _Pragma("unroll") for (int m = 0; m < 64; ++m) {                                                     \
-    if (m < 16 && VAR != 2 && VAR != 4 && VAR != 7 && VAR != 8) W4_RD(fa1, fb1, aad1 + co, bad1 + co, m);                      \
-    W4_MF1(MF, fa0, fb0, m);                                                                           \
-  }
-      if (kt == 0) { W4_STEP0(W4_MFMA0) } else { W4_STEP0(W4_MFMA) }
-#undef W4_STEP0
-      // ---- step 1: 8 MFMAs on f1, the K-tile hand-over, then the 16 reads of f0 = fragments (kt+1, ks 0) from the other buffer (one per
-      // MFMA) and the 16 DMA pieces of K-tile kt+2 into the buffer just released, one per 3.5 MFMAs
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-      for (int i = 0; i < 8; ++i) { W4_PIN(fa1[i]); W4_PIN(fb1[i]); }
-#pragma unroll
-      for (int m = 0; m < 8; ++m) W4_MF1(W4_MFMA, fa1, fb1, m);
-      if (VAR != 8) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // K-tile kt+1 landed (this wave's part)
-      else asm volatile("s_waitcnt vmcnt(48)" ::: "memory");           // (VAR 8: three more K-tiles may stay in flight)
-      if (VAR != 3 && VAR != 8) __builtin_amdgcn_s_barrier();
-      {
-        bf16_t* cb = smem + (kt & 1) * 32768;
-#pragma unroll
-        for (int m = 8; m < 64; ++m) {
-          if (m - 8 < 16 && VAR != 2 && VAR != 4 && VAR != 7 && VAR != 8) W4_RD(fa0, fb0, aad0 + cn, bad0 + cn, m - 8);
-          if (VAR != 1 && VAR != 4) {
-#pragma unroll
-            for (int d = 0; d < 16; ++d)
-              if (m == 8 + (7 * d) / 2) W4_PIECE(d, cb);
-          }
-          W4_MF1(W4_MFMA, fa1, fb1, m);
-        }
-      }
-      ADVANCE_STREAM();
-    }
+    W4_MAINLOOP(0)          // (per-wave phases 0..3 — hipBLASLt runs two copies of its loop one MFMA apart, chosen by the SIMD id — measured: no gain
+                            // here once the pieces are spread out, 1219-1241 us at 16384 x 4096 x 14336 either way; one copy is a quarter of the code)
     if ((p.dbg & 0x10000) && threadIdx.x == 0 && v == (int)blockIdx.x) {
       vp_dbg_stamps[blockIdx.x * 8 + 2] = wall_clock64();
       vp_dbg_stamps[blockIdx.x * 8 + 7] = clock64();
     }
+    W4_LGKM0();                                        // the next tile's first fragments have landed before compiler code may touch them
     asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");   // last MFMA results visible to the compiler's v_accvgpr_reads
 #pragma unroll
     for (int h = 0; h < 2; ++h)
@@ -1338,16 +1411,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the trailing dummy DMAs must not outlive the workgroup's LDS
 #undef TILE_OF
-#undef W4_DMA_A
-#undef W4_DMA_B
-#undef W4_PIECE
+#undef W4_DMA
+#undef W4_M0SET
+#undef W4_M0BUMP
+#undef W4_SOFF0
+#undef W4_SOFFBUMP
+#undef W4_KBUMP
 #undef ADVANCE_STREAM
 #undef W4_MFMA
 #undef W4_MFMA0
 #undef W4_LDS
 #undef W4_PIN
+#undef W4_LGKM0
+#undef W4_BAR
 #undef W4_MF1
-#undef W4_RD
+#undef W4_KTILE
+#undef W4_MAINLOOP
+#undef W4_AT
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1592,10 +1672,14 @@ int vp_gemm_bf16(int M, int N, int K, const void* A, long lda, const void* B, lo
   const long big_tiles = (long)((M + 255) / 256) * ((N + 255) / 256);
   {
     static int w4_env = -1;
-    if (w4_env < 0) { const char* e = getenv("VP_GEMM_W4"); w4_env = e ? atoi(e) : 0; }
+    if (w4_env < 0) { const char* e = getenv("VP_GEMM_W4"); w4_env = e ? atoi(e) : 1; }      // default since round 3 (VP_GEMM_W4=0: the 8-phase kernel)
+    if (g_dyn_mode == 1 && force_generic == 0) w4_env = w4_env == 1 ? 2 : w4_env;            // (2 = eligible but parked: see below)
     const bool w4_ok = fast && M % 256 == 0 && N % 256 == 0 && K % 128 == 0 && (big_tiles >= 192 || force_generic >= 8) &&
                        (!out_f32 || (!bias && !residual && (epilogue & 0xff) == EPI_NONE && ldc % 4 == 0 && (((uintptr_t)C) & 15) == 0));
-    if (w4_ok && (force_generic == 8 || (force_generic == 0 && w4_env == 1))) {
+    // the 4-wave kernel walks its tiles statically; next to RCCL kernels (vp_gemm_set_dynamic: world > 1) the 8-phase kernel's per-XCD tile
+    // claims keep a CU that a collective holds from stalling the whole grid, so the multi-GPU step stays on it
+    if (w4_ok && (force_generic == 8 || (force_generic == 0 && w4_env == 1 && g_dyn_mode != 1))) {
+      p.c_nt = (!out_f32 && N <= 8192 && (long)M * ldc * 2 < 0x7fffffffL && vp_c_nt_enabled()) ? 1 : 0;
       static bool attr_w4 = false;
       if (!attr_w4) {
         (void)hipFuncSetAttribute((const void*)gemm_nt_256w4<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
@@ -1605,17 +1689,6 @@ int vp_gemm_bf16(int M, int N, int K, const void* A, long lda, const void* B, lo
       const unsigned g4 = (unsigned)(big_tiles > 256 ? 256 : big_tiles);
       if (out_f32) hipLaunchKernelGGL(gemm_nt_256w4<true>, dim3(g4), dim3(256), 163840, stream, p);
       else hipLaunchKernelGGL(gemm_nt_256w4<false>, dim3(g4), dim3(256), 163840, stream, p);
-      return vp_check_launch("vp_gemm_bf16");
-    }
-    if (w4_ok && !out_f32 && ((force_generic >= 9 && force_generic <= 12) || force_generic == 16 || force_generic == 17)) {      // timing ablations of the 4-wave kernel (dev only, wrong results)
-      const unsigned g4 = (unsigned)(big_tiles > 256 ? 256 : big_tiles);
-#define W4_ABL(V)                                                                                                              \
-  {                                                                                                                            \
-    (void)hipFuncSetAttribute((const void*)gemm_nt_256w4<false, V>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);       \
-    hipLaunchKernelGGL((gemm_nt_256w4<false, V>), dim3(g4), dim3(256), 163840, stream, p);                                     \
-  }
-      if (force_generic == 9) W4_ABL(1) else if (force_generic == 10) W4_ABL(2) else if (force_generic == 11) W4_ABL(3) else if (force_generic == 16) W4_ABL(7) else if (force_generic == 17) W4_ABL(8) else W4_ABL(4)
-#undef W4_ABL
       return vp_check_launch("vp_gemm_bf16");
     }
   }
@@ -1691,12 +1764,25 @@ int vp_gemm_bf16_swiglu(int mode, int M, int N, int K, const void* A, long lda, 
                "vp_gemm_bf16_swiglu: backward operands");
   GemmArgs p{(const bf16_t*)A, (const bf16_t*)B, C, nullptr, nullptr, M, N, K, lda, ldb, ldc, 0, EPI_NONE, 0,
              mode, C2, ldc2, (const bf16_t*)aux, ldaux};
+  const long big_tiles = (long)(M / 256) * (N / 256);
+  {
+    static int w4_env = -1;
+    if (w4_env < 0) { const char* e = getenv("VP_GEMM_W4"); w4_env = e ? atoi(e) : 1; }
+    if (w4_env == 1 && g_dyn_mode != 1 && K % 128 == 0 && big_tiles >= 192) {               // same routing as vp_gemm_bf16
+      static bool attr_w4 = false;
+      if (!attr_w4) {
+        (void)hipFuncSetAttribute((const void*)gemm_nt_256w4<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
+        attr_w4 = true;
+      }
+      hipLaunchKernelGGL(gemm_nt_256w4<false>, dim3((unsigned)(big_tiles > 256 ? 256 : big_tiles)), dim3(256), 163840, stream, p);
+      return vp_check_launch("vp_gemm_bf16_swiglu");
+    }
+  }
   static bool attr_p8 = false;
   if (!attr_p8) {
     (void)hipFuncSetAttribute((const void*)gemm_nt_256p8<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
     attr_p8 = true;
   }
-  const long big_tiles = (long)(M / 256) * (N / 256);
   const unsigned g8 = (unsigned)(((K / 64) % 2 == 0 && big_tiles > 256) ? 256 : big_tiles);
   if (g8 == 256) p.sched = vp_sched_for(stream);
   vp_setup_balance(p, g8, stream);
