@@ -448,6 +448,143 @@ __device__ __forceinline__ void epilogue_swz(const GemmArgs& p, bf16_t* wave_lds
   }
 }
 
+// Epilogue of the 4-wave kernel (decoder GEMMs: no bias, no activation; optional residual; fused SwiGLU forward / backward).  The 256
+// accumulators live in AGPRs and NEVER become compiler-managed values: inline asm writes them straight from the AGPRs into the wave's 8 KB
+// staging slice as fp32 (ds_write_b128 takes AGPR data), 32 rows x 64 columns per pass, eight passes per wave; what the compiler sees is only
+// the read-back — rows re-laid so that a lane holds 8 (or 16) consecutive columns — bf16 rounding, residual / SwiGLU arithmetic and 16-byte
+// stores, all on ordinary VGPRs.  (Letting the compiler read the accumulators itself made it pull all 256 out of the AGPRs at the K loop's exit:
+// ~500 v_accvgpr_mov / scratch spills per output tile, epilogue 10 us against the 8-phase kernel's 4.)  fp32 rows are 256 B: the 16-byte chunk
+// index is XOR-ed with (row & 15) so that both the column-strided writes and the row-major reads are bank-conflict free.  Rounding points as
+// everywhere: accumulator -> bf16, (+ residual -> bf16) / (SwiGLU on bf16-rounded values): bit-identical to epilogue_swz.
+// Loads a pass needs (residual rows, saved gate|up rows) are issued one pass ahead.
+#define W4E_WRITE(ADDR, ACC, OFF) asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(ADDR), "a"(ACC), "n"(OFF) : "memory")
+__device__ __forceinline__ void epilogue_w4(const GemmArgs& p, bf16_t* wave_lds, f32x4 (&acc)[2][8][4], int mrow0, int ncol0, int lane) {
+  const int fr = lane & 15, g = lane >> 4;
+  const uint32_t lb = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)wave_lds;
+  uint32_t wad[4];                                      // write address of column block j: row fr (+ 16 t via the offset), chunk (4 j + g) ^ fr
+#pragma unroll
+  for (int j = 0; j < 4; ++j) wad[j] = lb + (uint32_t)(fr * 256 + (((j * 4 + g) ^ fr) << 4));
+  const float* stg = (const float*)wave_lds;
+  // pass hp = h * 4 + rq: columns ncol0 + 64 h .., rows mrow0 + 32 rq ..
+  auto dump = [&](int hp) __attribute__((always_inline)) {
+    const int h = hp >> 2, rq = hp & 3;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (t == 0) W4E_WRITE(wad[j], acc[h][rq * 2 + t][j], 0); else W4E_WRITE(wad[j], acc[h][rq * 2 + t][j], 4096);
+      }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  };
+  // 8 consecutive columns (chunks 2c, 2c + 1) of staged row r, rounded to bf16 pairs
+  auto rd8 = [&](int r, int c) __attribute__((always_inline)) -> u32x4 {
+    const f32x4 lo = *(const f32x4*)(stg + r * 64 + (((2 * c) ^ (r & 15)) << 2));
+    const f32x4 hi = *(const f32x4*)(stg + r * 64 + (((2 * c + 1) ^ (r & 15)) << 2));
+    u32x4 v;
+    v[0] = pack_bf16x2(lo[0], lo[1]); v[1] = pack_bf16x2(lo[2], lo[3]); v[2] = pack_bf16x2(hi[0], hi[1]); v[3] = pack_bf16x2(hi[2], hi[3]);
+    return v;
+  };
+  const int rl0 = lane >> 3, ch = lane & 7;             // read-back lane map: row rl0 + 8 it (it 0..3), columns 8 ch ..
+  if (p.mode == 2) {
+    bf16x8 gv[2][4], uv[2][4];
+    auto load2 = [&](int hp, int slot) __attribute__((always_inline)) {
+      const int h = hp >> 2, rq = hp & 3;
+      const bf16_t* gptr = p.aux + (long)(mrow0 + rq * 32 + rl0) * p.ldaux + 2 * (ncol0 + h * 64 + ch * 8);
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        gv[slot][it] = *(const bf16x8*)(gptr + (long)(it * 8) * p.ldaux);
+        uv[slot][it] = *(const bf16x8*)(gptr + (long)(it * 8) * p.ldaux + 8);
+      }
+    };
+    load2(0, 0);
+#pragma unroll
+    for (int hp = 0; hp < 8; ++hp) {
+      const int h = hp >> 2, rq = hp & 3, slot = hp & 1;
+      dump(hp);
+      if (hp + 1 < 8) load2(hp + 1, slot ^ 1);
+      bf16_t* dptr = (bf16_t*)p.C + (long)(mrow0 + rq * 32 + rl0) * p.ldc + 2 * (ncol0 + h * 64 + ch * 8);
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const bf16x8 dv = __builtin_bit_cast(bf16x8, rd8(it * 8 + rl0, ch));
+        bf16x8 og, ou;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float gg = bf2f((bf16_t)gv[slot][it][e]), uu = bf2f((bf16_t)uv[slot][it][e]), dd = bf2f((bf16_t)dv[e]);
+          const float sg = 1.f / (1.f + __expf(-gg));
+          og[e] = (short)f2bf(dd * uu * sg * (1.f + gg * (1.f - sg)));
+          ou[e] = (short)f2bf(dd * gg * sg);
+        }
+        *(bf16x8*)(dptr + (long)(it * 8) * p.ldc) = og;
+        *(bf16x8*)(dptr + (long)(it * 8) * p.ldc + 8) = ou;
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the slice is read before the next pass overwrites it
+    }
+    return;
+  }
+  if (p.mode == 1) {
+    // SwiGLU forward: lane (row rl + 16 it, it 0..1; chunk pair pr) holds 16 consecutive columns = one (g8 | u8) pair: stores both 16-byte halves
+    // of gate_up and the 8 act columns
+    const int rl = lane >> 2, pr = lane & 3;
+#pragma unroll
+    for (int hp = 0; hp < 8; ++hp) {
+      const int h = hp >> 2, rq = hp & 3;
+      dump(hp);
+      bf16_t* cptr = (bf16_t*)p.C + (long)(mrow0 + rq * 32 + rl) * p.ldc + ncol0 + h * 64 + pr * 16;
+      bf16_t* aptr = (bf16_t*)p.C2 + (long)(mrow0 + rq * 32 + rl) * p.ldc2 + ((ncol0 + h * 64) >> 1) + pr * 8;
+#pragma unroll
+      for (int it = 0; it < 2; ++it) {
+        const u32x4 gq = rd8(it * 16 + rl, 2 * pr), uq = rd8(it * 16 + rl, 2 * pr + 1);
+        *(u32x4*)(cptr + (long)(it * 16) * p.ldc) = gq;
+        *(u32x4*)(cptr + (long)(it * 16) * p.ldc + 8) = uq;
+        const bf16x8 gvv = __builtin_bit_cast(bf16x8, gq), uvv = __builtin_bit_cast(bf16x8, uq);
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (short)f2bf(bfround(silu(bf2f((bf16_t)gvv[e]))) * bf2f((bf16_t)uvv[e]));
+        *(bf16x8*)(aptr + (long)(it * 16) * p.ldc2) = o;
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    return;
+  }
+  // plain / residual
+  u32x4 rv[2][4];
+  const bool has_res = p.res != nullptr;
+  auto loadr = [&](int hp, int slot) __attribute__((always_inline)) {
+    const int h = hp >> 2, rq = hp & 3;
+    const bf16_t* rptr = p.res + (long)(mrow0 + rq * 32 + rl0) * p.ldr + ncol0 + h * 64 + ch * 8;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) rv[slot][it] = *(const u32x4*)(rptr + (long)(it * 8) * p.ldr);
+  };
+  if (has_res) loadr(0, 0);
+#pragma unroll
+  for (int hp = 0; hp < 8; ++hp) {
+    const int h = hp >> 2, rq = hp & 3, slot = hp & 1;
+    dump(hp);
+    if (has_res && hp + 1 < 8) loadr(hp + 1, slot ^ 1);
+    bf16_t* cptr = (bf16_t*)p.C + (long)(mrow0 + rq * 32 + rl0) * p.ldc + ncol0 + h * 64 + ch * 8;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      u32x4 v = rd8(it * 8 + rl0, ch);
+      if (has_res) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float lo = __builtin_bit_cast(float, v[e] << 16) + __builtin_bit_cast(float, rv[slot][it][e] << 16);
+          const float hi = __builtin_bit_cast(float, v[e] & 0xffff0000u) + __builtin_bit_cast(float, rv[slot][it][e] & 0xffff0000u);
+          v[e] = pack_bf16x2(lo, hi);
+        }
+      }
+      if (p.c_nt) {
+        const __amdgpu_buffer_rsrc_t crs = __builtin_amdgcn_make_buffer_rsrc((void*)p.C, 0, 0x7fffffff, 0x00020000);
+        __builtin_amdgcn_raw_buffer_store_b128(v, crs, (int)((const char*)cptr - (const char*)p.C), (int)((long)(it * 8) * p.ldc * 2), 2);
+      } else {
+        *(u32x4*)(cptr + (long)(it * 8) * p.ldc) = v;
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
+}
+#undef W4E_WRITE
+
 template <bool OUT_F32>
 __global__ __launch_bounds__(512) void gemm_nt_256(GemmArgs p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -1241,6 +1378,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #define TILE_OF(V) (sbm ? tile_coord_sb((V), tiles_m, tiles_n, sbm, sbn) : tile_coord_256((V), tiles_m, tiles_n))
   int v = blockIdx.x;
   TileCoord tc = TILE_OF(v);
+  if ((p.dbg & 0x10000) && threadIdx.x == 0) vp_dbg_stamps[blockIdx.x * 8 + 0] = wall_clock64();
   // DMA stream state (wave-uniform): next K-tile to fetch = K-tile `kn` of tile `vn`; its byte offset along K is the soffset `kofs`
   typedef uint32_t u32x4s __attribute__((ext_vector_type(4)));
   auto make_rs = [&](const bf16_t* base, long rows_ld) -> u32x4s {
@@ -1273,7 +1411,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     }                                                                                                  \
   }
 #define W4_MFMA(ACC, BF, AF) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(ACC) : "v"(BF), "v"(AF))
-#define W4_MFMA0(ACC, BF, AF) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=a"(ACC) : "v"(BF), "v"(AF))
+#define W4_MFMA0(ACC, BF, AF) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "+a"(ACC) : "v"(BF), "v"(AF))
 #define W4_LDS(DST, ADDR, OFF) do { asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(DST) : "v"(ADDR), "n"(OFF)); } while (0)
 #define W4_PIN(F) asm volatile("" : "+v"(F))
 #define W4_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
@@ -1369,8 +1507,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     }                                                                                                  \
   }
 
+  // The 256 accumulators are ONE value chain for the whole kernel: defined once here, then only ever modified in place ("+a") — also by the
+  // zero-initialising MFMA form of each output tile's first K-step.  With a fresh definition ("=a") per output tile the register allocator
+  // bridged the two definitions with ~500 v_accvgpr_mov per tile at the K loop's entry and exit (epilogue 10 us instead of 4).
+  f32x4 acc[2][8][4];                                  // [B fragment >> 2][A fragment][B fragment & 3]
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) asm volatile("" : "=a"(acc[h][i][j]));
   while (true) {
-    f32x4 acc[2][8][4];                                // [B fragment >> 2][A fragment][B fragment & 3]
     const TileCoord tcur = tc;
     if ((p.dbg & 0x10000) && threadIdx.x == 0 && v == (int)blockIdx.x) {
       vp_dbg_stamps[blockIdx.x * 8 + 1] = wall_clock64();
@@ -1382,20 +1529,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       vp_dbg_stamps[blockIdx.x * 8 + 2] = wall_clock64();
       vp_dbg_stamps[blockIdx.x * 8 + 7] = clock64();
     }
-    W4_LGKM0();                                        // the next tile's first fragments have landed before compiler code may touch them
+    W4_LGKM0();                                        // (the reads the last K-tile issued for the next tile's first fragments have landed)
+    // The fragment registers are NOT kept across the epilogue: with all 256 AGPRs holding accumulators the epilogue's own registers (staging
+    // addresses, two slots of prefetched residual / gate|up rows) did not fit beside 64 live fragment VGPRs and the allocator spilled
+    // accumulator tuples to scratch.  They are re-read (16 ds_read_b128, ~300 cycles) once the tile is stored.
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { asm volatile("" : "=v"(fa0[i])); asm volatile("" : "=v"(fb0[i])); }
     asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");   // last MFMA results visible to the compiler's v_accvgpr_reads
+    if (OUT_F32) {
 #pragma unroll
-    for (int h = 0; h < 2; ++h)
+      for (int h = 0; h < 2; ++h)
 #pragma unroll
-      for (int i = 0; i < 8; ++i)
+        for (int i = 0; i < 8; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) asm volatile("" : "+a"(acc[h][i][j]));
+          for (int j = 0; j < 4; ++j) asm volatile("" : "+a"(acc[h][i][j]));
+    }
     const int vnext = v + gridDim.x;
     const int mr = tcur.m0 + wr * 128, nc = tcur.n0 + wc * 128;
     if (!OUT_F32) {
       bf16_t* stage = smem + 65536 + wave * 4096;
-      epilogue_swz<2>(p, stage, acc[0], mr, nc, lane);
-      epilogue_swz<2>(p, stage, acc[1], mr, nc + 64, lane);
+      epilogue_w4(p, stage, acc, mr, nc, lane);        // (the launcher sends bias / activation epilogues and unaligned C to the 8-phase kernel:
+                                                       // the general epilogue's registers beside 256 accumulators made the allocator spill AGPRs)
     } else {
       float* c = (float*)p.C + (long)(mr + fr) * p.ldc + nc + g * 4;
 #pragma unroll
@@ -1405,11 +1559,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
           for (int j = 0; j < 4; ++j) *(f32x4*)(c + (long)(i * 16) * p.ldc + h * 64 + j * 16) = acc[h][i][j];
     }
+    if ((p.dbg & 0x10000) && threadIdx.x == 0 && v == (int)blockIdx.x) {
+      vp_dbg_stamps[blockIdx.x * 8 + 3] = wall_clock64();          // epilogue issued
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      vp_dbg_stamps[blockIdx.x * 8 + 4] = wall_clock64();          // ... and its stores drained
+    }
     if (vnext >= ntiles) break;
     v = vnext;
     tc = TILE_OF(v);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) { W4_LDS(fa0[r], aad0, r * 2048); W4_LDS(fb0[r], bad0, r * 2048); }      // K-tile 0 of the next tile: buffer 0 (nt is even)
+    W4_LGKM0();
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the trailing dummy DMAs must not outlive the workgroup's LDS
+  if ((p.dbg & 0x10000) && threadIdx.x == 0) vp_dbg_stamps[blockIdx.x * 8 + 5] = wall_clock64();
+  if ((p.dbg & 0x10000) && threadIdx.x == 0 && false) vp_dbg_stamps[blockIdx.x * 8 + 0] = 0;
 #undef TILE_OF
 #undef W4_DMA
 #undef W4_M0SET
@@ -1675,7 +1839,8 @@ int vp_gemm_bf16(int M, int N, int K, const void* A, long lda, const void* B, lo
     if (w4_env < 0) { const char* e = getenv("VP_GEMM_W4"); w4_env = e ? atoi(e) : 1; }      // default since round 3 (VP_GEMM_W4=0: the 8-phase kernel)
     if (g_dyn_mode == 1 && force_generic == 0) w4_env = w4_env == 1 ? 2 : w4_env;            // (2 = eligible but parked: see below)
     const bool w4_ok = fast && M % 256 == 0 && N % 256 == 0 && K % 128 == 0 && (big_tiles >= 192 || force_generic >= 8) &&
-                       (!out_f32 || (!bias && !residual && (epilogue & 0xff) == EPI_NONE && ldc % 4 == 0 && (((uintptr_t)C) & 15) == 0));
+                       !bias && (epilogue & 0xff) == EPI_NONE && (((uintptr_t)C) & 15) == 0 &&
+                       (out_f32 ? (!residual && ldc % 4 == 0) : (ldc % 8 == 0 && (!residual || (ldr % 8 == 0 && (((uintptr_t)residual) & 15) == 0))));
     // the 4-wave kernel walks its tiles statically; next to RCCL kernels (vp_gemm_set_dynamic: world > 1) the 8-phase kernel's per-XCD tile
     // claims keep a CU that a collective holds from stalling the whole grid, so the multi-GPU step stays on it
     if (w4_ok && (force_generic == 8 || (force_generic == 0 && w4_env == 1 && g_dyn_mode != 1))) {
