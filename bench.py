@@ -474,8 +474,9 @@ def main():
     ms = dt / args.steps * 1e3
     value = args.batch * world * args.steps / dt
 
-    # roofline of the dominant kernel: gemm_nt_256p8 (every GEMM with >= 192 256x256 output tiles routes to it; ~75 % of the
-    # step).  achieved = algorithmic 2*M*N*K of those launches / their HIP-event-timed duration on the launch stream.
+    # roofline of the dominant kernel: the persistent 256x256x64 bf16 MFMA GEMM (every GEMM with >= 192 256x256 output tiles routes to it:
+    # gemm_nt_256w4 since round 3, gemm_nt_256p8 with VP_GEMM_W4=0 or for the few shapes the 4-wave kernel does not take; ~80 % of the step).
+    # achieved = algorithmic 2*M*N*K of those launches / their HIP-event-timed duration on the launch stream.
     def is_p8(shp):
         M_, N_, K_ = shp
         return K_ % 64 == 0 and M_ >= 256 and N_ >= 256 and ((M_ + 255) // 256) * ((N_ + 255) // 256) >= 192
@@ -492,7 +493,10 @@ def main():
             traffic = json.load(fh).get("hbm_bytes_per_launch") if args.workload == "llama3_8b" else None
     except (OSError, ValueError):
         pass
-    roof = {"bound": "mfma", "kernel": "gemm_nt_256p8 (bf16 MFMA 16x16x32, persistent 256x256x64 tiles, two wave groups in ping-pong, 4 phases per K-tile)",
+    w4 = os.environ.get("VP_GEMM_W4", "1") != "0"
+    roof = {"bound": "mfma", "kernel": ("gemm_nt_256w4 (bf16 MFMA 16x16x32, persistent 256x256x64 tiles, one wave per SIMD with a 128x128 sub-tile in AGPRs, "
+                                        "hand-scheduled K loop: one LDS-DMA piece / ds_read per MFMA gap)" if w4 else
+                                        "gemm_nt_256p8 (bf16 MFMA 16x16x32, persistent 256x256x64 tiles, two wave groups in ping-pong, 4 phases per K-tile)"),
             "achieved": round(achieved, 1), "peak": PEAK_BF16_TF, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TF, 4),
             "traffic": traffic, "launches_per_step": len(big) // max(args.steps, 1),
             "avg_launch_ms": round(b_ms / max(len(big), 1), 4), "tflop_per_launch": round(b_fl / max(len(big), 1) / 1e12, 4),

@@ -1837,13 +1837,14 @@ int vp_gemm_bf16(int M, int N, int K, const void* A, long lda, const void* B, lo
   {
     static int w4_env = -1;
     if (w4_env < 0) { const char* e = getenv("VP_GEMM_W4"); w4_env = e ? atoi(e) : 1; }      // default since round 3 (VP_GEMM_W4=0: the 8-phase kernel)
-    if (g_dyn_mode == 1 && force_generic == 0) w4_env = w4_env == 1 ? 2 : w4_env;            // (2 = eligible but parked: see below)
     const bool w4_ok = fast && M % 256 == 0 && N % 256 == 0 && K % 128 == 0 && (big_tiles >= 192 || force_generic >= 8) &&
                        !bias && (epilogue & 0xff) == EPI_NONE && (((uintptr_t)C) & 15) == 0 &&
                        (out_f32 ? (!residual && ldc % 4 == 0) : (ldc % 8 == 0 && (!residual || (ldr % 8 == 0 && (((uintptr_t)residual) & 15) == 0))));
-    // the 4-wave kernel walks its tiles statically; next to RCCL kernels (vp_gemm_set_dynamic: world > 1) the 8-phase kernel's per-XCD tile
-    // claims keep a CU that a collective holds from stalling the whole grid, so the multi-GPU step stays on it
-    if (w4_ok && (force_generic == 8 || (force_generic == 0 && w4_env == 1 && g_dyn_mode != 1))) {
+    // The 4-wave kernel walks its tiles statically.  Next to RCCL kernels (world > 1) a CU that a collective holds delays that block's share
+    // (tools/gemm_interference.py: up to 1.45x for the launches that overlap a collective); in the PT step that is the handful of GEMMs under the
+    // 0.2 GB gradient all-reduce, against 6-10 % on every launch with the 8-phase kernel and its per-XCD tile claims — so the multi-GPU step uses
+    // it too (VP_GEMM_W4=0 / VP_GEMM_W4=2 "only when no collective can run beside it" select the 8-phase kernel).
+    if (w4_ok && (force_generic == 8 || (force_generic == 0 && (w4_env == 1 || (w4_env == 2 && g_dyn_mode != 1))))) {
       p.c_nt = (!out_f32 && N <= 8192 && (long)M * ldc * 2 < 0x7fffffffL && vp_c_nt_enabled()) ? 1 : 0;
       static bool attr_w4 = false;
       if (!attr_w4) {
@@ -1933,7 +1934,7 @@ int vp_gemm_bf16_swiglu(int mode, int M, int N, int K, const void* A, long lda, 
   {
     static int w4_env = -1;
     if (w4_env < 0) { const char* e = getenv("VP_GEMM_W4"); w4_env = e ? atoi(e) : 1; }
-    if (w4_env == 1 && g_dyn_mode != 1 && K % 128 == 0 && big_tiles >= 192) {               // same routing as vp_gemm_bf16
+    if ((w4_env == 1 || (w4_env == 2 && g_dyn_mode != 1)) && K % 128 == 0 && big_tiles >= 192) {        // same routing as vp_gemm_bf16
       static bool attr_w4 = false;
       if (!attr_w4) {
         (void)hipFuncSetAttribute((const void*)gemm_nt_256w4<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
