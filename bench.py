@@ -195,6 +195,32 @@ def k11_probe(cfg, B, world, dev, n=50):
         out[task] = {"D": D, "fwd_us": round(uf, 1), "bwd_us": round(ub, 1), "fwd_GBps": round(bf / uf / 1e3, 1), "bwd_GBps": round(bb / ub / 1e3, 1),
                      "fwd_frac_of_8TBps": round(bf / uf / 1e3 / 8000.0, 3), "bwd_frac_of_8TBps": round(bb / ub / 1e3 / 8000.0, 3),
                      "fwd_launches": 1, "bwd_launches": 1}
+    # every head of the step in ONE launch each way (vp_emb_loss_{fwd,bwd}_multi: what the engine issues): bytes of all tasks / one launch
+    tasks = [(t, out[t]["D"]) for t in ("depth", "seg", "gen") if t in out]
+    if len(tasks) > 1:
+        Bw = B * world
+        preds = [torch.randn(B, D, device=dev, dtype=torch.bfloat16) for _, D in tasks]
+        tgts = [torch.randn(Bw, D, device=dev, dtype=torch.bfloat16) for _, D in tasks]
+        masks = [torch.ones(B, device=dev) for _ in tasks]
+        scales = [torch.full((1,), 2.0, device=dev) for _ in tasks]
+        res = ops.emb_loss_fwd_multi(preds, tgts, masks, scales, [0.3] * len(tasks))
+        coefs = [c for _, c in res]
+
+        def t2(fn):
+            fn(); torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(n):
+                fn()
+            e1.record(); torch.cuda.synchronize()
+            return e0.elapsed_time(e1) / n * 1e3
+        uf = t2(lambda: ops.emb_loss_fwd_multi(preds, tgts, masks, scales, [0.3] * len(tasks)))
+        ub = t2(lambda: ops.emb_loss_bwd_multi(preds, tgts, coefs, [0.5] * len(tasks)))
+        bf = sum(2.0 * D * (B + Bw) for _, D in tasks); bb = sum(2.0 * D * (2 * B + Bw) for _, D in tasks)
+        out["all_heads_one_launch"] = {"tasks": [t for t, _ in tasks], "fwd_us": round(uf, 1), "bwd_us": round(ub, 1),
+                                       "fwd_GBps": round(bf / uf / 1e3, 1), "bwd_GBps": round(bb / ub / 1e3, 1),
+                                       "fwd_frac_of_8TBps": round(bf / uf / 1e3 / 8000.0, 3), "bwd_frac_of_8TBps": round(bb / ub / 1e3 / 8000.0, 3),
+                                       "fwd_launches": 1, "bwd_launches": 1}
     return out
 
 

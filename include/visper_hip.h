@@ -182,14 +182,22 @@ int vp_ce_fwd_bwd(long rows, int V, void* logits, long ld, const long* labels, f
  * contrastive} exactly as _emb_loss returns them (not yet multiplied by the task weight); coef (2B + B*Bw + 1 floats) carries the
  * backward coefficients and d loss / d logit_scale in its last slot.  workspace: vp_emb_loss_workspace(B, Bw, D) floats, uninitialised.
  * 0 < B <= 64 local predictions, B <= Bw <= 1024 gathered targets (rank-ordered, rank r's rows at r*B), D % 8 == 0; pred [B,D] and
- * tgt_all [Bw,D] bf16 row-major, 16-byte aligned.  logit_scale NULL = no contrastive term.  Calls on DIFFERENT streams may overlap
- * only if their stream handles hash to different counter slots (8 slots); calls on one stream are always safe. */
+ * tgt_all [Bw,D] bf16 row-major, 16-byte aligned.  logit_scale NULL = no contrastive term.  Every distinct stream gets its own ticket
+ * counters (up to 32 streams per process), so calls on different streams may overlap freely; calls on one stream are ordered by it. */
 long vp_emb_loss_workspace(int B, int Bw, long D);
 /* dev aid (tools/emb_loss_debug.py): device buffer of 8 int64 for in-kernel wall-clock stamps of later vp_emb_loss_fwd calls; NULL = off */
 int vp_debug_emb_loss_stamps(long long* dev_buf);
 int vp_emb_loss_fwd(int B, int Bw, long D, int rank, const void* pred, const void* tgt_all, const float* mask,
                     const float* logit_scale, float w_contrastive, float* out3, float* coef, float* workspace,
                     vp_stream_t stream);
+/* The same for `ntask` (<= 8) distillation heads in ONE launch each way (blockIdx.z = head): the heads of a step share B, Bw and rank and
+ * differ in D, pointers, workspace and contrastive weight (host arrays of length ntask).  The reference calls _emb_loss once per head and
+ * layer (base_ola_vlm.py:445-534). */
+int vp_emb_loss_fwd_multi(int ntask, int B, int Bw, const long* D, int rank, const void* const* pred, const void* const* tgt_all,
+                          const float* const* mask, const float* const* logit_scale, const float* w_contrastive, float* const* out3,
+                          float* const* coef, float* const* workspace, vp_stream_t stream);
+int vp_emb_loss_bwd_multi(int ntask, int B, int Bw, const long* D, int rank, const void* const* pred, const void* const* tgt_all,
+                          const float* const* coef, const float* grad_out, void* const* dpred, vp_stream_t stream);
 int vp_emb_loss_bwd(int B, int Bw, long D, int rank, const void* pred, const void* tgt_all, const float* coef,
                     float grad_out, void* dpred, vp_stream_t stream);
 

@@ -760,3 +760,25 @@ def test_xcd_speed_calibration_and_clock_probe(ops):
     ck = bench.clock_probe(torch.device("cuda"), n=6)
     assert 800 < ck["shader_clock_mhz"] <= 2500 and len(ck["per_xcd_mhz"]) == 8, ck
     assert 0.5 < ck["mfma_issue_util_in_k_loop"] <= 1.0, ck
+
+
+def test_emb_loss_multi_task_launch_equals_single_launches(ops):
+    """vp_emb_loss_{fwd,bwd}_multi: the three distillation heads of a step (different D, same B / Bw / rank) in ONE launch each way give
+    bit-identical losses, coefficients and d_pred to three single-head launches (same blocks, same summation order per head)."""
+    B, world, rank = 8, 2, 1
+    Ds = [1024, 576 * 64, 24 * 24 * 40]
+    g = torch.Generator(device="cuda").manual_seed(12)
+    preds = [(torch.randn(B, D, device="cuda", generator=g) * 1.3).to(torch.bfloat16) for D in Ds]
+    tgts = [torch.randn(B * world, D, device="cuda", generator=g).to(torch.bfloat16) for D in Ds]
+    masks = [torch.ones(B, device="cuda"), torch.tensor([1., 0., 1., 1., 0.5, 1., 1., 1.], device="cuda"), torch.ones(B, device="cuda")]
+    scales = [torch.tensor([2.0], device="cuda"), torch.tensor([1.5], device="cuda"), None]
+    single = [ops.emb_loss_fwd(p, t, m, s, 0.3, rank=rank) for p, t, m, s in zip(preds, tgts, masks, scales)]
+    multi = ops.emb_loss_fwd_multi(preds, tgts, masks, scales, [0.3] * 3, rank=rank)
+    for (o1, c1), (o2, c2) in zip(single, multi):
+        assert torch.equal(o1, o2) and torch.equal(c1, c2)
+    d1 = [ops.emb_loss_bwd(p, t, c, 0.5, rank=rank) for p, t, (_, c) in zip(preds, tgts, single)]
+    d2 = ops.emb_loss_bwd_multi(preds, tgts, [c for _, c in multi], [0.5] * 3, rank=rank)
+    for a, b in zip(d1, d2):
+        assert torch.equal(a, b)
+    again = ops.emb_loss_fwd_multi(preds, tgts, masks, scales, [0.3] * 3, rank=rank)          # counters re-armed per task
+    assert all(torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) for a, b in zip(multi, again))

@@ -25,3 +25,24 @@ ms = t(lambda: ops.attn_fwd(q, k, v, True))
 print(f"fwd  {ms:.3f} ms  {fl / ms / 1e9:.0f} TF/s")
 ms = t(lambda: ops.attn_bwd(q, k, v, o, lse, do, True, dq=dq, dk=dk, dv=dv))
 print(f"bwd  {ms:.3f} ms  {2.5 * fl / ms / 1e9:.0f} TF/s (algorithmic 2.5x fwd)")
+
+# comparison baseline only (like hipBLASLt in tools/gemm_bench.py): PyTorch's scaled_dot_product_attention (AOTriton flash kernels on ROCm), GQA
+# expanded to 32 kv heads, same causal shape; forward and forward+backward
+try:
+    import torch.nn.functional as F
+    qh = q.permute(0, 2, 1, 3).contiguous().requires_grad_(True)
+    kh = k.permute(0, 2, 1, 3).repeat_interleave(Hq // Hkv, 1).contiguous().requires_grad_(True)
+    vh = v.permute(0, 2, 1, 3).repeat_interleave(Hq // Hkv, 1).contiguous().requires_grad_(True)
+    doh = do.permute(0, 2, 1, 3).contiguous()
+    from torch.nn.attention import sdpa_kernel, SDPBackend
+    with sdpa_kernel(SDPBackend.FLASH_ATTENTION):
+        ms = t(lambda: F.scaled_dot_product_attention(qh, kh, vh, is_causal=True), n=10)
+        print(f"torch SDPA (flash / AOTriton) fwd  {ms:.3f} ms  {fl / ms / 1e9:.0f} TF/s")
+        oh = F.scaled_dot_product_attention(qh, kh, vh, is_causal=True)
+        def fb():
+            oh_ = F.scaled_dot_product_attention(qh, kh, vh, is_causal=True)
+            oh_.backward(doh)
+        msb = t(fb, n=10)
+        print(f"torch SDPA fwd+bwd {msb:.3f} ms -> bwd ~{msb - ms:.3f} ms  {2.5 * fl / (msb - ms) / 1e9:.0f} TF/s")
+except Exception as e:  # noqa: BLE001
+    print("torch SDPA comparison unavailable:", type(e).__name__, str(e)[:200])

@@ -69,6 +69,8 @@ _SIGS = {
     "vp_sumsq_nblk": [l],
     "vp_emb_loss_fwd": [i, i, l, i, p, p, p, p, f, p, p, p, p],
     "vp_emb_loss_bwd": [i, i, l, i, p, p, p, f, p, p],
+    "vp_emb_loss_fwd_multi": [i, i, i, p, i, p, p, p, p, p, p, p, p, p],
+    "vp_emb_loss_bwd_multi": [i, i, i, p, i, p, p, p, p, p, p],
     "vp_adamw": [l, p, p, p, p, p, f, f, f, f, f, i, f, p],
     "vp_comm_unique_id_bytes": [],
     "vp_comm_unique_id": [p],

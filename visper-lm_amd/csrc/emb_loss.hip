@@ -28,7 +28,8 @@ constexpr int G1 = 32;                 // blocks per first-level reduction group
 constexpr int MAX_GROUPS = 1024;       // njc * ngrp
 constexpr int N_SLOTS = 32;            // independent counter sets, one per DISTINCT stream (el_slot_for: a registry, not a hash, so two streams
                                        // can never share tickets); calls on one stream are ordered by the stream itself
-__device__ unsigned g_counters[N_SLOTS][1 + MAX_GROUPS];   // zero at module load; every launch leaves its slot zeroed again
+constexpr int MAX_TASKS = 8;           // distillation heads batched into one launch (vp_emb_loss_fwd_multi: blockIdx.z = task)
+__device__ unsigned g_counters[N_SLOTS][MAX_TASKS][1 + MAX_GROUPS];   // zero at module load; every launch leaves its slot zeroed again
 
 struct ElArgs {
   const bf16_t* pred;
@@ -41,7 +42,7 @@ struct ElArgs {
   float* part2;      // [njc][ngrp][NS]
   float* fin;        // PT[B][Bw] | TT[Bw] | PP[B] | SL[B]
   long D;
-  int B, Bw, rank, nblk, njc, ngrp, slot;
+  int B, Bw, rank, nblk, njc, ngrp, slot, task;
   float w_con;
   long long* dbg;    // dev aid: 8 wall-clock stamps (100 MHz) of the finishing block, or null
 };
@@ -207,9 +208,20 @@ __device__ void el_finalize(const ElArgs& a, float* PT, int ldpt, const float* T
 
 // grid (nblk, njc): block x streams k-steps {x*4 + wave + i * nblk*4}; chunk jc = gathered targets [jc*NG*16, (jc+1)*NG*16).
 // NPB = 16-row blocks of local predictions, NG = 16-row groups of gathered targets per chunk.
+struct ElMulti { ElArgs t[MAX_TASKS]; };
+
 template <int NPB, int NG>
-__global__ __launch_bounds__(256) void emb_loss_fwd_kernel(const ElArgs a) {
+__global__ __launch_bounds__(256) void emb_loss_fwd_kernel(const ElMulti mt) {
   constexpr int PB = NPB * 16, TC = NG * 16, NS = PB * TC + TC + 2 * PB;
+  // blockIdx.z = task (one launch for every distillation head of the step: same B / Bw, own D, pointers, workspace and ticket counters);
+  // the grid is sized for the longest task, the other tasks' surplus blocks leave at once (they hold no tickets)
+  // (static indices + selects: a DYNAMICALLY indexed array inside a by-value kernel argument returned wrong elements — the compiler bug round 2 met
+  // in the GEMM's balancing arguments)
+  ElArgs a = mt.t[0];
+#pragma unroll
+  for (int t = 1; t < MAX_TASKS; ++t)
+    if ((int)blockIdx.z == t) a = mt.t[t];
+  if ((int)blockIdx.x >= a.nblk || (int)blockIdx.y >= a.njc) return;
   __shared__ __attribute__((aligned(16))) float red[NS];
   __shared__ float ce[64], dce[64];
   __shared__ unsigned ticket;
@@ -250,7 +262,7 @@ __global__ __launch_bounds__(256) void emb_loss_fwd_kernel(const ElArgs a) {
     tt[ng] = 0.f;
   }
   const long nsteps = (D + 31) >> 5;
-  const long stride = (long)gridDim.x * 4;
+  const long stride = (long)a.nblk * 4;            // (not gridDim.x: the grid is sized for the longest task of the launch)
   // The local sample of pred row r is gathered target rank*B + r.  When rank*B is a multiple of 16 that row sits in THIS lane's
   // fragment of target group own_g + pb (chunk 0), so the smooth-L1 term needs no extra load; otherwise it is re-read (L1-resident).
   const int own_g = (a.rank * a.B) >> 4;
@@ -347,7 +359,7 @@ __global__ __launch_bounds__(256) void emb_loss_fwd_kernel(const ElArgs a) {
   // write-through `sc0 sc1` stores, every wave drains its own stores with an EXPLICIT s_waitcnt vmcnt(0) (inline asm: not left to what the
   // compiler happens to emit for __syncthreads), the workgroup barrier collects the waves, and only then one lane takes the agent-scope
   // ticket; the reducer reads the partials with `sc0 sc1` loads that bypass its L1 and the (non-coherent) L2 lines.
-  unsigned* cnt = g_counters[a.slot];
+  unsigned* cnt = g_counters[a.slot][a.task];
   const int grp = bx / G1, gsz = min(G1, a.nblk - grp * G1);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -435,9 +447,21 @@ __global__ __launch_bounds__(256) void emb_loss_fwd_kernel(const ElArgs a) {
 
 // dpred[b,d] = gout * ( a_b * clamp(p - t_own, -1, 1) + sum_j c_bj * t_j[d] - e_b * p[b,d] ); grid (feature slabs, ceil(B/8)):
 // a block row handles 8 local samples (8 x 8 fp32 accumulators per lane) and streams all Bw gathered targets once.
-__global__ __launch_bounds__(256) void emb_loss_bwd_kernel(const bf16_t* __restrict__ pred, const bf16_t* __restrict__ tgt_all,
-                                                           const float* __restrict__ coef, bf16_t* __restrict__ dpred, int B,
-                                                           int Bw, long D, int rank, float gout) {
+struct ElBwd { const bf16_t* pred; const bf16_t* tgt_all; const float* coef; bf16_t* dpred; long D; float gout; int nblk; };
+struct ElBwdMulti { ElBwd t[MAX_TASKS]; };
+
+__global__ __launch_bounds__(256) void emb_loss_bwd_kernel(const ElBwdMulti mt, int B, int Bw, int rank) {
+  ElBwd tk = mt.t[0];                                            // blockIdx.z = task (static indices + selects: see the forward kernel)
+#pragma unroll
+  for (int t = 1; t < MAX_TASKS; ++t)
+    if ((int)blockIdx.z == t) tk = mt.t[t];
+  if ((int)blockIdx.x >= tk.nblk) return;
+  const bf16_t* __restrict__ pred = tk.pred;
+  const bf16_t* __restrict__ tgt_all = tk.tgt_all;
+  const float* __restrict__ coef = tk.coef;
+  bf16_t* __restrict__ dpred = tk.dpred;
+  const long D = tk.D;
+  const float gout = tk.gout;
   extern __shared__ float cs[];                                  // [8][Bw] c_bj of this block row | a[8] | e[8]
   const int b0 = blockIdx.y * 8, nb = min(8, B - b0);
   for (int i = threadIdx.x; i < 8 * Bw; i += 256) {
@@ -450,7 +474,7 @@ __global__ __launch_bounds__(256) void emb_loss_bwd_kernel(const bf16_t* __restr
   }
   __syncthreads();
   const long nvec = D >> 3;
-  for (long i = blockIdx.x * 256L + threadIdx.x; i < nvec; i += gridDim.x * 256L) {
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < nvec; i += tk.nblk * 256L) {
     float acc[8][8];
 #pragma unroll
     for (int b = 0; b < 8; ++b)
@@ -523,7 +547,7 @@ ElPlan el_plan(int B, int Bw, long D) {
 }
 
 template <int NPB>
-void el_launch(int ng, dim3 grid, hipStream_t s, const ElArgs& a) {
+void el_launch(int ng, dim3 grid, hipStream_t s, const ElMulti& a) {
   switch (ng) {
     case 1: hipLaunchKernelGGL((emb_loss_fwd_kernel<NPB, 1>), grid, dim3(256), 0, s, a); break;
     case 2: hipLaunchKernelGGL((emb_loss_fwd_kernel<NPB, 2>), grid, dim3(256), 0, s, a); break;
@@ -549,43 +573,79 @@ long vp_emb_loss_workspace(int B, int Bw, long D) {
   return (long)p.njc * p.nblk * p.ns + (long)p.njc * p.ngrp * p.ns + (long)B * Bw + Bw + 2L * B + 64;
 }
 
+// One launch for `ntask` distillation heads that share (B, Bw, rank): task t has its own feature length D[t], pointers, workspace
+// (vp_emb_loss_workspace(B, Bw, D[t]) floats) and contrastive weight.  The reference calls _emb_loss once per head and layer
+// (base_ola_vlm.py:445-534); batching them turns 2 x ntask tiny launches per step into 2, and a single launch streams all heads' bytes.
+int vp_emb_loss_fwd_multi(int ntask, int B, int Bw, const long* D, int rank, const void* const* pred, const void* const* tgt_all,
+                          const float* const* mask, const float* const* logit_scale, const float* w_contrastive, float* const* out3,
+                          float* const* coef, float* const* workspace, hipStream_t s) {
+  VP_REQUIRE(ntask >= 1 && ntask <= MAX_TASKS && D && pred && tgt_all && mask && logit_scale && w_contrastive && out3 && coef && workspace,
+             VP_ERR_BAD_ARG, "vp_emb_loss_fwd_multi: 1 <= ntask <= %d and non-null arrays", MAX_TASKS);
+  VP_REQUIRE(B > 0 && B <= 64 && Bw >= B && Bw <= 1024, VP_ERR_UNSUPPORTED_SHAPE,
+             "vp_emb_loss_fwd: need 0<B<=64, B<=Bw<=1024 (got B=%d Bw=%d)", B, Bw);
+  VP_REQUIRE(rank >= 0 && (long)(rank + 1) * B <= Bw, VP_ERR_BAD_ARG, "vp_emb_loss_fwd: rank/B/Bw mismatch");
+  const int slot = el_slot_for(s);
+  VP_REQUIRE(slot >= 0, VP_ERR_UNSUPPORTED_SHAPE, "vp_emb_loss_fwd: more than %d distinct streams have used the loss", N_SLOTS);
+  ElMulti m;
+  ElPlan p0 = el_plan(B, Bw, D[0] > 0 ? D[0] : 8);
+  int gx = 0;
+  for (int t = 0; t < ntask; ++t) {
+    VP_REQUIRE(D[t] > 0 && D[t] % 8 == 0, VP_ERR_UNSUPPORTED_SHAPE, "vp_emb_loss_fwd: need D%%8==0 (got D=%ld)", D[t]);
+    VP_REQUIRE(pred[t] && tgt_all[t] && mask[t] && out3[t] && coef[t] && workspace[t], VP_ERR_BAD_ARG, "vp_emb_loss_fwd: null pointer");
+    VP_REQUIRE(((uintptr_t)pred[t] | (uintptr_t)tgt_all[t] | (uintptr_t)workspace[t]) % 16 == 0, VP_ERR_BAD_ARG,
+               "vp_emb_loss_fwd: pred / tgt_all / workspace must be 16-byte aligned");
+    const ElPlan p = el_plan(B, Bw, D[t]);                       // npb / ng / njc depend on (B, Bw) only: the same for every task
+    ElArgs& a = m.t[t];
+    a.pred = (const bf16_t*)pred[t]; a.tgt = (const bf16_t*)tgt_all[t]; a.mask = mask[t]; a.logit_scale = logit_scale[t];
+    a.out3 = out3[t]; a.coef = coef[t];
+    a.part = workspace[t];
+    a.part2 = a.part + (long)p.njc * p.nblk * p.ns;
+    a.fin = a.part2 + (long)p.njc * p.ngrp * p.ns;
+    a.D = D[t]; a.B = B; a.Bw = Bw; a.rank = rank; a.nblk = p.nblk; a.njc = p.njc; a.ngrp = p.ngrp;
+    a.slot = slot; a.task = t;
+    a.w_con = w_contrastive[t];
+    a.dbg = t == 0 ? g_dbg : nullptr;
+    gx = p.nblk > gx ? p.nblk : gx;
+    p0 = p;
+  }
+  const dim3 grid(gx, p0.njc, ntask);
+  if (p0.npb == 1) el_launch<1>(p0.ng, grid, s, m);
+  else if (p0.npb == 2) el_launch<2>(p0.ng, grid, s, m);
+  else el_launch<4>(p0.ng, grid, s, m);
+  return vp_check_launch("vp_emb_loss_fwd");
+}
+
 int vp_emb_loss_fwd(int B, int Bw, long D, int rank, const void* pred, const void* tgt_all, const float* mask,
                     const float* logit_scale, float w_contrastive, float* out3, float* coef, float* workspace, hipStream_t s) {
-  VP_REQUIRE(B > 0 && B <= 64 && Bw >= B && Bw <= 1024 && D > 0 && D % 8 == 0, VP_ERR_UNSUPPORTED_SHAPE,
-             "vp_emb_loss_fwd: need 0<B<=64, B<=Bw<=1024, D%%8==0 (got B=%d Bw=%d D=%ld)", B, Bw, D);
-  VP_REQUIRE(rank >= 0 && (long)(rank + 1) * B <= Bw, VP_ERR_BAD_ARG, "vp_emb_loss_fwd: rank/B/Bw mismatch");
   VP_REQUIRE(pred && tgt_all && mask && out3 && coef && workspace, VP_ERR_BAD_ARG, "vp_emb_loss_fwd: null pointer");
-  VP_REQUIRE(((uintptr_t)pred | (uintptr_t)tgt_all | (uintptr_t)workspace) % 16 == 0, VP_ERR_BAD_ARG,
-             "vp_emb_loss_fwd: pred / tgt_all / workspace must be 16-byte aligned");
-  const ElPlan p = el_plan(B, Bw, D);
-  ElArgs a;
-  a.pred = (const bf16_t*)pred; a.tgt = (const bf16_t*)tgt_all; a.mask = mask; a.logit_scale = logit_scale;
-  a.out3 = out3; a.coef = coef;
-  a.part = workspace;
-  a.part2 = a.part + (long)p.njc * p.nblk * p.ns;
-  a.fin = a.part2 + (long)p.njc * p.ngrp * p.ns;
-  a.D = D; a.B = B; a.Bw = Bw; a.rank = rank; a.nblk = p.nblk; a.njc = p.njc; a.ngrp = p.ngrp;
-  a.slot = el_slot_for(s);
-  VP_REQUIRE(a.slot >= 0, VP_ERR_UNSUPPORTED_SHAPE, "vp_emb_loss_fwd: more than %d distinct streams have used the loss", N_SLOTS);
-  a.w_con = w_contrastive;
-  a.dbg = g_dbg;
-  const dim3 grid(p.nblk, p.njc);
-  if (p.npb == 1) el_launch<1>(p.ng, grid, s, a);
-  else if (p.npb == 2) el_launch<2>(p.ng, grid, s, a);
-  else el_launch<4>(p.ng, grid, s, a);
-  return vp_check_launch("vp_emb_loss_fwd");
+  return vp_emb_loss_fwd_multi(1, B, Bw, &D, rank, &pred, &tgt_all, &mask, &logit_scale, &w_contrastive, &out3, &coef, &workspace, s);
+}
+
+int vp_emb_loss_bwd_multi(int ntask, int B, int Bw, const long* D, int rank, const void* const* pred, const void* const* tgt_all,
+                          const float* const* coef, const float* grad_out, void* const* dpred, hipStream_t s) {
+  VP_REQUIRE(ntask >= 1 && ntask <= MAX_TASKS && D && pred && tgt_all && coef && grad_out && dpred, VP_ERR_BAD_ARG,
+             "vp_emb_loss_bwd_multi: 1 <= ntask <= %d and non-null arrays", MAX_TASKS);
+  VP_REQUIRE(B > 0 && B <= 64 && Bw >= B && Bw <= 1024, VP_ERR_UNSUPPORTED_SHAPE,
+             "vp_emb_loss_bwd: need 0<B<=64, B<=Bw<=1024 (got B=%d Bw=%d)", B, Bw);
+  VP_REQUIRE(rank >= 0 && (long)(rank + 1) * B <= Bw, VP_ERR_BAD_ARG, "vp_emb_loss_bwd: bad args");
+  const int nby = (B + 7) / 8;
+  ElBwdMulti m;
+  int gx = 0;
+  for (int t = 0; t < ntask; ++t) {
+    VP_REQUIRE(D[t] > 0 && D[t] % 8 == 0, VP_ERR_UNSUPPORTED_SHAPE, "vp_emb_loss_bwd: need D%%8==0 (got D=%ld)", D[t]);
+    VP_REQUIRE(pred[t] && tgt_all[t] && coef[t] && dpred[t], VP_ERR_BAD_ARG, "vp_emb_loss_bwd: bad args");
+    const int nblk = (int)max(1L, min(2048L / nby, (D[t] / 8 + 255) / 256));
+    m.t[t] = ElBwd{(const bf16_t*)pred[t], (const bf16_t*)tgt_all[t], coef[t], (bf16_t*)dpred[t], D[t], grad_out[t], nblk};
+    gx = nblk > gx ? nblk : gx;
+  }
+  hipLaunchKernelGGL(emb_loss_bwd_kernel, dim3(gx, nby, ntask), dim3(256), (8 * Bw + 16) * sizeof(float), s, m, B, Bw, rank);
+  return vp_check_launch("vp_emb_loss_bwd");
 }
 
 int vp_emb_loss_bwd(int B, int Bw, long D, int rank, const void* pred, const void* tgt_all, const float* coef, float grad_out,
                     void* dpred, hipStream_t s) {
-  VP_REQUIRE(B > 0 && B <= 64 && Bw >= B && Bw <= 1024 && D > 0 && D % 8 == 0, VP_ERR_UNSUPPORTED_SHAPE,
-             "vp_emb_loss_bwd: need 0<B<=64, B<=Bw<=1024, D%%8==0 (got B=%d Bw=%d D=%ld)", B, Bw, D);
-  VP_REQUIRE(rank >= 0 && (long)(rank + 1) * B <= Bw && pred && tgt_all && coef && dpred, VP_ERR_BAD_ARG, "vp_emb_loss_bwd: bad args");
-  const int nby = (B + 7) / 8;
-  const int nblk = (int)max(1L, min(2048L / nby, (D / 8 + 255) / 256));
-  hipLaunchKernelGGL(emb_loss_bwd_kernel, dim3(nblk, nby), dim3(256), (8 * Bw + 16) * sizeof(float), s, (const bf16_t*)pred,
-                     (const bf16_t*)tgt_all, coef, (bf16_t*)dpred, B, Bw, D, rank, grad_out);
-  return vp_check_launch("vp_emb_loss_bwd");
+  VP_REQUIRE(pred && tgt_all && coef && dpred, VP_ERR_BAD_ARG, "vp_emb_loss_bwd: bad args");
+  return vp_emb_loss_bwd_multi(1, B, Bw, &D, rank, &pred, &tgt_all, &coef, &grad_out, &dpred, s);
 }
 
 }  // extern "C"

@@ -891,8 +891,25 @@ class Engine:
         run_heads = len(self.tasks) > 0 and S > ns
         if run_heads:
             targets = self._prepare_targets(batch, B)
-            for task, i, idx in self.tasks:
-                res = self._head_fwd_bwd(task, i, idx, states[idx], plan, batch, targets, compute_grads)
+            # every head's forward first, then ONE loss launch each way for all of them (vp_emb_loss_{fwd,bwd}_multi; the reference calls
+            # _emb_loss head by head: base_ola_vlm.py:445-534), then the heads' backward passes
+            ctxs = [self._head_fwd(task, i, idx, states[idx], plan, batch, targets, compute_grads) for task, i, idx in self.tasks]
+            live = [c for c in ctxs if c["tg"] is not None]
+            for c0 in range(0, len(live), 8):
+                grp = live[c0:c0 + 8]
+                outs = ops.emb_loss_fwd_multi([c["pred2"] for c in grp], [c["tg"][0] for c in grp], [c["tg"][1] for c in grp],
+                                              [c["scale"] for c in grp], [cfg.contrastive_loss_weight] * len(grp), rank=self.rank)
+                for c, (loss3, coef) in zip(grp, outs):
+                    c["res"]["loss3"], c["coef"] = loss3, coef
+                if compute_grads:
+                    dps = ops.emb_loss_bwd_multi([c["pred2"] for c in grp], [c["tg"][0] for c in grp], [c["coef"] for c in grp],
+                                                 [c["w_t"] for c in grp], rank=self.rank)
+                    for c, dp in zip(grp, dps):
+                        c["dpred"] = dp
+            for c in ctxs:
+                task, idx, res = c["task"], c["idx"], c["res"]
+                if compute_grads and c["tg"] is not None:
+                    self._head_bwd(c)
                 if res["loss3"] is not None:
                     out["layer_losses"][(task, idx)] = res["loss3"]
                     w_t = getattr(cfg, TASK_SPEC[task][0])[TASK_SPEC[task][2]]
@@ -1076,8 +1093,8 @@ class Engine:
         return out
 
     # ------------------------------------------------------------------------------------------ one head
-    def _head_fwd_bwd(self, task, i, idx, state, plan, batch, targets, compute_grads):
-        """TaskToken{Gen,Seg,Depth}Head on one layer state: forward, loss, and (eagerly) backward.
+    def _head_fwd(self, task, i, idx, state, plan, batch, targets, compute_grads):
+        """TaskToken{Gen,Seg,Depth}Head on one layer state: forward up to the loss input; returns the context _head_bwd continues from.
         resampler.py:202-224 / :46-75 / :9-16 ; gen_head.py:39-65 ; oneformer_head.py:224-258 ; da_v2_head.py:418-457."""
         cfg, ps, dev = self.cfg, self.ps, self.dev
         cname, _, wkey, sname, hname = TASK_SPEC[task]
@@ -1169,18 +1186,27 @@ class Engine:
             res["depth_feats"] = [t.view(B, nq, -1) for t in fe]
             res["depth_pred"] = self.dpt_forward(res["depth_feats"])
         tg = targets.get(task)
-        if tg is None:
-            return res
-        allt, mask = tg
-        pred2 = pred.view(B, -1)
-        scale = ps.p(sname) if (cfg.use_contrastive and sname in ps) else None
-        loss3, coef = ops.emb_loss_fwd(pred2, allt, mask, scale, cfg.contrastive_loss_weight, rank=self.rank)
-        res["loss3"] = loss3
-        if not compute_grads:
-            return res
-        w_t = float(hc[wkey])
-        # ---------------- backward ----------------
-        dpred = ops.emb_loss_bwd(pred2, allt, coef, w_t, rank=self.rank).view(B * nq, -1)
+        sname_ = sname
+        scale = ps.p(sname_) if (cfg.use_contrastive and sname_ in ps) else None
+        ctx = dict(task=task, i=i, idx=idx, res=res, tg=tg, pred2=pred.view(B, -1), scale=scale, w_t=float(hc[wkey]))
+        if tg is not None and compute_grads:
+            ctx["saved"] = dict(plan=plan, tb=tb, n=n, nq=nq, heads=heads, dh=dh, inner=inner, pf=pf, T=T, nl=nl, mode=mode, xt=xt, own=own,
+                                Dm=Dm, xin2=xin2, Px=Px, blocks=blocks, lat2=lat2, po=po, mo=mo, ro=ro, vout=vout, hname=hname, sname=sname,
+                                ad=ad if task == "depth" else None, zd=zd if task == "depth" else None)
+        return ctx
+
+    def _head_bwd(self, ctx):
+        """Backward of one head from d(loss)/d(pred) (ctx["dpred"], from the batched loss backward) to the layer-state rows it read, its own
+        parameters, the task-token / latent parameters and its logit scale."""
+        cfg, ps, dev = self.cfg, self.ps, self.dev
+        task, i, res = ctx["task"], ctx["i"], ctx["res"]
+        sv = ctx["saved"]
+        plan, tb, n, nq, heads, dh, inner, pf, T, nl, mode, xt, own = (sv[k] for k in ("plan", "tb", "n", "nq", "heads", "dh", "inner", "pf", "T", "nl", "mode", "xt", "own"))
+        Dm, xin2, Px, blocks, lat2, po, mo, ro, vout, hname, sname, ad, zd = (sv[k] for k in ("Dm", "xin2", "Px", "blocks", "lat2", "po", "mo", "ro", "vout", "hname", "sname", "ad", "zd"))
+        B, S, H = plan["B"], plan["S"], cfg.hidden_size
+        l1 = f"{hname}.{i}.linear_1."
+        w_t, coef, scale = ctx["w_t"], ctx["coef"], ctx["scale"]
+        dpred = ctx["dpred"].view(B * nq, -1)
         if scale is not None:
             self._acc(ps.g(sname), coef[-1:], w_t)
         if task == "depth":

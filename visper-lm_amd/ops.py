@@ -560,5 +560,36 @@ def emb_loss_bwd(pred, tgt_all, coef, grad_out, rank=0):
     return dpred
 
 
+def emb_loss_fwd_multi(preds, tgts, masks, scales, w_cons, rank=0):
+    """Every distillation head of the step in ONE launch (vp_emb_loss_fwd_multi): preds[t] [B, D_t] bf16, tgts[t] [Bw, D_t] bf16, masks[t] f32 [B],
+    scales[t] f32 [1] or None, w_cons[t] float.  -> [(out3, coef)] per head."""
+    n = len(preds)
+    B, Bw = preds[0].shape[0], tgts[0].shape[0]
+    dev = preds[0].device
+    Ds = (C.c_long * n)(*[int(x.shape[1]) for x in preds])
+    outs = []
+    parts = []
+    for t in range(n):
+        assert preds[t].is_contiguous() and tgts[t].is_contiguous() and preds[t].shape[0] == B and tgts[t].shape == (Bw, preds[t].shape[1])
+        parts.append(torch.empty(max(1, _lib.raw("vp_emb_loss_workspace", B, Bw, int(preds[t].shape[1]))), device=dev, dtype=torch.float32))
+        outs.append((torch.empty(3, device=dev, dtype=torch.float32), torch.empty(2 * B + B * Bw + 1, device=dev, dtype=torch.float32)))
+    arr = lambda xs: (C.c_void_p * n)(*[None if x is None else x.data_ptr() for x in xs])
+    wc = (C.c_float * n)(*[float(w) for w in w_cons])
+    _lib.call("vp_emb_loss_fwd_multi", n, B, Bw, Ds, rank, arr(preds), arr(tgts), arr(masks), arr(scales), wc, arr([o[0] for o in outs]),
+              arr([o[1] for o in outs]), arr(parts), _stream())
+    return outs
+
+
+def emb_loss_bwd_multi(preds, tgts, coefs, grad_outs, rank=0):
+    n = len(preds)
+    B, Bw = preds[0].shape[0], tgts[0].shape[0]
+    Ds = (C.c_long * n)(*[int(x.shape[1]) for x in preds])
+    dpreds = [torch.empty_like(x) for x in preds]
+    arr = lambda xs: (C.c_void_p * n)(*[x.data_ptr() for x in xs])
+    go = (C.c_float * n)(*[float(g) for g in grad_outs])
+    _lib.call("vp_emb_loss_bwd_multi", n, B, Bw, Ds, rank, arr(preds), arr(tgts), arr(coefs), go, arr(dpreds), _stream())
+    return dpreds
+
+
 def adamw_(p, g, m, v, shadow, lr, beta1, beta2, eps, wd, step, grad_scale=1.0):
     _lib.call("vp_adamw", p.numel(), _p(p), _p(g), _p(m), _p(v), _p(shadow), lr, beta1, beta2, eps, wd, step, grad_scale, _stream())
