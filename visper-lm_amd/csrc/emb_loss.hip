@@ -24,7 +24,10 @@
 
 namespace {
 
-constexpr int G1 = 32;                 // blocks per first-level reduction group
+#ifndef EL_G1
+#define EL_G1 16
+#endif
+constexpr int G1 = EL_G1;              // blocks per first-level reduction group (and the most groups the second level sums per chunk)
 constexpr int MAX_GROUPS = 1024;       // njc * ngrp
 constexpr int N_SLOTS = 32;            // independent counter sets, one per DISTINCT stream (el_slot_for: a registry, not a hash, so two streams
                                        // can never share tickets); calls on one stream are ordered by the stream itself
@@ -210,9 +213,22 @@ __device__ void el_finalize(const ElArgs& a, float* PT, int ldpt, const float* T
 // NPB = 16-row blocks of local predictions, NG = 16-row groups of gathered targets per chunk.
 struct ElMulti { ElArgs t[MAX_TASKS]; };
 
-template <int NPB, int NG>
-__global__ __launch_bounds__(256) void emb_loss_fwd_kernel(const ElMulti mt) {
+#ifndef EL_INFLIGHT
+#define EL_INFLIGHT 16                 // 16-byte fragment loads a lane keeps in flight per round (dev knob: tools/emb_loss_sweep.sh)
+#endif
+
+// PACK (B <= 8 and Bw <= 8: the single-GPU step): a 16-row MFMA operand holds the 8 samples at TWO different places of the feature axis
+// (rows 0-7: first half of the wave's k-step, rows 8-15: second half), so no lane loads a duplicate row; the two diagonal 8x8 blocks of the
+// 16x16 product are the two halves' dot products (the off-diagonal blocks mix the halves and are dropped).
+template <int NPB, int NG, bool PACK>
+__device__ __forceinline__ void emb_loss_fwd_body(const ElMulti mt) {
+  static_assert(!PACK || (NPB == 1 && NG == 1), "PACK is the 8 x 8 case");
   constexpr int PB = NPB * 16, TC = NG * 16, NS = PB * TC + TC + 2 * PB;
+  // NV consecutive 16-byte vectors per lane and k-step: the four k-groups of a row then cover a whole 128-byte line (NV = 2) instead of
+  // half of one (an MFMA only needs A and B to agree on the k order, so "lane g owns bytes [32g, 32g+32) of the line" is as good as any)
+  constexpr int NV = (2 * NPB + NG) <= 8 ? 2 : 1;
+  constexpr int KS = 32 * NV * (PACK ? 2 : 1);                   // feature elements per wave k-step
+  constexpr bool PAR = NS * 16 <= 40 * 1024;                     // the 4 waves' partials side by side in LDS, summed in one pass
   // blockIdx.z = task (one launch for every distillation head of the step: same B / Bw, own D, pointers, workspace and ticket counters);
   // the grid is sized for the longest task, the other tasks' surplus blocks leave at once (they hold no tickets)
   // (static indices + selects: a DYNAMICALLY indexed array inside a by-value kernel argument returned wrong elements — the compiler bug round 2 met
@@ -222,11 +238,13 @@ __global__ __launch_bounds__(256) void emb_loss_fwd_kernel(const ElMulti mt) {
   for (int t = 1; t < MAX_TASKS; ++t)
     if ((int)blockIdx.z == t) a = mt.t[t];
   if ((int)blockIdx.x >= a.nblk || (int)blockIdx.y >= a.njc) return;
-  __shared__ __attribute__((aligned(16))) float red[NS];
+  __shared__ __attribute__((aligned(16))) float red[PAR ? 4 * NS : NS];
   __shared__ float ce[64], dce[64];
   __shared__ unsigned ticket;
   const int jc = blockIdx.y, bx = blockIdx.x, tid = threadIdx.x;
   const int lane = tid & 63, wv = tid >> 6, r = lane & 15, g = lane >> 4;
+  const int rs = PACK ? (r & 7) : r;                             // sample row of this lane inside a 16-row operand
+  const int lo = (PACK ? (r >> 3) * 32 * NV : 0) + g * 8 * NV;   // lane's element offset inside the wave's k-step
   const bool first = jc == 0;
   const long long t_start = a.dbg ? wall_clock64() : 0;
   if (a.dbg && bx == 0 && jc == 0 && tid == 0) a.dbg[0] = t_start;
@@ -244,7 +262,7 @@ __global__ __launch_bounds__(256) void emb_loss_fwd_kernel(const ElMulti mt) {
   bool pok[NPB], tok[NG];
 #pragma unroll
   for (int pb = 0; pb < NPB; ++pb) {
-    const int row = pb * 16 + r;
+    const int row = pb * 16 + rs;
     pok[pb] = row < a.B;
     const int rc = min(row, a.B - 1);
     prow[pb] = a.pred + (long)rc * D;
@@ -256,104 +274,145 @@ __global__ __launch_bounds__(256) void emb_loss_fwd_kernel(const ElMulti mt) {
   }
 #pragma unroll
   for (int ng = 0; ng < NG; ++ng) {
-    const int j = jc * TC + ng * 16 + r;
+    const int j = jc * TC + ng * 16 + rs;
     tok[ng] = j < a.Bw;
     trow[ng] = a.tgt + (long)min(j, a.Bw - 1) * D;
     tt[ng] = 0.f;
   }
-  const long nsteps = (D + 31) >> 5;
+  const long nsteps = (D + KS - 1) / KS;
   const long stride = (long)a.nblk * 4;            // (not gridDim.x: the grid is sized for the longest task of the launch)
   // The local sample of pred row r is gathered target rank*B + r.  When rank*B is a multiple of 16 that row sits in THIS lane's
   // fragment of target group own_g + pb (chunk 0), so the smooth-L1 term needs no extra load; otherwise it is re-read (L1-resident).
   const int own_g = (a.rank * a.B) >> 4;
   const bool own_in_regs = first && ((a.rank * a.B) & 15) == 0 && own_g + NPB <= NG;
-  // DEPTH k-steps per round: all their 16-byte fragment loads are issued before the first MFMA (registers: DEPTH * (2 NPB + NG) * 4)
-  constexpr int DEPTH = (2 * NPB + NG) <= 4 ? 4 : ((2 * NPB + NG) <= 8 ? 2 : 1);
+  // DEPTH k-steps per round: all their 16-byte fragment loads are issued before the first MFMA (registers: DEPTH * NV * (2 NPB + NG) * 4)
+  constexpr int DEPTH = EL_INFLIGHT / ((2 * NPB + NG) * NV) > 0 ? EL_INFLIGHT / ((2 * NPB + NG) * NV) : 1;
   for (long s0 = (long)bx * 4 + wv; s0 < nsteps; s0 += DEPTH * stride) {
-    bf16x8 pa[DEPTH][NPB], tb[DEPTH][NG], ow[DEPTH][NPB];
-    bool ok[DEPTH];
+    bf16x8 pa[DEPTH][NV][NPB], tb[DEPTH][NV][NG], ow[DEPTH][NV][NPB];
+    bool ok[DEPTH][NV];
 #pragma unroll
-    for (int d = 0; d < DEPTH; ++d) {
-      const long s = s0 + d * stride;
-      const long off0 = s * 32 + g * 8;
-      ok[d] = s < nsteps && off0 < D;                          // D % 8 == 0: a lane's 8-vector is wholly inside or outside
-      const long off = ok[d] ? off0 : 0;
+    for (int d = 0; d < DEPTH; ++d)
 #pragma unroll
-      for (int pb = 0; pb < NPB; ++pb) pa[d][pb] = *(const bf16x8*)(prow[pb] + off);
+      for (int v = 0; v < NV; ++v) {
+        const long off0 = (s0 + d * stride) * KS + lo + v * 8;
+        ok[d][v] = off0 < D;                                     // D % 8 == 0: a lane's 8-vector is wholly inside or outside
+        const long off = ok[d][v] ? off0 : 0;
 #pragma unroll
-      for (int ng = 0; ng < NG; ++ng) tb[d][ng] = *(const bf16x8*)(trow[ng] + off);
+        for (int pb = 0; pb < NPB; ++pb) pa[d][v][pb] = *(const bf16x8*)(prow[pb] + off);
 #pragma unroll
-      for (int pb = 0; pb < NPB; ++pb) ow[d][pb] = (first && !own_in_regs) ? *(const bf16x8*)(orow[pb] + off) : zero8;
-    }
+        for (int ng = 0; ng < NG; ++ng) tb[d][v][ng] = *(const bf16x8*)(trow[ng] + off);
 #pragma unroll
-    for (int d = 0; d < DEPTH; ++d) {
+        for (int pb = 0; pb < NPB; ++pb) ow[d][v][pb] = (first && !own_in_regs) ? *(const bf16x8*)(orow[pb] + off) : zero8;
+      }
 #pragma unroll
-      for (int pb = 0; pb < NPB; ++pb) pa[d][pb] = (ok[d] && pok[pb]) ? pa[d][pb] : zero8;
+    for (int d = 0; d < DEPTH; ++d)
 #pragma unroll
-      for (int ng = 0; ng < NG; ++ng) tb[d][ng] = (ok[d] && tok[ng]) ? tb[d][ng] : zero8;
+      for (int v = 0; v < NV; ++v) {
 #pragma unroll
-      for (int pb = 0; pb < NPB; ++pb)
+        for (int pb = 0; pb < NPB; ++pb) pa[d][v][pb] = (ok[d][v] && pok[pb]) ? pa[d][v][pb] : zero8;
 #pragma unroll
-        for (int ng = 0; ng < NG; ++ng)
-          acc[pb][ng] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pa[d][pb], tb[d][ng], acc[pb][ng], 0, 0, 0);
+        for (int ng = 0; ng < NG; ++ng) tb[d][v][ng] = (ok[d][v] && tok[ng]) ? tb[d][v][ng] : zero8;
 #pragma unroll
-      for (int ng = 0; ng < NG; ++ng) tt[ng] = dot8(tb[d][ng], tb[d][ng], tt[ng]);
-      if (first) {
+        for (int pb = 0; pb < NPB; ++pb)
 #pragma unroll
-        for (int pb = 0; pb < NPB; ++pb) {
-          pp[pb] = dot8(pa[d][pb], pa[d][pb], pp[pb]);
-          bf16x8 o = ow[d][pb];
-          if (own_in_regs) {
+          for (int ng = 0; ng < NG; ++ng)
+            acc[pb][ng] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pa[d][v][pb], tb[d][v][ng], acc[pb][ng], 0, 0, 0);
 #pragma unroll
-            for (int ng = 0; ng < NG; ++ng) o = (ng == own_g + pb) ? tb[d][ng] : o;
+        for (int ng = 0; ng < NG; ++ng) tt[ng] = dot8(tb[d][v][ng], tb[d][v][ng], tt[ng]);
+        if (first) {
+#pragma unroll
+          for (int pb = 0; pb < NPB; ++pb) {
+            pp[pb] = dot8(pa[d][v][pb], pa[d][v][pb], pp[pb]);
+            bf16x8 o = ow[d][v][pb];
+            if (own_in_regs) {
+#pragma unroll
+              for (int ng = 0; ng < NG; ++ng) o = (ng == own_g + pb) ? tb[d][v][ng] : o;
+            }
+            sl[pb] = (ok[d][v] && pok[pb]) ? smooth_l1_8(pa[d][v][pb], o, sl[pb]) : sl[pb];
           }
-          sl[pb] = (ok[d] && pok[pb]) ? smooth_l1_8(pa[d][pb], o, sl[pb]) : sl[pb];
         }
       }
-    }
   }
   const long long t_stream = a.dbg ? wall_clock64() : 0;
-  // lane partials of the per-row sums: fold the 4 k-groups of the wave
+  // lane partials of the per-row sums: fold the 4 k-groups of the wave (PACK: and the two half-steps, rows r and r ^ 8)
 #pragma unroll
-  for (int ng = 0; ng < NG; ++ng) { tt[ng] += __shfl_xor(tt[ng], 16, 64); tt[ng] += __shfl_xor(tt[ng], 32, 64); }
+  for (int ng = 0; ng < NG; ++ng) {
+    tt[ng] += __shfl_xor(tt[ng], 16, 64); tt[ng] += __shfl_xor(tt[ng], 32, 64);
+    if (PACK) tt[ng] += __shfl_xor(tt[ng], 8, 64);
+  }
 #pragma unroll
   for (int pb = 0; pb < NPB; ++pb) {
     pp[pb] += __shfl_xor(pp[pb], 16, 64); pp[pb] += __shfl_xor(pp[pb], 32, 64);
     sl[pb] += __shfl_xor(sl[pb], 16, 64); sl[pb] += __shfl_xor(sl[pb], 32, 64);
+    if (PACK) { pp[pb] += __shfl_xor(pp[pb], 8, 64); sl[pb] += __shfl_xor(sl[pb], 8, 64); }
   }
-  // the 4 waves add into LDS one after the other (fixed order); MFMA C layout: col = lane & 15, row = (lane >> 4) * 4 + i
-#pragma unroll 1
-  for (int w = 0; w < 4; ++w) {
-    if (wv == w) {
+  if (PACK) {
+    // MFMA C layout: col = lane & 15, row = (lane >> 4) * 4 + i.  Element (b, j) of the first half sits in lane (g = b >> 2, r = j), its
+    // second-half partner (b + 8, j + 8) in lane (g + 2, r + 8) = lane + 40; everything else is cross-half and is zeroed.
+    const bool keep = g < 2 && r < 8;
 #pragma unroll
-      for (int pb = 0; pb < NPB; ++pb)
+    for (int i = 0; i < 4; ++i) {
+      const float other = __shfl(acc[0][0][i], (lane + 40) & 63, 64);
+      acc[0][0][i] = keep ? acc[0][0][i] + other : 0.f;
+    }
+  }
+  // cross-block layout of a partial: PT[PB][TC] | TT[TC] | PP[PB] | SL[PB]
+  const __amdgpu_buffer_rsrc_t prs = crsrc(a.part + ((long)jc * a.nblk + bx) * NS);
+  if (PAR) {
+    // every wave drops its partial into its own LDS copy, then one pass adds the four in wave order and sends the block's partial on its way
+    float* mine = red + wv * NS;
 #pragma unroll
-        for (int ng = 0; ng < NG; ++ng)
+    for (int pb = 0; pb < NPB; ++pb)
 #pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const int idx = (pb * 16 + g * 4 + i) * TC + ng * 16 + r;
-            red[idx] = (w == 0 ? 0.f : red[idx]) + acc[pb][ng][i];
-          }
-      if (g == 0) {
+      for (int ng = 0; ng < NG; ++ng)
 #pragma unroll
-        for (int ng = 0; ng < NG; ++ng) { const int idx = PB * TC + ng * 16 + r; red[idx] = (w == 0 ? 0.f : red[idx]) + tt[ng]; }
+        for (int i = 0; i < 4; ++i) mine[(pb * 16 + g * 4 + i) * TC + ng * 16 + r] = acc[pb][ng][i];
+    if (g == 0) {
 #pragma unroll
-        for (int pb = 0; pb < NPB; ++pb) {
-          const int i0 = PB * TC + TC + pb * 16 + r, i1 = i0 + PB;
-          red[i0] = (w == 0 ? 0.f : red[i0]) + pp[pb];
-          red[i1] = (w == 0 ? 0.f : red[i1]) + sl[pb];
-        }
+      for (int ng = 0; ng < NG; ++ng) mine[PB * TC + ng * 16 + r] = tt[ng];
+#pragma unroll
+      for (int pb = 0; pb < NPB; ++pb) {
+        mine[PB * TC + TC + pb * 16 + r] = pp[pb];
+        mine[PB * TC + TC + PB + pb * 16 + r] = sl[pb];
       }
     }
     __syncthreads();
+    for (int i = tid; i < NS / 4; i += 256) {
+      const f32x4* q = (const f32x4*)red + i;
+      cstore4(prs, 4 * i, ((q[0] + q[NS / 4]) + q[2 * (NS / 4)]) + q[3 * (NS / 4)]);
+    }
+  } else {
+    // the 4 waves add into LDS one after the other (fixed order)
+#pragma unroll 1
+    for (int w = 0; w < 4; ++w) {
+      if (wv == w) {
+#pragma unroll
+        for (int pb = 0; pb < NPB; ++pb)
+#pragma unroll
+          for (int ng = 0; ng < NG; ++ng)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const int idx = (pb * 16 + g * 4 + i) * TC + ng * 16 + r;
+              red[idx] = (w == 0 ? 0.f : red[idx]) + acc[pb][ng][i];
+            }
+        if (g == 0) {
+#pragma unroll
+          for (int ng = 0; ng < NG; ++ng) { const int idx = PB * TC + ng * 16 + r; red[idx] = (w == 0 ? 0.f : red[idx]) + tt[ng]; }
+#pragma unroll
+          for (int pb = 0; pb < NPB; ++pb) {
+            const int i0 = PB * TC + TC + pb * 16 + r, i1 = i0 + PB;
+            red[i0] = (w == 0 ? 0.f : red[i0]) + pp[pb];
+            red[i1] = (w == 0 ? 0.f : red[i1]) + sl[pb];
+          }
+        }
+      }
+      __syncthreads();
+    }
+    for (int i = tid; i < NS / 4; i += 256) cstore4(prs, 4 * i, *(const f32x4*)(red + 4 * i));
   }
   // Cross-block traffic (partials, tickets) goes through DEVICE-COHERENT accesses (agent-scope relaxed atomics = sc1 loads / stores
   // that bypass the per-XCD L2's non-coherent lines), ordered by vmcnt(0) + the workgroup barrier.  A __threadfence() here would
   // write back and invalidate the whole 4 MB L2 of the XCD once per wave: measured 118 us instead of ~10 for the depth loss.
-  {
-    const __amdgpu_buffer_rsrc_t rs = crsrc(a.part + ((long)jc * a.nblk + bx) * NS);
-    for (int i = tid; i < NS / 4; i += 256) cstore4(rs, 4 * i, *(const f32x4*)(red + 4 * i));
-  }
   // ---- level 1: the last block of each group of G1 sums the group's partials (fixed order)
   // Memory-model note (MI355X_MICROARCH.md, "Valid forms": {sc0 sc1 stores and loads on both sides} + a drained flag): the partials leave as
   // write-through `sc0 sc1` stores, every wave drains its own stores with an EXPLICIT s_waitcnt vmcnt(0) (inline asm: not left to what the
@@ -422,7 +481,7 @@ __global__ __launch_bounds__(256) void emb_loss_fwd_kernel(const ElMulti mt) {
       for (int i = tid; i < NS / 4; i += 256) {
         f32x4 v[G1];
 #pragma unroll
-        for (int q = 0; q < G1; ++q) v[q] = q < a.ngrp ? cload4(src, q * NS + 4 * i) : f32x4{0.f, 0.f, 0.f, 0.f};       // ngrp <= 32 (nblk <= 1024)
+        for (int q = 0; q < G1; ++q) v[q] = q < a.ngrp ? cload4(src, q * NS + 4 * i) : f32x4{0.f, 0.f, 0.f, 0.f};       // ngrp <= G1 (el_plan: nblk <= G1 * G1)
         f32x4 sum = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int q = 0; q < G1; ++q) sum += v[q];
@@ -443,6 +502,22 @@ __global__ __launch_bounds__(256) void emb_loss_fwd_kernel(const ElMulti mt) {
   if (a.dbg && tid == 0) {
     a.dbg[1] = t_start; a.dbg[2] = t_stream; a.dbg[3] = t_ticket1; a.dbg[4] = t_reduced; a.dbg[5] = wall_clock64();
   }
+}
+
+// Two entry points of the same body: the small shapes (every configuration the PT recipes run) are held to 3 waves per SIMD, so that the three
+// heads of a step (3 x 256 blocks in one launch) are all resident at once; the big-batch shapes keep the registers they need.
+template <int NPB, int NG, bool PACK>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void emb_loss_fwd_kernel3(const ElMulti mt) {
+  emb_loss_fwd_body<NPB, NG, PACK>(mt);
+}
+template <int NPB, int NG, bool PACK>
+__global__ __launch_bounds__(256) void emb_loss_fwd_kernel2(const ElMulti mt) {
+  emb_loss_fwd_body<NPB, NG, PACK>(mt);
+}
+template <int NPB, int NG, bool PACK>
+void el_launch1(dim3 grid, hipStream_t s, const ElMulti& a) {
+  if constexpr (NPB * NG <= 8) hipLaunchKernelGGL((emb_loss_fwd_kernel3<NPB, NG, PACK>), grid, dim3(256), 0, s, a);
+  else hipLaunchKernelGGL((emb_loss_fwd_kernel2<NPB, NG, PACK>), grid, dim3(256), 0, s, a);
 }
 
 // dpred[b,d] = gout * ( a_b * clamp(p - t_own, -1, 1) + sum_j c_bj * t_j[d] - e_b * p[b,d] ); grid (feature slabs, ceil(B/8)):
@@ -512,6 +587,7 @@ __global__ __launch_bounds__(256) void emb_loss_bwd_kernel(const ElBwdMulti mt, 
 
 struct ElPlan {
   int npb, ng, njc, nblk, ngrp, ns;
+  bool pack;
 };
 
 // One ticket-counter set per distinct stream, handed out in order of first use (a hash of the stream pointer let two streams
@@ -534,11 +610,14 @@ ElPlan el_plan(int B, int Bw, long D) {
   const int groups = (Bw + 15) / 16;
   p.ng = groups <= 1 ? 1 : (groups <= 2 ? 2 : (groups <= 4 ? 4 : 8));
   p.njc = (groups + p.ng - 1) / p.ng;
-  const long nsteps = (D + 31) / 32;
-  // >= 2 k-steps per wave, at most 1024 streaming blocks per chunk (4 per CU) and MAX_GROUPS first-level groups in total
-  static const long cap = getenv("VP_EL_NBLK") ? atol(getenv("VP_EL_NBLK")) : 512L;       // dev knob (tools/emb_loss_bench.py)
+  p.pack = B <= 8 && Bw <= 8;                                    // (then npb = ng = 1)
+  const int nv = (2 * p.npb + p.ng) <= 8 ? 2 : 1;                // = the kernel's NV / KS
+  const long ks = 32L * nv * (p.pack ? 2 : 1);
+  const long nsteps = (D + ks - 1) / ks;
+  // >= spw k-steps per wave, at most `cap` streaming blocks per chunk and MAX_GROUPS first-level groups in total
+  static const long cap = getenv("VP_EL_NBLK") ? atol(getenv("VP_EL_NBLK")) : 256L;       // dev knob (tools/emb_loss_bench.py)
   static const long spw = getenv("VP_EL_SPW") ? atol(getenv("VP_EL_SPW")) : 2L;             // target k-steps per wave
-  long nblk = max(1L, min(min(cap, 1024L), (nsteps + 4 * spw - 1) / (4 * spw)));
+  long nblk = max(1L, min(min(cap, (long)G1 * G1), (nsteps + 4 * spw - 1) / (4 * spw)));
   while (p.njc * ((nblk + G1 - 1) / G1) > MAX_GROUPS) nblk /= 2;
   p.nblk = (int)nblk;
   p.ngrp = (p.nblk + G1 - 1) / G1;
@@ -549,10 +628,10 @@ ElPlan el_plan(int B, int Bw, long D) {
 template <int NPB>
 void el_launch(int ng, dim3 grid, hipStream_t s, const ElMulti& a) {
   switch (ng) {
-    case 1: hipLaunchKernelGGL((emb_loss_fwd_kernel<NPB, 1>), grid, dim3(256), 0, s, a); break;
-    case 2: hipLaunchKernelGGL((emb_loss_fwd_kernel<NPB, 2>), grid, dim3(256), 0, s, a); break;
-    case 4: hipLaunchKernelGGL((emb_loss_fwd_kernel<NPB, 4>), grid, dim3(256), 0, s, a); break;
-    default: hipLaunchKernelGGL((emb_loss_fwd_kernel<NPB, 8>), grid, dim3(256), 0, s, a); break;
+    case 1: el_launch1<NPB, 1, false>(grid, s, a); break;
+    case 2: el_launch1<NPB, 2, false>(grid, s, a); break;
+    case 4: el_launch1<NPB, 4, false>(grid, s, a); break;
+    default: el_launch1<NPB, 8, false>(grid, s, a); break;
   }
 }
 
@@ -609,7 +688,8 @@ int vp_emb_loss_fwd_multi(int ntask, int B, int Bw, const long* D, int rank, con
     p0 = p;
   }
   const dim3 grid(gx, p0.njc, ntask);
-  if (p0.npb == 1) el_launch<1>(p0.ng, grid, s, m);
+  if (p0.pack) el_launch1<1, 1, true>(grid, s, m);
+  else if (p0.npb == 1) el_launch<1>(p0.ng, grid, s, m);
   else if (p0.npb == 2) el_launch<2>(p0.ng, grid, s, m);
   else el_launch<4>(p0.ng, grid, s, m);
   return vp_check_launch("vp_emb_loss_fwd");
@@ -617,6 +697,8 @@ int vp_emb_loss_fwd_multi(int ntask, int B, int Bw, const long* D, int rank, con
 
 int vp_emb_loss_fwd(int B, int Bw, long D, int rank, const void* pred, const void* tgt_all, const float* mask,
                     const float* logit_scale, float w_contrastive, float* out3, float* coef, float* workspace, hipStream_t s) {
+  VP_REQUIRE(B > 0 && B <= 64 && Bw >= B && Bw <= 1024, VP_ERR_UNSUPPORTED_SHAPE,
+             "vp_emb_loss_fwd: need 0<B<=64, B<=Bw<=1024 (got B=%d Bw=%d)", B, Bw);
   VP_REQUIRE(pred && tgt_all && mask && out3 && coef && workspace, VP_ERR_BAD_ARG, "vp_emb_loss_fwd: null pointer");
   return vp_emb_loss_fwd_multi(1, B, Bw, &D, rank, &pred, &tgt_all, &mask, &logit_scale, &w_contrastive, &out3, &coef, &workspace, s);
 }
