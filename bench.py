@@ -506,23 +506,30 @@ def main():
     # roofline of the dominant kernel: the persistent 256x256x64 bf16 MFMA GEMM (every GEMM with >= 192 256x256 output tiles routes to it:
     # gemm_nt_256w4 since round 3, gemm_nt_256p8 with VP_GEMM_W4=0 or for the few shapes the 4-wave kernel does not take; ~80 % of the step).
     # achieved = algorithmic 2*M*N*K of those launches / their HIP-event-timed duration on the launch stream.
-    def is_p8(shp):
+    w4 = os.environ.get("VP_GEMM_W4", "1") != "0"
+
+    def is_dom(shp, kind):
+        # the launcher's routing (gemm.hip vp_gemm_bf16 / vp_gemm_bf16_swiglu): >= 192 256x256 tiles; the 4-wave kernel takes the lean launches
+        # (no bias / activation) of 256/256/128-aligned problems, the 8-phase kernel the rest -> ONE kernel's launches, comparable with its
+        # rocprofv3 --stats line (profiles/rNN_bench_kernel_stats.csv)
         M_, N_, K_ = shp
-        return K_ % 64 == 0 and M_ >= 256 and N_ >= 256 and ((M_ + 255) // 256) * ((N_ + 255) // 256) >= 192
-    big = [(e0.elapsed_time(e1), f) for e0, e1, f, shp in prof if is_p8(shp)]
-    g_ms = sum(e0.elapsed_time(e1) for e0, e1, _, _ in prof)
-    g_fl = sum(f for _, _, f, _ in prof)
+        if kind == "tn" or not (K_ % 64 == 0 and M_ >= 256 and N_ >= 256 and ((M_ + 255) // 256) * ((N_ + 255) // 256) >= 192):
+            return False
+        lean = kind == "nt_lean" and M_ % 256 == 0 and N_ % 256 == 0 and K_ % 128 == 0
+        return lean if w4 else True
+    big = [(e0.elapsed_time(e1), f) for e0, e1, f, shp, kind in prof if is_dom(shp, kind)]
+    g_ms = sum(e0.elapsed_time(e1) for e0, e1, _, _, _ in prof)
+    g_fl = sum(f for _, _, f, _, _ in prof)
     b_ms, b_fl = sum(t for t, _ in big), sum(f for _, f in big)
     achieved = b_fl / (b_ms * 1e-3) / 1e12 if b_ms > 0 else 0.0
     traffic = None                                     # HBM bytes per launch from a separate rocprofv3 --pmc pass (profiles/)
     try:
         pdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
-        latest = sorted(f for f in os.listdir(pdir) if f.endswith("_pmc_p8.json"))[-1]        # newest round's PMC pass
+        latest = sorted(f for f in os.listdir(pdir) if f.endswith("_pmc_w4.json" if w4 else "_pmc_p8.json"))[-1]        # newest round's PMC pass of the kernel that runs
         with open(os.path.join(pdir, latest)) as fh:
             traffic = json.load(fh).get("hbm_bytes_per_launch") if args.workload == "llama3_8b" else None
     except (OSError, ValueError):
         pass
-    w4 = os.environ.get("VP_GEMM_W4", "1") != "0"
     roof = {"bound": "mfma", "kernel": ("gemm_nt_256w4 (bf16 MFMA 16x16x32, persistent 256x256x64 tiles, one wave per SIMD with a 128x128 sub-tile in AGPRs, "
                                         "hand-scheduled K loop: one LDS-DMA piece / ds_read per MFMA gap)" if w4 else
                                         "gemm_nt_256p8 (bf16 MFMA 16x16x32, persistent 256x256x64 tiles, two wave groups in ping-pong, 4 phases per K-tile)"),

@@ -16,7 +16,7 @@ e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=Tr
 e0.record(); eng.train_step(batch); eng.optimizer_step(1e-3); e1.record(); torch.cuda.synchronize()
 prof, ops.GEMM_PROF = ops.GEMM_PROF, None
 agg = collections.defaultdict(lambda: [0, 0.0, 0.0])
-for a, b, fl, shp in prof:
+for a, b, fl, shp, _kind in prof:
     r = agg[shp]; r[0] += 1; r[1] += a.elapsed_time(b); r[2] += fl
 tot = sum(r[1] for r in agg.values())
 print(f"step {e0.elapsed_time(e1):.1f} ms, GEMM {tot:.1f} ms in {len(prof)} launches")

@@ -31,6 +31,8 @@ constexpr int vp_w4_rd_slot(int g) {
     if (RG[r] == g) return r;
   return -1;
 }
+// byte offset of B fragment r = 4 h + 2 s + jj from the lane's base row: rows 64 h + 32 s + 4 jj of 128 bytes
+constexpr int vp_w4_boff(int r) { return ((r >> 2) * 64 + ((r >> 1) & 1) * 32 + (r & 1) * 4) * 128; }
 template <int N, class F>
 __device__ __forceinline__ void vp_static_for(F&& f) { vp_static_for_impl(static_cast<F&&>(f), std::make_integer_sequence<int, N>{}); }
 
@@ -448,142 +450,152 @@ __device__ __forceinline__ void epilogue_swz(const GemmArgs& p, bf16_t* wave_lds
   }
 }
 
-// Epilogue of the 4-wave kernel (decoder GEMMs: no bias, no activation; optional residual; fused SwiGLU forward / backward).  The 256
-// accumulators live in AGPRs and NEVER become compiler-managed values: inline asm writes them straight from the AGPRs into the wave's 8 KB
-// staging slice as fp32 (ds_write_b128 takes AGPR data), 32 rows x 64 columns per pass, eight passes per wave; what the compiler sees is only
-// the read-back — rows re-laid so that a lane holds 8 (or 16) consecutive columns — bf16 rounding, residual / SwiGLU arithmetic and 16-byte
-// stores, all on ordinary VGPRs.  (Letting the compiler read the accumulators itself made it pull all 256 out of the AGPRs at the K loop's exit:
-// ~500 v_accvgpr_mov / scratch spills per output tile, epilogue 10 us against the 8-phase kernel's 4.)  fp32 rows are 256 B: the 16-byte chunk
-// index is XOR-ed with (row & 15) so that both the column-strided writes and the row-major reads are bank-conflict free.  Rounding points as
-// everywhere: accumulator -> bf16, (+ residual -> bf16) / (SwiGLU on bf16-rounded values): bit-identical to epilogue_swz.
-// Loads a pass needs (residual rows, saved gate|up rows) are issued one pass ahead.
-#define W4E_WRITE(ADDR, ACC, OFF) asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(ADDR), "a"(ACC), "n"(OFF) : "memory")
-__device__ __forceinline__ void epilogue_w4(const GemmArgs& p, bf16_t* wave_lds, f32x4 (&acc)[2][8][4], int mrow0, int ncol0, int lane) {
-  const int fr = lane & 15, g = lane >> 4;
-  const uint32_t lb = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)wave_lds;
-  uint32_t wad[4];                                      // write address of column block j: row fr (+ 16 t via the offset), chunk (4 j + g) ^ fr
+// Epilogue of the 4-wave kernel (decoder GEMMs: no bias, no activation; optional residual; fused SwiGLU forward / backward): STRAIGHT from the
+// accumulators to global memory, no LDS pass.  An MFMA result lane holds 4 consecutive columns of one token row; which weight row sits in which
+// MFMA row of which B fragment is the K loop's free choice, and it reads them so that the four B fragments (2 s + jj) of a 64-column half h hand
+// lane (fr, g) the columns 64 h + 32 s + 8 g + 4 jj + e: two runs of 8 consecutive columns per accumulator row = two 16-byte bf16 stores, the
+// four lanes g of a row side by side (64 contiguous bytes per row and store instruction, the other half of the 128-byte line by the next one).
+// Round 3's first version staged every 32 x 64 block through LDS as fp32 (8 passes of write / wait / read / wait: 4.5 us per tile).
+// Rounding points as everywhere: accumulator -> bf16, (+ residual -> bf16) / (SwiGLU on bf16-rounded values): bit-identical to epilogue_swz.
+// SwiGLU forward: the (g8 | u8) column pairs of gate_up put the gate block in the even-g lanes and the up block in the odd-g lanes; one
+// v_permlane16_swap per dword (16-lane rows of two registers trade places) gives every lane a whole pair.
+__device__ __forceinline__ void epilogue_w4(const GemmArgs& p, f32x4 (&acc)[2][8][4], int mrow0, int ncol0, int lane) {
+  int fr = lane & 15, g = lane >> 4;
+  asm volatile("" : "+v"(fr), "+v"(g));      // opaque: keeps the lane offsets below from being hoisted out of the tile loop (and spilled across the K loop)
+  auto pk = [&](int h, int i, int s2) __attribute__((always_inline)) -> u32x4 {
+    // (explicit v_accvgpr_read per element: when the compiler copied the accumulators out of the AGPRs on its own it did so for all 256 at the
+    // K loop's exit and spilled ~150 tuples to scratch)
+    f32x4 a, b;
 #pragma unroll
-  for (int j = 0; j < 4; ++j) wad[j] = lb + (uint32_t)(fr * 256 + (((j * 4 + g) ^ fr) << 4));
-  const float* stg = (const float*)wave_lds;
-  // pass hp = h * 4 + rq: columns ncol0 + 64 h .., rows mrow0 + 32 rq ..
-  auto dump = [&](int hp) __attribute__((always_inline)) {
-    const int h = hp >> 2, rq = hp & 3;
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        if (t == 0) W4E_WRITE(wad[j], acc[h][rq * 2 + t][j], 0); else W4E_WRITE(wad[j], acc[h][rq * 2 + t][j], 4096);
-      }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  };
-  // 8 consecutive columns (chunks 2c, 2c + 1) of staged row r, rounded to bf16 pairs
-  auto rd8 = [&](int r, int c) __attribute__((always_inline)) -> u32x4 {
-    const f32x4 lo = *(const f32x4*)(stg + r * 64 + (((2 * c) ^ (r & 15)) << 2));
-    const f32x4 hi = *(const f32x4*)(stg + r * 64 + (((2 * c + 1) ^ (r & 15)) << 2));
+    for (int e = 0; e < 4; ++e) {
+      float x, y;
+      asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(x) : "a"(acc[h][i][2 * s2][e]));
+      asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(y) : "a"(acc[h][i][2 * s2 + 1][e]));
+      a[e] = x; b[e] = y;
+    }
     u32x4 v;
-    v[0] = pack_bf16x2(lo[0], lo[1]); v[1] = pack_bf16x2(lo[2], lo[3]); v[2] = pack_bf16x2(hi[0], hi[1]); v[3] = pack_bf16x2(hi[2], hi[3]);
+    v[0] = pack_bf16x2(a[0], a[1]); v[1] = pack_bf16x2(a[2], a[3]); v[2] = pack_bf16x2(b[0], b[1]); v[3] = pack_bf16x2(b[2], b[3]);
     return v;
   };
-  const int rl0 = lane >> 3, ch = lane & 7;             // read-back lane map: row rl0 + 8 it (it 0..3), columns 8 ch ..
-  if (p.mode == 2) {
-    bf16x8 gv[2][4], uv[2][4];
-    auto load2 = [&](int hp, int slot) __attribute__((always_inline)) {
-      const int h = hp >> 2, rq = hp & 3;
-      const bf16_t* gptr = p.aux + (long)(mrow0 + rq * 32 + rl0) * p.ldaux + 2 * (ncol0 + h * 64 + ch * 8);
+  // The epilogue is VALU-ISSUE bound (one wave per SIMD: every instruction costs its 4 cycles; a first version with 64-bit pointers and the
+  // residual / cache-policy choices inside the store loop spent 25 instructions per 16-byte store: 4.1 us per tile even with only 32 blocks on
+  // the chip).  Every matrix is therefore addressed through a buffer descriptor based at THIS WAVE's 128 x 128 sub-tile (scalar arithmetic):
+  // lane offset (fr * ld + 8 g) elements, + 16 ld per A fragment, the column part in the instruction's immediate.
+  auto tile_rs = [&](const void* base, long ld, long col) __attribute__((always_inline)) -> __amdgpu_buffer_rsrc_t {
+    const uint64_t b = (uint64_t)(uintptr_t)base + (uint64_t)(((long)mrow0 * ld + col) * 2);
+    const uint64_t bu = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(b >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)b);
+    return __builtin_amdgcn_make_buffer_rsrc((void*)(uintptr_t)bu, 0, 0x7fffffff, 0x00020000);
+  };
+#ifndef W4E_ONLY
+#define W4E_ONLY 0
+#endif
+  if ((W4E_ONLY == 0 || W4E_ONLY == 3) && p.mode == 2) {
+    // SwiGLU backward: the accumulators are d(act); act block (64 h + 32 s + 8 g ..+7) <-> the 32 bytes (g8 | u8) at twice that column of the saved
+    // gate_up (aux) and of d(gate_up) (C).  The saved rows of half h = 1 are fetched into the registers half h = 0 has just consumed.
+    const __amdgpu_buffer_rsrc_t ars = tile_rs(p.aux, p.ldaux, 2L * ncol0), drs = tile_rs(p.C, p.ldc, 2L * ncol0);
+    const int aoff = (fr * p.ldaux + g * 16) * 2, astep = p.ldaux * 32, doff = (fr * p.ldc + g * 16) * 2, dstep = p.ldc * 32;
+    u32x4 gv[8][2], uv[8][2];
 #pragma unroll
-      for (int it = 0; it < 4; ++it) {
-        gv[slot][it] = *(const bf16x8*)(gptr + (long)(it * 8) * p.ldaux);
-        uv[slot][it] = *(const bf16x8*)(gptr + (long)(it * 8) * p.ldaux + 8);
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        gv[i][s2] = __builtin_amdgcn_raw_buffer_load_b128(ars, aoff + i * astep, s2 * 128, 0);
+        uv[i][s2] = __builtin_amdgcn_raw_buffer_load_b128(ars, aoff + i * astep, s2 * 128 + 16, 0);
       }
-    };
-    load2(0, 0);
 #pragma unroll
-    for (int hp = 0; hp < 8; ++hp) {
-      const int h = hp >> 2, rq = hp & 3, slot = hp & 1;
-      dump(hp);
-      if (hp + 1 < 8) load2(hp + 1, slot ^ 1);
-      bf16_t* dptr = (bf16_t*)p.C + (long)(mrow0 + rq * 32 + rl0) * p.ldc + 2 * (ncol0 + h * 64 + ch * 8);
+    for (int h = 0; h < 2; ++h)
 #pragma unroll
-      for (int it = 0; it < 4; ++it) {
-        const bf16x8 dv = __builtin_bit_cast(bf16x8, rd8(it * 8 + rl0, ch));
-        bf16x8 og, ou;
+      for (int i = 0; i < 8; ++i) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const float gg = bf2f((bf16_t)gv[slot][it][e]), uu = bf2f((bf16_t)uv[slot][it][e]), dd = bf2f((bf16_t)dv[e]);
-          const float sg = 1.f / (1.f + __expf(-gg));
-          og[e] = (short)f2bf(dd * uu * sg * (1.f + gg * (1.f - sg)));
-          ou[e] = (short)f2bf(dd * gg * sg);
+        for (int s2 = 0; s2 < 2; ++s2) {
+          const bf16x8 dv = __builtin_bit_cast(bf16x8, pk(h, i, s2));
+          const bf16x8 gq = __builtin_bit_cast(bf16x8, gv[i][s2]), uq = __builtin_bit_cast(bf16x8, uv[i][s2]);
+          bf16x8 og, ou;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float gg = bf2f((bf16_t)gq[e]), uu = bf2f((bf16_t)uq[e]), dd = bf2f((bf16_t)dv[e]);
+            const float sg = 1.f / (1.f + __expf(-gg));
+            og[e] = (short)f2bf(dd * uu * sg * (1.f + gg * (1.f - sg)));
+            ou[e] = (short)f2bf(dd * gg * sg);
+          }
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, og), drs, doff + i * dstep, h * 256 + s2 * 128, 0);
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, ou), drs, doff + i * dstep, h * 256 + s2 * 128 + 16, 0);
+          if (h == 0) {
+            gv[i][s2] = __builtin_amdgcn_raw_buffer_load_b128(ars, aoff + i * astep, 256 + s2 * 128, 0);
+            uv[i][s2] = __builtin_amdgcn_raw_buffer_load_b128(ars, aoff + i * astep, 256 + s2 * 128 + 16, 0);
+          }
         }
-        *(bf16x8*)(dptr + (long)(it * 8) * p.ldc) = og;
-        *(bf16x8*)(dptr + (long)(it * 8) * p.ldc + 8) = ou;
+        __builtin_amdgcn_sched_barrier(0);
       }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the slice is read before the next pass overwrites it
-    }
     return;
   }
-  if (p.mode == 1) {
-    // SwiGLU forward: lane (row rl + 16 it, it 0..1; chunk pair pr) holds 16 consecutive columns = one (g8 | u8) pair: stores both 16-byte halves
-    // of gate_up and the 8 act columns
-    const int rl = lane >> 2, pr = lane & 3;
+  const __amdgpu_buffer_rsrc_t crs = tile_rs(p.C, p.ldc, ncol0);
+  const int coff = (fr * p.ldc + g * 8) * 2, cstep = p.ldc * 32;
+  if ((W4E_ONLY == 0 || W4E_ONLY == 2) && p.mode == 1) {
+    // SwiGLU forward: C = gate_up (raw), C2 = act.  After the swap the even-g lanes hold pair g / 2, the odd-g lanes pair (g + 3) / 2 of the half.
+    const int pq = (g & 1) ? (g + 3) >> 1 : g >> 1;
+    const __amdgpu_buffer_rsrc_t ars = tile_rs(p.C2, p.ldc2, ncol0 >> 1);
+    const int aoff = (fr * p.ldc2 + pq * 8) * 2, astep = p.ldc2 * 32;
 #pragma unroll
-    for (int hp = 0; hp < 8; ++hp) {
-      const int h = hp >> 2, rq = hp & 3;
-      dump(hp);
-      bf16_t* cptr = (bf16_t*)p.C + (long)(mrow0 + rq * 32 + rl) * p.ldc + ncol0 + h * 64 + pr * 16;
-      bf16_t* aptr = (bf16_t*)p.C2 + (long)(mrow0 + rq * 32 + rl) * p.ldc2 + ((ncol0 + h * 64) >> 1) + pr * 8;
+    for (int h = 0; h < 2; ++h)
 #pragma unroll
-      for (int it = 0; it < 2; ++it) {
-        const u32x4 gq = rd8(it * 16 + rl, 2 * pr), uq = rd8(it * 16 + rl, 2 * pr + 1);
-        *(u32x4*)(cptr + (long)(it * 16) * p.ldc) = gq;
-        *(u32x4*)(cptr + (long)(it * 16) * p.ldc + 8) = uq;
-        const bf16x8 gvv = __builtin_bit_cast(bf16x8, gq), uvv = __builtin_bit_cast(bf16x8, uq);
+      for (int i = 0; i < 8; ++i) {
+        u32x4 x = pk(h, i, 0), y = pk(h, i, 1);
+        __builtin_amdgcn_raw_buffer_store_b128(x, crs, coff + i * cstep, h * 128, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(y, crs, coff + i * cstep, h * 128 + 64, 0);
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+          const auto r = __builtin_amdgcn_permlane16_swap(x[d], y[d], false, false);
+          x[d] = r[0]; y[d] = r[1];
+        }
+        const bf16x8 gvv = __builtin_bit_cast(bf16x8, x), uvv = __builtin_bit_cast(bf16x8, y);
         bf16x8 o;
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[e] = (short)f2bf(bfround(silu(bf2f((bf16_t)gvv[e]))) * bf2f((bf16_t)uvv[e]));
-        *(bf16x8*)(aptr + (long)(it * 16) * p.ldc2) = o;
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), ars, aoff + i * astep, h * 64, 0);
+        __builtin_amdgcn_sched_barrier(0);
       }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    }
     return;
   }
-  // plain / residual
-  u32x4 rv[2][4];
-  const bool has_res = p.res != nullptr;
-  auto loadr = [&](int hp, int slot) __attribute__((always_inline)) {
-    const int h = hp >> 2, rq = hp & 3;
-    const bf16_t* rptr = p.res + (long)(mrow0 + rq * 32 + rl0) * p.ldr + ncol0 + h * 64 + ch * 8;
+  // plain / residual: the residual / non-temporal choices are made once per tile, not per store
+  if (W4E_ONLY > 1) return;
+  auto body = [&](auto res_c, auto nt_c) __attribute__((always_inline)) {
+    constexpr bool RES = decltype(res_c)::value, NT = decltype(nt_c)::value;
+    u32x4 rv[8][2];
+    const __amdgpu_buffer_rsrc_t rrs = tile_rs(RES ? (const void*)p.res : p.C, RES ? p.ldr : p.ldc, ncol0);
+    const int roff = (fr * p.ldr + g * 8) * 2, rstep = p.ldr * 32;
+    if (RES) {
 #pragma unroll
-    for (int it = 0; it < 4; ++it) rv[slot][it] = *(const u32x4*)(rptr + (long)(it * 8) * p.ldr);
-  };
-  if (has_res) loadr(0, 0);
+      for (int i = 0; i < 8; ++i)
 #pragma unroll
-  for (int hp = 0; hp < 8; ++hp) {
-    const int h = hp >> 2, rq = hp & 3, slot = hp & 1;
-    dump(hp);
-    if (has_res && hp + 1 < 8) loadr(hp + 1, slot ^ 1);
-    bf16_t* cptr = (bf16_t*)p.C + (long)(mrow0 + rq * 32 + rl0) * p.ldc + ncol0 + h * 64 + ch * 8;
-#pragma unroll
-    for (int it = 0; it < 4; ++it) {
-      u32x4 v = rd8(it * 8 + rl0, ch);
-      if (has_res) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float lo = __builtin_bit_cast(float, v[e] << 16) + __builtin_bit_cast(float, rv[slot][it][e] << 16);
-          const float hi = __builtin_bit_cast(float, v[e] & 0xffff0000u) + __builtin_bit_cast(float, rv[slot][it][e] & 0xffff0000u);
-          v[e] = pack_bf16x2(lo, hi);
-        }
-      }
-      if (p.c_nt) {
-        const __amdgpu_buffer_rsrc_t crs = __builtin_amdgcn_make_buffer_rsrc((void*)p.C, 0, 0x7fffffff, 0x00020000);
-        __builtin_amdgcn_raw_buffer_store_b128(v, crs, (int)((const char*)cptr - (const char*)p.C), (int)((long)(it * 8) * p.ldc * 2), 2);
-      } else {
-        *(u32x4*)(cptr + (long)(it * 8) * p.ldc) = v;
-      }
+        for (int s2 = 0; s2 < 2; ++s2) rv[i][s2] = __builtin_amdgcn_raw_buffer_load_b128(rrs, roff + i * rstep, s2 * 64, 0);
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  }
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          u32x4 v = pk(h, i, s2);
+          if (RES) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float lo = __builtin_bit_cast(float, v[e] << 16) + __builtin_bit_cast(float, rv[i][s2][e] << 16);
+              const float hi = __builtin_bit_cast(float, v[e] & 0xffff0000u) + __builtin_bit_cast(float, rv[i][s2][e] & 0xffff0000u);
+              v[e] = pack_bf16x2(lo, hi);
+            }
+            if (h == 0) rv[i][s2] = __builtin_amdgcn_raw_buffer_load_b128(rrs, roff + i * rstep, 128 + s2 * 64, 0);
+          }
+          if (NT) __builtin_amdgcn_raw_buffer_store_b128(v, crs, coff + i * cstep, h * 128 + s2 * 64, 2);
+          else __builtin_amdgcn_raw_buffer_store_b128(v, crs, coff + i * cstep, h * 128 + s2 * 64, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+  };
+  using T_ = std::true_type; using F_ = std::false_type;
+  if (p.res != nullptr) { if (p.c_nt) body(T_{}, T_{}); else body(T_{}, F_{}); }
+  else { if (p.c_nt) body(F_{}, T_{}); else body(F_{}, F_{}); }
 }
-#undef W4E_WRITE
 
 template <bool OUT_F32>
 __global__ __launch_bounds__(512) void gemm_nt_256(GemmArgs p) {
@@ -1358,13 +1370,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   // it is chunk (q & 7) ^ ((row >> 1) & 7) of that row on the source side, so the 128-byte LDS rows read conflict-free with ds_read_b128
   const int drow = tid >> 3, dsw = ((tid & 7) ^ ((drow >> 1) & 7)) << 3;
   // one lane offset per operand (bytes into the 256-row panel); the piece (32 rows each) and the K-tile go into the scalar offset
-  const uint32_t vA = (uint32_t)(drow * p.lda + dsw) * 2u, vB = (uint32_t)(drow * p.ldb + dsw) * 2u;
+  // B rows are swizzled by ((row >> 3) & 3) * 2 + ((row >> 1) & 1) instead: the fragment reads below visit them in the epilogue's column order
+  const int dswb = ((tid & 7) ^ ((((drow >> 3) & 3) << 1) | ((drow >> 1) & 1))) << 3;
+  const uint32_t vA = (uint32_t)(drow * p.lda + dsw) * 2u, vB = (uint32_t)(drow * p.ldb + dswb) * 2u;
   const uint32_t stepA = __builtin_amdgcn_readfirstlane((uint32_t)(32 * p.lda * 2)), stepB = __builtin_amdgcn_readfirstlane((uint32_t)(32 * p.ldb * 2));
   // fragment read addresses (bytes): + i * 2048 per 16-row block; one set per LDS buffer so the loop needs no address arithmetic
   const int fsw0 = (g ^ ((fr >> 1) & 7)) << 3, fsw1 = ((4 + g) ^ ((fr >> 1) & 7)) << 3;
   const uint32_t ldsb = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)smem;
   const uint32_t aad0 = ldsb + 2u * (uint32_t)((wr * 128 + fr) * 64 + fsw0), aad1 = ldsb + 2u * (uint32_t)((wr * 128 + fr) * 64 + fsw1);
-  const uint32_t bad0 = ldsb + 32768u + 2u * (uint32_t)((wc * 128 + fr) * 64 + fsw0), bad1 = ldsb + 32768u + 2u * (uint32_t)((wc * 128 + fr) * 64 + fsw1);
+  // B fragment r = 4 h + 2 s + jj, MFMA row fr  <-  tile row 64 h + 32 s + 8 (fr >> 2) + 4 jj + (fr & 3)  (see epilogue_w4): lane base row
+  // 8 (fr >> 2) + (fr & 3), fragment offset W4_BOFF(r) rows; that row's swizzle key is fr >> 1 for every fragment, like the A side's
+  const int brow = wc * 128 + ((fr >> 2) << 3) + (fr & 3);
+  const uint32_t bad0 = ldsb + 32768u + 2u * (uint32_t)(brow * 64 + fsw0), bad1 = ldsb + 32768u + 2u * (uint32_t)(brow * 64 + fsw1);
   uint32_t aad0x = aad0 + 65536u, aad1x = aad1 + 65536u, bad0x = bad0 + 65536u, bad1x = bad1 + 65536u;
   asm volatile("" : "+v"(aad0x), "+v"(aad1x), "+v"(bad0x), "+v"(bad1x));     // keep them in registers (not re-derived inside the loop)
   // LDS destination of this wave's first piece in buffer 0 / 1 (every piece is 1 KB per wave, 4 KB per workgroup; 16 pieces = one buffer)
@@ -1436,7 +1453,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   W4_BAR();
   bf16x8 fa0[8], fb0[8], fa1[8], fb1[8];
 #pragma unroll
-  for (int r = 0; r < 8; ++r) { W4_LDS(fa0[r], aad0, r * 2048); W4_LDS(fb0[r], bad0, r * 2048); }
+  for (int r = 0; r < 8; ++r) { W4_LDS(fa0[r], aad0, r * 2048); W4_LDS(fb0[r], bad0, vp_w4_boff(r)); }
   // asm ds_reads are invisible to the compiler's wait-count bookkeeping: if it moves or spills one of these registers before the data has
   // landed it saves garbage (seen: a scratch_store of fa0[7] right behind its ds_read, in front of the per-wave dispatch below).  Every point
   // where compiler-generated code follows in-flight fragment reads therefore waits for them first.
@@ -1471,7 +1488,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       if (g_ >= 22 && g_ <= 57 && (g_ - 22) % 5 == 0) W4_M0BUMP();                                     \
       if (g_ >= 23 && g_ <= 53 && (g_ - 23) % 5 == 0) W4_SOFFBUMP(stepA);          /* 23,28..53: 7 bumps between the 8 pieces */ \
       if constexpr (g_ >= 24 && g_ <= 40 && ((g_ - 24) % 5 == 0 || (g_ - 24) % 5 == 1))    /* B fragments: gaps 24,25,29,30,..,39,40 */ \
-        W4_LDS(fb1[(((g_ - 24) / 5) * 2 + (g_ - 24) % 5) & 7], rb1_, ((((g_ - 24) / 5) * 2 + (g_ - 24) % 5) & 7) * 2048); \
+        W4_LDS(fb1[(((g_ - 24) / 5) * 2 + (g_ - 24) % 5) & 7], rb1_, vp_w4_boff((((g_ - 24) / 5) * 2 + (g_ - 24) % 5) & 7)); \
       if (g_ == 58) W4_SOFF0();                                                    /* B operand starts at the K-tile's offset again */ \
       if (g_ == 44) W4_LGKM0();                                                                        \
       if (g_ == 45) W4_BAR();                                                      /* the B half is free */ \
@@ -1493,7 +1510,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       if (g_ == 53) W4_KBUMP();                                                                        \
       constexpr int r_ = vp_w4_rd_slot(g_);                                        /* the 16 fragments of K-step 0 of K-tile kt+1 */ \
       if constexpr (r_ >= 0 && r_ < 8) W4_LDS(fa0[r_ & 7], ra0n_, (r_ & 7) * 2048);                    \
-      if constexpr (r_ >= 8) W4_LDS(fb0[r_ & 7], rb0n_, (r_ & 7) * 2048);                              \
+      if constexpr (r_ >= 8) W4_LDS(fb0[r_ & 7], rb0n_, vp_w4_boff(r_ & 7));                              \
     });                                                                                                \
     ADVANCE_STREAM();                                                                                  \
   }
@@ -1547,17 +1564,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const int vnext = v + gridDim.x;
     const int mr = tcur.m0 + wr * 128, nc = tcur.n0 + wc * 128;
     if (!OUT_F32) {
-      bf16_t* stage = smem + 65536 + wave * 4096;
-      epilogue_w4(p, stage, acc, mr, nc, lane);        // (the launcher sends bias / activation epilogues and unaligned C to the 8-phase kernel:
+      epilogue_w4(p, acc, mr, nc, lane);        // (the launcher sends bias / activation epilogues and unaligned C to the 8-phase kernel:
                                                        // the general epilogue's registers beside 256 accumulators made the allocator spill AGPRs)
     } else {
-      float* c = (float*)p.C + (long)(mr + fr) * p.ldc + nc + g * 4;
+      float* c = (float*)p.C + (long)(mr + fr) * p.ldc + nc + g * 8;
 #pragma unroll
       for (int h = 0; h < 2; ++h)
 #pragma unroll
         for (int i = 0; i < 8; ++i)
 #pragma unroll
-          for (int j = 0; j < 4; ++j) *(f32x4*)(c + (long)(i * 16) * p.ldc + h * 64 + j * 16) = acc[h][i][j];
+          for (int j = 0; j < 4; ++j) *(f32x4*)(c + (long)(i * 16) * p.ldc + h * 64 + (j >> 1) * 32 + (j & 1) * 4) = acc[h][i][j];
     }
     if ((p.dbg & 0x10000) && threadIdx.x == 0 && v == (int)blockIdx.x) {
       vp_dbg_stamps[blockIdx.x * 8 + 3] = wall_clock64();          // epilogue issued
@@ -1568,7 +1584,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     v = vnext;
     tc = TILE_OF(v);
 #pragma unroll
-    for (int r = 0; r < 8; ++r) { W4_LDS(fa0[r], aad0, r * 2048); W4_LDS(fb0[r], bad0, r * 2048); }      // K-tile 0 of the next tile: buffer 0 (nt is even)
+    for (int r = 0; r < 8; ++r) { W4_LDS(fa0[r], aad0, r * 2048); W4_LDS(fb0[r], bad0, vp_w4_boff(r)); }      // K-tile 0 of the next tile: buffer 0 (nt is even)
     W4_LGKM0();
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the trailing dummy DMAs must not outlive the workgroup's LDS
@@ -1839,13 +1855,15 @@ int vp_gemm_bf16(int M, int N, int K, const void* A, long lda, const void* B, lo
     if (w4_env < 0) { const char* e = getenv("VP_GEMM_W4"); w4_env = e ? atoi(e) : 1; }      // default since round 3 (VP_GEMM_W4=0: the 8-phase kernel)
     const bool w4_ok = fast && M % 256 == 0 && N % 256 == 0 && K % 128 == 0 && (big_tiles >= 192 || force_generic >= 8) &&
                        !bias && (epilogue & 0xff) == EPI_NONE && (((uintptr_t)C) & 15) == 0 &&
-                       (out_f32 ? (!residual && ldc % 4 == 0) : (ldc % 8 == 0 && (!residual || (ldr % 8 == 0 && (((uintptr_t)residual) & 15) == 0))));
+                       (out_f32 ? (!residual && ldc % 4 == 0)
+                                : (ldc % 8 == 0 && ldc < (1L << 22) &&                       // (32-bit byte offsets inside a 128-row sub-tile)
+                                   (!residual || (ldr % 8 == 0 && ldr < (1L << 22) && (((uintptr_t)residual) & 15) == 0))));
     // The 4-wave kernel walks its tiles statically.  Next to RCCL kernels (world > 1) a CU that a collective holds delays that block's share
     // (tools/gemm_interference.py: up to 1.45x for the launches that overlap a collective); in the PT step that is the handful of GEMMs under the
     // 0.2 GB gradient all-reduce, against 6-10 % on every launch with the 8-phase kernel and its per-XCD tile claims — so the multi-GPU step uses
     // it too (VP_GEMM_W4=0 / VP_GEMM_W4=2 "only when no collective can run beside it" select the 8-phase kernel).
     if (w4_ok && (force_generic == 8 || (force_generic == 0 && (w4_env == 1 || (w4_env == 2 && g_dyn_mode != 1))))) {
-      p.c_nt = (!out_f32 && N <= 8192 && (long)M * ldc * 2 < 0x7fffffffL && vp_c_nt_enabled()) ? 1 : 0;
+      p.c_nt = (!out_f32 && N <= 8192 && vp_c_nt_enabled()) ? 1 : 0;
       static bool attr_w4 = false;
       if (!attr_w4) {
         (void)hipFuncSetAttribute((const void*)gemm_nt_256w4<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
@@ -1934,7 +1952,7 @@ int vp_gemm_bf16_swiglu(int mode, int M, int N, int K, const void* A, long lda, 
   {
     static int w4_env = -1;
     if (w4_env < 0) { const char* e = getenv("VP_GEMM_W4"); w4_env = e ? atoi(e) : 1; }
-    if ((w4_env == 1 || (w4_env == 2 && g_dyn_mode != 1)) && K % 128 == 0 && big_tiles >= 192) {        // same routing as vp_gemm_bf16
+    if ((w4_env == 1 || (w4_env == 2 && g_dyn_mode != 1)) && K % 128 == 0 && big_tiles >= 192 && ldc < (1L << 21) && ldc2 < (1L << 21) && ldaux < (1L << 21)) {   // same routing as vp_gemm_bf16
       static bool attr_w4 = false;
       if (!attr_w4) {
         (void)hipFuncSetAttribute((const void*)gemm_nt_256w4<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);

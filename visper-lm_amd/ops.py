@@ -60,7 +60,7 @@ def gemm(a, w, bias=None, residual=None, epi=EPI_NONE, out=None, out_f32=False, 
               1 if out.dtype == torch.float32 else 0, int(force_generic), _stream())
     if GEMM_PROF is not None:
         e1.record()
-        GEMM_PROF.append((e0, e1, 2.0 * M * N * K, (M, N, K)))
+        GEMM_PROF.append((e0, e1, 2.0 * M * N * K, (M, N, K), "nt_lean" if (bias is None and epi == 0) else "nt_epi"))
     return out
 
 
@@ -152,7 +152,7 @@ def gemm_swiglu_fwd(a, w_gu):
     _lib.call("vp_gemm_bf16_swiglu", 1, M, N, K, _p(a), lda, _p(w_gu), ldb, _p(gu), N, _p(act), N // 2, None, 0, _stream())
     if GEMM_PROF is not None:
         e1.record()
-        GEMM_PROF.append((e0, e1, 2.0 * M * N * K, (M, N, K)))
+        GEMM_PROF.append((e0, e1, 2.0 * M * N * K, (M, N, K), "nt_lean"))
     return gu, act
 
 
@@ -169,7 +169,7 @@ def gemm_swiglu_bwd(dy, w_down_T, gate_up):
               _stream())
     if GEMM_PROF is not None:
         e1.record()
-        GEMM_PROF.append((e0, e1, 2.0 * M * N * K, (M, N, K)))
+        GEMM_PROF.append((e0, e1, 2.0 * M * N * K, (M, N, K), "nt_lean"))
     return dgu
 
 
@@ -193,7 +193,7 @@ def gemm_tn(a, b, out=None, out_f32=True, accumulate=False):
     _lib.call("vp_gemm_tn_bf16", M, N, K, _p(a), lda, _p(b), ldb, _p(out), out.stride(0), int(out_f32), int(accumulate), _stream())
     if GEMM_PROF is not None:
         e1.record()
-        GEMM_PROF.append((e0, e1, 2.0 * M * N * K, (M, N, K)))
+        GEMM_PROF.append((e0, e1, 2.0 * M * N * K, (M, N, K), "tn"))
     return out
 
 
