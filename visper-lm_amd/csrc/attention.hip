@@ -1292,6 +1292,237 @@ _Pragma("unroll") \
 }
 
 // ================================================================================================
+// forward for D = 128, round 3: 32x32x16 MFMAs with the swapped product S^T = K Q^T.
+// Block = 8 waves x 32 query rows (256 rows of one q head, one block per CU, two waves per SIMD); K / V stream through a 4-stage ring of
+// 64-key tiles (global_load_lds, swizzled source chunks, counted vmcnt, one raw s_barrier per tile) — every tile is fetched once per 256 rows.
+//   * S^T[key][query]: the lane owns ONE query (lane & 31) and 32 of the tile's 64 scores of it (the other 32 sit in lane ^ 32): running max,
+//     exp2, row sum are lane-local scalars; one cross-half exchange only when the max jumps by more than 2^8 (T13 defer-max).
+//   * O^T[d][query] += V^T P^T: the P^T operand (16 keys x 32 queries, lane = query, 8 key slots) is a plain bf16 pack of 8 CONSECUTIVE
+//     accumulator registers of S^T (register 8 t + s of key block kb <-> key 32 kb + 16 t + 8 (s >> 2) + 4 hh + (s & 3), hh = lane >> 5);
+//     the V^T operand gathers the SAME keys per slot with two transposing reads (4 consecutive keys each), so no lane exchange is needed,
+//     and O's columns stay with the lane that owns the query: the rescale is a per-lane scalar multiply.
+//   * a 1 KB K or V fragment feeds a 32x32x16 MFMA = 16 K MACs (the 16-row kernel: 8 K) -> half the LDS bytes per flop.
+// ================================================================================================
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+constexpr int FWDM_STAGE = 2 * 64 * 128;              // bf16 units: K tile (64 keys) | V tile
+constexpr int FWDM_LDS = 4 * FWDM_STAGE * 2;          // bytes (128 KB)
+
+template <bool CAUSAL>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_fwd128m_kernel(AttnParams p) {
+  constexpr int D = 128;
+  extern __shared__ __attribute__((aligned(16))) unsigned char attn_smem[];
+  bf16_t* const ring = (bf16_t*)attn_smem;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int nqb = (p.Sq + 255) >> 8;
+  const int qb = nqb - 1 - VP_BZ(p);                   // z is the slowest dispatch index: heavy (late) causal blocks first
+  const int hx = blockIdx.x;
+  const int h = (p.Hq & 7) == 0 ? (hx & 7) * (p.Hq >> 3) + (hx >> 3) : hx;     // whole GQA groups per XCD
+  const int b = VP_BY(p), hk = h / (p.Hq / p.Hkv);
+  const int q0 = qb * 256, qw0 = q0 + wave * 32;
+  const int kvlen = p.kv_len ? min(p.kv_len[b], p.Skv) : p.Skv;
+  const int off = p.Skv - p.Sq;
+  const float c = p.scale * LOG2E;
+  const int ql = lane & 31, hh = lane >> 5;
+  const int qrow = qw0 + ql;
+
+  bf16x8 qf[8];                                         // B operand of S^T: lane = query, 8 features at 16 ks + 8 hh
+  {
+    const bf16_t* qp = p.q + (long)b * p.q_bs + (long)min(qrow, p.Sq - 1) * p.q_ts + (long)h * D;      // clamped; rows >= Sq are never stored
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) qf[ks] = *(const bf16x8*)(qp + ks * 16 + hh * 8);
+  }
+  f32x16 oacc[4];                                       // O^T: feature 32 db + 8 (i >> 2) + 4 hh + (i & 3) of this lane's query
+#pragma unroll
+  for (int d = 0; d < 4; ++d)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) oacc[d][i] = 0.f;
+  float m = -1e30f, l = 0.f;                            // m is kept PRE-scaled: m = c * max(raw score)
+
+  int kend = kvlen;
+  if (CAUSAL) kend = min(kend, q0 + 256 + off);
+  int kstart = 0;
+  if (p.window > 0) kstart = max(0, (q0 + off - p.window + 1)) & ~63;
+  const int nit = kend > kstart ? (kend - kstart + 63) / 64 : 0;
+  const int last_w = CAUSAL ? min(nit - 1, (qw0 + 31 + off - kstart) >> 6) : nit - 1;     // tiles this WAVE needs
+  const char* kb_ = (const char*)(p.k + (long)b * p.k_bs + (long)hk * D);
+  const char* vb_ = (const char*)(p.v + (long)b * p.v_bs + (long)hk * D);
+
+  // one LDS-DMA instruction of tile t (piece 0..3: K rows drow, K rows drow + 32, V rows drow, V rows drow + 32); lane-derived values are
+  // re-derived per call.  Inside the loop the four pieces are spread between the P V MFMAs: a global_load_lds holds the issuing wave ~80
+  // cycles, and all eight waves of the block issuing four of them back to back right behind the barrier queue up at the CU's one address unit.
+  auto issue1 = [&](int t, int st, int ln, int piece) {
+    const int k0 = kstart + min(t, nit - 1) * 64;
+    const int drow = wave * 4 + (ln >> 4);
+    // K rows: chunk ^ (row & 15): conflict-free ds_read_b128 (16 rows x one chunk per lane group)
+    // V rows: chunk ^ 4 (row & 3).  A transposing read of this kernel touches 4 rows x 4 chunks x 2 halves per 32-lane group (two 16-lane
+    // groups share the rows and differ in the chunk): with the K swizzle 16 (row, chunk) pairs fall on 4 slots (PMC: 6 conflict cycles per
+    // read); row & 3 moved to the chunk's bits 2-3 gives every lane of the group its own 8 bytes of the 256-byte bank row
+    const int dch = ((ln & 15) ^ ((piece & 2) ? ((drow & 3) << 2) : (drow & 15))) * 8;
+    bf16_t* sb = ring + st * FWDM_STAGE + ((piece & 2) ? 8192 : 0) + ((piece & 1) ? (8 + wave) * 512 : wave * 512);
+    const unsigned r = (unsigned)min(k0 + drow + ((piece & 1) ? 32 : 0), p.Skv - 1);
+    const char* gb = (piece & 2) ? vb_ : kb_;
+    const unsigned ts = (piece & 2) ? (unsigned)p.v_ts : (unsigned)p.k_ts;
+    ATTN_GLDS(gb + (size_t)((r * ts + dch) * 2u), sb, 16);
+  };
+  auto issue = [&](int t, int st, int ln) { issue1(t, st, ln, 0); issue1(t, st, ln, 1); issue1(t, st, ln, 2); issue1(t, st, ln, 3); };
+  f32x16 sa[2], sb2[2];                                 // S^T of the current / next tile: [key block]
+  // S^T(tile at KS_PTR): K fragment (kb, ks) = row 32 kb + (lane & 31), 16-byte chunk 2 ks + hh, swizzled by (row & 15)
+#define FWDM_QK(DST, KS_PTR, RB)                                                                               \
+  _Pragma("unroll") for (int kb = 0; kb < 2; ++kb) {                                                           \
+    _Pragma("unroll") for (int ks = 0; ks < 8; ++ks) {                                                         \
+      const bf16x8 ka = *(const bf16x8*)((KS_PTR) + ((RB) ^ (ks * 16)) + kb * 4096);                            \
+      if (ks == 0) { _Pragma("unroll") for (int i = 0; i < 16; ++i) DST[kb][i] = 0.f; }                        \
+      DST[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka, qf[ks], DST[kb], 0, 0, 0);                          \
+    }                                                                                                          \
+  }
+  if (nit > 0) {
+    issue(0, 0, lane); issue(1, 1, lane); issue(2, 2, lane);
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // tile 0 landed (this wave's part)
+    __builtin_amdgcn_s_barrier();
+    const int rbase = (lane & 31) * 128 + (((lane >> 5) ^ (lane & 15)) << 3);
+    FWDM_QK(sa, ring, rbase)
+  }
+#define FWDM_VRD(N) { vlo[N] = tr_read_asm<((N) >> 2) * 4096>(va0[(N) & 3]); vhi[N] = tr_read_asm<((N) >> 2) * 4096 + 2048>(va0[(N) & 3]); }
+#define FWDM_PV(N)            /* step N: feature block N & 3, key group N >> 2 (four accumulator chains alternate) */ \
+  {                                                                                                            \
+    if ((N) + 2 < 16) { FWDM_VRD(((N) + 2) & 15) ATTN_LGKM(4); }                                               \
+    else if ((N) + 2 == 16) { ATTN_LGKM(2); }                                                                  \
+    else { ATTN_LGKM(0); }                                                                                     \
+    bf16x8 vtf = tr_join(vlo[N], vhi[N]);                                                                      \
+    ATTN_PIN(vtf);                                                                                             \
+    oacc[(N) & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vtf, pf[(N) >> 2], oacc[(N) & 3], 0, 0, 0);        \
+    if (((N) & 3) == 1) issue1(it3_, it3_ & 3, ln, (N) >> 2);                                                  \
+    if ((N) & 1) __builtin_amdgcn_sched_barrier(0);                                                            \
+  }
+#define FWDM_ITER(IT, SC, SN)                                                                                  \
+  {                                                                                                            \
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                                                           \
+    __builtin_amdgcn_sched_barrier(0);                                                                         \
+    __builtin_amdgcn_s_barrier();                                                                              \
+    __builtin_amdgcn_sched_barrier(0);                                                                         \
+    int ln = threadIdx.x & 63;                                                                                 \
+    asm volatile("" : "+v"(ln));                                                                               \
+    const int it3_ = (IT) + 3;                                                                                 \
+    const int fr_ = ln & 15, h2 = ln >> 5, gq = (ln >> 4) & 1;                                                 \
+    const int rbase = (ln & 31) * 128 + ((h2 ^ fr_) << 3);                                                     \
+    /* transposing V reads: lane i of a 16-lane group supplies 4 features of key row (4 hh + (i >> 2)) [+ 8 for the second read] */ \
+    const int trow = 4 * h2 + (fr_ >> 2);                                                                      \
+    const int tb0 = trow * 128 + (((2 * gq + ((ln & 3) >> 1)) ^ ((trow & 3) << 2)) << 3) + (ln & 1) * 4;        \
+    /* second read of a fragment: row + 8, same swizzle phase -> + 2048 bytes in the immediate */              \
+    const bf16_t* Vs = ring + ((IT) & 3) * FWDM_STAGE + 8192;                                                  \
+    const bf16_t* Kn = ring + (((IT) + 1) & 3) * FWDM_STAGE;                                                   \
+    const int k0 = kstart + (IT) * 64;                                                                         \
+    {                                                                                                          \
+      const bool need_mask = (k0 + 64 > kvlen) || (CAUSAL && (k0 + 63 > qw0 + off)) || (p.window > 0);         \
+      if (need_mask) {                                                                                         \
+        const int dq_ = qw0 + (ln & 31) + off - k0 - 4 * h2;                                                   \
+        const int kl = kvlen - k0 - 4 * h2;                                                                    \
+        const int hi = CAUSAL ? min(kl, dq_ + 1) : kl;                                                         \
+        const int lo = p.window > 0 ? dq_ - p.window : -1000000;                                               \
+        const float ninf_ = -INFINITY;                                                                         \
+        _Pragma("unroll") for (int kb = 0; kb < 2; ++kb)                                                       \
+          _Pragma("unroll") for (int i = 0; i < 16; ++i) {                                                     \
+            const int e = kb * 32 + 8 * (i >> 2) + (i & 3);                                                    \
+            /* in place (tied asm operand): a C++ select inside this branch left two copies of the 32 score registers live */ \
+            const unsigned long long ok_ = __builtin_amdgcn_ballot_w64(e < hi && e > lo);                      \
+            asm volatile("v_cndmask_b32 %0, %1, %0, %2" : "+v"(SC[kb][i]) : "v"(ninf_), "s"(ok_));             \
+          }                                                                                                    \
+      }                                                                                                        \
+      float mx = vmax3(SC[0][0], SC[0][1], SC[0][2]);                                                          \
+      _Pragma("unroll") for (int i = 3; i < 15; i += 2) mx = vmax3(mx, SC[0][i], SC[0][i + 1]);                \
+      mx = vmax3(mx, SC[0][15], SC[1][0]);                                                                     \
+      _Pragma("unroll") for (int i = 1; i < 15; i += 2) mx = vmax3(mx, SC[1][i], SC[1][i + 1]);                \
+      mx = fmaxf(mx, SC[1][15]) * c;                                                                           \
+      if (!__all(mx <= m + RESCALE_THR)) {                                                                     \
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));                                                                \
+        const float mnew = fmaxf(m, mx);                                                                       \
+        const float alpha = fast_exp2(m - mnew);                                                               \
+        l *= alpha;                                                                                            \
+        _Pragma("unroll") for (int d = 0; d < 4; ++d)                                                          \
+          _Pragma("unroll") for (int i = 0; i < 16; ++i) oacc[d][i] *= alpha;                                  \
+        m = mnew;                                                                                              \
+      }                                                                                                        \
+      const bool have_next = (IT) + 1 <= last_w;                                                               \
+      float rs0 = 0.f, rs1 = 0.f;                                                                              \
+      __builtin_amdgcn_sched_barrier(0);                                                                       \
+      if (have_next) {                                                                                         \
+        float c2 = c;                                                                                          \
+        asm volatile("" : "+v"(c2));                                                                           \
+        /* S^T(next tile) MFMAs with the exponentials of this tile in their shadow: 2 scores per MFMA; K fragments three steps ahead */ \
+        bf16x8 kf[16];                                                                                         \
+        kf[0] = *(const bf16x8*)(Kn + rbase);                                                                  \
+        kf[1] = *(const bf16x8*)(Kn + rbase + 4096);                                                           \
+        _Pragma("unroll") for (int n = 0; n < 16; ++n) {           /* step n: k-step n >> 1 of key block n & 1 (two accumulator chains alternate) */ \
+          const int kb = n & 1, ks = n >> 1;                                                                   \
+          if (n + 2 < 16) kf[n + 2] = *(const bf16x8*)(Kn + (rbase ^ (((n + 2) >> 1) * 16)) + ((n + 2) & 1) * 4096); \
+          if (ks == 0) { _Pragma("unroll") for (int i = 0; i < 16; ++i) SN[kb][i] = 0.f; }                     \
+          SN[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[n], qf[ks], SN[kb], 0, 0, 0);                     \
+          _Pragma("unroll") for (int j = 2 * n; j < 2 * n + 2; ++j) {                                          \
+            const float e_ = fast_exp2(fmaf(SC[j >> 4][j & 15], c2, -m));                                      \
+            SC[j >> 4][j & 15] = e_;                                                                           \
+            if (j & 1) rs1 += e_; else rs0 += e_;                                                              \
+          }                                                                                                    \
+          __builtin_amdgcn_sched_barrier(0);                                                                   \
+        }                                                                                                      \
+      } else {                                                                                                 \
+        _Pragma("unroll") for (int j = 0; j < 32; ++j) {                                                       \
+          const float e_ = fast_exp2(fmaf(SC[j >> 4][j & 15], c, -m));                                         \
+          SC[j >> 4][j & 15] = e_;                                                                             \
+          if (j & 1) rs1 += e_; else rs0 += e_;                                                                \
+        }                                                                                                      \
+      }                                                                                                        \
+      l += rs0 + rs1;                                                                                          \
+      /* P^T operands: (kb, t) = registers 8 t .. 8 t + 7 of key block kb */                                   \
+      bf16x8 pf[4];                                                                                            \
+      _Pragma("unroll") for (int kt = 0; kt < 4; ++kt) {                                                       \
+        const int kb = kt >> 1, t = kt & 1;                                                                    \
+        pf[kt] = __builtin_bit_cast(bf16x8, u32x4{pack_bf16x2(SC[kb][8 * t + 0], SC[kb][8 * t + 1]), pack_bf16x2(SC[kb][8 * t + 2], SC[kb][8 * t + 3]), \
+                                                  pack_bf16x2(SC[kb][8 * t + 4], SC[kb][8 * t + 5]), pack_bf16x2(SC[kb][8 * t + 6], SC[kb][8 * t + 7])}); \
+      }                                                                                                        \
+      __builtin_amdgcn_sched_barrier(0);                                                                       \
+      const uint32_t vs_addr = attn_lds_addr(Vs);                                                              \
+      /* O^T += V^T P^T: 16 MFMAs, step n = 4 db + kt; V^T fragment = two transposing reads (keys 16 kt + 4 hh .. and + 8), two steps ahead */ \
+      const uint32_t va0[4] = {vs_addr + 2u * (uint32_t)tb0, vs_addr + 2u * (uint32_t)(tb0 ^ 32), vs_addr + 2u * (uint32_t)(tb0 ^ 64), vs_addr + 2u * (uint32_t)(tb0 ^ 96)}; \
+      s16x4 vlo[16], vhi[16];                                                                                  \
+      FWDM_VRD(0) FWDM_VRD(1)                                                                                   \
+      FWDM_PV(0) FWDM_PV(1) FWDM_PV(2) FWDM_PV(3) FWDM_PV(4) FWDM_PV(5) FWDM_PV(6) FWDM_PV(7)                  \
+      FWDM_PV(8) FWDM_PV(9) FWDM_PV(10) FWDM_PV(11) FWDM_PV(12) FWDM_PV(13) FWDM_PV(14) FWDM_PV(15)            \
+    }                                                                                                          \
+  }
+  // the wave's own tiles (a conditional body inside ONE loop over all tiles cost 40 registers: every accumulator became a phi) ...
+  for (int it = 0; it <= last_w; it += 2) {
+    FWDM_ITER(it, sa, sb2)
+    if (it + 1 <= last_w) FWDM_ITER(it + 1, sb2, sa)
+  }
+  // ... then the tiles above its diagonal that the block's other waves still need: keep the barrier count and feed the ring
+  for (int it = last_w + 1; it < nit; ++it) {
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    issue(it + 3, (it + 3) & 3, lane);
+  }
+#undef FWDM_ITER
+#undef FWDM_PV
+#undef FWDM_VRD
+#undef FWDM_QK
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // trailing (dummy) DMAs must not outlive the block's LDS
+  l += __shfl_xor(l, 32, 64);
+  if (qrow < p.Sq) {
+    const float inv = l > 0.f ? 1.f / l : 0.f;
+    bf16_t* op = p.o + (long)b * p.o_bs + (long)qrow * p.o_ts + (long)h * D;
+#pragma unroll
+    for (int db = 0; db < 4; ++db)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        bf16x4 o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = (short)f2bf(oacc[db][4 * j + r] * inv);
+        *(bf16x4*)(op + db * 32 + 8 * j + 4 * hh) = o;
+      }
+    if (p.lse && hh == 0) p.lse[((long)b * p.Hq + h) * p.Sq + qrow] = (l > 0.f) ? m + log2f(l) : -1e30f;
+  }
+}
+
+// ================================================================================================
 // C ABI
 // ================================================================================================
 template <int D>
@@ -1309,6 +1540,12 @@ static bool vp_fwd128_enabled() {                      // VP_ATTN_FWD128=1 selec
   return v != 0;
 }
 
+static bool vp_fwdm_enabled() {                        // VP_ATTN_FWDM=1 selects the 32x32x16 swapped-product forward (D = 128)
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("VP_ATTN_FWDM"); v = e ? atoi(e) : 0; }
+  return v != 0;
+}
+
 template <int D>
 static int launch_fwd(const AttnParams& p_in, int causal, hipStream_t s) {
   AttnParams p = p_in;
@@ -1322,6 +1559,19 @@ static int launch_fwd(const AttnParams& p_in, int causal, hipStream_t s) {
     attr = true;
   }
   const dim3 grid = p.order ? dim3(p.Hq, (p.Sq + 127) / 128, p.B) : dim3(p.Hq, p.B, (p.Sq + 127) / 128);
+  if (D == 128 && !p.bias_h && !p.bias_b && vp_fwdm_enabled()) {        // round 3: 32x32x16 swapped-product kernel, 256-row blocks
+    static bool attrm = false;
+    if (!attrm) {
+      (void)hipFuncSetAttribute((const void*)attn_fwd128m_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, FWDM_LDS);
+      (void)hipFuncSetAttribute((const void*)attn_fwd128m_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, FWDM_LDS);
+      attrm = true;
+    }
+    const int nb = (p.Sq + 255) / 256;
+    const dim3 gm = p.order ? dim3(p.Hq, nb, p.B) : dim3(p.Hq, p.B, nb);
+    if (causal) hipLaunchKernelGGL((attn_fwd128m_kernel<true>), gm, dim3(512), FWDM_LDS, s, p);
+    else hipLaunchKernelGGL((attn_fwd128m_kernel<false>), gm, dim3(512), FWDM_LDS, s, p);
+    return vp_check_launch("vp_attn_fwd");
+  }
   if (D == 128 && !p.bias_h && !p.bias_b && vp_fwd128_enabled()) {      // DMA-ring kernel (32 query rows per wave)
     static bool attr128 = false;
     if (!attr128) {
