@@ -1304,14 +1304,15 @@ _Pragma("unroll") \
 //   * a 1 KB K or V fragment feeds a 32x32x16 MFMA = 16 K MACs (the 16-row kernel: 8 K) -> half the LDS bytes per flop.
 // ================================================================================================
 typedef __attribute__((ext_vector_type(16))) float f32x16;
-constexpr int FWDM_STAGE = 2 * 64 * 128;              // bf16 units: K tile (64 keys) | V tile
-constexpr int FWDM_LDS = 4 * FWDM_STAGE * 2;          // bytes (128 KB)
+typedef uint32_t fwdm_u32x4s __attribute__((ext_vector_type(4)));
+// ring: [K stage 0..3 (64 keys x 128 features, 16 KB each)] [V stage 0..3]: every K fragment address is one loop-invariant VGPR + a 16-bit
+// immediate (stage, key block), every V fragment address likewise (the loop is unrolled by four, so the stage is a literal)
+constexpr int FWDM_LDS = 8 * 64 * 128 * 2;            // bytes (128 KB)
 
 template <bool CAUSAL>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_fwd128m_kernel(AttnParams p) {
   constexpr int D = 128;
   extern __shared__ __attribute__((aligned(16))) unsigned char attn_smem[];
-  bf16_t* const ring = (bf16_t*)attn_smem;
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int nqb = (p.Sq + 255) >> 8;
   const int qb = nqb - 1 - VP_BZ(p);                   // z is the slowest dispatch index: heavy (late) causal blocks first
@@ -1344,166 +1345,220 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   if (p.window > 0) kstart = max(0, (q0 + off - p.window + 1)) & ~63;
   const int nit = kend > kstart ? (kend - kstart + 63) / 64 : 0;
   const int last_w = CAUSAL ? min(nit - 1, (qw0 + 31 + off - kstart) >> 6) : nit - 1;     // tiles this WAVE needs
-  const char* kb_ = (const char*)(p.k + (long)b * p.k_bs + (long)hk * D);
-  const char* vb_ = (const char*)(p.v + (long)b * p.v_bs + (long)hk * D);
 
-  // one LDS-DMA instruction of tile t (piece 0..3: K rows drow, K rows drow + 32, V rows drow, V rows drow + 32); lane-derived values are
-  // re-derived per call.  Inside the loop the four pieces are spread between the P V MFMAs: a global_load_lds holds the issuing wave ~80
-  // cycles, and all eight waves of the block issuing four of them back to back right behind the barrier queue up at the CU's one address unit.
-  auto issue1 = [&](int t, int st, int ln, int piece) {
-    const int k0 = kstart + min(t, nit - 1) * 64;
-    const int drow = wave * 4 + (ln >> 4);
-    // K rows: chunk ^ (row & 15): conflict-free ds_read_b128 (16 rows x one chunk per lane group)
-    // V rows: chunk ^ 4 (row & 3).  A transposing read of this kernel touches 4 rows x 4 chunks x 2 halves per 32-lane group (two 16-lane
-    // groups share the rows and differ in the chunk): with the K swizzle 16 (row, chunk) pairs fall on 4 slots (PMC: 6 conflict cycles per
-    // read); row & 3 moved to the chunk's bits 2-3 gives every lane of the group its own 8 bytes of the 256-byte bank row
-    const int dch = ((ln & 15) ^ ((piece & 2) ? ((drow & 3) << 2) : (drow & 15))) * 8;
-    bf16_t* sb = ring + st * FWDM_STAGE + ((piece & 2) ? 8192 : 0) + ((piece & 1) ? (8 + wave) * 512 : wave * 512);
-    const unsigned r = (unsigned)min(k0 + drow + ((piece & 1) ? 32 : 0), p.Skv - 1);
-    const char* gb = (piece & 2) ? vb_ : kb_;
-    const unsigned ts = (piece & 2) ? (unsigned)p.v_ts : (unsigned)p.k_ts;
-    ATTN_GLDS(gb + (size_t)((r * ts + dch) * 2u), sb, 16);
+  // ---- LDS-DMA: buffer_load ... lds with a per-(batch, kv head) descriptor (rows past Skv read as zeros: no clamps), ONE lane offset per
+  // operand, the tile / piece in the scalar offset, the LDS destination in m0: no vector arithmetic per piece.  Piece 0 / 1 = K rows drow,
+  // drow + 32 of the tile, 2 / 3 = V likewise (drow = 4 wave + lane / 16: a wave instruction fills 4 rows = 1 KB of LDS).
+  const uint32_t ldsb = attn_lds_addr(attn_smem);
+  auto make_rs = [&](const bf16_t* base, long ts) -> fwdm_u32x4s {
+    const uint64_t a = (uint64_t)(uintptr_t)base;
+    fwdm_u32x4s r;
+    r[0] = __builtin_amdgcn_readfirstlane((uint32_t)a);
+    r[1] = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32) & 0xffffu);
+    r[2] = __builtin_amdgcn_readfirstlane((uint32_t)((((long)p.Skv - 1) * ts + D) * 2));
+    r[3] = 0x00020000u;
+    return r;
   };
-  auto issue = [&](int t, int st, int ln) { issue1(t, st, ln, 0); issue1(t, st, ln, 1); issue1(t, st, ln, 2); issue1(t, st, ln, 3); };
-  f32x16 sa[2], sb2[2];                                 // S^T of the current / next tile: [key block]
-  // S^T(tile at KS_PTR): K fragment (kb, ks) = row 32 kb + (lane & 31), 16-byte chunk 2 ks + hh, swizzled by (row & 15)
-#define FWDM_QK(DST, KS_PTR, RB)                                                                               \
-  _Pragma("unroll") for (int kb = 0; kb < 2; ++kb) {                                                           \
-    _Pragma("unroll") for (int ks = 0; ks < 8; ++ks) {                                                         \
-      const bf16x8 ka = *(const bf16x8*)((KS_PTR) + ((RB) ^ (ks * 16)) + kb * 4096);                            \
-      if (ks == 0) { _Pragma("unroll") for (int i = 0; i < 16; ++i) DST[kb][i] = 0.f; }                        \
-      DST[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka, qf[ks], DST[kb], 0, 0, 0);                          \
-    }                                                                                                          \
+  const fwdm_u32x4s rsK = make_rs(p.k + (long)b * p.k_bs + (long)hk * D, p.k_ts), rsV = make_rs(p.v + (long)b * p.v_bs + (long)hk * D, p.v_ts);
+  uint32_t vK, vV;
+  {
+    const int drow = wave * 4 + (lane >> 4);
+    // K rows: chunk ^ (row & 15): conflict-free ds_read_b128 (16 rows x one chunk per lane group).  V rows: chunk ^ 4 (row & 3): a transposing
+    // read of this kernel touches 4 rows x 4 chunks x 2 halves per 32-lane group (two 16-lane groups share the rows and differ in the chunk);
+    // with the K swizzle 16 (row, chunk) pairs fall on 4 slots (PMC: 6 conflict cycles per read), this way every lane has its own 8 bytes
+    vK = (uint32_t)((drow * p.k_ts + (((lane & 15) ^ (drow & 15)) << 3)) * 2);
+    vV = (uint32_t)((drow * p.v_ts + (((lane & 15) ^ ((drow & 3) << 2)) << 3)) * 2);
+    asm volatile("" : "+v"(vK), "+v"(vV));
   }
+  const uint32_t kts2 = __builtin_amdgcn_readfirstlane((uint32_t)(p.k_ts * 2)), vts2 = __builtin_amdgcn_readfirstlane((uint32_t)(p.v_ts * 2));
+  const uint32_t m0w = __builtin_amdgcn_readfirstlane(ldsb + (uint32_t)wave * 1024u);
+#define FWDM_DMA(T, ST, PIECE)                                                                                  \
+  {                                                                                                             \
+    const uint32_t row_ = (uint32_t)(kstart + (T) * 64 + (((PIECE) & 1) ? 32 : 0));                              \
+    const uint32_t so_ = row_ * (((PIECE) & 2) ? vts2 : kts2);                                                   \
+    const uint32_t m0_ = m0w + (uint32_t)((ST) * 16384 + (((PIECE) & 1) ? 8192 : 0) + (((PIECE) & 2) ? 65536 : 0)); \
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(m0_), "v"(((PIECE) & 2) ? vV : vK), \
+                 "s"(((PIECE) & 2) ? rsV : rsK), "s"(so_) : "memory");                                          \
+  }
+#define FWDM_DMA4(T, ST) { FWDM_DMA(T, ST, 0) FWDM_DMA(T, ST, 1) FWDM_DMA(T, ST, 2) FWDM_DMA(T, ST, 3) }
+
+  // ---- fragment addresses (bytes, loop-invariant).  K fragment (kb, ks): row 32 kb + (lane & 31), 16-byte chunk (2 ks + hh) ^ (row & 15)
+  uint32_t ka[8];
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks) {
+    ka[ks] = ldsb + (uint32_t)(((lane & 31) * 128 + (((2 * ks + hh) ^ (lane & 15)) << 3)) * 2);
+    asm volatile("" : "+v"(ka[ks]));
+  }
+  // V^T fragment (db, kt): two transposing reads; lane i of a 16-lane group supplies 4 features of key row 16 kt + 4 hh + (i >> 2) [+ 8]
+  uint32_t va0[4];
+  {
+    const int fr_ = lane & 15, gq = (lane >> 4) & 1, trow = 4 * hh + (fr_ >> 2);
+#pragma unroll
+    for (int db = 0; db < 4; ++db) {
+      va0[db] = ldsb + 65536u + (uint32_t)((trow * 128 + (((4 * db + 2 * gq + ((lane & 3) >> 1)) ^ ((trow & 3) << 2)) << 3) + (lane & 1) * 4) * 2);
+      asm volatile("" : "+v"(va0[db]));
+    }
+  }
+#define FWDM_KRD(DST, ST, N) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(DST) : "v"(ka[(N) >> 1]), "n"((ST) * 16384 + ((N) & 1) * 8192))
+#define FWDM_VRD(ST, N)                                                                                         \
+  {                                                                                                             \
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(vlo[N]) : "v"(va0[(N) & 3]), "n"((ST) * 16384 + ((N) >> 2) * 4096)); \
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(vhi[N]) : "v"(va0[(N) & 3]), "n"((ST) * 16384 + ((N) >> 2) * 4096 + 2048)); \
+  }
+
+  f32x16 sa[2], sb2[2];                                 // S^T of the current / next tile: [key block]
   if (nit > 0) {
-    issue(0, 0, lane); issue(1, 1, lane); issue(2, 2, lane);
+    FWDM_DMA4(0, 0) FWDM_DMA4(min(1, nit - 1), 1) FWDM_DMA4(min(2, nit - 1), 2)
     asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // tile 0 landed (this wave's part)
     __builtin_amdgcn_s_barrier();
-    const int rbase = (lane & 31) * 128 + (((lane >> 5) ^ (lane & 15)) << 3);
-    FWDM_QK(sa, ring, rbase)
+    bf16x8 kf[16];
+#define FWDM_P0(N) FWDM_KRD(kf[N], 0, N);
+    FWDM_P0(0) FWDM_P0(1) FWDM_P0(2) FWDM_P0(3) FWDM_P0(4) FWDM_P0(5) FWDM_P0(6) FWDM_P0(7)
+    FWDM_P0(8) FWDM_P0(9) FWDM_P0(10) FWDM_P0(11) FWDM_P0(12) FWDM_P0(13) FWDM_P0(14) FWDM_P0(15)
+#undef FWDM_P0
+    ATTN_LGKM(0);
+#pragma unroll
+    for (int n = 0; n < 16; ++n) {
+      ATTN_PIN(kf[n]);
+      if (n < 2) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) sa[n & 1][i] = 0.f;
+      }
+      sa[n & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[n], qf[n >> 1], sa[n & 1], 0, 0, 0);
+    }
   }
-#define FWDM_VRD(N) { vlo[N] = tr_read_asm<((N) >> 2) * 4096>(va0[(N) & 3]); vhi[N] = tr_read_asm<((N) >> 2) * 4096 + 2048>(va0[(N) & 3]); }
-#define FWDM_PV(N)            /* step N: feature block N & 3, key group N >> 2 (four accumulator chains alternate) */ \
-  {                                                                                                            \
-    if ((N) + 2 < 16) { FWDM_VRD(((N) + 2) & 15) ATTN_LGKM(4); }                                               \
-    else if ((N) + 2 == 16) { ATTN_LGKM(2); }                                                                  \
-    else { ATTN_LGKM(0); }                                                                                     \
-    bf16x8 vtf = tr_join(vlo[N], vhi[N]);                                                                      \
-    ATTN_PIN(vtf);                                                                                             \
-    oacc[(N) & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vtf, pf[(N) >> 2], oacc[(N) & 3], 0, 0, 0);        \
-    if (((N) & 3) == 1) issue1(it3_, it3_ & 3, ln, (N) >> 2);                                                  \
-    if ((N) & 1) __builtin_amdgcn_sched_barrier(0);                                                            \
+  // One tile.  STG = its ring stage (literal).  A: mask (diagonal / ragged tiles), lane-local max, rare rescale.  B: S^T of the NEXT tile
+  // (16 MFMAs, two accumulator chains alternating, K fragments three steps ahead by asm reads with counted waits) with this tile's 32
+  // exponentials in the MFMAs' shadow, 2 per MFMA — ALWAYS run, also behind the wave's last tile (a second code path for "no next tile"
+  // made every score register a phi: 32 v_mov per tile).  C: O^T += V^T P^T (16 MFMAs, four chains alternating, transposing reads two steps
+  // ahead), one LDS-DMA piece of tile it + 3 per four MFMAs.
+#define FWDM_QK(SN, SC, NS, N)                                                                                  \
+  {                                                                                                             \
+    if ((N) + 3 < 16) { FWDM_KRD(kf[((N) + 3) & 15], NS, ((N) + 3) & 15); ATTN_LGKM(3); }                        \
+    else if ((N) + 3 == 16) { ATTN_LGKM(2); }                                                                   \
+    else if ((N) + 3 == 17) { ATTN_LGKM(1); }                                                                   \
+    else { ATTN_LGKM(0); }                                                                                      \
+    ATTN_PIN(kf[N]);                                                                                            \
+    if ((N) < 2) { _Pragma("unroll") for (int i = 0; i < 16; ++i) SN[(N) & 1][i] = 0.f; }                       \
+    SN[(N) & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[N], qf[(N) >> 1], SN[(N) & 1], 0, 0, 0);            \
+    {                                                                                                           \
+      const float e0_ = fast_exp2(fmaf(SC[(N) >> 3][(2 * (N)) & 15], c2, -m));                                  \
+      const float e1_ = fast_exp2(fmaf(SC[(N) >> 3][(2 * (N) + 1) & 15], c2, -m));                              \
+      SC[(N) >> 3][(2 * (N)) & 15] = e0_;                                                                       \
+      SC[(N) >> 3][(2 * (N) + 1) & 15] = e1_;                                                                   \
+      rs0 += e0_;                                                                                               \
+      rs1 += e1_;                                                                                               \
+    }                                                                                                           \
+    __builtin_amdgcn_sched_barrier(0);                                                                          \
   }
-#define FWDM_ITER(IT, SC, SN)                                                                                  \
-  {                                                                                                            \
-    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                                                           \
-    __builtin_amdgcn_sched_barrier(0);                                                                         \
-    __builtin_amdgcn_s_barrier();                                                                              \
-    __builtin_amdgcn_sched_barrier(0);                                                                         \
-    int ln = threadIdx.x & 63;                                                                                 \
-    asm volatile("" : "+v"(ln));                                                                               \
-    const int it3_ = (IT) + 3;                                                                                 \
-    const int fr_ = ln & 15, h2 = ln >> 5, gq = (ln >> 4) & 1;                                                 \
-    const int rbase = (ln & 31) * 128 + ((h2 ^ fr_) << 3);                                                     \
-    /* transposing V reads: lane i of a 16-lane group supplies 4 features of key row (4 hh + (i >> 2)) [+ 8 for the second read] */ \
-    const int trow = 4 * h2 + (fr_ >> 2);                                                                      \
-    const int tb0 = trow * 128 + (((2 * gq + ((ln & 3) >> 1)) ^ ((trow & 3) << 2)) << 3) + (ln & 1) * 4;        \
-    /* second read of a fragment: row + 8, same swizzle phase -> + 2048 bytes in the immediate */              \
-    const bf16_t* Vs = ring + ((IT) & 3) * FWDM_STAGE + 8192;                                                  \
-    const bf16_t* Kn = ring + (((IT) + 1) & 3) * FWDM_STAGE;                                                   \
-    const int k0 = kstart + (IT) * 64;                                                                         \
-    {                                                                                                          \
-      const bool need_mask = (k0 + 64 > kvlen) || (CAUSAL && (k0 + 63 > qw0 + off)) || (p.window > 0);         \
-      if (need_mask) {                                                                                         \
-        const int dq_ = qw0 + (ln & 31) + off - k0 - 4 * h2;                                                   \
-        const int kl = kvlen - k0 - 4 * h2;                                                                    \
-        const int hi = CAUSAL ? min(kl, dq_ + 1) : kl;                                                         \
-        const int lo = p.window > 0 ? dq_ - p.window : -1000000;                                               \
-        const float ninf_ = -INFINITY;                                                                         \
-        _Pragma("unroll") for (int kb = 0; kb < 2; ++kb)                                                       \
-          _Pragma("unroll") for (int i = 0; i < 16; ++i) {                                                     \
-            const int e = kb * 32 + 8 * (i >> 2) + (i & 3);                                                    \
-            /* in place (tied asm operand): a C++ select inside this branch left two copies of the 32 score registers live */ \
-            const unsigned long long ok_ = __builtin_amdgcn_ballot_w64(e < hi && e > lo);                      \
-            asm volatile("v_cndmask_b32 %0, %1, %0, %2" : "+v"(SC[kb][i]) : "v"(ninf_), "s"(ok_));             \
-          }                                                                                                    \
-      }                                                                                                        \
-      float mx = vmax3(SC[0][0], SC[0][1], SC[0][2]);                                                          \
-      _Pragma("unroll") for (int i = 3; i < 15; i += 2) mx = vmax3(mx, SC[0][i], SC[0][i + 1]);                \
-      mx = vmax3(mx, SC[0][15], SC[1][0]);                                                                     \
-      _Pragma("unroll") for (int i = 1; i < 15; i += 2) mx = vmax3(mx, SC[1][i], SC[1][i + 1]);                \
-      mx = fmaxf(mx, SC[1][15]) * c;                                                                           \
-      if (!__all(mx <= m + RESCALE_THR)) {                                                                     \
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));                                                                \
-        const float mnew = fmaxf(m, mx);                                                                       \
-        const float alpha = fast_exp2(m - mnew);                                                               \
-        l *= alpha;                                                                                            \
-        _Pragma("unroll") for (int d = 0; d < 4; ++d)                                                          \
-          _Pragma("unroll") for (int i = 0; i < 16; ++i) oacc[d][i] *= alpha;                                  \
-        m = mnew;                                                                                              \
-      }                                                                                                        \
-      const bool have_next = (IT) + 1 <= last_w;                                                               \
-      float rs0 = 0.f, rs1 = 0.f;                                                                              \
-      __builtin_amdgcn_sched_barrier(0);                                                                       \
-      if (have_next) {                                                                                         \
-        float c2 = c;                                                                                          \
-        asm volatile("" : "+v"(c2));                                                                           \
-        /* S^T(next tile) MFMAs with the exponentials of this tile in their shadow: 2 scores per MFMA; K fragments three steps ahead */ \
-        bf16x8 kf[16];                                                                                         \
-        kf[0] = *(const bf16x8*)(Kn + rbase);                                                                  \
-        kf[1] = *(const bf16x8*)(Kn + rbase + 4096);                                                           \
-        _Pragma("unroll") for (int n = 0; n < 16; ++n) {           /* step n: k-step n >> 1 of key block n & 1 (two accumulator chains alternate) */ \
-          const int kb = n & 1, ks = n >> 1;                                                                   \
-          if (n + 2 < 16) kf[n + 2] = *(const bf16x8*)(Kn + (rbase ^ (((n + 2) >> 1) * 16)) + ((n + 2) & 1) * 4096); \
-          if (ks == 0) { _Pragma("unroll") for (int i = 0; i < 16; ++i) SN[kb][i] = 0.f; }                     \
-          SN[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[n], qf[ks], SN[kb], 0, 0, 0);                     \
-          _Pragma("unroll") for (int j = 2 * n; j < 2 * n + 2; ++j) {                                          \
-            const float e_ = fast_exp2(fmaf(SC[j >> 4][j & 15], c2, -m));                                      \
-            SC[j >> 4][j & 15] = e_;                                                                           \
-            if (j & 1) rs1 += e_; else rs0 += e_;                                                              \
-          }                                                                                                    \
-          __builtin_amdgcn_sched_barrier(0);                                                                   \
-        }                                                                                                      \
-      } else {                                                                                                 \
-        _Pragma("unroll") for (int j = 0; j < 32; ++j) {                                                       \
-          const float e_ = fast_exp2(fmaf(SC[j >> 4][j & 15], c, -m));                                         \
-          SC[j >> 4][j & 15] = e_;                                                                             \
-          if (j & 1) rs1 += e_; else rs0 += e_;                                                                \
-        }                                                                                                      \
-      }                                                                                                        \
-      l += rs0 + rs1;                                                                                          \
-      /* P^T operands: (kb, t) = registers 8 t .. 8 t + 7 of key block kb */                                   \
-      bf16x8 pf[4];                                                                                            \
-      _Pragma("unroll") for (int kt = 0; kt < 4; ++kt) {                                                       \
-        const int kb = kt >> 1, t = kt & 1;                                                                    \
-        pf[kt] = __builtin_bit_cast(bf16x8, u32x4{pack_bf16x2(SC[kb][8 * t + 0], SC[kb][8 * t + 1]), pack_bf16x2(SC[kb][8 * t + 2], SC[kb][8 * t + 3]), \
-                                                  pack_bf16x2(SC[kb][8 * t + 4], SC[kb][8 * t + 5]), pack_bf16x2(SC[kb][8 * t + 6], SC[kb][8 * t + 7])}); \
-      }                                                                                                        \
-      __builtin_amdgcn_sched_barrier(0);                                                                       \
-      const uint32_t vs_addr = attn_lds_addr(Vs);                                                              \
-      /* O^T += V^T P^T: 16 MFMAs, step n = 4 db + kt; V^T fragment = two transposing reads (keys 16 kt + 4 hh .. and + 8), two steps ahead */ \
-      const uint32_t va0[4] = {vs_addr + 2u * (uint32_t)tb0, vs_addr + 2u * (uint32_t)(tb0 ^ 32), vs_addr + 2u * (uint32_t)(tb0 ^ 64), vs_addr + 2u * (uint32_t)(tb0 ^ 96)}; \
-      s16x4 vlo[16], vhi[16];                                                                                  \
-      FWDM_VRD(0) FWDM_VRD(1)                                                                                   \
-      FWDM_PV(0) FWDM_PV(1) FWDM_PV(2) FWDM_PV(3) FWDM_PV(4) FWDM_PV(5) FWDM_PV(6) FWDM_PV(7)                  \
-      FWDM_PV(8) FWDM_PV(9) FWDM_PV(10) FWDM_PV(11) FWDM_PV(12) FWDM_PV(13) FWDM_PV(14) FWDM_PV(15)            \
-    }                                                                                                          \
+#define FWDM_PV(ST, N)            /* step N: feature block N & 3, key group N >> 2 */                           \
+  {                                                                                                             \
+    if ((N) + 2 < 16) { FWDM_VRD(ST, ((N) + 2) & 15) ATTN_LGKM(4); }                                            \
+    else if ((N) + 2 == 16) { ATTN_LGKM(2); }                                                                   \
+    else { ATTN_LGKM(0); }                                                                                      \
+    bf16x8 vtf = tr_join(vlo[N], vhi[N]);                                                                       \
+    ATTN_PIN(vtf);                                                                                              \
+    oacc[(N) & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vtf, pf[(N) >> 2], oacc[(N) & 3], 0, 0, 0);          \
+    if (((N) & 3) == 1) FWDM_DMA(t3_, ((ST) + 3) & 3, (N) >> 2)                                                 \
+    if ((N) & 1) __builtin_amdgcn_sched_barrier(0);                                                             \
+  }
+#define FWDM_ITER(IT, STG, SC, SN)                                                                              \
+  {                                                                                                             \
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                                                            \
+    __builtin_amdgcn_sched_barrier(0);                                                                          \
+    __builtin_amdgcn_s_barrier();                                                                               \
+    __builtin_amdgcn_sched_barrier(0);                                                                          \
+    const int t3_ = min((IT) + 3, nit - 1);                                                                     \
+    const int k0 = kstart + (IT) * 64;                                                                          \
+    const bool need_mask = (k0 + 64 > kvlen) || (CAUSAL && (k0 + 63 > qw0 + off)) || (p.window > 0);            \
+    if (need_mask) {                                                                                            \
+      int ln = threadIdx.x & 63;                                                                                \
+      asm volatile("" : "+v"(ln));                                                                              \
+      const int dq_ = qw0 + (ln & 31) + off - k0 - 4 * (ln >> 5);                                               \
+      const int kl = kvlen - k0 - 4 * (ln >> 5);                                                                \
+      const int hi = CAUSAL ? min(kl, dq_ + 1) : kl;                                                            \
+      const int lo = p.window > 0 ? dq_ - p.window : -1000000;                                                  \
+      const float ninf_ = -INFINITY;                                                                            \
+      _Pragma("unroll") for (int kb = 0; kb < 2; ++kb)                                                          \
+        _Pragma("unroll") for (int i = 0; i < 16; ++i) {                                                        \
+          const int e = kb * 32 + 8 * (i >> 2) + (i & 3);                                                       \
+          const unsigned long long ok_ = __builtin_amdgcn_ballot_w64(e < hi && e > lo);                         \
+          asm volatile("v_cndmask_b32 %0, %1, %0, %2" : "+v"(SC[kb][i]) : "v"(ninf_), "s"(ok_));                \
+        }                                                                                                       \
+    }                                                                                                           \
+    float mx = vmax3(SC[0][0], SC[0][1], SC[0][2]);                                                             \
+    _Pragma("unroll") for (int i = 3; i < 15; i += 2) mx = vmax3(mx, SC[0][i], SC[0][i + 1]);                   \
+    mx = vmax3(mx, SC[0][15], SC[1][0]);                                                                        \
+    _Pragma("unroll") for (int i = 1; i < 15; i += 2) mx = vmax3(mx, SC[1][i], SC[1][i + 1]);                   \
+    mx = fmaxf(mx, SC[1][15]) * c;                                                                              \
+    if (!__all(mx <= m + RESCALE_THR)) {                                                                        \
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));                                                                   \
+      const float mnew = fmaxf(m, mx);                                                                          \
+      const float alpha = fast_exp2(m - mnew);                                                                  \
+      l *= alpha;                                                                                               \
+      _Pragma("unroll") for (int d = 0; d < 4; ++d)                                                             \
+        _Pragma("unroll") for (int i = 0; i < 16; ++i) oacc[d][i] *= alpha;                                     \
+      m = mnew;                                                                                                 \
+    }                                                                                                           \
+    float rs0 = 0.f, rs1 = 0.f;                                                                                 \
+    float c2 = c;                                                                                               \
+    asm volatile("" : "+v"(c2));                                                                                \
+    __builtin_amdgcn_sched_barrier(0);                                                                          \
+    {                                                                                                           \
+      bf16x8 kf[16];                                                                                            \
+      FWDM_KRD(kf[0], ((STG) + 1) & 3, 0); FWDM_KRD(kf[1], ((STG) + 1) & 3, 1); FWDM_KRD(kf[2], ((STG) + 1) & 3, 2); \
+      FWDM_QK(SN, SC, ((STG) + 1) & 3, 0) FWDM_QK(SN, SC, ((STG) + 1) & 3, 1) FWDM_QK(SN, SC, ((STG) + 1) & 3, 2) FWDM_QK(SN, SC, ((STG) + 1) & 3, 3) \
+      FWDM_QK(SN, SC, ((STG) + 1) & 3, 4) FWDM_QK(SN, SC, ((STG) + 1) & 3, 5) FWDM_QK(SN, SC, ((STG) + 1) & 3, 6) FWDM_QK(SN, SC, ((STG) + 1) & 3, 7) \
+      FWDM_QK(SN, SC, ((STG) + 1) & 3, 8) FWDM_QK(SN, SC, ((STG) + 1) & 3, 9) FWDM_QK(SN, SC, ((STG) + 1) & 3, 10) FWDM_QK(SN, SC, ((STG) + 1) & 3, 11) \
+      FWDM_QK(SN, SC, ((STG) + 1) & 3, 12) FWDM_QK(SN, SC, ((STG) + 1) & 3, 13) FWDM_QK(SN, SC, ((STG) + 1) & 3, 14) FWDM_QK(SN, SC, ((STG) + 1) & 3, 15) \
+    }                                                                                                           \
+    l += rs0 + rs1;                                                                                             \
+    bf16x8 pf[4];                               /* P^T operands: (kb, t) = registers 8 t .. 8 t + 7 of key block kb */ \
+    _Pragma("unroll") for (int kt = 0; kt < 4; ++kt) {                                                          \
+      const int kb = kt >> 1, t = kt & 1;                                                                       \
+      pf[kt] = __builtin_bit_cast(bf16x8, u32x4{pack_bf16x2(SC[kb][8 * t + 0], SC[kb][8 * t + 1]), pack_bf16x2(SC[kb][8 * t + 2], SC[kb][8 * t + 3]), \
+                                                pack_bf16x2(SC[kb][8 * t + 4], SC[kb][8 * t + 5]), pack_bf16x2(SC[kb][8 * t + 6], SC[kb][8 * t + 7])}); \
+    }                                                                                                           \
+    __builtin_amdgcn_sched_barrier(0);                                                                          \
+    {                                                                                                           \
+      s16x4 vlo[16], vhi[16];                                                                                   \
+      FWDM_VRD(STG, 0) FWDM_VRD(STG, 1)                                                                         \
+      FWDM_PV(STG, 0) FWDM_PV(STG, 1) FWDM_PV(STG, 2) FWDM_PV(STG, 3) FWDM_PV(STG, 4) FWDM_PV(STG, 5) FWDM_PV(STG, 6) FWDM_PV(STG, 7) \
+      FWDM_PV(STG, 8) FWDM_PV(STG, 9) FWDM_PV(STG, 10) FWDM_PV(STG, 11) FWDM_PV(STG, 12) FWDM_PV(STG, 13) FWDM_PV(STG, 14) FWDM_PV(STG, 15) \
+    }                                                                                                           \
   }
   // the wave's own tiles (a conditional body inside ONE loop over all tiles cost 40 registers: every accumulator became a phi) ...
-  for (int it = 0; it <= last_w; it += 2) {
-    FWDM_ITER(it, sa, sb2)
-    if (it + 1 <= last_w) FWDM_ITER(it + 1, sb2, sa)
+  if (last_w >= 0) {
+    for (int it = 0;; it += 4) {
+      FWDM_ITER(it, 0, sa, sb2)
+      if (it + 1 > last_w) break;
+      FWDM_ITER(it + 1, 1, sb2, sa)
+      if (it + 2 > last_w) break;
+      FWDM_ITER(it + 2, 2, sa, sb2)
+      if (it + 3 > last_w) break;
+      FWDM_ITER(it + 3, 3, sb2, sa)
+      if (it + 4 > last_w) break;
+    }
   }
   // ... then the tiles above its diagonal that the block's other waves still need: keep the barrier count and feed the ring
-  for (int it = last_w + 1; it < nit; ++it) {
+  for (int it = max(last_w, -1) + 1; it < nit; ++it) {
     asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    issue(it + 3, (it + 3) & 3, lane);
+    const int t3 = min(it + 3, nit - 1), st3 = (it + 3) & 3;
+    const uint32_t so_k = (uint32_t)(kstart + t3 * 64) * kts2, so_v = (uint32_t)(kstart + t3 * 64) * vts2;
+    const uint32_t m0_ = m0w + (uint32_t)st3 * 16384u;
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(m0_), "v"(vK), "s"(rsK), "s"(so_k) : "memory");
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(m0_ + 8192u), "v"(vK), "s"(rsK), "s"(so_k + 32u * kts2) : "memory");
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(m0_ + 65536u), "v"(vV), "s"(rsV), "s"(so_v) : "memory");
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(m0_ + 65536u + 8192u), "v"(vV), "s"(rsV), "s"(so_v + 32u * vts2) : "memory");
   }
 #undef FWDM_ITER
 #undef FWDM_PV
-#undef FWDM_VRD
 #undef FWDM_QK
+#undef FWDM_VRD
+#undef FWDM_KRD
+#undef FWDM_DMA4
+#undef FWDM_DMA
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // trailing (dummy) DMAs must not outlive the block's LDS
   l += __shfl_xor(l, 32, 64);
   if (qrow < p.Sq) {
