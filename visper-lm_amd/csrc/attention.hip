@@ -1595,9 +1595,9 @@ static bool vp_fwd128_enabled() {                      // VP_ATTN_FWD128=1 selec
   return v != 0;
 }
 
-static bool vp_fwdm_enabled() {                        // VP_ATTN_FWDM=1 selects the 32x32x16 swapped-product forward (D = 128)
+static bool vp_fwdm_enabled() {                        // the 32x32x16 swapped-product forward (D = 128) is the default since round 3; VP_ATTN_FWDM=0: the 16-row kernel
   static int v = -1;
-  if (v < 0) { const char* e = getenv("VP_ATTN_FWDM"); v = e ? atoi(e) : 0; }
+  if (v < 0) { const char* e = getenv("VP_ATTN_FWDM"); v = e ? atoi(e) : 1; }
   return v != 0;
 }
 
