@@ -35,14 +35,15 @@ def _ms(fn, n=6):
 
 
 def test_gemm_floor(ops):
-    """Decoder-shaped GEMMs on the default large-problem kernel: measured 1.20-1.48 PFLOP/s; floor 0.85."""
+    """Decoder-shaped GEMMs on the default large-problem kernel (round 3: the 4-wave kernel, 1.40-1.60 PFLOP/s in short bursts; the 8-phase
+    kernel measured 1.20-1.48): floor 1.05, under both but above what the plain 256-tile kernel reaches."""
     for (M, N, K) in [(16384, 4096, 4096), (16384, 14336, 4096)]:
         a = torch.randn(M, K, device="cuda", dtype=torch.bfloat16)
         w = torch.randn(N, K, device="cuda", dtype=torch.bfloat16) * 0.05
         out = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
         ms = _ms(lambda: ops.gemm(a, w, out=out))
         tf = 2.0 * M * N * K / ms / 1e9
-        assert tf > 850.0, f"gemm {M}x{N}x{K}: {tf:.0f} TFLOP/s"
+        assert tf > 1050.0, f"gemm {M}x{N}x{K}: {tf:.0f} TFLOP/s"
 
 
 def test_gemm_tn_floor(ops):
@@ -57,7 +58,8 @@ def test_gemm_tn_floor(ops):
 
 
 def test_attention_floor(ops):
-    """Llama-3-8B train-step attention (B 8, 32/8 heads, S 2048, D 128, causal): measured fwd 0.42-0.44 ms, bwd 1.19-1.26 ms."""
+    """Llama-3-8B train-step attention (B 8, 32/8 heads, S 2048, D 128, causal): measured fwd 0.32-0.37 ms in short bursts (round 3's
+    32x32x16 kernel; the 16-row kernel 0.36-0.44), bwd 1.04-1.26 ms."""
     B, Hq, Hkv, S, D = 8, 32, 8, 2048, 128
     qkv = torch.randn(B, S, (Hq + 2 * Hkv) * D, device="cuda", dtype=torch.bfloat16)
     q = qkv[..., :Hq * D].unflatten(-1, (Hq, D))
@@ -67,5 +69,5 @@ def test_attention_floor(ops):
     o, lse = ops.attn_fwd(q, k, v, True)
     fwd = _ms(lambda: ops.attn_fwd(q, k, v, True))
     bwd = _ms(lambda: ops.attn_bwd(q, k, v, o, lse, do, True))
-    assert fwd < 0.60, f"attention forward {fwd:.3f} ms"
-    assert bwd < 1.70, f"attention backward {bwd:.3f} ms"
+    assert fwd < 0.50, f"attention forward {fwd:.3f} ms"
+    assert bwd < 1.60, f"attention backward {bwd:.3f} ms"
