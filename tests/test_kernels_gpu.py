@@ -2,6 +2,8 @@
 reference op, plain torch math otherwise).  Inputs are bf16-rounded on the host so both sides see the
 same values; tolerances are stated per test (bf16 outputs: ~2^-8 relative)."""
 import math
+import os
+import sys
 
 import numpy as np
 import pytest
@@ -690,6 +692,19 @@ def test_attention_d128_dma_kernels_edges(ops, B, Hq, Hkv, Sq, Skv, causal, wind
         for b, n in enumerate(kvl):
             assert float(dk[b, n:].float().abs().max() if n < Skv else 0.0) == 0.0
             assert float(dv[b, n:].float().abs().max() if n < Skv else 0.0) == 0.0
+
+
+def test_attention_forward_variants_by_env():
+    """The opt-in D = 128 forward kernels (the launcher reads its switches once per process, so each variant runs in a child process):
+    VP_ATTN_FWDQ=1 = one wave per SIMD with O^T / Q in AGPRs, VP_ATTN_FWDM=0 = round 2's 16-row kernel, VP_ATTN_FWD128=1 = the 32-row
+    DMA-ring kernel.  Each re-runs the D = 128 edge cases and the decoder-shaped case of this file."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for env in ({"VP_ATTN_FWDQ": "1"}, {"VP_ATTN_FWDM": "0"}, {"VP_ATTN_FWDM": "0", "VP_ATTN_FWD128": "1"}):
+        r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-k",
+                            "test_attention_d128_dma_kernels_edges or test_attention_fwd_bwd or test_attention_fused_qkv_views_and_kvlen or test_attention_sliding_window"],
+                           capture_output=True, text=True, timeout=900, cwd=root, env=dict(os.environ, **env))
+        assert r.returncode == 0 and " passed" in r.stdout, (env, r.stdout[-1500:], r.stderr[-500:])
 
 
 def test_attention_with_additive_biases(ops):

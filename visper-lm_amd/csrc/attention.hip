@@ -1578,6 +1578,329 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 }
 
 // ================================================================================================
+// forward for D = 128, one wave per SIMD (VP_ATTN_FWDQ=1): the attn_fwd128m structure with 4 waves x 64 query rows — a K / V fragment feeds TWO
+// MFMAs, no partner wave competes for the matrix pipe — and the register file split by who touches what: O^T (128 registers) and the Q
+// fragments (64) live in AGPRs and are only ever MFMA operands (inline-asm MFMAs with "a" constraints: left to itself hipcc parked VALU-touched
+// values in AGPRs and moved 477 registers per tile back and forth); the two S^T buffers, P^T and everything the softmax touches stay in VGPRs.
+// The rare rescale of O^T goes through v_accvgpr_read / write pairs.
+// ================================================================================================
+template <bool CAUSAL>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void attn_fwd128q_kernel(AttnParams p) {
+  constexpr int NQ = 2;
+  constexpr int NW = 8 / NQ;
+  constexpr int NPK = 2 * NQ;
+  constexpr int D = 128;
+  extern __shared__ __attribute__((aligned(16))) unsigned char attn_smem[];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int nqb = (p.Sq + 255) >> 8;
+  const int qb = nqb - 1 - VP_BZ(p);                   // z is the slowest dispatch index: heavy (late) causal blocks first
+  const int hx = blockIdx.x;
+  const int h = (p.Hq & 7) == 0 ? (hx & 7) * (p.Hq >> 3) + (hx >> 3) : hx;     // whole GQA groups per XCD
+  const int b = VP_BY(p), hk = h / (p.Hq / p.Hkv);
+  const int q0 = qb * 256, qw0 = q0 + wave * 32 * NQ;
+  const int kvlen = p.kv_len ? min(p.kv_len[b], p.Skv) : p.Skv;
+  const int off = p.Skv - p.Sq;
+  const float c = p.scale * LOG2E;
+  const int ql = lane & 31, hh = lane >> 5;
+
+  bf16x8 qf[NQ][8];
+#pragma unroll
+  for (int qb_ = 0; qb_ < NQ; ++qb_) {
+    const bf16_t* qp = p.q + (long)b * p.q_bs + (long)min(qw0 + qb_ * 32 + ql, p.Sq - 1) * p.q_ts + (long)h * D;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) qf[qb_][ks] = *(const bf16x8*)(qp + ks * 16 + hh * 8);
+  }
+#pragma unroll
+  for (int qb_ = 0; qb_ < NQ; ++qb_)
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) asm volatile("" : "+a"(qf[qb_][ks]));       // from here on an AGPR tuple (only "a"-constrained uses follow)
+  f32x16 oacc[NQ][4];
+#pragma unroll
+  for (int qb_ = 0; qb_ < NQ; ++qb_)
+#pragma unroll
+    for (int d = 0; d < 4; ++d)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) oacc[qb_][d][i] = 0.f;
+#pragma unroll
+  for (int qb_ = 0; qb_ < NQ; ++qb_)
+#pragma unroll
+    for (int d = 0; d < 4; ++d) asm volatile("" : "+a"(oacc[qb_][d]));
+  float m[NQ], l[NQ];
+#pragma unroll
+  for (int qb_ = 0; qb_ < NQ; ++qb_) { m[qb_] = -1e30f; l[qb_] = 0.f; }
+
+  int kend = kvlen;
+  if (CAUSAL) kend = min(kend, q0 + 256 + off);
+  int kstart = 0;
+  if (p.window > 0) kstart = max(0, (q0 + off - p.window + 1)) & ~63;
+  const int nit = kend > kstart ? (kend - kstart + 63) / 64 : 0;
+  const int last_w = CAUSAL ? min(nit - 1, (qw0 + 32 * NQ - 1 + off - kstart) >> 6) : nit - 1;     // tiles this WAVE needs
+
+  // ---- LDS-DMA: buffer_load ... lds with a per-(batch, kv head) descriptor (rows past Skv read as zeros: no clamps), ONE lane offset per
+  // operand, the tile / piece in the scalar offset, the LDS destination in m0: no vector arithmetic per piece.  Piece 0 / 1 = K rows drow,
+  // drow + 32 of the tile, 2 / 3 = V likewise (drow = 4 wave + lane / 16: a wave instruction fills 4 rows = 1 KB of LDS).
+  const uint32_t ldsb = attn_lds_addr(attn_smem);
+  auto make_rs = [&](const bf16_t* base, long ts) -> fwdm_u32x4s {
+    const uint64_t a = (uint64_t)(uintptr_t)base;
+    fwdm_u32x4s r;
+    r[0] = __builtin_amdgcn_readfirstlane((uint32_t)a);
+    r[1] = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32) & 0xffffu);
+    r[2] = __builtin_amdgcn_readfirstlane((uint32_t)((((long)p.Skv - 1) * ts + D) * 2));
+    r[3] = 0x00020000u;
+    return r;
+  };
+  const fwdm_u32x4s rsK = make_rs(p.k + (long)b * p.k_bs + (long)hk * D, p.k_ts), rsV = make_rs(p.v + (long)b * p.v_bs + (long)hk * D, p.v_ts);
+  uint32_t vK, vV;
+  {
+    const int drow = wave * 4 + (lane >> 4);
+    // K rows: chunk ^ (row & 15): conflict-free ds_read_b128 (16 rows x one chunk per lane group).  V rows: chunk ^ 4 (row & 3): a transposing
+    // read of this kernel touches 4 rows x 4 chunks x 2 halves per 32-lane group (two 16-lane groups share the rows and differ in the chunk);
+    // with the K swizzle 16 (row, chunk) pairs fall on 4 slots (PMC: 6 conflict cycles per read), this way every lane has its own 8 bytes
+    vK = (uint32_t)((drow * p.k_ts + (((lane & 15) ^ (drow & 15)) << 3)) * 2);
+    vV = (uint32_t)((drow * p.v_ts + (((lane & 15) ^ ((drow & 3) << 2)) << 3)) * 2);
+    asm volatile("" : "+v"(vK), "+v"(vV));
+  }
+  const uint32_t kts2 = __builtin_amdgcn_readfirstlane((uint32_t)(p.k_ts * 2)), vts2 = __builtin_amdgcn_readfirstlane((uint32_t)(p.v_ts * 2));
+  const uint32_t m0w = __builtin_amdgcn_readfirstlane(ldsb + (uint32_t)wave * 1024u);
+#define FWDQ_QK0(S_, KF_, QA_) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(S_) : "v"(KF_), "a"(QA_))
+#define FWDQ_QK(S_, KF_, QA_) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(S_) : "v"(KF_), "a"(QA_))
+#define FWDQ_PV(O_, VF_, PF_) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(O_) : "v"(VF_), "v"(PF_))
+#define FWDM_DMA(T, ST, PIECE)                                                                                  \
+  {                                                                                                             \
+    const uint32_t row_ = (uint32_t)(kstart + (T) * 64 + ((PIECE) % NPK) * NW * 4);                              \
+    const uint32_t so_ = row_ * (((PIECE) >= NPK) ? vts2 : kts2);                                                \
+    const uint32_t m0_ = m0w + (uint32_t)((ST) * 16384 + ((PIECE) % NPK) * NW * 1024 + (((PIECE) >= NPK) ? 65536 : 0)); \
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(m0_), "v"(((PIECE) >= NPK) ? vV : vK), \
+                 "s"(((PIECE) >= NPK) ? rsV : rsK), "s"(so_) : "memory");                                       \
+  }
+#define FWDM_DMA_ALL(T, ST) { _Pragma("unroll") for (int pc_ = 0; pc_ < 2 * NPK; ++pc_) FWDM_DMA(T, ST, pc_) }
+
+  // ---- fragment addresses (bytes, loop-invariant).  K fragment (kb, ks): row 32 kb + (lane & 31), 16-byte chunk (2 ks + hh) ^ (row & 15)
+  uint32_t ka[8];
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks) {
+    ka[ks] = ldsb + (uint32_t)(((lane & 31) * 128 + (((2 * ks + hh) ^ (lane & 15)) << 3)) * 2);
+    asm volatile("" : "+v"(ka[ks]));
+  }
+  // V^T fragment (db, kt): two transposing reads; lane i of a 16-lane group supplies 4 features of key row 16 kt + 4 hh + (i >> 2) [+ 8]
+  uint32_t va0[4];
+  {
+    const int fr_ = lane & 15, gq = (lane >> 4) & 1, trow = 4 * hh + (fr_ >> 2);
+#pragma unroll
+    for (int db = 0; db < 4; ++db) {
+      va0[db] = ldsb + 65536u + (uint32_t)((trow * 128 + (((4 * db + 2 * gq + ((lane & 3) >> 1)) ^ ((trow & 3) << 2)) << 3) + (lane & 1) * 4) * 2);
+      asm volatile("" : "+v"(va0[db]));
+    }
+  }
+#define FWDM_KRD(DST, ST, N) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(DST) : "v"(ka[(N) >> 1]), "n"((ST) * 16384 + ((N) & 1) * 8192))
+#define FWDM_VRD(ST, N)                                                                                         \
+  {                                                                                                             \
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(vlo[N]) : "v"(va0[(N) & 3]), "n"((ST) * 16384 + ((N) >> 2) * 4096)); \
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(vhi[N]) : "v"(va0[(N) & 3]), "n"((ST) * 16384 + ((N) >> 2) * 4096 + 2048)); \
+  }
+
+  f32x16 sa[NQ][2], sb2[NQ][2];
+  if (nit > 0) {
+    FWDM_DMA_ALL(0, 0) FWDM_DMA_ALL(min(1, nit - 1), 1) FWDM_DMA_ALL(min(2, nit - 1), 2)
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * 2 * NPK) : "memory");
+    __builtin_amdgcn_s_barrier();
+    bf16x8 kf[16];
+#define FWDM_P0(N) FWDM_KRD(kf[N], 0, N);
+    FWDM_P0(0) FWDM_P0(1) FWDM_P0(2) FWDM_P0(3) FWDM_P0(4) FWDM_P0(5) FWDM_P0(6) FWDM_P0(7)
+    FWDM_P0(8) FWDM_P0(9) FWDM_P0(10) FWDM_P0(11) FWDM_P0(12) FWDM_P0(13) FWDM_P0(14) FWDM_P0(15)
+#undef FWDM_P0
+    ATTN_LGKM(0);
+#pragma unroll
+    for (int n = 0; n < 16; ++n) {
+      ATTN_PIN(kf[n]);
+#pragma unroll
+      for (int qb_ = 0; qb_ < NQ; ++qb_) {
+        if (n < 2) FWDQ_QK0(sa[qb_][n & 1], kf[n], qf[qb_][n >> 1]);
+        else FWDQ_QK(sa[qb_][n & 1], kf[n], qf[qb_][n >> 1]);
+      }
+    }
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // asm MFMAs: the compiler inserts no MFMA -> VALU wait states itself
+  }
+  // One tile.  STG = its ring stage (literal).  A: mask (diagonal / ragged tiles), lane-local max, rare rescale.  B: S^T of the NEXT tile
+  // (16 MFMAs, two accumulator chains alternating, K fragments three steps ahead by asm reads with counted waits) with this tile's 32
+  // exponentials in the MFMAs' shadow, 2 per MFMA — ALWAYS run, also behind the wave's last tile (a second code path for "no next tile"
+  // made every score register a phi: 32 v_mov per tile).  C: O^T += V^T P^T (16 MFMAs, four chains alternating, transposing reads two steps
+  // ahead), one LDS-DMA piece of tile it + 3 per four MFMAs.
+#define FWDM_QK(SN, SC, NS, N)                                                                                  \
+  {                                                                                                             \
+    if ((N) + 3 < 16) { FWDM_KRD(kf[((N) + 3) & 15], NS, ((N) + 3) & 15); ATTN_LGKM(3); }                        \
+    else if ((N) + 3 == 16) { ATTN_LGKM(2); }                                                                   \
+    else if ((N) + 3 == 17) { ATTN_LGKM(1); }                                                                   \
+    else { ATTN_LGKM(0); }                                                                                      \
+    ATTN_PIN(kf[N]);                                                                                            \
+    _Pragma("unroll") for (int qb_ = 0; qb_ < NQ; ++qb_) {                                                      \
+      if ((N) < 2) FWDQ_QK0(SN[qb_][(N) & 1], kf[N], qf[qb_][(N) >> 1]);                                         \
+      else FWDQ_QK(SN[qb_][(N) & 1], kf[N], qf[qb_][(N) >> 1]);                                                 \
+      const float e0_ = fast_exp2(fmaf(SC[qb_][(N) >> 3][(2 * (N)) & 15], c2, -m[qb_]));                        \
+      const float e1_ = fast_exp2(fmaf(SC[qb_][(N) >> 3][(2 * (N) + 1) & 15], c2, -m[qb_]));                    \
+      SC[qb_][(N) >> 3][(2 * (N)) & 15] = e0_;                                                                  \
+      SC[qb_][(N) >> 3][(2 * (N) + 1) & 15] = e1_;                                                              \
+      rs0[qb_] += e0_;                                                                                          \
+      rs1[qb_] += e1_;                                                                                          \
+      if (NQ == 2) __builtin_amdgcn_sched_barrier(0);                                                           \
+    }                                                                                                           \
+    if (NQ == 1) __builtin_amdgcn_sched_barrier(0);                                                             \
+  }
+#define FWDM_PV(ST, N)            /* step N: feature block N & 3, key group N >> 2 */                           \
+  {                                                                                                             \
+    if ((N) + 2 < 16) { FWDM_VRD(ST, ((N) + 2) & 15) ATTN_LGKM(4); }                                            \
+    else if ((N) + 2 == 16) { ATTN_LGKM(2); }                                                                   \
+    else { ATTN_LGKM(0); }                                                                                      \
+    bf16x8 vtf = tr_join(vlo[N], vhi[N]);                                                                       \
+    ATTN_PIN(vtf);                                                                                              \
+    _Pragma("unroll") for (int qb_ = 0; qb_ < NQ; ++qb_)                                                        \
+      FWDQ_PV(oacc[qb_][(N) & 3], vtf, pf[qb_][(N) >> 2]);                                                      \
+    if (((N) % (4 / NQ)) == 1 % (4 / NQ)) FWDM_DMA(t3_, ((ST) + 3) & 3, (N) / (4 / NQ))                          \
+    if (((N) & 1) || NQ == 2) __builtin_amdgcn_sched_barrier(0);                                                \
+  }
+#define FWDM_ITER(IT, STG, SC, SN)                                                                              \
+  {                                                                                                             \
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NPK) : "memory");                                              \
+    __builtin_amdgcn_sched_barrier(0);                                                                          \
+    __builtin_amdgcn_s_barrier();                                                                               \
+    __builtin_amdgcn_sched_barrier(0);                                                                          \
+    const int t3_ = min((IT) + 3, nit - 1);                                                                     \
+    const int k0 = kstart + (IT) * 64;                                                                          \
+    const bool need_mask = (k0 + 64 > kvlen) || (CAUSAL && (k0 + 63 > qw0 + off)) || (p.window > 0);            \
+    float mx[NQ];                                                                                               \
+    _Pragma("unroll") for (int qb_ = 0; qb_ < NQ; ++qb_) {                                                      \
+      if (need_mask) {                                                                                          \
+        int ln = threadIdx.x & 63;                                                                              \
+        asm volatile("" : "+v"(ln));                                                                            \
+        const int dq_ = qw0 + qb_ * 32 + (ln & 31) + off - k0 - 4 * (ln >> 5);                                  \
+        const int kl = kvlen - k0 - 4 * (ln >> 5);                                                              \
+        const int hi = CAUSAL ? min(kl, dq_ + 1) : kl;                                                          \
+        const int lo = p.window > 0 ? dq_ - p.window : -1000000;                                                \
+        const float ninf_ = -INFINITY;                                                                          \
+        _Pragma("unroll") for (int kb = 0; kb < 2; ++kb)                                                        \
+          _Pragma("unroll") for (int i = 0; i < 16; ++i) {                                                      \
+            const int e = kb * 32 + 8 * (i >> 2) + (i & 3);                                                     \
+            const unsigned long long ok_ = __builtin_amdgcn_ballot_w64(e < hi && e > lo);                       \
+            asm volatile("v_cndmask_b32 %0, %1, %0, %2" : "+v"(SC[qb_][kb][i]) : "v"(ninf_), "s"(ok_));         \
+          }                                                                                                     \
+      }                                                                                                         \
+      float mx_ = vmax3(SC[qb_][0][0], SC[qb_][0][1], SC[qb_][0][2]);                                           \
+      _Pragma("unroll") for (int i = 3; i < 15; i += 2) mx_ = vmax3(mx_, SC[qb_][0][i], SC[qb_][0][i + 1]);     \
+      mx_ = vmax3(mx_, SC[qb_][0][15], SC[qb_][1][0]);                                                          \
+      _Pragma("unroll") for (int i = 1; i < 15; i += 2) mx_ = vmax3(mx_, SC[qb_][1][i], SC[qb_][1][i + 1]);     \
+      mx[qb_] = fmaxf(mx_, SC[qb_][1][15]) * c;                                                                 \
+    }                                                                                                           \
+    bool calm_ = mx[0] <= m[0] + RESCALE_THR;                                                                   \
+    if (NQ == 2) calm_ = calm_ && (mx[NQ - 1] <= m[NQ - 1] + RESCALE_THR);                                      \
+    if (!__all(calm_)) {                                                                                        \
+      _Pragma("unroll") for (int qb_ = 0; qb_ < NQ; ++qb_) {                                                    \
+        const float mxx = fmaxf(mx[qb_], __shfl_xor(mx[qb_], 32, 64));                                          \
+        const float mnew = fmaxf(m[qb_], mxx);                                                                  \
+        const float alpha = fast_exp2(m[qb_] - mnew);                                                           \
+        l[qb_] *= alpha;                                                                                        \
+        asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");                                                     \
+        _Pragma("unroll") for (int d = 0; d < 4; ++d)                                                           \
+          _Pragma("unroll") for (int i = 0; i < 16; ++i) {                                                      \
+            float t_;                                                                                           \
+            asm volatile("v_accvgpr_read_b32 %0, %1\n\tv_mul_f32 %0, %2, %0\n\tv_accvgpr_write_b32 %1, %0" : "=&v"(t_), "+a"(oacc[qb_][d][i]) : "v"(alpha)); \
+          }                                                                                                     \
+        m[qb_] = mnew;                                                                                          \
+      }                                                                                                         \
+    }                                                                                                           \
+    float rs0[NQ], rs1[NQ];                                                                                     \
+    _Pragma("unroll") for (int qb_ = 0; qb_ < NQ; ++qb_) { rs0[qb_] = 0.f; rs1[qb_] = 0.f; }                    \
+    float c2 = c;                                                                                               \
+    asm volatile("" : "+v"(c2));                                                                                \
+    __builtin_amdgcn_sched_barrier(0);                                                                          \
+    {                                                                                                           \
+      bf16x8 kf[16];                                                                                            \
+      FWDM_KRD(kf[0], ((STG) + 1) & 3, 0); FWDM_KRD(kf[1], ((STG) + 1) & 3, 1); FWDM_KRD(kf[2], ((STG) + 1) & 3, 2); \
+      FWDM_QK(SN, SC, ((STG) + 1) & 3, 0) FWDM_QK(SN, SC, ((STG) + 1) & 3, 1) FWDM_QK(SN, SC, ((STG) + 1) & 3, 2) FWDM_QK(SN, SC, ((STG) + 1) & 3, 3) \
+      FWDM_QK(SN, SC, ((STG) + 1) & 3, 4) FWDM_QK(SN, SC, ((STG) + 1) & 3, 5) FWDM_QK(SN, SC, ((STG) + 1) & 3, 6) FWDM_QK(SN, SC, ((STG) + 1) & 3, 7) \
+      FWDM_QK(SN, SC, ((STG) + 1) & 3, 8) FWDM_QK(SN, SC, ((STG) + 1) & 3, 9) FWDM_QK(SN, SC, ((STG) + 1) & 3, 10) FWDM_QK(SN, SC, ((STG) + 1) & 3, 11) \
+      FWDM_QK(SN, SC, ((STG) + 1) & 3, 12) FWDM_QK(SN, SC, ((STG) + 1) & 3, 13) FWDM_QK(SN, SC, ((STG) + 1) & 3, 14) FWDM_QK(SN, SC, ((STG) + 1) & 3, 15) \
+    }                                                                                                           \
+    bf16x8 pf[NQ][4];                                                                                           \
+    _Pragma("unroll") for (int qb_ = 0; qb_ < NQ; ++qb_) {                                                      \
+      l[qb_] += rs0[qb_] + rs1[qb_];                                                                            \
+      _Pragma("unroll") for (int kt = 0; kt < 4; ++kt) {                                                        \
+        const int kb = kt >> 1, t = kt & 1;                                                                     \
+        pf[qb_][kt] = __builtin_bit_cast(bf16x8, u32x4{pack_bf16x2(SC[qb_][kb][8 * t + 0], SC[qb_][kb][8 * t + 1]), pack_bf16x2(SC[qb_][kb][8 * t + 2], SC[qb_][kb][8 * t + 3]), \
+                                                       pack_bf16x2(SC[qb_][kb][8 * t + 4], SC[qb_][kb][8 * t + 5]), pack_bf16x2(SC[qb_][kb][8 * t + 6], SC[qb_][kb][8 * t + 7])}); \
+      }                                                                                                         \
+    }                                                                                                           \
+    __builtin_amdgcn_sched_barrier(0);                                                                          \
+    {                                                                                                           \
+      s16x4 vlo[16], vhi[16];                                                                                   \
+      FWDM_VRD(STG, 0) FWDM_VRD(STG, 1)                                                                         \
+      FWDM_PV(STG, 0) FWDM_PV(STG, 1) FWDM_PV(STG, 2) FWDM_PV(STG, 3) FWDM_PV(STG, 4) FWDM_PV(STG, 5) FWDM_PV(STG, 6) FWDM_PV(STG, 7) \
+      FWDM_PV(STG, 8) FWDM_PV(STG, 9) FWDM_PV(STG, 10) FWDM_PV(STG, 11) FWDM_PV(STG, 12) FWDM_PV(STG, 13) FWDM_PV(STG, 14) FWDM_PV(STG, 15) \
+    }                                                                                                           \
+  }
+  // the wave's own tiles (a conditional body inside ONE loop over all tiles cost 40 registers: every accumulator became a phi) ...
+  if (last_w >= 0) {
+    for (int it = 0;; it += 4) {
+      FWDM_ITER(it, 0, sa, sb2)
+      if (it + 1 > last_w) break;
+      FWDM_ITER(it + 1, 1, sb2, sa)
+      if (it + 2 > last_w) break;
+      FWDM_ITER(it + 2, 2, sa, sb2)
+      if (it + 3 > last_w) break;
+      FWDM_ITER(it + 3, 3, sb2, sa)
+      if (it + 4 > last_w) break;
+    }
+  }
+  // ... then the tiles above its diagonal that the block's other waves still need: keep the barrier count and feed the ring
+  for (int it = max(last_w, -1) + 1; it < nit; ++it) {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NPK) : "memory");
+    __builtin_amdgcn_s_barrier();
+    const int t3 = min(it + 3, nit - 1), st3 = (it + 3) & 3;
+#pragma unroll
+    for (int pc = 0; pc < 2 * NPK; ++pc) {
+      const uint32_t row_ = (uint32_t)(kstart + t3 * 64 + (pc % NPK) * NW * 4);
+      const uint32_t so_ = row_ * ((pc >= NPK) ? vts2 : kts2);
+      const uint32_t m0_ = m0w + (uint32_t)st3 * 16384u + (uint32_t)((pc % NPK) * NW * 1024 + ((pc >= NPK) ? 65536 : 0));
+      asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(m0_), "v"((pc >= NPK) ? vV : vK), "s"((pc >= NPK) ? rsV : rsK), "s"(so_) : "memory");
+    }
+  }
+#undef FWDM_ITER
+#undef FWDM_PV
+#undef FWDM_QK
+#undef FWDM_VRD
+#undef FWDM_KRD
+#undef FWDM_DMA_ALL
+#undef FWDQ_QK0
+#undef FWDQ_QK
+#undef FWDQ_PV
+#undef FWDM_DMA
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // trailing (dummy) DMAs must not outlive the block's LDS
+  asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+#pragma unroll
+  for (int qb_ = 0; qb_ < NQ; ++qb_) {
+    const int qrow = qw0 + qb_ * 32 + ql;
+    const float lt = l[qb_] + __shfl_xor(l[qb_], 32, 64);
+    if (qrow < p.Sq) {
+      const float inv = lt > 0.f ? 1.f / lt : 0.f;
+      bf16_t* op = p.o + (long)b * p.o_bs + (long)qrow * p.o_ts + (long)h * D;
+#pragma unroll
+      for (int db = 0; db < 4; ++db)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          bf16x4 o;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float t_;
+            asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(t_) : "a"(oacc[qb_][db][4 * j + r]));
+            o[r] = (short)f2bf(t_ * inv);
+          }
+          *(bf16x4*)(op + db * 32 + 8 * j + 4 * hh) = o;
+        }
+      if (p.lse && hh == 0) p.lse[((long)b * p.Hq + h) * p.Sq + qrow] = (lt > 0.f) ? m[qb_] + log2f(lt) : -1e30f;
+    }
+  }
+}
+
+// ================================================================================================
 // C ABI
 // ================================================================================================
 template <int D>
@@ -1614,6 +1937,21 @@ static int launch_fwd(const AttnParams& p_in, int causal, hipStream_t s) {
     attr = true;
   }
   const dim3 grid = p.order ? dim3(p.Hq, (p.Sq + 127) / 128, p.B) : dim3(p.Hq, p.B, (p.Sq + 127) / 128);
+  static int fwdq = -1;
+  if (fwdq < 0) { const char* e = getenv("VP_ATTN_FWDQ"); fwdq = e ? atoi(e) : 0; }
+  if (D == 128 && !p.bias_h && !p.bias_b && fwdq) {                     // one wave per SIMD, O^T / Q in AGPRs (see attn_fwd128q_kernel)
+    static bool attrq = false;
+    if (!attrq) {
+      (void)hipFuncSetAttribute((const void*)attn_fwd128q_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, FWDM_LDS);
+      (void)hipFuncSetAttribute((const void*)attn_fwd128q_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, FWDM_LDS);
+      attrq = true;
+    }
+    const int nb = (p.Sq + 255) / 256;
+    const dim3 gq = p.order ? dim3(p.Hq, nb, p.B) : dim3(p.Hq, p.B, nb);
+    if (causal) hipLaunchKernelGGL((attn_fwd128q_kernel<true>), gq, dim3(256), FWDM_LDS, s, p);
+    else hipLaunchKernelGGL((attn_fwd128q_kernel<false>), gq, dim3(256), FWDM_LDS, s, p);
+    return vp_check_launch("vp_attn_fwd");
+  }
   if (D == 128 && !p.bias_h && !p.bias_b && vp_fwdm_enabled()) {        // round 3: 32x32x16 swapped-product kernel, 256-row blocks
     static bool attrm = false;
     if (!attrm) {
