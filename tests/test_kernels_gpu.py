@@ -694,6 +694,37 @@ def test_attention_d128_dma_kernels_edges(ops, B, Hq, Hkv, Sq, Skv, causal, wind
             assert float(dv[b, n:].float().abs().max() if n < Skv else 0.0) == 0.0
 
 
+@pytest.mark.parametrize("causal", [True, False])
+def test_attention_d128_rescale_branch_mid_sequence(ops, causal):
+    """The deferred running max of the D = 128 forward kernels (O / l are only rescaled when a tile's max exceeds the running max by > 2^8):
+    on random inputs that branch fires in the first tile only, so a stale or half-applied rescale later in the sequence would go unnoticed.
+    Here a few keys are aligned with a few query rows so that their scores jump by ~30 and then by another ~16 log2 units in LATER tiles
+    (key positions in both key blocks of a 64-key tile and in both lane halves of the 32x32 layout; query rows in different waves), the rest
+    of the rows stay ordinary.  Forward vs fp32 softmax over the whole tensor, backward (which consumes the forward's lse) vs autograd."""
+    B, Hq, Hkv, S, D = 1, 4, 2, 512, 128
+    q, k, v, do = rnd(B, S, Hq, D, seed=301), rnd(B, S, Hkv, D, seed=302), rnd(B, S, Hkv, D, seed=303), rnd(B, S, Hq, D, seed=304)
+    u = torch.ones(D) / math.sqrt(D)
+    for j, mag in ((130, 16.0), (140, 16.0), (170, 16.0), (300, 24.0), (450, 32.0)):
+        k[0, j, :, :] = (mag * u).to(BF)
+        v[0, j, :, :] = (v[0, j, :, :].float() * 3.0).to(BF)
+    for r in (5, 135, 200, 260, 310, 400, 460, 511):
+        q[0, r, :, :] = (16.0 * u + 0.5 * q[0, r, :, :].float()).to(BF)
+    qr, kr, vr = (t.float().requires_grad_(True) for t in (q, k, v))
+    ref = attn_ref(qr, kr, vr, causal)
+    ref.backward(do.float())
+    qd, kd, vd = dev(q), dev(k), dev(v)
+    o, lse = ops.attn_fwd(qd, kd, vd, causal)
+    close(o, ref, what="attn fwd (rescale branch)")
+    # the aligned rows really are dominated by a late key (otherwise this test exercises nothing)
+    with torch.no_grad():
+        sc = (qr[0, 511, 0] @ kr[0, :, 0].T) / math.sqrt(D)
+        assert float(sc.max() - sc[:128].max()) * 1.4427 > 16.0
+    dq, dk, dv = ops.attn_bwd(qd, kd, vd, o, lse, dev(do), causal)
+    close(dq, qr.grad, rtol=3e-2, what="attn dq (rescale branch)")
+    close(dk, kr.grad, rtol=3e-2, what="attn dk (rescale branch)")
+    close(dv, vr.grad, rtol=3e-2, what="attn dv (rescale branch)")
+
+
 def test_attention_forward_variants_by_env():
     """The opt-in D = 128 forward kernels (the launcher reads its switches once per process, so each variant runs in a child process):
     VP_ATTN_FWDQ=1 = one wave per SIMD with O^T / Q in AGPRs, VP_ATTN_FWDM=0 = round 2's 16-row kernel, VP_ATTN_FWD128=1 = the 32-row
@@ -702,7 +733,8 @@ def test_attention_forward_variants_by_env():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     for env in ({"VP_ATTN_FWDQ": "1"}, {"VP_ATTN_FWDM": "0"}, {"VP_ATTN_FWDM": "0", "VP_ATTN_FWD128": "1"}):
         r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-k",
-                            "test_attention_d128_dma_kernels_edges or test_attention_fwd_bwd or test_attention_fused_qkv_views_and_kvlen or test_attention_sliding_window"],
+                            "test_attention_d128_dma_kernels_edges or test_attention_fwd_bwd or test_attention_fused_qkv_views_and_kvlen or test_attention_sliding_window "
+                            "or test_attention_d128_rescale_branch_mid_sequence"],
                            capture_output=True, text=True, timeout=900, cwd=root, env=dict(os.environ, **env))
         assert r.returncode == 0 and " passed" in r.stdout, (env, r.stdout[-1500:], r.stderr[-500:])
 
