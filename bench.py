@@ -364,6 +364,51 @@ def alt_transport_legs(args, eng, dist, rank, world, legs, diag, timed_leg, max_
             bail.set()
 
 
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher environment: start the N ranks OURSELVES, one process per GPU, the way the
+    reference's own script does (scripts/train/pretrain.sh:15 `deepspeed ...` spawns the ranks; the caller never does).  The parent holds
+    no GPU: it re-runs this file under torch.distributed.run on 127.0.0.1 with a free port, relays the ranks' stderr, and prints the ONE
+    JSON line rank 0 produced.  Fails loudly when the node has fewer than N GPUs (VP_TEST_SHARED_GPU=1, the one-GPU test hook, excepted)."""
+    import signal
+    import subprocess
+    n = args.gpus
+    shared = os.environ.get("VP_TEST_SHARED_GPU") == "1"
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if have < n and not shared:
+        raise SystemExit(f"bench.py --gpus {n}: this node exposes {have} GPU(s); refusing to run fewer ranks than asked for")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), MASTER_ADDR="127.0.0.1",
+               VP_BENCH_SELF_LAUNCHED="1")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    limit = float(os.environ.get("VP_BENCH_LAUNCH_TIMEOUT", "2400"))
+    p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, start_new_session=True, cwd=ROOT)
+    try:
+        out, _ = p.communicate(timeout=limit)
+    except subprocess.TimeoutExpired:
+        os.killpg(p.pid, signal.SIGKILL)                    # the process group WE started (start_new_session): nothing else
+        out, _ = p.communicate()
+        sys.stderr.write(f"bench.py: the {n}-rank job did not finish within {limit:.0f} s and was killed\n")
+    lines = [ln for ln in (out or "").splitlines() if ln.startswith("{") and '"metric"' in ln]
+    if not lines:
+        sys.stderr.write((out or "")[-4000:])
+        raise SystemExit(f"bench.py --gpus {n}: the ranks produced no result line (exit code {p.returncode})")
+    res = json.loads(lines[-1])
+    if res.get("n_gpus") != n:
+        raise SystemExit(f"bench.py --gpus {n}: the communicator reported {res.get('n_gpus')} ranks: {lines[-1][:400]}")
+    if p.returncode not in (0, None):                      # a complete, checked line exists: a crash during teardown does not void it
+        sys.stderr.write(f"bench.py: ranks exited with code {p.returncode} after producing the result line\n")
+    print(lines[-1], flush=True)
+    raise SystemExit(0)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -389,8 +434,12 @@ def main():
     ap.add_argument("--force-dist", action="store_true", help="initialise the RCCL process group even with one rank (test hook)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        launch_ranks(args)                              # never returns
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and not args.force_dist:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s)")
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a MI355X: the product path has no CPU fallback")
@@ -542,7 +591,7 @@ def main():
     g_fl = sum(f for _, _, f, _, _ in prof)
     b_ms, b_fl = sum(t for t, _ in big), sum(f for _, f in big)
     achieved = b_fl / (b_ms * 1e-3) / 1e12 if b_ms > 0 else 0.0
-    traffic = None                                     # HBM bytes per launch from a separate rocprofv3 --pmc pass (profiles/)
+    traffic, latest = None, None                       # HBM bytes per launch from a separate rocprofv3 --pmc pass (profiles/)
     try:
         pdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
         latest = sorted(f for f in os.listdir(pdir) if f.endswith("_pmc_w4.json" if w4 else "_pmc_p8.json"))[-1]        # newest round's PMC pass of the kernel that runs
@@ -554,7 +603,8 @@ def main():
                                         "hand-scheduled K loop: one LDS-DMA piece / ds_read per MFMA gap)" if w4 else
                                         "gemm_nt_256p8 (bf16 MFMA 16x16x32, persistent 256x256x64 tiles, two wave groups in ping-pong, 4 phases per K-tile)"),
             "achieved": round(achieved, 1), "peak": PEAK_BF16_TF, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TF, 4),
-            "traffic": traffic, "launches_per_step": len(big) // max(args.steps, 1),
+            "traffic": traffic, "traffic_source": (f"profiles/{latest} (a separate rocprofv3 --pmc pass of this command, committed; not measured in this run)"
+                                                   if traffic is not None else None), "launches_per_step": len(big) // max(args.steps, 1),
             "avg_launch_ms": round(b_ms / max(len(big), 1), 4), "tflop_per_launch": round(b_fl / max(len(big), 1) / 1e12, 4),
             "kernel_ms_per_step": round(b_ms / args.steps, 2), "all_gemm_ms_per_step": round(g_ms / args.steps, 2),
             "all_gemm_tflop_per_step": round(g_fl / args.steps / 1e12, 2)}
@@ -566,14 +616,14 @@ def main():
                             (0 if cfg.is_convnext else 4.0 * 577 * 577 * cfg.vit_hidden * (cfg.vit_layers - 1))) / 1e12
     exec_tf = g_fl / args.steps / 1e12 + attn_tf
     roof["executed_tflop_per_step"] = round(exec_tf, 2)
-    roof["step_frac_of_peak"] = round(exec_tf / (ms * 1e-3) / PEAK_BF16_TF, 4)
-    roof["step_frac_of_peak_nominal_table"] = round(value / world * step_tf / PEAK_BF16_TF, 4)
 
     def assemble():
+        roof["step_frac_of_peak"] = round(exec_tf / (ms * 1e-3) / PEAK_BF16_TF, 4)           # of the headline leg's step time
+        roof["step_frac_of_peak_nominal_table"] = round(value / world * step_tf / PEAK_BF16_TF, 4)
         return {"metric": "train-step images/sec (NTP+distill), ViT-L+Llama3-8B seq2048" if args.workload == "llama3_8b" else
                ("train-step images/sec (NTP only, IFT stage: whole LLM trainable), ViT-L+Llama3-8B seq2048" if args.workload == "ift"
                 else f"train-step images/sec (NTP+distill), {args.workload}"), "value": round(value, 4), "unit": "images/s",
-               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 2), "higher_is_better": True,
+               "n_gpus": (dist.get_world_size() if dist is not None else 1), "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 2), "higher_is_better": True,
                "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic (random-init weights, random images/tokens/targets)",
                "config": {"workload": {"llama3_8b": "configs[1]: CLIP-ViT-L/14-336 + Llama-3-8B PT step, 3 distill heads (d18,s18,g20), 336px",
                                        "convnext": "configs[3]: CLIP-ConvNeXt-XXL (768px) + Llama-3-8B PT step, 3 distill heads",
@@ -592,6 +642,19 @@ def main():
                            emit_partial=lambda: print(json.dumps(assemble(), default=str), flush=True))
     if diag is not None:
         diag.pop("_ctx", None)
+        # Headline leg (north_star: "RCCL all-reduce ... on a side HIP stream" = the C ABI's own communicator, vp_comm_*): the torch.distributed
+        # leg runs FIRST because it cannot take the job down, the native leg second behind the watchdog; when the native leg completed — same
+        # K steps between the same fences, gradients and gathered targets bit-identical on every rank (asserted in exchange_points) — ITS time is
+        # the line's `value`; otherwise the torch leg's stays.  Every rank takes the same decision from the same all-reduced numbers.
+        nat = diag.get("native") if legs[0] != "native" else None
+        diag["headline_transport"] = legs[0]
+        if isinstance(nat, dict) and "ms_per_step" in nat and "error" not in nat:
+            ms = nat["ms_per_step"]
+            dt = ms * 1e-3 * args.steps
+            value = args.batch * world * args.steps / dt
+            diag["headline_transport"] = "native"
+        info = diag.get(diag["headline_transport"], {}).get("vp_comm_info")
+        diag["n_ranks_seen"] = {"torch.distributed": dist.get_world_size(), "vp_comm_info": info["world"] if info else None}
     if rank == 0:
         res = assemble()
         # the stand-alone probes run AFTER the timed region and must never cost the line: a failing probe is reported as its error string

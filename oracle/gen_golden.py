@@ -602,11 +602,84 @@ def run_units():
     print("units written:", sorted(res)[:8], "...")
 
 
+CNX_PREFIX = "model.vision_tower.vision_tower."
+
+
+def cnx_timm_to_hf(name):
+    """timm ConvNeXt state-dict name (what open_clip's `visual.trunk` holds, and what this repo's checkpoints / oracle use) -> the name of the
+    same tensor in transformers.ConvNextModel, an independent third-party implementation of the published ConvNeXt block."""
+    parts = name.split(".")
+    if parts[0] == "stem":
+        return ("embeddings.patch_embeddings." if parts[1] == "0" else "embeddings.layernorm.") + parts[2]
+    assert parts[0] == "stages", name
+    st = f"encoder.stages.{parts[1]}."
+    if parts[2] == "downsample":
+        return st + f"downsampling_layer.{parts[3]}.{parts[4]}"
+    blk = st + f"layers.{parts[3]}."                       # stages.i.blocks.j.<rest>
+    rest = ".".join(parts[4:])
+    table = {"gamma": "layer_scale_parameter", "conv_dw.weight": "dwconv.weight", "conv_dw.bias": "dwconv.bias",
+             "norm.weight": "layernorm.weight", "norm.bias": "layernorm.bias", "mlp.fc1.weight": "pwconv1.weight",
+             "mlp.fc1.bias": "pwconv1.bias", "mlp.fc2.weight": "pwconv2.weight", "mlp.fc2.bias": "pwconv2.bias"}
+    return blk + table[rest]
+
+
+def run_convnext():
+    """Row a2 pin.  timm / open_clip are absent, so the reference's `CLIPConvNextVisionTower._forward`
+    (clip_convnext_encoder.py:150-174 — it only touches `vision_tower.stem`, `.stages`, `.norm_pre`) is run HERE on a stand-in trunk assembled from
+    the sub-modules of transformers.ConvNextModel: an implementation of the published ConvNeXt block written by other people than timm's and
+    than this repo's.  Weights: the closed-form recipe by timm name, loaded into the HF modules through the name map above.  The fixture holds
+    the reference call's output, the name map and the dims — tensors and strings only."""
+    from transformers import ConvNextConfig, ConvNextModel
+    from ola_vlm.model.multimodal_encoder.clip_convnext_encoder import CLIPConvNextVisionTower
+    from visper_lm_amd.config import VisperConfig
+    from visper_lm_amd.params import param_shapes
+    dims, depths, px = (32, 64, 96, 128), (1, 2, 3, 1), 160                       # 160 / 32 = 5 -> 25 tokens
+    hf = ConvNextModel(ConvNextConfig(num_channels=3, patch_size=4, num_stages=4, hidden_sizes=list(dims), depths=list(depths),
+                                      hidden_act="gelu", layer_scale_init_value=1.0)).eval()
+    vc = VisperConfig(mm_vision_tower="CLIP-convnext-pin", cnx_dims=dims, cnx_depths=depths)
+    shapes = {k[len(CNX_PREFIX):]: tuple(v) for k, v in param_shapes(vc).items() if k.startswith(CNX_PREFIX)}
+    sd = hf.state_dict()
+    name_map, new_sd = {}, {}
+    for k, shp in shapes.items():
+        h = cnx_timm_to_hf(k)
+        assert h in sd and tuple(sd[h].shape) == shp, (k, h, shp)
+        name_map[k] = h
+        new_sd[h] = WT.tensor(CNX_PREFIX + k, shp, 0.5) if k.endswith("gamma") else WT.param(CNX_PREFIX + k, shp)
+    left = sorted(set(sd) - set(new_sd))
+    assert left == ["layernorm.bias", "layernorm.weight"], left                   # HF's pooled-output norm: not on the reference's path
+    hf.load_state_dict(new_sd, strict=False)
+
+    class Trunk(torch.nn.Module):                                                  # the three attributes the reference touches, nothing else
+        def __init__(self):
+            super().__init__()
+            self.stem, self.stages, self.norm_pre = hf.embeddings, hf.encoder.stages, torch.nn.Identity()
+    tower = CLIPConvNextVisionTower.__new__(CLIPConvNextVisionTower)
+    torch.nn.Module.__init__(tower)
+    tower.vision_tower, tower.is_loaded, tower.is_multi_stage = Trunk(), True, False
+    tower._image_size, tower._interp_size, tower._reduction = px, None, 32
+    images = WT.tensor("cnx_pin_images", (2, 3, px, px))
+    with torch.no_grad():
+        feats = tower._forward(images)                                            # the reference's own code path
+        stage_outs, x = [], hf.embeddings(images)
+        for st in hf.encoder.stages:
+            x = st(x)
+            stage_outs.append(x)
+    assert feats.shape == (2, (px // 32) ** 2, dims[-1]), feats.shape
+    assert tower.num_patches == (px // 32) ** 2
+    res = {"features": feats.numpy(), "dims": np.array(dims), "depths": np.array(depths), "px": np.array(px),
+           "eps": np.array(1e-6), "name_map": np.array(json.dumps(name_map))}
+    for i, so in enumerate(stage_outs):
+        res[f"stage{i}_sub"] = sub(so)
+        res[f"stage{i}_norm"] = np.array(float(so.norm()))
+    np.savez_compressed(os.path.join(OUT, "convnext.npz"), **res)
+    print("convnext written:", feats.shape, float(feats.abs().mean()))
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
     setup_reference()
-    which = sys.argv[1:] or ["units", "llama", "phi3", "ift", "ift_tok", "nt0", "data", "dino", "clipemb", "swin"]
+    which = sys.argv[1:] or ["units", "llama", "phi3", "ift", "ift_tok", "nt0", "data", "dino", "clipemb", "swin", "convnext"]
     if "units" in which:
         run_units()
     if "llama" in which:
@@ -627,3 +700,5 @@ if __name__ == "__main__":
         run_clip_embed_teacher()
     if "swin" in which:
         run_swin_teacher()
+    if "convnext" in which:
+        run_convnext()

@@ -1,9 +1,12 @@
 """CLIP-ConvNeXt trunk (BASELINE configs[3]; clip_convnext_encoder.py:150-174 drives timm's ConvNeXt.stem / .stages / .norm_pre).
-timm / open_clip are NOT installed here and there is no network, so the row stays "parity unpinned" against timm itself.  What CAN be
-pinned is pinned here: the oracle's restatement against an INDEPENDENT assembly of stock torch.nn modules wired per the public ConvNeXt
-block definition and loaded through timm's state-dict names — piece by piece (LayerNorm2d on channels-first maps, depthwise 7x7,
-layer scale, 2x2/s2 downsample, stem) and end to end — so the only thing left unverified is that timm's modules are what the public
-definition says they are."""
+timm / open_clip are NOT installed here and there is no network.  Two pins:
+ (1) tests/golden/convnext.npz (oracle/gen_golden.py run_convnext): the REFERENCE's own `CLIPConvNextVisionTower._forward` run on a stand-in
+     trunk made of transformers.ConvNextModel's sub-modules — a third-party implementation of the published block, independent of timm and of
+     this repo — with the closed-form weights loaded through a timm-name -> HF-name map.  The oracle must reproduce its output
+     (test_oracle_matches_reference_forward_on_hf_convnext).  This is the row's pin.
+ (2) the oracle against an assembly of stock torch.nn modules wired per the public block definition and loaded through timm's state-dict
+     names, piece by piece — kept from round 2.
+What stays unverifiable here: that timm's own modules compute what HF's and the paper's do (same published architecture)."""
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -69,6 +72,47 @@ def _case(dims=(16, 32, 48, 64), depths=(1, 2, 2, 1), px=64):
     m.load_state_dict({k[len(P):]: v for k, v in W.items()})
     images = WT.tensor("cnx_pin_images", (2, 3, px, px))
     return cfg, m.eval(), W, images
+
+
+def test_oracle_matches_reference_forward_on_hf_convnext():
+    """Pin (1): oracle.convnext_features == the reference's _forward over transformers.ConvNextModel's modules (golden)."""
+    import json
+    import os
+    import numpy as np
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "convnext.npz"))
+    dims, depths, px = tuple(int(x) for x in g["dims"]), tuple(int(x) for x in g["depths"]), int(g["px"])
+    cfg = O.make_config(cnx_dims=dims, cnx_depths=depths, cnx_eps=float(g["eps"]))
+    name_map = json.loads(str(g["name_map"]))
+    W = {}
+    for k in name_map:                                            # timm names: the keys of this repo's checkpoints
+        shp = _timm_shape(k, dims)
+        W[P + k] = WT.tensor(P + k, shp, 0.5) if k.endswith("gamma") else WT.param(P + k, shp)
+    images = WT.tensor("cnx_pin_images", (2, 3, px, px))
+    got = O.convnext_features(images, W, cfg)
+    ref = torch.from_numpy(g["features"])
+    assert got.shape == ref.shape == (2, (px // 32) ** 2, dims[-1])
+    err = float((got - ref).abs().max() / ref.abs().max())
+    assert err < 2e-5, err
+    # and the name map covers exactly the parameter set this repo declares for the tower
+    from visper_lm_amd.config import VisperConfig
+    from visper_lm_amd.params import param_shapes
+    vc = VisperConfig(mm_vision_tower="CLIP-convnext-pin", cnx_dims=dims, cnx_depths=depths)
+    assert {k[len(P):] for k in param_shapes(vc) if k.startswith(P)} == set(name_map)
+
+
+def _timm_shape(k, dims):
+    parts = k.split(".")
+    if parts[0] == "stem":
+        return (dims[0], 3, 4, 4) if parts[1] == "0" and parts[2] == "weight" else (dims[0],)
+    i = int(parts[1])
+    C = dims[i]
+    if parts[2] == "downsample":
+        if parts[3] == "0":
+            return (dims[i - 1],)
+        return (C, dims[i - 1], 2, 2) if parts[4] == "weight" else (C,)
+    rest = ".".join(parts[4:])
+    return {"gamma": (C,), "conv_dw.weight": (C, 1, 7, 7), "conv_dw.bias": (C,), "norm.weight": (C,), "norm.bias": (C,),
+            "mlp.fc1.weight": (4 * C, C), "mlp.fc1.bias": (4 * C,), "mlp.fc2.weight": (C, 4 * C), "mlp.fc2.bias": (C,)}[rest]
 
 
 def test_state_dict_names_are_timm_convnext_names():

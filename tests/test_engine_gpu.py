@@ -1,6 +1,7 @@
 """End-to-end GPU parity of the PT train step (C-ABI kernels composed by Engine) against the CPU oracle and
 the golden vectors produced by the reference itself.  bf16 compute vs fp32 golden: tolerances are stated."""
 import copy
+import os
 import json
 
 import numpy as np
@@ -217,6 +218,42 @@ def test_convnext_tower_matches_oracle():
     got = eng.vit_forward(images.cuda()).float().cpu().view(1, 576, 192)
     err = (got - ref).abs().max() / ref.abs().max()
     assert err < 3e-2, float(err)
+
+
+def test_convnext_tower_matches_reference_golden():
+    """Row a2 pin on the GPU: the HIP ConvNeXt tower against tests/golden/convnext.npz = the REFERENCE's own CLIPConvNextVisionTower._forward
+    (clip_convnext_encoder.py:150-174) run over transformers.ConvNextModel's modules (oracle/gen_golden.py run_convnext).  The golden is fp32; the
+    tower computes in bf16 — the oracle on the same bf16-rounded weights is logged beside it so the bound is dtype, not algorithm."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import numpy as np
+    from oracle import visper_oracle as O, weights as WT
+    from visper_lm_amd.config import VisperConfig
+    from visper_lm_amd.engine import Engine
+    from visper_lm_amd.params import param_shapes
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "convnext.npz"))
+    dims, depths, px = tuple(int(x) for x in g["dims"]), tuple(int(x) for x in g["depths"]), int(g["px"])
+    cfg = VisperConfig(mm_vision_tower="CLIP-convnext-pin", cnx_dims=dims, cnx_depths=depths, cnx_eps=float(g["eps"]), cnx_image=px,
+                       vocab_size=1024, hidden_size=128, intermediate_size=256, num_hidden_layers=1, num_attention_heads=4,
+                       num_key_value_heads=2, aux_mode="", num_task_tokens=0)
+    shapes = param_shapes(cfg)
+    W = {k: WT.param(k, s) for k, s in shapes.items()}
+    for k in W:
+        if k.endswith(".gamma"):
+            W[k] = WT.tensor(k, shapes[k], 0.5)
+    images = WT.tensor("cnx_pin_images", (2, 3, px, px))
+    ref = torch.from_numpy(g["features"])
+    ocfg = O.make_config(**{k: v for k, v in cfg.to_dict().items() if k in vars(O.make_config())})
+    Wq = {k: v.to(BF).float() for k, v in W.items()}
+    orc = O.convnext_features(images.to(BF).float(), Wq, ocfg)
+    eng = Engine(cfg)
+    eng.load_weights(W)
+    got = eng.vit_forward(images.cuda()).float().cpu().view(ref.shape)
+    check("convnext_pin/oracle_bf16_weights_vs_reference_golden", max_rel(orc, ref), 2e-2)
+    check("convnext_pin/hip_vs_reference_golden", max_rel(got, ref), 4e-2)
+    check("convnext_pin/hip_vs_oracle_same_bf16_weights", max_rel(got, orc), 3e-2)
+    cos = torch.nn.functional.cosine_similarity(got.reshape(1, -1), ref.reshape(1, -1)).item()
+    check("convnext_pin/hip_vs_reference_golden_1-cos", 1.0 - cos, 1e-3)
 
 
 def _edge_case(ocfg_kw, mutate, min_cos=0.985, tag="edge", max_norm=3e-2):

@@ -86,7 +86,8 @@ def test_gemm_256_tile_kernel(ops, M, N, K):
     close(o, ref, what=f"gemm 8-phase {M}x{N}x{K}")
 
 
-@pytest.mark.parametrize("M,N,K", [(512, 512, 128), (256, 768, 384), (4608, 4096, 384), (8192, 4096, 512)])
+@pytest.mark.parametrize("M,N,K", [(512, 512, 128), (256, 768, 384), (4608, 4096, 384), (8192, 4096, 512), (1024, 1024, 4096),
+                                   (8192, 6144, 1024), (2048, 4096, 14336), (16384, 4096, 256)])
 def test_gemm_4wave_kernel(ops, M, N, K):
     """One-wave-per-SIMD 256-tile kernel (force code 8): plain, bias + GELU + residual epilogue, fp32 output; single tiles, a persistent grid with
     1-2 tiles per block and the super-block walk."""

@@ -108,6 +108,40 @@ def test_bench_two_ranks_on_one_gpu_control_flow():
     assert abs(res["value"] - 16 / (res["ms_per_step"] / 1e3)) < 0.05 * res["value"]
 
 
+def test_bench_starts_its_own_ranks():
+    """plain `python bench.py --gpus 2` — NO torchrun around it — must start two ranks itself (bench.launch_ranks, like the
+    reference's `deepspeed` line in scripts/train/pretrain.sh:15), and report n_gpus from the communicator.  Two ranks share the test GPU over
+    gloo (VP_TEST_SHARED_GPU); on a real node the same path is one process per GPU over RCCL."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env["VP_TEST_SHARED_GPU"] = "1"
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--layers", "2", "--batch", "2",
+           "--no-cpu-baseline", "--no-probes"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=root, env=env)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{") and '"metric"' in l]
+    assert r.returncode == 0 and len(lines) == 1, r.stdout[-1500:] + r.stderr[-2500:]
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 2 and res["config"]["global_batch"] == 4 and res["multi_gpu"]["torch_world_size"] == 2
+    assert len(res["multi_gpu"]["per_rank_ms_per_step"]) == 2
+    assert "exposed_comm_ms_per_step" in res["multi_gpu"][res["multi_gpu"]["headline_transport"]]
+
+
+def test_bench_refuses_more_gpus_than_the_node_has():
+    """`--gpus N` on a node with fewer GPUs fails loudly instead of running fewer ranks."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    n = torch.cuda.device_count() + 1
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "VP_TEST_SHARED_GPU")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(n), "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=300, cwd=root, env=env)
+    assert r.returncode != 0 and "refusing" in (r.stderr + r.stdout), r.stdout[-500:] + r.stderr[-500:]
+    assert '"metric"' not in r.stdout
+
+
 NATIVE2 = r'''
 import os, sys, torch, torch.distributed as dist
 sys.path.insert(0, os.environ["VP_ROOT"])

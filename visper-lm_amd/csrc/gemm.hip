@@ -1512,6 +1512,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       if constexpr (r_ >= 0 && r_ < 8) W4_LDS(fa0[r_ & 7], ra0n_, (r_ & 7) * 2048);                    \
       if constexpr (r_ >= 8) W4_LDS(fb0[r_ & 7], rb0n_, vp_w4_boff(r_ & 7));                              \
     });                                                                                                \
+    W4_LGKM0();          /* the fa0 / fb0 reads issued above are in flight and ADVANCE_STREAM is compiler-generated code: wait first (the invariant \
+                            stated at the prologue; the reads are >= 15 MFMAs old here, so the wait is already satisfied in practice) */ \
     ADVANCE_STREAM();                                                                                  \
   }
 #define W4_MAINLOOP(PH)                                                                                \

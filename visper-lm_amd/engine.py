@@ -702,6 +702,16 @@ class Engine:
         for k in ("labels", "attention_mask", "position_ids"):
             plan[k] = torch.from_numpy(hp[k])
         tabs = hp["tables"]                                           # name -> int32 array
+        # the compacted lm_head rows are padded to whole 256-row GEMM tiles with rows that carry no label (gathered as zeros, label -100: zero
+        # loss, zero d_logits, never scattered back) so that every chunk of the two vocabulary-wide GEMMs takes the aligned 4-wave kernel
+        ce_labels = hp["ce_labels"]
+        n_ce = int(tabs["ce_rows"].size)
+        if n_ce >= 512 and n_ce % 256:
+            pad = 256 - n_ce % 256
+            tabs = dict(tabs, ce_rows=np.concatenate([tabs["ce_rows"], np.zeros(pad, np.int32)]),
+                        ce_kind=np.concatenate([tabs["ce_kind"], np.full(pad, -1, np.int32)]))
+            ce_labels = np.concatenate([ce_labels, np.full(pad, IGNORE_INDEX, ce_labels.dtype)])
+            n_ce += pad
         offs, tot = {}, 0
         for name, a in tabs.items():
             offs[name] = (tot, a.size)
@@ -713,7 +723,8 @@ class Engine:
             hv[o:o + n] = a.reshape(-1)
         devbuf = host.to(self.dev, non_blocking=True)
         M = plan["B"] * plan["S"]
-        shift_h = torch.from_numpy(np.concatenate([hp["shift_labels"], hp["ce_labels"]])).pin_memory()
+        plan["n_ce"] = n_ce
+        shift_h = torch.from_numpy(np.concatenate([hp["shift_labels"], ce_labels])).pin_memory()
         plan["_host_bufs"] = (host, shift_h)                          # keep the pinned sources alive until the async copies ran
         shift_d = shift_h.to(self.dev, non_blocking=True)
         plan["shift_labels"], plan["ce_labels"] = shift_d[:M], shift_d[M:]
@@ -852,9 +863,10 @@ class Engine:
         gscale = 1.0 / n_valid if n_valid > 0 else float("nan")
         compact = (not self.keep_logits) and 0 < n_valid < M
         if compact:
-            h_ce = torch.empty(n_valid, H, device=dev, dtype=BF16)
+            Mc = plan["n_ce"]                                    # n_valid rounded up to whole 256-row tiles (pad rows: zeros, label -100)
+            h_ce = torch.empty(Mc, H, device=dev, dtype=BF16)
             ops.gather_rows([hidden], plan["ce_kind"], plan["ce_rows"], H, h_ce)
-            lab_ce, Mc = plan["ce_labels"], n_valid
+            lab_ce = plan["ce_labels"]
         else:
             h_ce, lab_ce, Mc = hidden, plan["shift_labels"], M
         d_hce = torch.empty(Mc, H, device=dev, dtype=BF16) if compute_grads else None
