@@ -45,7 +45,8 @@ int vp_device_info(int* cu_count, int* wave_size, long* lds_bytes_per_cu);
  * out_f32=1 writes fp32 (used for weight gradients). force_generic: 0 = auto (256x256 8-phase ping-pong kernel for
  * large problems, 128x128 otherwise, bounds-checked generic kernel when K%64 != 0 or rows are not 16-B aligned),
  * 1 = generic, 2 = 128-tile, 3 = the simple persistent 256-tile kernel (kept as the A/B reference), 7 = 8-phase,
- * 8 = experimental one-wave-per-SIMD 256-tile kernel (aligned shapes only; 9-12 = its timing ablations, wrong results). */
+ * 8 = the one-wave-per-SIMD 256-tile kernel (the auto choice for aligned large problems), 13 = 4-phase variant of the 8-phase
+ * kernel.  Every code computes the same result (the tests compare them bit for bit); any other value is VP_ERR_BAD_ARG. */
 int vp_gemm_bf16(int M, int N, int K, const void* A, long lda, const void* B, long ldb, void* C, long ldc,
                  const void* bias, const void* residual, long ldr, int epilogue, int out_f32, int force_generic,
                  vp_stream_t stream);
@@ -69,16 +70,7 @@ int vp_gemm_tn_bf16(int M, int N, int K, const void* A, long lda, const void* B,
  * (Engine.set_distributed does this for world > 1; the reference leaves this to DeepSpeed's stream overlap,
  * scripts/zero2.json "overlap_comm").  Returns the previous setting.  Off by default. */
 int vp_gemm_set_dynamic(int on);
-/* dev aid (tools/gemm_interference.py): `blocks` workgroups pinning 64 KB of LDS each and spinning for `cycles` shader cycles. */
-int vp_debug_occupy(int blocks, long cycles, vp_stream_t stream);
-
-/* dev aid (tools/gemm_stamps.py): per-block timestamps written by gemm_nt_256p8 when VP_GEMM_DBG=65536; 256*8 longs. */
-/* relative speeds of the 8 XCDs (each its own DVFS domain), or NULL = off: the persistent GEMM moves K prefixes of output tiles from slow
-   XCDs to fast ones; bit-identical results.  Experimental, off until called (visper_lm_amd.ops.calibrate_xcd_balance, VP_GEMM_BALANCE=1) */
-int vp_gemm_set_xcd_speeds(const float* speeds8);
-int vp_debug_stamps(long* host);
-int vp_debug_attn_stamps(long* host);   /* dev aid: phase cycle sums of the D = 128 forward (VP_ATTN_DBG=1 launches) */
-int vp_debug_gemm_flags(int flags);   /* measurement aid: 0x10000 = in-kernel wall-clock / shader-cycle stamps of the first tile */
+/* (measurement / development entry points — vp_debug_* — are NOT part of this ABI: include/visper_hip_debug.h, built with -DVP_DEBUG) */
 
 int vp_transpose_bf16(int rows, int cols, const void* in, long ld_in, void* out, long ld_out, vp_stream_t stream);
 
@@ -185,8 +177,6 @@ int vp_ce_fwd_bwd(long rows, int V, void* logits, long ld, const long* labels, f
  * tgt_all [Bw,D] bf16 row-major, 16-byte aligned.  logit_scale NULL = no contrastive term.  Every distinct stream gets its own ticket
  * counters (up to 32 streams per process), so calls on different streams may overlap freely; calls on one stream are ordered by it. */
 long vp_emb_loss_workspace(int B, int Bw, long D);
-/* dev aid (tools/emb_loss_debug.py): device buffer of 8 int64 for in-kernel wall-clock stamps of later vp_emb_loss_fwd calls; NULL = off */
-int vp_debug_emb_loss_stamps(long long* dev_buf);
 int vp_emb_loss_fwd(int B, int Bw, long D, int rank, const void* pred, const void* tgt_all, const float* mask,
                     const float* logit_scale, float w_contrastive, float* out3, float* coef, float* workspace,
                     vp_stream_t stream);

@@ -9,8 +9,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HEADER = os.path.join(ROOT, "include", "visper_hip.h")
 
 
-def _declared():
-    src = re.sub(r"/\*.*?\*/", "", open(HEADER).read(), flags=re.S)
+DEBUG_HEADER = os.path.join(ROOT, "include", "visper_hip_debug.h")
+
+
+def _declared(header=HEADER):
+    src = re.sub(r"/\*.*?\*/", "", open(header).read(), flags=re.S)
     return sorted(set(re.findall(r"^(?:const char\*|int|long)\s+(vp_\w+)\s*\(", src, flags=re.M)))
 
 
@@ -29,6 +32,18 @@ def test_ctypes_binding_covers_the_header():
     declared, bound = set(_declared()), set(_lib.EXPORTS)
     assert bound <= declared, sorted(bound - declared)
     assert declared == bound, sorted(declared ^ bound)
+
+
+def test_debug_entry_points_are_outside_the_product_abi():
+    """vp_debug_* live in include/visper_hip_debug.h (built with -DVP_DEBUG), never in the product header; the binding keeps them apart too."""
+    from visper_lm_amd import _lib
+    assert not [n for n in _declared() if n.startswith("vp_debug")]
+    dbg = set(_declared(DEBUG_HEADER))
+    assert dbg == set(_lib._DEBUG_SIGS) and all(n.startswith("vp_debug_") for n in dbg)
+    assert not (dbg & set(_lib.EXPORTS))
+    lib = _lib.load()
+    have = [hasattr(lib, n) for n in sorted(dbg)]
+    assert all(have) or not any(have), dict(zip(sorted(dbg), have))         # a build has all of them (VP_DEBUG=1) or none (sealed)
 
 
 def test_bad_arguments_return_codes_not_crashes():

@@ -127,9 +127,50 @@ def test_convnext_xxl_tower_full_size_finite_and_deterministic():
     assert float((inner - inner[0]).abs().max()) <= 1e-2 * float(inner.abs().max())
 
 
-def test_attention_d128_dma_ring_forward_matches_default():
-    """The opt-in DMA-ring forward (VP_ATTN_FWD128=1: 4 waves x 32 query rows, lazy row max) against the default kernel on the decoder
-    shape: same lse and outputs up to bf16 rounding (different max bookkeeping), incl. ragged kv_len and a sliding window."""
+def _two_steps_bitwise(cfg, B, T, S_expect):
+    import bench
+    from visper_lm_amd.engine import Engine
+    eng = Engine(cfg)
+    eng.init_random(0)
+    batch = bench.make_batch(cfg, B, T, 0, torch.device("cuda"))
+    o1 = eng.train_step(batch); g1 = eng.ps.grad.clone(); l1 = o1["loss"].clone()
+    ll1 = {k: v.clone() for k, v in o1["layer_losses"].items()}
+    o2 = eng.train_step(batch)
+    torch.cuda.synchronize()
+    assert o1["plan"]["S"] == S_expect, o1["plan"]["S"]
+    assert torch.isfinite(l1).all() and torch.isfinite(g1).all() and float(g1.norm()) > 0
+    assert len(ll1) == 3 and all(torch.isfinite(v).all() for v in ll1.values())
+    assert torch.equal(l1, o2["loss"]) and torch.equal(g1, eng.ps.grad)
+    assert all(torch.equal(ll1[k], o2["layer_losses"][k]) for k in ll1)
+    return o1
+
+
+def test_config4_phi3_full_depth_step_is_deterministic_and_finite():
+    """BASELINE configs[4] ITSELF, the step `bench.py --workload phi3` times: CLIP-ViT-L + Phi-3-mini-4k at full depth (32 layers, 32 MHA heads x
+    96, fused qkv / gate_up, sliding window 2047 inclusive), B=4, T=3497 -> post-splice S=4096 > window, three distillation heads: S as configured,
+    finite losses / per-layer losses / gradients, two steps from the same state bitwise identical (ola_phi3.py)."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from visper_lm_amd.config import phi3_mini
+    cfg = phi3_mini()
+    out = _two_steps_bitwise(cfg, 4, 3497, 4096)
+    assert out["plan"]["n_valid"] == 4 * (3497 - 1 - (cfg.num_sys_tokens + 6))
+
+
+def test_config3_convnext_full_step_is_deterministic_and_finite():
+    """BASELINE configs[3] ITSELF, the step `bench.py --workload convnext` times: CLIP-ConvNeXt-XXL at 768 px (576 x 3072 features,
+    clip_convnext_encoder.py:92-101,150-174) -> projector 3072 -> 4096 -> Llama-3-8B at full depth, B=8, S=2048, three distillation heads."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from visper_lm_amd.config import llama3_8b_convnext
+    cfg = llama3_8b_convnext()
+    out = _two_steps_bitwise(cfg, 8, 1449, 2048)
+    assert tuple(out["image_features"].shape)[-1] == 4096
+
+
+def test_attention_d128_generic_forward_matches_default():
+    """The generic 16-row forward (VP_ATTN_FWDM=0) against the default 32x32x16 swapped-product kernel on the decoder shape: same lse and
+    outputs up to bf16 rounding (different max bookkeeping), incl. ragged kv_len and a sliding window."""
     import os
     import subprocess
     import sys
@@ -152,7 +193,7 @@ torch.save(outs, os.environ["VP_OUT"])
     res = {}
     for flag in ("0", "1"):
         out = f"/tmp/vp_attn_ab_{flag}.pt"
-        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, VP_ROOT=root, VP_OUT=out, VP_ATTN_FWD128=flag),
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, VP_ROOT=root, VP_OUT=out, VP_ATTN_FWDM=flag),
                            capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, r.stderr[-2000:]
         res[flag] = torch.load(out)

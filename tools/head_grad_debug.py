@@ -1,5 +1,5 @@
 """Dev aid (gpurun): full-width heads, per-parameter gradient direction error vs the fp32 oracle, with the engine's weight-gradient GEMMs
-and with an fp32 torch matmul in their place (VP_DEBUG_WGRAD_TORCH=1) -> separates the wgrad kernels from everything upstream."""
+and with an fp32 torch matmul monkey-patched over Engine._wgrad -> separates the wgrad kernels from everything upstream."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -15,7 +15,13 @@ cfg.image_gen = dict(cfg.image_gen, img_layer_indices="2")
 res = {}
 for mode in ("engine", "torch_wgrad"):
     if mode == "torch_wgrad":
-        os.environ["VP_DEBUG_WGRAD_TORCH"] = "1"
+        from visper_lm_amd.engine import Engine
+
+        def _torch_wgrad(self, x2d, dy2d, gview, accumulate=False):
+            g2 = gview.view(dy2d.shape[1], x2d.shape[1])
+            r = dy2d.float().t() @ x2d.float()
+            g2.copy_(g2 + r if accumulate else r)
+        Engine._wgrad = _torch_wgrad
     got, Wc, batch, tr = T._hip_step(cfg, 2, 128)
     res[mode] = got
 ref = T._oracle_step(cfg, Wc, batch, tr, torch.float32, got["rows"])

@@ -22,11 +22,6 @@ _SIGS = {
     "vp_gemm_bf16": [i, i, i, p, l, p, l, p, l, p, p, l, i, i, i, p],
     "vp_gemm_bf16_swiglu": [i, i, i, i, p, l, p, l, p, l, p, l, p, l, p],
     "vp_gemm_set_dynamic": [i],
-    "vp_debug_occupy": [i, l, p],
-    "vp_debug_gemm_flags": [i],
-    "vp_gemm_set_xcd_speeds": [p],
-    "vp_debug_stamps": [p],
-    "vp_debug_attn_stamps": [p],
     "vp_gemm_tn_bf16": [i, i, i, p, l, p, l, p, l, i, i, p],
     "vp_transpose_bf16": [i, i, p, l, p, l, p],
     "vp_rmsnorm_fwd": [i, i, p, l, p, f, p, l, p, p],
@@ -65,7 +60,6 @@ _SIGS = {
                     i, i, f, p, p, p, p],
     "vp_ce_fwd_bwd": [l, i, p, l, p, p, f, i, p],
     "vp_emb_loss_workspace": [i, i, l],
-    "vp_debug_emb_loss_stamps": [p],
     "vp_sumsq_nblk": [l],
     "vp_emb_loss_fwd": [i, i, l, i, p, p, p, p, f, p, p, p, p],
     "vp_emb_loss_bwd": [i, i, l, i, p, p, p, f, p, p],
@@ -83,6 +77,14 @@ _SIGS = {
 }
 _RET_LONG = {"vp_emb_loss_workspace"}
 EXPORTS = ["vp_last_error_string"] + list(_SIGS)
+# measurement / development entry points (include/visper_hip_debug.h): present only in a -DVP_DEBUG build; bound when the library has them
+_DEBUG_SIGS = {
+    "vp_debug_occupy": [i, l, p],
+    "vp_debug_gemm_flags": [i],
+    "vp_debug_stamps": [p],
+    "vp_debug_attn_stamps": [p],
+    "vp_debug_emb_loss_stamps": [p],
+}
 
 _lib = None
 
@@ -101,12 +103,18 @@ def load():
             fn = getattr(lib, name)
             fn.argtypes = args
             fn.restype = C.c_long if name in _RET_LONG else C.c_int
+        for name, args in _DEBUG_SIGS.items():
+            if hasattr(lib, name):
+                fn = getattr(lib, name)
+                fn.argtypes, fn.restype = args, C.c_int
         _lib = lib
     return _lib
 
 
 def call(name, *args):
     lib = load()
+    if name in _DEBUG_SIGS and not hasattr(lib, name):
+        raise RuntimeError(f"{name}: this libvisper_hip.so was built without -DVP_DEBUG (make VP_DEBUG=1)")
     rc = getattr(lib, name)(*args)
     if rc != 0:
         raise RuntimeError(f"{name} failed ({rc}): {lib.vp_last_error_string().decode()}")

@@ -642,7 +642,9 @@ long long* g_dbg = nullptr;
 extern "C" {
 
 // dev aid (tools/emb_loss_debug.py): device buffer of 8 int64 receiving wall-clock stamps of the next vp_emb_loss_fwd calls (NULL = off)
+#ifdef VP_DEBUG
 int vp_debug_emb_loss_stamps(long long* dev_buf) { g_dbg = dev_buf; return VP_OK; }
+#endif
 
 // fp32 workspace of vp_emb_loss_fwd, in floats: per-block partials + group partials + final statistics (contents need not be
 // initialised; nothing is kept between calls).

@@ -58,13 +58,6 @@ struct GemmArgs {
   long ldaux;
   // dynamic tile scheduling (8-phase kernel, persistent grid only): 8 per-XCD claim counters + a done counter, or NULL = static v += 256
   int* sched;
-  // XCD speed balancing (8-phase kernel, static persistent grid only; see the kernel): workspace (256 x 256 KB of fp32 accumulators),
-  // flags (one per donor block, value = bal_seq of the launch that filled the slot), relative XCD speeds, partner XCD (-1: none)
-  float* bal_ws;
-  int* bal_flags;
-  int bal_seq;
-  unsigned long bal_speed_lo, bal_speed_hi;             // relative XCD speeds in 1/16384ths, 16 bits each (XCDs 0-3 | 4-7)
-  unsigned int bal_partner;                             // 4 bits per XCD: partner XCD + 1, 0 = none  (scalars: no dynamic kernarg indexing)
   // bf16 C tiles leave with non-temporal stores (set by the launcher for N <= 8192, the shapes where it measures +1...2 %: the output does not
   // evict the operand panels from the XCD's L2; hipBLASLt's kernels store C the same way.  Wider outputs measured -0.7 %.)
   int c_nt;
@@ -727,9 +720,8 @@ __global__ __launch_bounds__(512) void gemm_nt_256(GemmArgs p) {
 //     every barrier (the wait at the end of phase k's R retires exactly the piece phase k+1 reads first).
 // ------------------------------------------------------------------------------------------------
 #define STAMP(I) if ((p.dbg & 0x10000) && threadIdx.x == 0 && first_tile) vp_dbg_stamps[blockIdx.x * 8 + (I)] = wall_clock64();
-template <bool OUT_F32, bool PH4 = false, bool BAL = false>      // PH4: 4 phases per K-tile (32 MFMAs each, half the barriers), see the loop;
-__global__ __launch_bounds__(512) void gemm_nt_256p8(GemmArgs p) {    // BAL: the experimental XCD speed balancing (its own instantiation: the
-                                                                       // seam code costs the default kernel 0.5-0.7 % when merely compiled in)
+template <bool OUT_F32, bool PH4 = false>      // PH4: 4 phases per K-tile (32 MFMAs each, half the barriers), see the loop
+__global__ __launch_bounds__(512) void gemm_nt_256p8(GemmArgs p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   bf16_t* smem = (bf16_t*)smem_raw;                    // [buf][A 256x64 | B 256x64]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -807,50 +799,7 @@ __global__ __launch_bounds__(512) void gemm_nt_256p8(GemmArgs p) {    // BAL: th
   }
 #define END_R() asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); VP_BAR();     /* ds_reads keep flying across the barrier; the MFMAs wait for them */
 
-  // ---- XCD speed balancing.  Every XCD is its own DVFS domain and under the package power cap they settle 3-5 % apart, so with equal tile
-  // counts the slowest XCD finishes last while the others idle.  Blocks of a faster XCD (donors) therefore START with the leading bal_ks
-  // K-tiles of the LAST output tile of the same-slot block of their slower partner XCD (receiver), park the fp32 accumulators in a
-  // workspace (write-through stores, then a flag), and go on with their own tiles; the receiver, when it reaches that tile several tile
-  // times later, loads the accumulators instead of zeros and continues the K loop at K-tile bal_ks.  The accumulation order of every output
-  // element is unchanged (K-tiles 0, 1, 2, ... into the same fp32 accumulator), so the result is BIT-IDENTICAL for every bal_ks.
-  // bal_ks equalises the finish times of the pair: (R_d + f) / s_d = (R_r - f) / s_r with R = own tiles, s = measured XCD speed, f = bal_ks / nt.
-  // The pair parameters are RE-DERIVED from the kernel arguments wherever they are needed (tile seams only) instead of being kept in registers
-  // across the K loop: the loop runs at the register limit, and values spilled around it come back through scratch loads whose vmcnt waits
-  // drain the DMA ring.
-  struct Bal { int ks, vlast, slot; bool donor; };
-  auto bal_eval = [&]() -> Bal {
-    Bal r{0, -1, 0, false};
-    int me = blockIdx.x;
-    asm volatile("" : "+s"(me));                         // opaque: no common-subexpression reuse across the K loop
-    if (BAL && p.bal_ws && gridDim.x == 256 && p.sched == nullptr && !OUT_F32) {
-      const int xme = me & 7, xp = (int)((p.bal_partner >> (4 * xme)) & 15u) - 1;
-      if (xp >= 0) {
-        const int pb = (me & ~7) | xp;
-        const int r_me = (ntiles - 1 - me) / 256 + 1, r_p = (ntiles - 1 - pb) / 256 + 1;
-        // integer arithmetic (speeds in 1/16384ths): every evaluation, in the donor and in the receiver, must give the SAME bal_ks
-        const int s_me = (int)(((xme < 4 ? p.bal_speed_lo : p.bal_speed_hi) >> (16 * (xme & 3))) & 0xffffu);
-        const int s_p = (int)(((xp < 4 ? p.bal_speed_lo : p.bal_speed_hi) >> (16 * (xp & 3))) & 0xffffu);
-        r.donor = s_me > s_p || (s_me == s_p && xme < xp);
-        const int sd = r.donor ? s_me : s_p, sr = r.donor ? s_p : s_me;
-        const int rd = r.donor ? r_me : r_p, rr = r.donor ? r_p : r_me;
-        const long num = ((long)rr * sd - (long)rd * sr) * (long)nt;       // f * nt * (sd + sr)
-        const int ks = (rr >= 2 && num > 0) ? 2 * (int)(num / (2L * (sd + sr))) : 0;
-        r.ks = max(0, min(ks, nt - 2));
-        const int rb = r.donor ? pb : me;                // the receiver block and its last output tile
-        r.vlast = rb + 256 * ((ntiles - 1 - rb) / 256);
-        r.slot = r.donor ? me : pb;                      // workspace slot / flag = the donor's block index
-      }
-    }
-    return r;
-  };
-  bool partial;                                          // the current segment is a donated K prefix (accumulators go to the workspace)
-  int v, kn;                                             // current output tile; K-tiles of the current segment (even)
-  {
-    const Bal b0 = BAL ? bal_eval() : Bal{0, -1, 0, false};
-    partial = BAL && b0.ks > 0 && b0.donor;
-    v = partial ? b0.vlast : (int)blockIdx.x;
-    kn = partial ? b0.ks : nt;
-  }
+  int v = (int)blockIdx.x;                               // current output tile
   bool first_tile = true;
   __shared__ int s_next;
   const bool dyn = p.sched != nullptr && gridDim.x == 256;
@@ -883,35 +832,13 @@ __global__ __launch_bounds__(512) void gemm_nt_256p8(GemmArgs p) {    // BAL: th
     STAMP(1);
     if ((p.dbg & 0x10000) && threadIdx.x == 0 && first_tile) vp_dbg_stamps[blockIdx.x * 8 + 6] = clock64();   // shader cycles
     f32x4 acc[8][4];
-    const Bal bt = BAL ? bal_eval() : Bal{0, -1, 0, false};
-    if (BAL && bt.ks > 0 && !bt.donor && v == bt.vlast) {
-      // the donor parked this tile's accumulators after its first bal_ks K-tiles (long ago: it did that before its own tiles): take them over
-      if (tid == 0) {                                    // (bounded: a lost donor must not hang the GPU; the tile would then be wrong)
-        for (int spin = 0; spin < (1 << 22) && __hip_atomic_load(p.bal_flags + bt.slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != p.bal_seq; ++spin)
-          __builtin_amdgcn_s_sleep(8);
-      }
-      VP_BAR();
-      // 16-byte loads that bypass this CU's L1 and are served fresh by the fabric (cache policy sc0 sc1 = aux 17; the donor stored write-through)
-      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(p.bal_ws + (long)bt.slot * 65536), 0, 65536 * 4, 0x00020000);
-#pragma unroll
-      for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          acc[i][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, tid * 16, (i * 4 + j) * 8192, 17));
-      // a wait the COMPILER sees (builtin, not asm): otherwise its scoreboard carries these loads into the K loop and it drains the DMA ring
-      // with a vmcnt(0) in front of the first MFMA of every K-tile (measured: 1330 -> 1000 TFLOP/s).  Also retires the K-tile DMA in flight.
-      __builtin_amdgcn_s_waitcnt(0x0F70);               // vmcnt(0)
-    } else {
 #pragma unroll
       for (int i = 0; i < 8; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
     if (wr == 1) VP_BAR();                             // stagger: group 1 runs one barrier behind
     const TileCoord tcur = tc;
-    const bool partial_cur = partial;
-    const int kn_cur = kn;
-    int vnext = (BAL && partial) ? (int)blockIdx.x : v + (int)gridDim.x;      // after the donated prefix: the block's own first tile
+    int vnext = v + (int)gridDim.x;
     // Dynamic scheduling (used when another kernel, e.g. an RCCL collective, may hold some CUs: a block that starts late would otherwise
     // do its whole static share after everyone else has finished).  Each XCD's 32 resident blocks claim the XCD's tiles in order from a
     // per-XCD counter, so tile v still runs on XCD v & 7 and the super-block walk keeps its L2 residency.  The claim for the NEXT tile is made
@@ -920,25 +847,18 @@ __global__ __launch_bounds__(512) void gemm_nt_256p8(GemmArgs p) {    // BAL: th
       const int kq = atomicAdd(p.sched + (blockIdx.x & 7), 1);
       s_next = (kq >> 5) * 256 + (kq & 31) * 8 + (int)(blockIdx.x & 7);
     }
-    // Everything the COMPILER has in flight (spill reloads of the seam code, the accumulator loads) is retired here, once per output tile and
-    // while the epilogue's stores drain anyway: otherwise hipcc places that vmcnt(0) at the first use INSIDE the K loop, where it empties the
-    // DMA ring on every K-tile (measured 1330 -> 1000 TFLOP/s)
-    if (BAL) __builtin_amdgcn_s_waitcnt(0x0F70);
-    for (int t = 0; t < kn_cur; ++t) {
+    for (int t = 0; t < nt; ++t) {
       const int cur = t & 1;
       const bf16_t* As = smem + cur * 32768;
       const bf16_t* Bs = As + 16384;
       // the K-tile stream continues into this block's NEXT output tile (or a harmless re-fetch at the very end)
-      if (t + 1 < kn_cur) {
+      if (t + 1 < nt) {
 #pragma unroll
         for (int pc = 0; pc < 4; ++pc) { src[pc][0] += 64; src[pc][1] += 64; }
       } else {
         if (dyn) vnext = __builtin_amdgcn_readfirstlane(*(volatile int*)&s_next);
         if (vnext < ntiles) tc = TILE_OF(vnext);
-        const Bal bn = BAL ? bal_eval() : Bal{0, -1, 0, false};
-        const int k0n = (BAL && bn.ks > 0 && !bn.donor && vnext == bn.vlast) ? bn.ks : 0;     // the receiver's last tile starts where its donor stopped
-        SET_SRC(tc, k0n);
-        kn = nt - k0n;
+        SET_SRC(tc, 0);
       }
       if (PH4) {
         // 4-phase variant: a piece issued in the R part of phase X is retired for BOTH wave groups only after the barrier that ends the M part
@@ -1009,29 +929,7 @@ __global__ __launch_bounds__(512) void gemm_nt_256p8(GemmArgs p) {    // BAL: th
     if ((p.dbg & 0x10000) && threadIdx.x == 0 && first_tile) vp_dbg_stamps[blockIdx.x * 8 + 7] = clock64();
     // buffer 1 (the last K-tile's, nt is even) is free for C staging; buffer 0 is receiving the next tile's first K-tile
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    if (BAL && partial_cur) {
-      // donated K prefix: park the accumulators (write-through 16-byte stores, 8 KB contiguous per instruction across the block), then the flag
-      const Bal be = bal_eval();
-      // plain 16-byte stores through ONE advancing pointer (32 hoisted addresses would spill; buffer stores make hipcc treat the LDS-DMA ring as
-      // aliasing every LDS read: a vmcnt(0) per K-tile), then an agent-scope release by one lane (writes the XCD L2's dirty lines back), then the flag
-      float* wp = p.bal_ws + (long)be.slot * 65536 + tid * 4;
-#pragma unroll
-      for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          *(f32x4*)wp = acc[i][j];
-          wp += 2048;
-          asm volatile("" : "+v"(wp));
-        }
-      __builtin_amdgcn_s_waitcnt(0x0F70);               // this wave's stores have reached the L2 ...
-      VP_BAR();                                          // ... and so have every other wave's
-      if (tid == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __hip_atomic_store(p.bal_flags + be.slot, p.bal_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-      partial = false;
-    } else if (!OUT_F32) {
+    if (!OUT_F32) {
       epilogue_swz<2>(p, smem + ((nt - 1) & 1) * 32768 + wave * 4096, acc, tcur.m0 + wr * 128, tcur.n0 + wc * 64, lane);
     } else {
       // fp32 output (weight gradients): interior, plain tiles go straight from the accumulators as 16-byte stores
@@ -1730,44 +1628,6 @@ static int* vp_sched_for(hipStream_t s) {
   return d;
 }
 
-// ---- XCD speed balancing state (see gemm_nt_256p8): relative speeds set by vp_gemm_set_xcd_speeds, fastest paired with slowest
-static float g_xcd_speed[8] = {1, 1, 1, 1, 1, 1, 1, 1};
-static signed char g_xcd_partner[8] = {-1, -1, -1, -1, -1, -1, -1, -1};
-static bool g_bal_have = false;
-static std::mutex g_bal_mu;
-struct BalSlot { float* ws; int* flags; int seq; };
-static void vp_setup_balance(GemmArgs& p, unsigned grid, hipStream_t s) {
-  if (grid != 256 || p.sched || ((p.dbg & 0x10000) && !(p.dbg & 0x100000))) return;     // stamps measure the UNBALANCED kernel unless 0x100000
-  std::lock_guard<std::mutex> lk(g_bal_mu);
-  if (!g_bal_have) return;
-  static std::unordered_map<hipStream_t, BalSlot> tab;   // one workspace per stream: launches on one stream are ordered, so a slot is free again
-  auto it = tab.find(s);                                 // (its receiver ran) before the next launch's donor writes it
-  if (it == tab.end()) {
-    BalSlot b{nullptr, nullptr, 0};
-    if (hipMalloc(&b.ws, 256L * 65536 * sizeof(float)) != hipSuccess) return;
-    if (hipMalloc(&b.flags, 256 * sizeof(int)) != hipSuccess || hipMemset(b.flags, 0, 256 * sizeof(int)) != hipSuccess) {
-      (void)hipFree(b.ws);
-      return;
-    }
-    it = tab.emplace(s, b).first;
-  }
-  BalSlot& b = it->second;
-  b.seq = b.seq == 0x7fffffff ? 1 : b.seq + 1;
-  p.bal_ws = b.ws;
-  p.bal_flags = b.flags;
-  p.bal_seq = b.seq;
-  float mean = 0.f;
-  for (int x = 0; x < 8; ++x) mean += g_xcd_speed[x] * 0.125f;
-  p.bal_speed_lo = p.bal_speed_hi = 0;
-  p.bal_partner = 0;
-  for (int x = 0; x < 8; ++x) {
-    float v = g_xcd_speed[x] / mean * 16384.f + 0.5f;
-    v = v < 1.f ? 1.f : (v > 65535.f ? 65535.f : v);
-    (x < 4 ? p.bal_speed_lo : p.bal_speed_hi) |= (unsigned long)(unsigned int)v << (16 * (x & 3));
-    p.bal_partner |= (unsigned int)(g_xcd_partner[x] + 1) << (4 * x);
-  }
-}
-
 static bool vp_c_nt_enabled() {                        // VP_GEMM_C_NT=0 switches the non-temporal C stores off (A/B)
   static int e = -1;
   if (e < 0) { const char* v = getenv("VP_GEMM_C_NT"); e = v ? atoi(v) : 1; }
@@ -1784,31 +1644,6 @@ static bool vp_ph4_enabled() {
 
 extern "C" {
 
-// Relative speeds of the 8 XCDs (any positive scale; measured by the caller, e.g. from vp_debug_stamps under load), or NULL to switch the
-// balancing off (the default: nothing is balanced until this is called; measured net effect so far -1...-3 %).  The persistent GEMM then moves a K prefix of one output tile per block from each slow XCD to its faster partner (fastest
-// with slowest, ...); results are bit-identical with and without (the kernel's comment has the argument).
-int vp_gemm_set_xcd_speeds(const float* speeds8) {
-  std::lock_guard<std::mutex> lk(g_bal_mu);
-  g_bal_have = false;
-  for (int x = 0; x < 8; ++x) g_xcd_partner[x] = -1;
-  if (!speeds8) return VP_OK;
-  int order[8];
-  for (int x = 0; x < 8; ++x) {
-    VP_REQUIRE(speeds8[x] > 0.f && speeds8[x] < 1e30f, VP_ERR_BAD_ARG, "vp_gemm_set_xcd_speeds: speed[%d] = %g", x, (double)speeds8[x]);
-    g_xcd_speed[x] = speeds8[x];
-    order[x] = x;
-  }
-  for (int a = 0; a < 8; ++a)                             // descending by speed (stable)
-    for (int b = a + 1; b < 8; ++b)
-      if (g_xcd_speed[order[b]] > g_xcd_speed[order[a]]) { const int t = order[a]; order[a] = order[b]; order[b] = t; }
-  for (int i = 0; i < 4; ++i) {
-    const int f = order[i], sl = order[7 - i];
-    if (g_xcd_speed[f] > 1.002f * g_xcd_speed[sl]) { g_xcd_partner[f] = (signed char)sl; g_xcd_partner[sl] = (signed char)f; }
-  }
-  g_bal_have = true;
-  return VP_OK;
-}
-
 // 1: the persistent GEMM claims its tiles dynamically (per-XCD counters) so that CUs held by a concurrent kernel (RCCL) only cost their own
 // share; 0: static assignment (default).  Returns the previous setting.
 int vp_gemm_set_dynamic(int on) {
@@ -1817,6 +1652,7 @@ int vp_gemm_set_dynamic(int on) {
   return prev;
 }
 
+#ifdef VP_DEBUG
 // dev aid (tools/gemm_interference.py): `blocks` workgroups that each pin 64 KB of LDS (so no 8-phase GEMM block fits beside them) and spin
 // for `cycles` shader cycles -- a stand-in for a collective kernel holding CUs
 int vp_debug_occupy(int blocks, long cycles, hipStream_t stream) {
@@ -1826,18 +1662,21 @@ int vp_debug_occupy(int blocks, long cycles, hipStream_t stream) {
   hipLaunchKernelGGL(occupy_kernel, dim3(blocks), dim3(64), 65536, stream, cycles);
   return vp_check_launch("vp_debug_occupy");
 }
+#endif
 
 static int g_gemm_dbg = -1;                           // VP_GEMM_DBG, or vp_debug_gemm_flags()
 static int vp_gemm_dbg() {
   if (g_gemm_dbg < 0) { const char* e = getenv("VP_GEMM_DBG"); g_gemm_dbg = e ? atoi(e) : 0; }
   return g_gemm_dbg;
 }
+#ifdef VP_DEBUG
 // measurement aid (bench.py: shader clock under load): 0x10000 = the persistent kernel's first tile writes wall-clock / shader-cycle stamps
 int vp_debug_gemm_flags(int flags) { g_gemm_dbg = flags; return 0; }
 
 int vp_debug_stamps(long* host) {
   return hipMemcpyFromSymbol(host, HIP_SYMBOL(vp_dbg_stamps), sizeof(long) * 256 * 8) == hipSuccess ? 0 : 1;
 }
+#endif
 
 int vp_gemm_bf16(int M, int N, int K, const void* A, long lda, const void* B, long ldb, void* C, long ldc,
                  const void* bias, const void* residual, long ldr, int epilogue, int out_f32, int force_generic,
@@ -1846,6 +1685,8 @@ int vp_gemm_bf16(int M, int N, int K, const void* A, long lda, const void* B, lo
   VP_REQUIRE(A && B && C, VP_ERR_BAD_ARG, "vp_gemm_bf16: null operand");
   VP_REQUIRE(lda >= K && ldb >= K && ldc >= N, VP_ERR_BAD_ARG, "vp_gemm_bf16: leading dims too small");
   VP_REQUIRE((epilogue & 0xff) >= 0 && (epilogue & 0xff) <= 3, VP_ERR_BAD_ARG, "vp_gemm_bf16: bad epilogue %d", epilogue);
+  VP_REQUIRE(force_generic == 0 || force_generic == 1 || force_generic == 2 || force_generic == 3 || force_generic == 7 || force_generic == 8 ||
+                 force_generic == 13, VP_ERR_BAD_ARG, "vp_gemm_bf16: unknown kernel selector %d", force_generic);
   GemmArgs p{(const bf16_t*)A, (const bf16_t*)B, C, (const bf16_t*)bias, (const bf16_t*)residual, M, N, K,
              lda, ldb, ldc, ldr, epilogue, 0, 0, nullptr, 0, nullptr, 0};
   p.dbg = vp_gemm_dbg();
@@ -1855,7 +1696,7 @@ int vp_gemm_bf16(int M, int N, int K, const void* A, long lda, const void* B, lo
   {
     static int w4_env = -1;
     if (w4_env < 0) { const char* e = getenv("VP_GEMM_W4"); w4_env = e ? atoi(e) : 1; }      // default since round 3 (VP_GEMM_W4=0: the 8-phase kernel)
-    const bool w4_ok = fast && M % 256 == 0 && N % 256 == 0 && K % 128 == 0 && (big_tiles >= 192 || force_generic >= 8) &&
+    const bool w4_ok = fast && M % 256 == 0 && N % 256 == 0 && K % 128 == 0 && (big_tiles >= 192 || force_generic == 8) &&
                        !bias && (epilogue & 0xff) == EPI_NONE && (((uintptr_t)C) & 15) == 0 &&
                        (out_f32 ? (!residual && ldc % 4 == 0)
                                 : (ldc % 8 == 0 && ldc < (1L << 22) &&                       // (32-bit byte offsets inside a 128-row sub-tile)
@@ -1889,18 +1730,15 @@ int vp_gemm_bf16(int M, int N, int K, const void* A, long lda, const void* B, lo
     // for every output tile); otherwise one block per output tile
     const unsigned g8 = (unsigned)(((K / 64) % 2 == 0 && big_tiles > 256 && !(p.dbg & 0x20000)) ? 256 : big_tiles);
     if (g8 == 256) p.sched = vp_sched_for(stream);
-    if (!out_f32) vp_setup_balance(p, g8, stream);
     p.c_nt = (!out_f32 && N <= 8192 && (long)M * ldc * 2 < 0x7fffffffL && vp_c_nt_enabled()) ? 1 : 0;
     if (out_f32) hipLaunchKernelGGL(gemm_nt_256p8<true>, dim3(g8), dim3(512), 131072, stream, p);
     else if (vp_ph4_enabled() && force_generic == 0) {
       static bool attr_p4 = false;
       if (!attr_p4) {
         (void)hipFuncSetAttribute((const void*)gemm_nt_256p8<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
-        (void)hipFuncSetAttribute((const void*)gemm_nt_256p8<false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
         attr_p4 = true;
       }
-      if (p.bal_ws) hipLaunchKernelGGL((gemm_nt_256p8<false, true, true>), dim3(g8), dim3(512), 131072, stream, p);
-      else hipLaunchKernelGGL((gemm_nt_256p8<false, true>), dim3(g8), dim3(512), 131072, stream, p);
+      hipLaunchKernelGGL((gemm_nt_256p8<false, true>), dim3(g8), dim3(512), 131072, stream, p);
     } else hipLaunchKernelGGL(gemm_nt_256p8<false>, dim3(g8), dim3(512), 131072, stream, p);
   } else if (fast && force_generic == 13 && !out_f32) {       // 4-phase variant of the 8-phase kernel (A/B testing)
     (void)hipFuncSetAttribute((const void*)gemm_nt_256p8<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
@@ -1971,16 +1809,13 @@ int vp_gemm_bf16_swiglu(int mode, int M, int N, int K, const void* A, long lda, 
   }
   const unsigned g8 = (unsigned)(((K / 64) % 2 == 0 && big_tiles > 256) ? 256 : big_tiles);
   if (g8 == 256) p.sched = vp_sched_for(stream);
-  vp_setup_balance(p, g8, stream);
   if (vp_ph4_enabled()) {
     static bool attr_p4 = false;
     if (!attr_p4) {
       (void)hipFuncSetAttribute((const void*)gemm_nt_256p8<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
-      (void)hipFuncSetAttribute((const void*)gemm_nt_256p8<false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
       attr_p4 = true;
     }
-    if (p.bal_ws) hipLaunchKernelGGL((gemm_nt_256p8<false, true, true>), dim3(g8), dim3(512), 131072, stream, p);
-    else hipLaunchKernelGGL((gemm_nt_256p8<false, true>), dim3(g8), dim3(512), 131072, stream, p);
+    hipLaunchKernelGGL((gemm_nt_256p8<false, true>), dim3(g8), dim3(512), 131072, stream, p);
   } else hipLaunchKernelGGL(gemm_nt_256p8<false>, dim3(g8), dim3(512), 131072, stream, p);
   return vp_check_launch("vp_gemm_bf16_swiglu");
 }

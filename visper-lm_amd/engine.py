@@ -631,10 +631,6 @@ class Engine:
         M = x2d.shape[0]
         N, K = dy2d.shape[1], x2d.shape[1]
         g2 = gview.view(N, K)
-        if os.environ.get("VP_DEBUG_WGRAD_TORCH"):                 # dev aid (tools/head_grad_debug.py): fp32 torch matmul as the checker
-            r = dy2d.float().t() @ x2d.float()
-            g2.copy_(g2 + r if accumulate else r)
-            return
         if (ops.gemm_tn_ok(N, K, M) and dy2d.stride(0) % 8 == 0 and x2d.stride(0) % 8 == 0 and dy2d.stride(1) == 1 and x2d.stride(1) == 1
                 and (dy2d.data_ptr() | x2d.data_ptr() | g2.data_ptr()) % 16 == 0):
             ops.gemm_tn(dy2d, x2d, out=g2, accumulate=accumulate)

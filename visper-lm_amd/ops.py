@@ -64,65 +64,6 @@ def gemm(a, w, bias=None, residual=None, epi=EPI_NONE, out=None, out_f32=False, 
     return out
 
 
-def set_xcd_speeds(speeds):
-    """Relative speeds of the 8 XCDs for the persistent GEMM's load balancing (vp_gemm_set_xcd_speeds), or None = off."""
-    if speeds is None:
-        _lib.call("vp_gemm_set_xcd_speeds", None)
-        return
-    assert len(speeds) == 8
-    _lib.call("vp_gemm_set_xcd_speeds", (C.c_float * 8)(*[float(x) for x in speeds]))
-
-
-_XCD_CALIBRATED = None
-
-
-def calibrate_xcd_balance(device="cuda", launches=48, force=False):
-    """Each XCD is its own DVFS domain; under the package power cap they settle a few percent apart (measured 3-5 % on MI355X), and with
-    equal tile counts the slowest XCD sets every GEMM's time.  Measures the XCDs' relative speeds under GEMM load (in-kernel wall-clock stamps
-    of a stamped launch after `launches` warm ones: when each XCD's blocks finish an equal share of tiles) and hands them to the library,
-    whose persistent GEMM then moves work from the slow XCDs to the fast ones -- bit-identical results (csrc/gemm.hip).
-    EXPERIMENTAL and off by default (measured so far: the hand-off costs more than the tail it removes): only runs with
-    VP_GEMM_BALANCE=1, once per process.  Returns the speeds (mean 1.0) or None."""
-    global _XCD_CALIBRATED
-    import os
-    import numpy as np
-    if os.environ.get("VP_GEMM_BALANCE", "0") != "1" and not force:
-        return None
-    if _XCD_CALIBRATED is not None and not force:
-        return _XCD_CALIBRATED
-    M, N, K = 16384, 4096, 4096
-    a = torch.randn(M, K, device=device, dtype=BF16)
-    w = torch.randn(N, K, device=device, dtype=BF16) * 0.02
-    o = torch.empty(M, N, device=device, dtype=BF16)
-    set_xcd_speeds(None)
-    for _ in range(launches):
-        gemm(a, w, out=o)
-    t = np.zeros(8)
-    reps = 4
-    buf = (C.c_long * 2048)()
-    for _ in range(reps):                                # stamped launches (balancing is off while the stamps are on)
-        _lib.call("vp_debug_gemm_flags", 0x10000)
-        try:
-            gemm(a, w, out=o)
-            torch.cuda.synchronize()
-        finally:
-            _lib.call("vp_debug_gemm_flags", 0)
-        _lib.call("vp_debug_stamps", buf)
-        st = np.array(buf[:], dtype=np.int64).reshape(256, 8)
-        end = (st[:, 5] - st[:, 0].min()).astype(np.float64)          # block end times, 10 ns ticks
-        t += np.array([end[x::8].mean() for x in range(8)])
-        for _ in range(4):
-            gemm(a, w, out=o)
-    speeds = (1.0 / t)
-    speeds = speeds / speeds.mean()
-    if not np.all(np.isfinite(speeds)) or speeds.min() < 0.8 or speeds.max() > 1.25:     # implausible stamps: leave the balancing off
-        _XCD_CALIBRATED = None
-        return None
-    set_xcd_speeds(speeds.tolist())
-    _XCD_CALIBRATED = [round(float(x), 4) for x in speeds]
-    return _XCD_CALIBRATED
-
-
 def swiglu_fusable(M, N, K):
     """Shapes the fused SwiGLU GEMM epilogues accept (vp_gemm_bf16_swiglu: 8-phase kernel, interior tiles only)."""
     return M % 256 == 0 and N % 256 == 0 and K % 64 == 0
