@@ -633,6 +633,7 @@ def main():
                           "global_batch": args.batch * world, "per_gpu_batch": args.batch, "seq_len": S, "text_len": args.text_len,
                           "parallelism": f"dp{world}", "decoder_layers": cfg.num_hidden_layers, "loss": round(loss, 4),
                           "depth_decoder": bool(cfg.depth_decoder), "fresh_batch_per_step": not args.same_batch,
+                          "peak_mem_gb": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 1),
                           "lm_head_rows": f"{n_valid_rows} labelled of {args.batch * S} (rows with label -100 skip lm_head + CE: zero loss, zero d_logits)",
                           "valid": args.layers is None},
                "roofline": roof, **({"multi_gpu": diag} if diag is not None else {})}

@@ -175,7 +175,8 @@ int vp_ce_fwd_bwd(long rows, int V, void* logits, long ld, const long* labels, f
  * backward coefficients and d loss / d logit_scale in its last slot.  workspace: vp_emb_loss_workspace(B, Bw, D) floats, uninitialised.
  * 0 < B <= 64 local predictions, B <= Bw <= 1024 gathered targets (rank-ordered, rank r's rows at r*B), D % 8 == 0; pred [B,D] and
  * tgt_all [Bw,D] bf16 row-major, 16-byte aligned.  logit_scale NULL = no contrastive term.  Every distinct stream gets its own ticket
- * counters (up to 32 streams per process), so calls on different streams may overlap freely; calls on one stream are ordered by it. */
+ * counters (32 sets, re-assigned least-recently-used once more than 32 streams have called), so calls on different streams may overlap
+ * freely; calls on one stream are ordered by it. */
 long vp_emb_loss_workspace(int B, int Bw, long D);
 int vp_emb_loss_fwd(int B, int Bw, long D, int rank, const void* pred, const void* tgt_all, const float* mask,
                     const float* logit_scale, float w_contrastive, float* out3, float* coef, float* workspace,

@@ -19,6 +19,21 @@ def _trip_err(mine, theirs):
     return max(abs(float(a) - float(b)) / max(abs(float(b)), 1e-6) for a, b in zip(mine, theirs))
 
 
+def _bf16_cpu_layer_dev(O, ocfg, W, batch, ref32):
+    """The reference-style CPU path — bf16 weights, bf16 activations, PyTorch's bf16 CPU ops (what north_star compares against) — measured against
+    the fp32-math oracle on the same bf16-rounded weights: {head-layer key: worst relative deviation of its (emb, sl1, con) triple}.  This is the
+    dtype's own noise floor; a HIP layer loss is held to max(1e-3 (north_star), 1.5 x this)."""
+    Wb = {k: v.detach().to(BF) for k, v in W.items()}
+    bb = {k: (v.to(BF) if (torch.is_tensor(v) and v.is_floating_point() and not k.endswith("_mask")) else v) for k, v in batch.items()}
+    with torch.no_grad():
+        refb = O.forward(Wb, bb, ocfg, need_logits=False)
+    return {key: _trip_err([float(x) for x in refb["layer_losses"][key]], [float(x) for x in trip]) for key, trip in ref32["layer_losses"].items()}
+
+
+def _layer_loss_bound(dev):
+    return max(1e-3, 1.5 * dev)
+
+
 def _to_gpu_batch(batch):
     return {k: (v.cuda() if (k == "images" or k.endswith("_target") or k.endswith("_mask")) else v) for k, v in batch.items()}
 
@@ -46,7 +61,8 @@ def tiny():
     bq = {k: (v.to(BF).float() if (v.is_floating_point() and not k.endswith("_mask")) else v) for k, v in batch.items()}
     ref = O.forward(Wq, bq, ocfg)
     ref["loss"].backward()
-    return dict(cfg=cfg, ocfg=ocfg, W=W, Wq=Wq, batch=batch, g=g, out=out, grads=grads, ref=ref, tr=tr, eng=eng)
+    cpu_dev = _bf16_cpu_layer_dev(O, ocfg, W, batch, ref)
+    return dict(cfg=cfg, ocfg=ocfg, W=W, Wq=Wq, batch=batch, g=g, out=out, grads=grads, ref=ref, tr=tr, eng=eng, cpu_dev=cpu_dev)
 
 
 def rel(a, b):
@@ -83,7 +99,9 @@ def test_losses_match_oracle_and_reference_golden(tiny):
     for i, key in enumerate(names):
         mine = out["layer_losses"][key].float().cpu().numpy()
         theirs = np.array([float(x) for x in ref["layer_losses"][key]])
-        check(f"tiny/layer_loss/{key[0]}@{key[1]}_vs_oracle", _trip_err(mine, theirs), 5e-3)
+        dev = tiny["cpu_dev"][key]                                       # the reference-style bf16 CPU path's own distance from fp32 truth
+        check(f"tiny/layer_loss/{key[0]}@{key[1]}_INFO_bf16_cpu_path_vs_fp32_truth", dev, float("inf"))
+        check(f"tiny/layer_loss/{key[0]}@{key[1]}_vs_oracle", _trip_err(mine, theirs), _layer_loss_bound(dev))
         check(f"tiny/layer_loss/{key[0]}@{key[1]}_vs_reference_golden", _trip_err(mine, g["keep_layer_losses"][i]), 1e-2)
 
 
@@ -277,9 +295,11 @@ def _edge_case(ocfg_kw, mutate, min_cos=0.985, tag="edge", max_norm=3e-2):
     ref["loss"].backward()
     check(f"{tag}/text_loss_rel", rel(out["text_loss"], ref["text_loss"]), 1e-3)
     check(f"{tag}/loss_rel", rel(out["loss"], ref["loss"]), 1e-3)
+    cpu_dev = _bf16_cpu_layer_dev(O, ocfg, W, batch, ref)
     for key, trip in ref["layer_losses"].items():
         mine = out["layer_losses"][key].float().cpu().numpy()
-        check(f"{tag}/layer_loss/{key[0]}@{key[1]}", _trip_err(mine, [float(x) for x in trip]), 1.2e-2)
+        check(f"{tag}/layer_loss/{key[0]}@{key[1]}_INFO_bf16_cpu_path_vs_fp32_truth", cpu_dev[key], float("inf"))
+        check(f"{tag}/layer_loss/{key[0]}@{key[1]}", _trip_err(mine, [float(x) for x in trip]), _layer_loss_bound(cpu_dev[key]))
     for k in eng.ps.index:
         got = eng.ps.g(k).detach().float().cpu()
         want = Wq[k].grad

@@ -535,6 +535,36 @@ def test_emb_loss_concurrent_streams(ops):
     assert torch.equal(again[0], alone[0][0]) and torch.equal(again[1], alone[0][1])
 
 
+def test_emb_loss_more_streams_than_counter_sets(ops):
+    """the registry of per-stream ticket-counter sets (32) must not fill up for good.  40 distinct streams — more than there are sets,
+    some created and dropped in between — call the loss twice each; the least recently used set is re-assigned behind a fence event.  Every
+    result must equal the bits of the same call on the default stream, also when earlier streams come back after their set was handed on."""
+    B, Bw, D = 8, 8, 576 * 64
+    g = torch.Generator(device="cuda").manual_seed(10)
+    pred = (torch.randn(B, D, device="cuda", generator=g) * 1.1).to(torch.bfloat16)
+    tgt = torch.randn(Bw, D, device="cuda", generator=g).to(torch.bfloat16)
+    mask, ls = torch.ones(B, device="cuda"), torch.tensor([2.0], device="cuda")
+    ref = ops.emb_loss_fwd(pred, tgt, mask, ls, 0.3)
+    torch.cuda.synchronize()
+    keep = []
+    for i in range(40):
+        st = torch.cuda.Stream()
+        if i % 3:
+            keep.append(st)
+        with torch.cuda.stream(st):
+            for _ in range(2):
+                out3, coef = ops.emb_loss_fwd(pred, tgt, mask, ls, 0.3)
+        st.synchronize()
+        assert torch.equal(out3, ref[0]) and torch.equal(coef, ref[1]), i
+    for st in keep[:8]:                                                       # the earliest streams again: their sets were re-assigned meanwhile
+        with torch.cuda.stream(st):
+            out3, coef = ops.emb_loss_fwd(pred, tgt, mask, ls, 0.3)
+        st.synchronize()
+        assert torch.equal(out3, ref[0]) and torch.equal(coef, ref[1])
+    again = ops.emb_loss_fwd(pred, tgt, mask, ls, 0.3)
+    assert torch.equal(again[0], ref[0]) and torch.equal(again[1], ref[1])
+
+
 def test_dpt_conv_helpers(ops):
     """conv.hip (frozen DPT decoder, da_v2_head.py:182-321): im2col3x3 + GEMM == F.conv2d, GEMM + pixel shuffle ==
     F.conv_transpose2d(k = stride), bilinear align_corners=True, per-image min-max normalisation."""
@@ -673,10 +703,10 @@ def test_gemm_random_shape_sweep(ops):
     (1, 2, 2, 31, 31, True, 0, None),            # shorter than one tile
     (1, 2, 1, 257, 257, False, 0, [200]),        # non-causal + padding, one key past two 128-key blocks
 ])
-def test_attention_d128_dma_kernels_edges(ops, B, Hq, Hkv, Sq, Skv, causal, window, kvl):
-    """The D = 128 DMA-ring kernels (dK/dV, dQ) and the D = 128 forward on shapes that exercise clamped tile rows, the causal offset,
-    windows and kv_len masking, forward and backward against fp32 attention."""
-    D = 128
+@pytest.mark.parametrize("D", [128, 96])
+def test_attention_d128_dma_kernels_edges(ops, B, Hq, Hkv, Sq, Skv, causal, window, kvl, D):
+    """The DMA-ring kernels (dK/dV, dQ; D = 128 and, with 3 of 4 k-steps / 6 of 8 feature blocks, Phi-3's D = 96) and the matching forward on
+    shapes that exercise clamped tile rows, the causal offset, windows and kv_len masking, forward and backward against fp32 attention."""
     q, k, v, do = rnd(B, Sq, Hq, D, seed=81), rnd(B, Skv, Hkv, D, seed=82), rnd(B, Skv, Hkv, D, seed=83), rnd(B, Sq, Hq, D, seed=84)
     qr, kr, vr = (t.float().requires_grad_(True) for t in (q, k, v))
     ref = attn_ref(qr, kr, vr, causal, kv_len=kvl, window=window)
@@ -693,6 +723,33 @@ def test_attention_d128_dma_kernels_edges(ops, B, Hq, Hkv, Sq, Skv, causal, wind
         for b, n in enumerate(kvl):
             assert float(dk[b, n:].float().abs().max() if n < Skv else 0.0) == 0.0
             assert float(dv[b, n:].float().abs().max() if n < Skv else 0.0) == 0.0
+
+
+@pytest.mark.parametrize("S,window,kvl", [(700, 0, None), (700, 300, [700, 512]), (257, 64, None)])
+def test_attention_d96_fused_qkv_views_fwd_bwd(ops, S, window, kvl):
+    """Phi-3's layout (ola_phi3.py -> HF Phi3Attention: ONE qkv_proj output, 32 MHA heads x 96): q / k / v are strided views of one [B, S, 3 H D]
+    tensor whose LAST row / head ends the allocation (the D = 96 kernels keep 128-wide LDS rows: their DMA lanes for the 4 unused chunks must
+    stay inside the tensor), dq / dk / dv are written into views of one buffer.  Forward + backward against fp32 attention, causal, with a sliding
+    window longer and shorter than a tile and a right-padded batch."""
+    B, H, D = 2, 4, 96
+    qkv = rnd(B, S, 3 * H * D, seed=131)
+    do = rnd(B, S, H, D, seed=132)
+    q, k, v = (qkv[..., i * H * D:(i + 1) * H * D].reshape(B, S, H, D) for i in range(3))
+    qr, kr, vr = (t.float().requires_grad_(True) for t in (q, k, v))
+    ref = attn_ref(qr, kr, vr, True, kv_len=kvl, window=window)
+    ref.backward(do.float())
+    d = dev(qkv)
+    qd, kd, vd = (d[..., i * H * D:(i + 1) * H * D].view(B, S, H, D) for i in range(3))
+    kv = None if kvl is None else torch.tensor(kvl, dtype=torch.int32).cuda()
+    o, lse = ops.attn_fwd(qd, kd, vd, True, window=window, kv_len=kv)
+    close(o, ref, what="attn d96 fwd")
+    dqkv = torch.full_like(d, float("nan"))
+    dq, dk, dv = (dqkv[..., i * H * D:(i + 1) * H * D].view(B, S, H, D) for i in range(3))
+    ops.attn_bwd(qd, kd, vd, o, lse, dev(do), True, window=window, kv_len=kv, dq=dq, dk=dk, dv=dv)
+    assert torch.isfinite(dqkv.float()).all()                                # every element of the three views was written
+    close(dq, qr.grad, rtol=3e-2, what="attn d96 dq")
+    close(dk, kr.grad, rtol=3e-2, what="attn d96 dk")
+    close(dv, vr.grad, rtol=3e-2, what="attn d96 dv")
 
 
 @pytest.mark.parametrize("causal", [True, False])

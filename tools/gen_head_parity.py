@@ -1,0 +1,54 @@
+"""Dev aid (gpurun): where does the gen head's layer loss pick up its error?  For the tiny e2e case and the text-only-sample edge case prints, for the
+HIP engine and for the reference-style bf16 CPU path (oracle on bf16 weights with PyTorch's bf16 ops), against the fp32-math oracle on the same
+bf16-rounded weights: the (emb, sl1, con) triple's relative errors per head and the prediction's element-wise error (rms / max, relative to the
+prediction's rms).  VERDICT r3 next-6."""
+import os, sys, json
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import torch
+from oracle import cases, visper_oracle as O
+from visper_lm_amd.config import VisperConfig
+from visper_lm_amd.engine import Engine
+
+BF = torch.bfloat16
+
+
+def run(tag, mutate):
+    ocfg, W, batch, g = cases.tiny_llama_case()
+    batch = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in batch.items()}
+    mutate(batch)
+    eng = Engine(VisperConfig(**vars(ocfg)))
+    eng.load_weights(W)
+    gb = {k: (v.cuda() if (k == "images" or k.endswith("_target") or k.endswith("_mask")) else v) for k, v in batch.items()}
+    out = eng.train_step(gb)
+    Wq = {k: v.to(BF).float() for k, v in W.items()}
+    bq = {k: (v.to(BF).float() if (torch.is_tensor(v) and v.is_floating_point() and not k.endswith("_mask")) else v) for k, v in batch.items()}
+    Wb = {k: v.to(BF) for k, v in W.items()}
+    bb = {k: (v.to(BF) if (torch.is_tensor(v) and v.is_floating_point() and not k.endswith("_mask")) else v) for k, v in batch.items()}
+    with torch.no_grad():
+        r32 = O.forward(Wq, bq, ocfg, need_logits=False)
+        rbf = O.forward(Wb, bb, ocfg, need_logits=False)
+    for key, trip in r32["layer_losses"].items():
+        t32 = [float(x) for x in trip]
+        hip = out["layer_losses"][key].float().cpu().tolist()
+        cpu = [float(x) for x in rbf["layer_losses"][key]]
+        e = lambda a: [abs(x - y) / max(abs(y), 1e-6) for x, y in zip(a, t32)]
+        print(f"{tag} {key}: truth {[round(x, 5) for x in t32]} | HIP rel err {['%.1e' % x for x in e(hip)]} | bf16-CPU rel err {['%.1e' % x for x in e(cpu)]}")
+    for task in ("gen", "seg", "depth"):
+        p32 = r32[f"{task}_embs"][0]
+        p32 = (p32[0] if isinstance(p32, (list, tuple)) else p32).float().reshape(-1)
+        pb = rbf[f"{task}_embs"][0]
+        pb = (pb[0] if isinstance(pb, (list, tuple)) else pb).float().reshape(-1)
+        ph = out["embs"][task][0]
+        ph = (ph[0] if isinstance(ph, (list, tuple)) else ph).float().cpu().reshape(-1)
+        if ph.numel() != p32.numel():
+            print(f"{tag} {task}: pred shapes differ {ph.shape} {p32.shape}")
+            continue
+        rms = float(p32.pow(2).mean().sqrt())
+        for nm, x in (("HIP", ph), ("bf16-CPU", pb)):
+            d = x - p32
+            print(f"{tag} {task} pred ({p32.numel()} el, rms {rms:.3f}): {nm} rms err {float(d.pow(2).mean().sqrt()) / rms:.2e} max err {float(d.abs().max()) / rms:.2e} mean err {float(d.mean()) / rms:+.2e}")
+
+
+run("tiny", lambda b: None)
+run("no_image", lambda b: b["input_ids"].__setitem__((1, 38), 7))

@@ -497,18 +497,20 @@ static int launch_fwd(const AttnParams& p_in, int causal, hipStream_t s) {
     attr = true;
   }
   const dim3 grid = p.order ? dim3(p.Hq, (p.Sq + 127) / 128, p.B) : dim3(p.Hq, p.B, (p.Sq + 127) / 128);
-  if (D == 128 && !p.bias_h && !p.bias_b && vp_fwdm_enabled()) {        // round 3: 32x32x16 swapped-product kernel, 256-row blocks
-    static bool attrm = false;
-    if (!attrm) {
-      (void)hipFuncSetAttribute((const void*)attn_fwd128m_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, FWDM_LDS);
-      (void)hipFuncSetAttribute((const void*)attn_fwd128m_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, FWDM_LDS);
-      attrm = true;
+  if constexpr (D == 128 || D == 96) {
+    if (!p.bias_h && !p.bias_b && vp_fwdm_enabled()) {                  // 32x32x16 swapped-product kernel, 256-row blocks (attention_d128.h)
+      static bool attrm = false;
+      if (!attrm) {
+        (void)hipFuncSetAttribute((const void*)attn_fwd128m_kernel<true, D>, hipFuncAttributeMaxDynamicSharedMemorySize, FWDM_LDS);
+        (void)hipFuncSetAttribute((const void*)attn_fwd128m_kernel<false, D>, hipFuncAttributeMaxDynamicSharedMemorySize, FWDM_LDS);
+        attrm = true;
+      }
+      const int nb = (p.Sq + 255) / 256;
+      const dim3 gm = p.order ? dim3(p.Hq, nb, p.B) : dim3(p.Hq, p.B, nb);
+      if (causal) hipLaunchKernelGGL((attn_fwd128m_kernel<true, D>), gm, dim3(512), FWDM_LDS, s, p);
+      else hipLaunchKernelGGL((attn_fwd128m_kernel<false, D>), gm, dim3(512), FWDM_LDS, s, p);
+      return vp_check_launch("vp_attn_fwd");
     }
-    const int nb = (p.Sq + 255) / 256;
-    const dim3 gm = p.order ? dim3(p.Hq, nb, p.B) : dim3(p.Hq, p.B, nb);
-    if (causal) hipLaunchKernelGGL((attn_fwd128m_kernel<true>), gm, dim3(512), FWDM_LDS, s, p);
-    else hipLaunchKernelGGL((attn_fwd128m_kernel<false>), gm, dim3(512), FWDM_LDS, s, p);
-    return vp_check_launch("vp_attn_fwd");
   }
   if (D == 128 && causal && !p.bias_h && !p.bias_b && getenv("VP_ATTN_DBG")) {       // dev aid: phase stamps
     (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<D, true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kv_lds_bytes<D>());
@@ -528,48 +530,56 @@ template <int D>
 static int launch_bwd(const AttnParams& p_in, int causal, hipStream_t s) {
   AttnParams p = p_in;
   p.order = (p.B <= 65535 && (p.Skv + 127) / 128 <= 65535 && (p.Sq + 127) / 128 <= 65535) ? vp_attn_order() : 0;
-  const long rows = (long)p.B * p.Hq * p.Sq;
-  if (D != 128) hipLaunchKernelGGL((attn_delta_kernel<D>), dim3((unsigned)min(8192L, (rows + 15) / 16)), dim3(256), 0, s, p);
-  static bool attr = false;
-  if (!attr) {
-    (void)hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<D, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kv_lds_bytes<D>());
-    (void)hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<D, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kv_lds_bytes<D>());
-    attr = true;
-  }
   const dim3 g1 = p.order ? dim3(p.Hkv, (p.Skv + 127) / 128, p.B) : dim3(p.Hkv, p.B, (p.Skv + 127) / 128);
   const dim3 g2 = p.order ? dim3(p.Hq, (p.Sq + 127) / 128, p.B) : dim3(p.Hq, p.B, (p.Sq + 127) / 128);
-  if (D == 128) {
+  if constexpr (D == 128 || D == 96) {
+    // the LDS-DMA ring kernels (attention_d128.h): dQ first — it also writes the (lse, delta) pairs the dK/dV kernel streams
     static bool attr2 = false;
     if (!attr2) {
-      (void)hipFuncSetAttribute((const void*)attn_bwd_dkdv128_kernel<true, DKDV_KT>, hipFuncAttributeMaxDynamicSharedMemorySize, DKDV128_LDS);
-      (void)hipFuncSetAttribute((const void*)attn_bwd_dkdv128_kernel<false, DKDV_KT>, hipFuncAttributeMaxDynamicSharedMemorySize, DKDV128_LDS);
-      (void)hipFuncSetAttribute((const void*)attn_bwd_dq128_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, DQ128_LDS);
-      (void)hipFuncSetAttribute((const void*)attn_bwd_dq128_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, DQ128_LDS);
+      (void)hipFuncSetAttribute((const void*)attn_bwd_dkdv128_kernel<true, DKDV_KT, false, D>, hipFuncAttributeMaxDynamicSharedMemorySize, DKDV128_LDS);
+      (void)hipFuncSetAttribute((const void*)attn_bwd_dkdv128_kernel<false, DKDV_KT, false, D>, hipFuncAttributeMaxDynamicSharedMemorySize, DKDV128_LDS);
+      (void)hipFuncSetAttribute((const void*)attn_bwd_dq128_kernel<true, false, D>, hipFuncAttributeMaxDynamicSharedMemorySize, DQ128_LDS);
+      (void)hipFuncSetAttribute((const void*)attn_bwd_dq128_kernel<false, false, D>, hipFuncAttributeMaxDynamicSharedMemorySize, DQ128_LDS);
       attr2 = true;
     }
-    if (p.rope_cos) {                                   // fused RoPE backward: its own instantiations (training: causal only)
-      if (!causal) { vp_set_error("vp_attn_bwd_rope: causal attention only"); return VP_ERR_UNSUPPORTED_SHAPE; }
-      static bool attr3 = false;
-      if (!attr3) {
-        (void)hipFuncSetAttribute((const void*)attn_bwd_dkdv128_kernel<true, DKDV_KT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, DKDV128_LDS);
-        (void)hipFuncSetAttribute((const void*)attn_bwd_dq128_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, DQ128_LDS);
-        attr3 = true;
+    if (p.rope_cos) {                                   // fused RoPE backward: its own instantiations (training: causal, D = 128 only)
+      if constexpr (D == 128) {
+        if (!causal) { vp_set_error("vp_attn_bwd_rope: causal attention only"); return VP_ERR_UNSUPPORTED_SHAPE; }
+        static bool attr3 = false;
+        if (!attr3) {
+          (void)hipFuncSetAttribute((const void*)attn_bwd_dkdv128_kernel<true, DKDV_KT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, DKDV128_LDS);
+          (void)hipFuncSetAttribute((const void*)attn_bwd_dq128_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, DQ128_LDS);
+          attr3 = true;
+        }
+        hipLaunchKernelGGL((attn_bwd_dq128_kernel<true, true>), g2, dim3(256), DQ128_LDS, s, p);
+        hipLaunchKernelGGL((attn_bwd_dkdv128_kernel<true, DKDV_KT, true>), g1, dim3(64 * (8 / DKDV_KT)), DKDV128_LDS, s, p);
+      } else {
+        vp_set_error("vp_attn_bwd_rope: head_dim 128 only");
+        return VP_ERR_UNSUPPORTED_SHAPE;
       }
-      hipLaunchKernelGGL((attn_bwd_dq128_kernel<true, true>), g2, dim3(256), DQ128_LDS, s, p);          // dQ first: it also writes delta
-      hipLaunchKernelGGL((attn_bwd_dkdv128_kernel<true, DKDV_KT, true>), g1, dim3(64 * (8 / DKDV_KT)), DKDV128_LDS, s, p);
     } else if (causal) {
-      hipLaunchKernelGGL((attn_bwd_dq128_kernel<true>), g2, dim3(256), DQ128_LDS, s, p);
-      hipLaunchKernelGGL((attn_bwd_dkdv128_kernel<true, DKDV_KT>), g1, dim3(64 * (8 / DKDV_KT)), DKDV128_LDS, s, p);
+      hipLaunchKernelGGL((attn_bwd_dq128_kernel<true, false, D>), g2, dim3(256), DQ128_LDS, s, p);
+      hipLaunchKernelGGL((attn_bwd_dkdv128_kernel<true, DKDV_KT, false, D>), g1, dim3(64 * (8 / DKDV_KT)), DKDV128_LDS, s, p);
     } else {
-      hipLaunchKernelGGL((attn_bwd_dq128_kernel<false>), g2, dim3(256), DQ128_LDS, s, p);
-      hipLaunchKernelGGL((attn_bwd_dkdv128_kernel<false, DKDV_KT>), g1, dim3(64 * (8 / DKDV_KT)), DKDV128_LDS, s, p);
+      hipLaunchKernelGGL((attn_bwd_dq128_kernel<false, false, D>), g2, dim3(256), DQ128_LDS, s, p);
+      hipLaunchKernelGGL((attn_bwd_dkdv128_kernel<false, DKDV_KT, false, D>), g1, dim3(64 * (8 / DKDV_KT)), DKDV128_LDS, s, p);
     }
-  } else if (causal) {
-    hipLaunchKernelGGL((attn_bwd_dkdv_kernel<D, true>), g1, dim3(512), 0, s, p);
-    hipLaunchKernelGGL((attn_bwd_dq_kernel<D, true>), g2, dim3(512), kv_lds_bytes<D>(), s, p);
   } else {
-    hipLaunchKernelGGL((attn_bwd_dkdv_kernel<D, false>), g1, dim3(512), 0, s, p);
-    hipLaunchKernelGGL((attn_bwd_dq_kernel<D, false>), g2, dim3(512), kv_lds_bytes<D>(), s, p);
+    const long rows = (long)p.B * p.Hq * p.Sq;
+    hipLaunchKernelGGL((attn_delta_kernel<D>), dim3((unsigned)min(8192L, (rows + 15) / 16)), dim3(256), 0, s, p);
+    static bool attr = false;
+    if (!attr) {
+      (void)hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<D, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kv_lds_bytes<D>());
+      (void)hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<D, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kv_lds_bytes<D>());
+      attr = true;
+    }
+    if (causal) {
+      hipLaunchKernelGGL((attn_bwd_dkdv_kernel<D, true>), g1, dim3(512), 0, s, p);
+      hipLaunchKernelGGL((attn_bwd_dq_kernel<D, true>), g2, dim3(512), kv_lds_bytes<D>(), s, p);
+    } else {
+      hipLaunchKernelGGL((attn_bwd_dkdv_kernel<D, false>), g1, dim3(512), 0, s, p);
+      hipLaunchKernelGGL((attn_bwd_dq_kernel<D, false>), g2, dim3(512), kv_lds_bytes<D>(), s, p);
+    }
   }
   return vp_check_launch("vp_attn_bwd");
 }

@@ -50,11 +50,12 @@ static __device__ __forceinline__ bf16x8 tr_join(s16x4 lo, s16x4 hi) {
 
 // store one row's 128 features (this lane: blocks d = 0..7, features d*16 + 4g + r) as bf16, optionally rotated back by RoPE^T:
 // x1 = feature f < 64, x2 = feature f + 64; out1 = bf(bf(x1 c) + bf(x2 s)), out2 = bf(bf(x2 c) + bf(-x1 s))  (vp_rope with inverse = 1)
-template <bool ROPE>
-static __device__ __forceinline__ void store_row128(bf16_t* dst, const f32x4 (&acc)[8], float scale, int g, const float* cs, const float* sn) {
-  if (!ROPE) {
+template <bool ROPE, int NDB = 8>
+static __device__ __forceinline__ void store_row128(bf16_t* dst, const f32x4 (&acc)[NDB], float scale, int g, const float* cs, const float* sn) {
+  static_assert(!ROPE || NDB == 8, "the fused RoPE^T store pairs feature f with f + 64");
+  if constexpr (!ROPE) {
 #pragma unroll
-    for (int d = 0; d < 8; ++d) {
+    for (int d = 0; d < NDB; ++d) {
       bf16x4 a;
 #pragma unroll
       for (int r = 0; r < 4; ++r) a[r] = (short)f2bf(acc[d][r] * scale);
@@ -83,10 +84,14 @@ static __device__ __forceinline__ void store_row128(bf16_t* dst, const f32x4 (&a
 constexpr int DKDV128_STAGE = 2 * 32 * 128 + 128;     // bf16 units: Q tile | dO tile | 32 (lse, delta) fp32 pairs
 constexpr int DKDV128_LDS = 4 * DKDV128_STAGE * 2;    // bytes
 
-template <bool CAUSAL, int KT, bool ROPE = false>      // KT = 16-key column tiles per wave: 2 -> 4 waves x 32 keys, 1 -> 8 waves x 16 keys (128 keys per block)
+// D = 128 or 96 (Phi-3): the LDS tiles keep 128-feature rows and the same swizzle; with D = 96 the contraction runs over 3 instead of 4 k-steps
+// and 6 instead of 8 output feature blocks, so the 4 LDS chunks per row that hold no feature of this head are never read (their DMA lanes
+// re-fetch chunk 0: always inside the tensor).
+template <bool CAUSAL, int KT, bool ROPE = false, int D = 128>      // KT = 16-key column tiles per wave: 2 -> 4 waves x 32 keys, 1 -> 8 waves x 16 keys (128 keys per block)
 __global__ __launch_bounds__(64 * (8 / KT)) __attribute__((amdgpu_waves_per_eu(KT == 2 ? 2 : 4, KT == 2 ? 2 : 4)))
 void attn_bwd_dkdv128_kernel(AttnParams p) {
-  constexpr int D = 128, NKS = 4, NDB = 8, NW = 8 / KT, NI = 8 / NW;      // NI = DMA instructions per wave per 32-row tile
+  static_assert(D == 128 || D == 96, "D");
+  constexpr int NKS = D / 32, NDB = D / 16, NW = 8 / KT, NI = 8 / NW;      // NI = DMA instructions per wave per 32-row tile
   extern __shared__ __attribute__((aligned(16))) unsigned char attn_smem[];
   bf16_t* const ring = (bf16_t*)attn_smem;
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), fr = lane & 15, g = lane >> 4;
@@ -140,7 +145,8 @@ void attn_bwd_dkdv128_kernel(AttnParams p) {
     for (int i = 0; i < NI; ++i) {
       const int blk = i * NW + wave;                   // 4-row group of the tile this instruction fills
       const int drow = blk * 4 + (ln >> 4);
-      const int dch = ((ln & 15) ^ (drow & 15)) * 8;
+      int dch = ((ln & 15) ^ (drow & 15)) * 8;
+      if (D < 128 && dch >= D) dch = 0;                  // (a chunk no fragment read ever touches: keep its source inside the tensor)
       const unsigned r = (unsigned)min(q0 + drow, p.Sq - 1);
       ATTN_GLDS(qb + (size_t)((r * qts + dch) * 2u), sb + blk * 512, 16);
       ATTN_GLDS(gb + (size_t)((r * gts + dch) * 2u), sb + 4096 + blk * 512, 16);
@@ -252,8 +258,8 @@ void attn_bwd_dkdv128_kernel(AttnParams p) {
       bf16_t* dkp = p.dk + (long)b * p.dk_bs + (long)key * p.dk_ts + (long)hk * D;
       bf16_t* dvp = p.dv + (long)b * p.dv_bs + (long)key * p.dv_ts + (long)hk * D;
       const long pp = ROPE ? (p.rope_pos ? (long)p.rope_pos[(long)b * p.Skv + key] : (long)key) * 64 : 0;
-      store_row128<ROPE>(dkp, dk[kt], p.scale, g, p.rope_cos + pp, p.rope_sin + pp);
-      store_row128<false>(dvp, dv[kt], 1.f, g, nullptr, nullptr);
+      store_row128<ROPE, NDB>(dkp, dk[kt], p.scale, g, p.rope_cos + pp, p.rope_sin + pp);
+      store_row128<false, NDB>(dvp, dv[kt], 1.f, g, nullptr, nullptr);
     }
   }
 }
@@ -265,9 +271,10 @@ void attn_bwd_dkdv128_kernel(AttnParams p) {
 constexpr int DQ128_STAGE = 2 * 32 * 128;             // bf16 units: K tile | V tile
 constexpr int DQ128_LDS = 4 * DQ128_STAGE * 2;        // bytes
 
-template <bool CAUSAL, bool ROPE = false>
+template <bool CAUSAL, bool ROPE = false, int D = 128>      // D = 128 or 96 (see attn_bwd_dkdv128_kernel)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_bwd_dq128_kernel(AttnParams p) {
-  constexpr int D = 128, NKS = 4, NDB = 8;
+  static_assert(D == 128 || D == 96, "D");
+  constexpr int NKS = D / 32, NDB = D / 16;
   extern __shared__ __attribute__((aligned(16))) unsigned char attn_smem[];
   bf16_t* const ring = (bf16_t*)attn_smem;
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -331,7 +338,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   auto issue = [&](int t, int st, int ln) {            // lane-derived values are re-derived per call (see the dK/dV kernel)
     const int k0 = kstart + min(t, nit - 1) * 32;
     const int drow = wave * 4 + (ln >> 4);
-    const int dch = ((ln & 15) ^ (drow & 15)) * 8;
+    int dch = ((ln & 15) ^ (drow & 15)) * 8;
+    if (D < 128 && dch >= D) dch = 0;                    // (never read: see attn_bwd_dkdv128_kernel)
     bf16_t* sb = ring + st * DQ128_STAGE;
     const unsigned r0 = (unsigned)min(k0 + drow, p.Skv - 1), r1 = (unsigned)min(k0 + drow + 16, p.Skv - 1);
     const unsigned kts = (unsigned)p.k_ts, vts = (unsigned)p.v_ts;
@@ -438,7 +446,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     if (qrow < p.Sq) {
       bf16_t* dqp = p.dq + (long)b * p.dq_bs + (long)qrow * p.dq_ts + (long)h * D;
       const long pp = ROPE ? (p.rope_pos ? (long)p.rope_pos[(long)b * p.Sq + qrow] : (long)(qrow + p.Skv - p.Sq)) * 64 : 0;
-      store_row128<ROPE>(dqp, dq[qt], p.scale, lane >> 4, p.rope_cos + pp, p.rope_sin + pp);
+      store_row128<ROPE, NDB>(dqp, dq[qt], p.scale, lane >> 4, p.rope_cos + pp, p.rope_sin + pp);
     }
   }
 }
@@ -461,9 +469,16 @@ typedef uint32_t fwdm_u32x4s __attribute__((ext_vector_type(4)));
 // immediate (stage, key block), every V fragment address likewise (the loop is unrolled by four, so the stage is a literal)
 constexpr int FWDM_LDS = 8 * 64 * 128 * 2;            // bytes (128 KB)
 
-template <bool CAUSAL>
+// D = 128 or 96 (Phi-3): LDS rows stay 128 features wide with the same swizzle; with D = 96 a tile takes 12 instead of 16 MFMAs in each of the
+// two products (6 k-steps x 2 key blocks; 3 feature blocks x 4 key groups), the 4 chunks per row that belong to no feature of this head are
+// never read (their DMA lanes fetch the neighbouring head's bytes, or zeros past the end: the buffer descriptor's range check).
+template <bool CAUSAL, int D = 128>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_fwd128m_kernel(AttnParams p) {
-  constexpr int D = 128;
+  static_assert(D == 128 || D == 96, "D");
+  constexpr int NQS = D / 16;                            // k-steps of S^T = K Q^T
+  constexpr int NQK = 2 * NQS;                           // its MFMA steps per tile: step n = (k-step n >> 1, key block n & 1)
+  constexpr int NOB = D / 32;                            // 32-feature blocks of O^T
+  constexpr int NPV = 4 * NOB;                           // MFMA steps of O^T += V^T P^T: step n = (feature block n % NOB, key group n / NOB)
   extern __shared__ __attribute__((aligned(16))) unsigned char attn_smem[];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int nqb = (p.Sq + 255) >> 8;
@@ -478,15 +493,15 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   const int ql = lane & 31, hh = lane >> 5;
   const int qrow = qw0 + ql;
 
-  bf16x8 qf[8];                                         // B operand of S^T: lane = query, 8 features at 16 ks + 8 hh
+  bf16x8 qf[NQS];                                       // B operand of S^T: lane = query, 8 features at 16 ks + 8 hh
   {
     const bf16_t* qp = p.q + (long)b * p.q_bs + (long)min(qrow, p.Sq - 1) * p.q_ts + (long)h * D;      // clamped; rows >= Sq are never stored
 #pragma unroll
-    for (int ks = 0; ks < 8; ++ks) qf[ks] = *(const bf16x8*)(qp + ks * 16 + hh * 8);
+    for (int ks = 0; ks < NQS; ++ks) qf[ks] = *(const bf16x8*)(qp + ks * 16 + hh * 8);
   }
-  f32x16 oacc[4];                                       // O^T: feature 32 db + 8 (i >> 2) + 4 hh + (i & 3) of this lane's query
+  f32x16 oacc[NOB];                                     // O^T: feature 32 db + 8 (i >> 2) + 4 hh + (i & 3) of this lane's query
 #pragma unroll
-  for (int d = 0; d < 4; ++d)
+  for (int d = 0; d < NOB; ++d)
 #pragma unroll
     for (int i = 0; i < 16; ++i) oacc[d][i] = 0.f;
   float m = -1e30f, l = 0.f;                            // m is kept PRE-scaled: m = c * max(raw score)
@@ -535,18 +550,18 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #define FWDM_DMA4(T, ST) { FWDM_DMA(T, ST, 0) FWDM_DMA(T, ST, 1) FWDM_DMA(T, ST, 2) FWDM_DMA(T, ST, 3) }
 
   // ---- fragment addresses (bytes, loop-invariant).  K fragment (kb, ks): row 32 kb + (lane & 31), 16-byte chunk (2 ks + hh) ^ (row & 15)
-  uint32_t ka[8];
+  uint32_t ka[NQS];
 #pragma unroll
-  for (int ks = 0; ks < 8; ++ks) {
+  for (int ks = 0; ks < NQS; ++ks) {
     ka[ks] = ldsb + (uint32_t)(((lane & 31) * 128 + (((2 * ks + hh) ^ (lane & 15)) << 3)) * 2);
     asm volatile("" : "+v"(ka[ks]));
   }
   // V^T fragment (db, kt): two transposing reads; lane i of a 16-lane group supplies 4 features of key row 16 kt + 4 hh + (i >> 2) [+ 8]
-  uint32_t va0[4];
+  uint32_t va0[NOB];
   {
     const int fr_ = lane & 15, gq = (lane >> 4) & 1, trow = 4 * hh + (fr_ >> 2);
 #pragma unroll
-    for (int db = 0; db < 4; ++db) {
+    for (int db = 0; db < NOB; ++db) {
       va0[db] = ldsb + 65536u + (uint32_t)((trow * 128 + (((4 * db + 2 * gq + ((lane & 3) >> 1)) ^ ((trow & 3) << 2)) << 3) + (lane & 1) * 4) * 2);
       asm volatile("" : "+v"(va0[db]));
     }
@@ -554,8 +569,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #define FWDM_KRD(DST, ST, N) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(DST) : "v"(ka[(N) >> 1]), "n"((ST) * 16384 + ((N) & 1) * 8192))
 #define FWDM_VRD(ST, N)                                                                                         \
   {                                                                                                             \
-    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(vlo[N]) : "v"(va0[(N) & 3]), "n"((ST) * 16384 + ((N) >> 2) * 4096)); \
-    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(vhi[N]) : "v"(va0[(N) & 3]), "n"((ST) * 16384 + ((N) >> 2) * 4096 + 2048)); \
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(vlo[N]) : "v"(va0[(N) % NOB]), "n"((ST) * 16384 + ((N) / NOB) * 4096)); \
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(vhi[N]) : "v"(va0[(N) % NOB]), "n"((ST) * 16384 + ((N) / NOB) * 4096 + 2048)); \
   }
 
   f32x16 sa[2], sb2[2];                                 // S^T of the current / next tile: [key block]
@@ -564,13 +579,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // tile 0 landed (this wave's part)
     __builtin_amdgcn_s_barrier();
     bf16x8 kf[16];
-#define FWDM_P0(N) FWDM_KRD(kf[N], 0, N);
+#define FWDM_P0(N) if constexpr ((N) < NQK) FWDM_KRD(kf[N], 0, N);
     FWDM_P0(0) FWDM_P0(1) FWDM_P0(2) FWDM_P0(3) FWDM_P0(4) FWDM_P0(5) FWDM_P0(6) FWDM_P0(7)
     FWDM_P0(8) FWDM_P0(9) FWDM_P0(10) FWDM_P0(11) FWDM_P0(12) FWDM_P0(13) FWDM_P0(14) FWDM_P0(15)
 #undef FWDM_P0
     ATTN_LGKM(0);
 #pragma unroll
-    for (int n = 0; n < 16; ++n) {
+    for (int n = 0; n < NQK; ++n) {
       ATTN_PIN(kf[n]);
       if (n < 2) {
 #pragma unroll
@@ -585,33 +600,31 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   // made every score register a phi: 32 v_mov per tile).  C: O^T += V^T P^T (16 MFMAs, four chains alternating, transposing reads two steps
   // ahead), one LDS-DMA piece of tile it + 3 per four MFMAs.
 #define FWDM_QK(SN, SC, NS, N)                                                                                  \
-  {                                                                                                             \
-    if ((N) + 3 < 16) { FWDM_KRD(kf[((N) + 3) & 15], NS, ((N) + 3) & 15); ATTN_LGKM(3); }                        \
-    else if ((N) + 3 == 16) { ATTN_LGKM(2); }                                                                   \
-    else if ((N) + 3 == 17) { ATTN_LGKM(1); }                                                                   \
+  if constexpr ((N) < NQK) {                                                                                    \
+    if constexpr ((N) + 3 < NQK) { FWDM_KRD(kf[((N) + 3) & 15], NS, ((N) + 3) & 15); ATTN_LGKM(3); }             \
+    else if constexpr ((N) + 3 == NQK) { ATTN_LGKM(2); }                                                        \
+    else if constexpr ((N) + 3 == NQK + 1) { ATTN_LGKM(1); }                                                    \
     else { ATTN_LGKM(0); }                                                                                      \
     ATTN_PIN(kf[N]);                                                                                            \
     if ((N) < 2) { _Pragma("unroll") for (int i = 0; i < 16; ++i) SN[(N) & 1][i] = 0.f; }                       \
     SN[(N) & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[N], qf[(N) >> 1], SN[(N) & 1], 0, 0, 0);            \
-    {                                                                                                           \
-      const float e0_ = fast_exp2(fmaf(SC[(N) >> 3][(2 * (N)) & 15], c2, -m));                                  \
-      const float e1_ = fast_exp2(fmaf(SC[(N) >> 3][(2 * (N) + 1) & 15], c2, -m));                              \
-      SC[(N) >> 3][(2 * (N)) & 15] = e0_;                                                                       \
-      SC[(N) >> 3][(2 * (N) + 1) & 15] = e1_;                                                                   \
-      rs0 += e0_;                                                                                               \
-      rs1 += e1_;                                                                                               \
+    /* this tile's 32 exponentials spread over the NQK steps: 2 per step (D = 128), 2-3 per step (D = 96); even ones sum into rs0 */ \
+    _Pragma("unroll") for (int e_ = (32 * (N)) / NQK; e_ < (32 * ((N) + 1)) / NQK; ++e_) {                      \
+      const float ev_ = fast_exp2(fmaf(SC[e_ >> 4][e_ & 15], c2, -m));                                          \
+      SC[e_ >> 4][e_ & 15] = ev_;                                                                               \
+      if (e_ & 1) rs1 += ev_; else rs0 += ev_;                                                                  \
     }                                                                                                           \
     __builtin_amdgcn_sched_barrier(0);                                                                          \
   }
-#define FWDM_PV(ST, N)            /* step N: feature block N & 3, key group N >> 2 */                           \
-  {                                                                                                             \
-    if ((N) + 2 < 16) { FWDM_VRD(ST, ((N) + 2) & 15) ATTN_LGKM(4); }                                            \
-    else if ((N) + 2 == 16) { ATTN_LGKM(2); }                                                                   \
+#define FWDM_PV(ST, N)            /* step N: feature block N % NOB, key group N / NOB */                        \
+  if constexpr ((N) < NPV) {                                                                                    \
+    if constexpr ((N) + 2 < NPV) { FWDM_VRD(ST, ((N) + 2) & 15) ATTN_LGKM(4); }                                  \
+    else if constexpr ((N) + 2 == NPV) { ATTN_LGKM(2); }                                                        \
     else { ATTN_LGKM(0); }                                                                                      \
     bf16x8 vtf = tr_join(vlo[N], vhi[N]);                                                                       \
     ATTN_PIN(vtf);                                                                                              \
-    oacc[(N) & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vtf, pf[(N) >> 2], oacc[(N) & 3], 0, 0, 0);          \
-    if (((N) & 3) == 1) FWDM_DMA(t3_, ((ST) + 3) & 3, (N) >> 2)                                                 \
+    oacc[(N) % NOB] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vtf, pf[(N) / NOB], oacc[(N) % NOB], 0, 0, 0);    \
+    if constexpr (((N) % NOB) == 1) FWDM_DMA(t3_, ((ST) + 3) & 3, (N) / NOB)                                    \
     if ((N) & 1) __builtin_amdgcn_sched_barrier(0);                                                             \
   }
 #define FWDM_ITER(IT, STG, SC, SN)                                                                              \
@@ -648,7 +661,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       const float mnew = fmaxf(m, mx);                                                                          \
       const float alpha = fast_exp2(m - mnew);                                                                  \
       l *= alpha;                                                                                               \
-      _Pragma("unroll") for (int d = 0; d < 4; ++d)                                                             \
+      _Pragma("unroll") for (int d = 0; d < NOB; ++d)                                                           \
         _Pragma("unroll") for (int i = 0; i < 16; ++i) oacc[d][i] *= alpha;                                     \
       m = mnew;                                                                                                 \
     }                                                                                                           \
@@ -717,7 +730,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const float inv = l > 0.f ? 1.f / l : 0.f;
     bf16_t* op = p.o + (long)b * p.o_bs + (long)qrow * p.o_ts + (long)h * D;
 #pragma unroll
-    for (int db = 0; db < 4; ++db)
+    for (int db = 0; db < NOB; ++db)
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         bf16x4 o;

@@ -20,7 +20,6 @@
 #include <type_traits>
 #include <stdlib.h>
 #include <mutex>
-#include <unordered_map>
 
 namespace {
 
@@ -590,18 +589,42 @@ struct ElPlan {
   bool pack;
 };
 
-// One ticket-counter set per distinct stream, handed out in order of first use (a hash of the stream pointer let two streams
-// share a set).  Returns -1 when more than N_SLOTS different streams have called the loss (the caller reports VP_ERR_UNSUPPORTED_SHAPE).
+// One ticket-counter set per distinct stream (a registry, not a hash: two live streams never share a set).  N_SLOTS sets exist; when a 33rd
+// stream shows up the least recently used set is re-assigned to it (the registry used to fill up for good — short-lived streams,
+// graph-capture streams and torch's stream pools reach 32 — and every later call failed).  A set is only handed on after the last launch
+// that used it has finished: each launch records a fence event behind itself (el_slot_done) and eviction waits for it on the host (the rare
+// path; ~never blocks, that launch is >= 31 other streams' launches old).  A destroyed stream whose handle value is reused simply finds its
+// old set again — harmless for the same reason (every launch leaves its counters zeroed).
+struct ElSlot { hipStream_t stream; hipEvent_t fence; unsigned long tick; bool used; };
+static std::mutex g_slot_mu;
+static ElSlot g_slots[N_SLOTS];
+static unsigned long g_slot_tick = 0;
 int el_slot_for(hipStream_t s) {
-  static std::mutex mu;
-  static std::unordered_map<hipStream_t, int> slots;
-  std::lock_guard<std::mutex> lk(mu);
-  auto it = slots.find(s);
-  if (it != slots.end()) return it->second;
-  if ((int)slots.size() >= N_SLOTS) return -1;
-  const int id = (int)slots.size();
-  slots.emplace(s, id);
+  std::lock_guard<std::mutex> lk(g_slot_mu);
+  int free_id = -1, lru = 0;
+  for (int i = 0; i < N_SLOTS; ++i) {
+    if (g_slots[i].used && g_slots[i].stream == s) { g_slots[i].tick = ++g_slot_tick; return i; }
+    if (!g_slots[i].used && free_id < 0) free_id = i;
+    if (g_slots[i].used && g_slots[i].tick < g_slots[lru].tick) lru = i;
+  }
+  int id = free_id;
+  if (id < 0) {                                                    // evict: wait until the set's last launch is done, then hand it on
+    id = lru;
+    if (g_slots[id].fence && hipEventSynchronize(g_slots[id].fence) != hipSuccess) (void)hipGetLastError();
+  } else if (hipEventCreateWithFlags(&g_slots[id].fence, hipEventDisableTiming) != hipSuccess) {
+    g_slots[id].fence = nullptr;
+    (void)hipGetLastError();
+    return -1;
+  }
+  g_slots[id].stream = s; g_slots[id].used = true; g_slots[id].tick = ++g_slot_tick;
   return id;
+}
+void el_slot_done(int id, hipStream_t s) {                          // fence behind the launch that just used set `id`
+  std::lock_guard<std::mutex> lk(g_slot_mu);
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(s, &cap) != hipSuccess) { (void)hipGetLastError(); return; }
+  if (cap != hipStreamCaptureStatusNone) return;                   // inside a graph capture: no host-visible fence (the graph's stream orders replays)
+  if (g_slots[id].fence && hipEventRecord(g_slots[id].fence, s) != hipSuccess) (void)hipGetLastError();
 }
 
 ElPlan el_plan(int B, int Bw, long D) {
@@ -666,7 +689,7 @@ int vp_emb_loss_fwd_multi(int ntask, int B, int Bw, const long* D, int rank, con
              "vp_emb_loss_fwd: need 0<B<=64, B<=Bw<=1024 (got B=%d Bw=%d)", B, Bw);
   VP_REQUIRE(rank >= 0 && (long)(rank + 1) * B <= Bw, VP_ERR_BAD_ARG, "vp_emb_loss_fwd: rank/B/Bw mismatch");
   const int slot = el_slot_for(s);
-  VP_REQUIRE(slot >= 0, VP_ERR_UNSUPPORTED_SHAPE, "vp_emb_loss_fwd: more than %d distinct streams have used the loss", N_SLOTS);
+  VP_REQUIRE(slot >= 0, VP_ERR_HIP, "vp_emb_loss_fwd: could not create the fence event of a ticket-counter set");
   ElMulti m;
   ElPlan p0 = el_plan(B, Bw, D[0] > 0 ? D[0] : 8);
   int gx = 0;
@@ -694,6 +717,7 @@ int vp_emb_loss_fwd_multi(int ntask, int B, int Bw, const long* D, int rank, con
   else if (p0.npb == 1) el_launch<1>(p0.ng, grid, s, m);
   else if (p0.npb == 2) el_launch<2>(p0.ng, grid, s, m);
   else el_launch<4>(p0.ng, grid, s, m);
+  el_slot_done(slot, s);
   return vp_check_launch("vp_emb_loss_fwd");
 }
 

@@ -790,12 +790,10 @@ class Engine:
     # ------------------------------------------------------------------------------------------ the step
     def train_step(self, batch, compute_grads=True):
         """One fused forward+backward.  Returns dict(loss, text_loss, per-task losses, layer_losses, ...) of device
-        scalars (fp32 tensors); gradients of the trainable set are in self.ps.grad (zeroed first)."""
-        cfg, fz, ps, dev = self.cfg, self.fz, self.ps, self.dev
-        H = cfg.hidden_size
+        scalars (fp32 tensors); gradients of the trainable set are in self.ps.grad (zeroed first).
+        Stages (each its own method): _embed (a1..a5) -> _decoder_fwd (a6) -> _ntp (a7) -> _heads (a8..a14) -> _decoder_bwd -> _splice_bwd."""
+        ps = self.ps
         plan = self.build_plan(batch["input_ids"], batch.get("attention_mask"), batch.get("labels"))
-        B, S = plan["B"], plan["S"]
-        M = B * S
         if compute_grads:
             if self.train_llm:
                 # every decoder / lm_head / norm gradient is overwritten by its wgrad GEMM below: clear only what accumulates
@@ -810,32 +808,63 @@ class Engine:
         x, feats, z1, a1, img = self._embed(batch["images"], plan)
         out["image_features"] = img
         out["inputs_embeds"] = self.present(x, plan)
-        nt = cfg.num_task_tokens
 
-        # ---- decoder (a6)
+        dec = self._decoder_fwd(x, plan, compute_grads)
+        out["hidden"] = self.present(dec["hidden"], plan)
+        text_loss, d_hidden = self._ntp(dec["hidden"], plan, compute_grads, out)
+        task_loss, d_state = self._heads(dec["states"], plan, batch, compute_grads, out)
+        if compute_grads and self.world > 1:
+            self._reducer().start_early()                    # heads + logit scales: overlap with the decoder backward
+        loss = text_loss.clone()
+        for task in ("seg", "depth", "gen"):                                 # sum order: ola_llama.py:143-144
+            if task in task_loss:
+                loss = loss + task_loss[task]
+                out[f"{task}_loss"] = task_loss[task]
+        out["loss"] = loss
+        if not compute_grads:
+            return out
+        dx = self._decoder_bwd(d_hidden, dec, d_state, plan)
+        out["d_inputs_embeds"] = self.present(dx, plan)
+        self._splice_bwd(dx, plan, feats, z1, a1)
+        return out
+
+    def _attn_window(self):
+        """kernels keep keys with q - key < window; transformers 4.41.1 (the reference's pin) keeps q - key <= sliding_window"""
+        cfg = self.cfg
+        return (int(cfg.sliding_window) + int(bool(getattr(cfg, "sliding_window_inclusive", False)))) if cfg.sliding_window else 0
+
+    def _qkv_views(self, t, B, S):
+        cfg = self.cfg
         nh, nkv, hd = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim
-        Fi = cfg.intermediate_size
+        t3 = t.view(B, S, -1)
+        return (t3[..., :nh * hd].view(B, S, nh, hd), t3[..., nh * hd:(nh + nkv) * hd].view(B, S, nkv, hd),
+                t3[..., (nh + nkv) * hd:].view(B, S, nkv, hd))
+
+    def _decoder_fwd(self, x, plan, compute_grads):
+        """a6: the decoder stack (ola_llama.py:105-119 -> HF LlamaModel / Phi3Model).  Returns the final pre-norm state, the normed hidden
+        state, what the backward pass needs per layer, and the tapped layer states (layer_states[i] = output of layer i + 1, the last one
+        post-norm: ola_llama.py:117-119)."""
+        cfg, fz = self.cfg, self.fz
+        B, S = plan["B"], plan["S"]
+        M = B * S
+        nh, nkv, hd = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim
         cos_t, sin_t = self.rope(S)
         kv_len = None if plan["full"] else plan["lens"]
-        # kernels keep keys with q - key < window; transformers 4.41.1 (the reference's pin) keeps q - key <= sliding_window
-        window = (int(cfg.sliding_window) + int(bool(getattr(cfg, "sliding_window_inclusive", False)))) if cfg.sliding_window else 0
+        window = self._attn_window()
         L = cfg.num_hidden_layers
-        saved = []
-        states = {}
+        saved, states = [], {}
+        il = self.gu_interleaved
+        fuse = il and ops.swiglu_fusable(M, 2 * cfg.intermediate_size, cfg.hidden_size) and \
+            ops.swiglu_fusable(M, cfg.intermediate_size, cfg.hidden_size)
         for l in range(L):
             o = f"dec.{l}."
             xn, rstd1 = ops.rmsnorm_fwd(x, fz[o + "ln1"], cfg.rms_norm_eps)
             qkv = ops.gemm(xn, fz[o + "wqkv"])
             ops.rope_(qkv, M, S, nh + nkv, hd, cos_t, sin_t)
-            q4 = qkv.view(B, S, -1)[..., :nh * hd].view(B, S, nh, hd)
-            k4 = qkv.view(B, S, -1)[..., nh * hd:(nh + nkv) * hd].view(B, S, nkv, hd)
-            v4 = qkv.view(B, S, -1)[..., (nh + nkv) * hd:].view(B, S, nkv, hd)
+            q4, k4, v4 = self._qkv_views(qkv, B, S)
             att, lse = ops.attn_fwd(q4, k4, v4, causal=True, window=window, kv_len=kv_len)
             h1 = ops.gemm(att.view(M, nh * hd), fz[o + "wo"], residual=x)
             hn, rstd2 = ops.rmsnorm_fwd(h1, fz[o + "ln2"], cfg.rms_norm_eps)
-            il = self.gu_interleaved
-            fuse = il and ops.swiglu_fusable(M, 2 * cfg.intermediate_size, cfg.hidden_size) and \
-                ops.swiglu_fusable(M, cfg.intermediate_size, cfg.hidden_size)
             if fuse:
                 gu, act = ops.gemm_swiglu_fwd(hn, fz[o + "wgu"])
             else:
@@ -850,11 +879,16 @@ class Engine:
         hidden, rstd_f = ops.rmsnorm_fwd(x, fz["norm"], cfg.rms_norm_eps)
         if (L - 1) in self.tapped:
             states[L - 1] = hidden              # layer_states[-1] is the post-norm state (ola_llama.py:117-119)
-        out["hidden"] = self.present(hidden, plan)
+        return dict(x=x, hidden=hidden, rstd_f=rstd_f, saved=saved, states=states)
 
-        # ---- lm_head + NTP loss (a7), row-chunked; dlogits -> d_hidden in the same sweep.  Unless the caller wants the logits, only the
-        #      rows that carry a label go through the two vocabulary-wide GEMMs and the cross-entropy (the others have zero loss and zero
-        #      d_logits): their hidden rows are compacted by one row gather, and d_hidden is scattered back with zeros elsewhere
+    def _ntp(self, hidden, plan, compute_grads, out):
+        """a7: lm_head + NTP loss (ola_llama.py:121-136), row-chunked; dlogits -> d_hidden in the same sweep.  Unless the caller wants the
+        logits, only the rows that carry a label go through the two vocabulary-wide GEMMs and the cross-entropy (the others have zero loss
+        and zero d_logits): their hidden rows are compacted by one row gather, and d_hidden is scattered back with zeros elsewhere.
+        Returns (text_loss, d_hidden or None)."""
+        fz, ps, dev = self.fz, self.ps, self.dev
+        H = self.cfg.hidden_size
+        M = plan["B"] * plan["S"]
         n_valid = plan["n_valid"]
         gscale = 1.0 / n_valid if n_valid > 0 else float("nan")
         compact = (not self.keep_logits) and 0 < n_valid < M
@@ -888,57 +922,54 @@ class Engine:
         out["text_loss"] = text_loss
         if logits_keep is not None:
             out["logits"] = self.present(torch.cat(logits_keep, 0), plan)
+        return text_loss, d_hidden
 
-        # ---- heads + embedding losses (a8..a14), forward and backward back-to-back per head
-        d_state = {}
-        task_loss = {}
+    def _heads(self, states, plan, batch, compute_grads, out):
+        """a8..a14: every distillation head on its layer state — all forwards, ONE loss launch each way for all of them
+        (vp_emb_loss_{fwd,bwd}_multi; the reference calls _emb_loss head by head: base_ola_vlm.py:445-534), the heads' backward passes, and the
+        scatter of their input gradients back to full-length layer-state gradients.  Returns (task_loss {task: scalar}, d_state {layer: [M, H]}).
+        Peak memory: every head's saved activations stay live until its own backward ran, i.e. all heads' at once (the price of the single
+        loss launch); bench.py reports the step's peak allocation (`peak_mem_gb`), DESIGN.md section 3 has the measured numbers."""
+        cfg, dev = self.cfg, self.dev
+        H = cfg.hidden_size
+        B, S = plan["B"], plan["S"]
+        M = B * S
+        d_state, task_loss = {}, {}
         out["layer_losses"] = {}
         out["embs"] = {}
         dx_parts = {l: [] for l in self.tapped}
-        ns = cfg.num_sys_tokens
-        run_heads = len(self.tasks) > 0 and S > ns
-        if run_heads:
-            targets = self._prepare_targets(batch, B)
-            # every head's forward first, then ONE loss launch each way for all of them (vp_emb_loss_{fwd,bwd}_multi; the reference calls
-            # _emb_loss head by head: base_ola_vlm.py:445-534), then the heads' backward passes
-            ctxs = [self._head_fwd(task, i, idx, states[idx], plan, batch, targets, compute_grads) for task, i, idx in self.tasks]
-            live = [c for c in ctxs if c["tg"] is not None]
-            for c0 in range(0, len(live), 8):
-                grp = live[c0:c0 + 8]
-                outs = ops.emb_loss_fwd_multi([c["pred2"] for c in grp], [c["tg"][0] for c in grp], [c["tg"][1] for c in grp],
-                                              [c["scale"] for c in grp], [cfg.contrastive_loss_weight] * len(grp), rank=self.rank)
-                for c, (loss3, coef) in zip(grp, outs):
-                    c["res"]["loss3"], c["coef"] = loss3, coef
-                if compute_grads:
-                    dps = ops.emb_loss_bwd_multi([c["pred2"] for c in grp], [c["tg"][0] for c in grp], [c["coef"] for c in grp],
-                                                 [c["w_t"] for c in grp], rank=self.rank)
-                    for c, dp in zip(grp, dps):
-                        c["dpred"] = dp
-            for c in ctxs:
-                task, idx, res = c["task"], c["idx"], c["res"]
-                if compute_grads and c["tg"] is not None:
-                    self._head_bwd(c)
-                if res["loss3"] is not None:
-                    out["layer_losses"][(task, idx)] = res["loss3"]
-                    w_t = getattr(cfg, TASK_SPEC[task][0])[TASK_SPEC[task][2]]
-                    task_loss[task] = res["loss3"][0:1] * w_t if task not in task_loss else task_loss[task] + res["loss3"][0:1] * w_t
-                out["embs"].setdefault(task, []).append(res["emb"])
-                if "depth_pred" in res:
-                    out.setdefault("depth_preds", []).append(res["depth_pred"])
-                    out.setdefault("depth_feats", []).append(res["depth_feats"])
-                if compute_grads and res["dx"] is not None:
-                    dx_parts[idx].append((task, res["dx"]))
-        if compute_grads and self.world > 1:
-            self._reducer().start_early()                    # heads + logit scales: overlap with the decoder backward
-        loss = text_loss.clone()
-        for task in ("seg", "depth", "gen"):                                 # sum order: ola_llama.py:143-144
-            if task in task_loss:
-                loss = loss + task_loss[task]
-                out[f"{task}_loss"] = task_loss[task]
-        out["loss"] = loss
+        if not (len(self.tasks) > 0 and S > cfg.num_sys_tokens):
+            return task_loss, d_state
+        targets = self._prepare_targets(batch, B)
+        ctxs = [self._head_fwd(task, i, idx, states[idx], plan, batch, targets, compute_grads) for task, i, idx in self.tasks]
+        live = [c for c in ctxs if c["tg"] is not None]
+        for c0 in range(0, len(live), 8):
+            grp = live[c0:c0 + 8]
+            outs = ops.emb_loss_fwd_multi([c["pred2"] for c in grp], [c["tg"][0] for c in grp], [c["tg"][1] for c in grp],
+                                          [c["scale"] for c in grp], [cfg.contrastive_loss_weight] * len(grp), rank=self.rank)
+            for c, (loss3, coef) in zip(grp, outs):
+                c["res"]["loss3"], c["coef"] = loss3, coef
+            if compute_grads:
+                dps = ops.emb_loss_bwd_multi([c["pred2"] for c in grp], [c["tg"][0] for c in grp], [c["coef"] for c in grp],
+                                             [c["w_t"] for c in grp], rank=self.rank)
+                for c, dp in zip(grp, dps):
+                    c["dpred"] = dp
+        for c in ctxs:
+            task, idx, res = c["task"], c["idx"], c["res"]
+            if compute_grads and c["tg"] is not None:
+                self._head_bwd(c)
+            if res["loss3"] is not None:
+                out["layer_losses"][(task, idx)] = res["loss3"]
+                w_t = getattr(cfg, TASK_SPEC[task][0])[TASK_SPEC[task][2]]
+                task_loss[task] = res["loss3"][0:1] * w_t if task not in task_loss else task_loss[task] + res["loss3"][0:1] * w_t
+            out["embs"].setdefault(task, []).append(res["emb"])
+            if "depth_pred" in res:
+                out.setdefault("depth_preds", []).append(res["depth_pred"])
+                out.setdefault("depth_feats", []).append(res["depth_feats"])
+            if compute_grads and res["dx"] is not None:
+                dx_parts[idx].append((task, res["dx"]))
         if not compute_grads:
-            return out
-
+            return task_loss, d_state
         # ---- scatter head input grads back to their layer states
         for l, parts in dx_parts.items():
             if not parts:
@@ -965,8 +996,20 @@ class Engine:
             ds = torch.empty(M, H, device=dev, dtype=BF16)
             ops.gather_sum_rows(cat, inv_t, len(parts), 1.0, ds)
             d_state[l] = ds
+        return task_loss, d_state
 
-        # ---- decoder backward (dgrad only: LLM frozen)
+    def _decoder_bwd(self, d_hidden, dec, d_state, plan):
+        """Backward of the decoder stack: dgrad only when the LLM is frozen (PT stage, ola_vlm_train.py:1127-1131), + weight gradients and
+        per-layer gradient buckets when cfg.train_llm (IFT stage).  Returns d inputs_embeds [M, H]."""
+        cfg, fz, ps = self.cfg, self.fz, self.ps
+        B, S = plan["B"], plan["S"]
+        M = B * S
+        nh, nkv, hd = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim
+        L = cfg.num_hidden_layers
+        cos_t, sin_t = self.rope(S)
+        kv_len = None if plan["full"] else plan["lens"]
+        window = self._attn_window()
+        x, rstd_f, saved = dec["x"], dec["rstd_f"], dec["saved"]
         if (L - 1) in d_state:
             ops.add(d_hidden, d_state[L - 1], out=d_hidden)
         train_llm = self.train_llm
@@ -1003,12 +1046,8 @@ class Engine:
                 self._wgrad(att.view(M, nh * hd), d_h1, ps.g(pl + "self_attn.o_proj.weight"))
             d_att = ops.gemm(d_h1, fz[o + "wo_T"])
             dqkv = torch.empty_like(qkv)
-            q4 = qkv.view(B, S, -1)[..., :nh * hd].view(B, S, nh, hd)
-            k4 = qkv.view(B, S, -1)[..., nh * hd:(nh + nkv) * hd].view(B, S, nkv, hd)
-            v4 = qkv.view(B, S, -1)[..., (nh + nkv) * hd:].view(B, S, nkv, hd)
-            dq4 = dqkv.view(B, S, -1)[..., :nh * hd].view(B, S, nh, hd)
-            dk4 = dqkv.view(B, S, -1)[..., nh * hd:(nh + nkv) * hd].view(B, S, nkv, hd)
-            dv4 = dqkv.view(B, S, -1)[..., (nh + nkv) * hd:].view(B, S, nkv, hd)
+            q4, k4, v4 = self._qkv_views(qkv, B, S)
+            dq4, dk4, dv4 = self._qkv_views(dqkv, B, S)
             if hd == 128 and not os.environ.get("VP_NO_FUSED_ROPE"):     # RoPE^T of dq / dk fused into the attention-backward stores
                 ops.attn_bwd(q4, k4, v4, att, lse, d_att.view(B, S, nh, hd), causal=True, window=window, kv_len=kv_len,
                              dq=dq4, dk=dk4, dv=dv4, rope=(cos_t, sin_t))
@@ -1025,11 +1064,14 @@ class Engine:
                 self._reduce_range(*self._llm_ranges[o])        # this layer's gradients are final
             dx = ops.rmsnorm_bwd(d_xn, x_in, fz[o + "ln1"], rstd1, dres=d_h1)
             saved[l] = None
-        out["d_inputs_embeds"] = self.present(dx, plan)
         if train_llm:                                           # embed_tokens.weight.grad: scatter-add of the text rows
             ops.scatter_add_rows_(ps.g("model.embed_tokens.weight"), dx, plan["embed_idx"])
+        return dx
 
-        # ---- splice backward: image rows -> projector, task-token rows -> special-token parameters
+    def _splice_bwd(self, dx, plan, feats, z1, a1):
+        """Backward of the splice and the projector: image rows -> mm_projector (a3), task-token rows -> special-token parameters (a4)."""
+        cfg, ps, dev = self.cfg, self.ps, self.dev
+        H = cfg.hidden_size
         d_img = torch.empty(max(plan["n_img"], 1) * N_IMG_TOK, H, device=dev, dtype=BF16)
         ops.gather_sum_rows(dx, plan["img_dst"], 1, 1.0, d_img)
         if plan["n_tok_rows"] > 0:
@@ -1047,11 +1089,9 @@ class Engine:
                         self._static[key] = (torch.arange(g.shape[0], device=dev, dtype=torch.int32) // grp + off).to(torch.int32)
                     ops.gather_sum_rows(d_tok, self._static[key], 1, 1.0 / grp, g, accumulate=True)
                 off += nr
-        # ---- projector backward
         d_a1 = self._lin_bwd(a1, d_img, "model.mm_projector.2.weight", "model.mm_projector.2.bias", need_dx=True)
         d_z1 = ops.act_bwd(d_a1, z1, ops.EPI_GELU)
         self._lin_bwd(feats, d_z1, "model.mm_projector.0.weight", "model.mm_projector.0.bias", need_dx=False)
-        return out
 
     # ------------------------------------------------------------------------------------------ targets
     def _prepare_targets(self, batch, B=None):

@@ -27,7 +27,8 @@ def register_auto_classes():
 
             def to_visper(self):
                 base = visper_cfg_cls().to_dict()
-                c = visper_cfg_cls(**{k: getattr(self, k) for k in base if hasattr(self, k)})
+                drop = getattr(visper_cfg_cls, "STORED_KEYS_IGNORED", ())
+                c = visper_cfg_cls(**{k: getattr(self, k) for k in base if hasattr(self, k) and k not in drop})
                 c.model_type = model_type
                 return c
         HFConfig.model_type = model_type

@@ -297,6 +297,7 @@ class EngineModule(nn.Module):
             size += nb
         shards.append(cur)
         cfgd = {k: (list(v) if isinstance(v, tuple) else v) for k, v in self.config.to_dict().items()}
+        cfgd.pop("task_token_layout", None)                            # derived by the model class (PT: pooled; IFT: from task_token_format)
         cfgd["model_type"] = getattr(self.config, "model_type", "ola_llama")
         cfgd["architectures"] = [type(self).__name__]
         with open(os.path.join(save_directory, "config.json"), "w") as fh:
@@ -324,6 +325,8 @@ class EngineModule(nn.Module):
             cfgd = json.load(fh)
         cfgd.pop("architectures", None)
         cfgd.pop("model_type", None)                                 # the loading CLASS names the model type (a PT directory loaded into the
+        for k in getattr(cls.config_class, "STORED_KEYS_IGNORED", ()):   # (IFT classes: trainability belongs to the class, not to the checkpoint)
+            cfgd.pop(k, None)
         cfgd.update(config_overrides)                                # IFT class is a llava_* model from then on), not the stored string
         config = cls.config_class(**cfgd)
         model = cls(config, device=device, dtype=dtype, init="empty")
@@ -351,6 +354,8 @@ class _OlaCausalLMBase(OlaLlavaMetaForCausalLM, BaseOLA_VLM, EngineModule):
     model_cls = OlaLlavaLlamaModel
 
     def __init__(self, config, device="cuda", dtype=torch.bfloat16, init="random", seed=0):
+        # the PT stage always pools the depth / seg task tokens (ola_arch.py:224-254), whatever an IFT-stage class left in a reused config
+        config.task_token_layout = "pooled"
         EngineModule.__init__(self, config, device=device, dtype=dtype, init=init, seed=seed)
         self.NUM_SYS_TOKENS = config.num_sys_tokens                   # ola_llama.py:65-69 / ola_phi3.py:68
         self.init_heads(config)

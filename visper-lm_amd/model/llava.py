@@ -40,6 +40,12 @@ def _ift_kwargs(kw):
     are ignored; the only way to freeze the LLM in these classes is the explicit `freeze_llm=True` (constructor or from_pretrained
     override; the analogue of train.py's `freeze_backbone`)."""
     kw = dict(kw)
+    if kw.get("train_llm") is False:
+        # an explicit constructor argument (the loaders drop a STORED train_llm / aux_heads before they get here: STORED_KEYS_IGNORED):
+        # say loudly that the value is not honoured
+        import warnings
+        warnings.warn("train_llm=False is ignored by the IFT-stage classes (a PT checkpoint's config always carries it); pass freeze_llm=True "
+                      "to keep the LLM frozen", stacklevel=3)
     freeze = bool(kw.pop("freeze_llm", False))
     for k in ("train_llm", "aux_heads", "model_type"):
         kw.pop(k, None)
@@ -51,6 +57,7 @@ class LlavaConfig(VisperConfig):
     A PT-stage checkpoint's config carries aux_mode / num_task_tokens / task_token_format and is honoured (llava_arch.py:49-50,
     67-94): the task-token rows are spliced in the layout `task_token_format` names (LlavaMetaForCausalLM below)."""
     model_type = "llava_llama"
+    STORED_KEYS_IGNORED = ("train_llm", "aux_heads")       # dropped from a loaded config.json (EngineModule.from_pretrained, hf_auto)
 
     def __init__(self, **kw):
         super().__init__(**_ift_kwargs(kw))
@@ -58,6 +65,7 @@ class LlavaConfig(VisperConfig):
 
 class LlavaPhi3Config(VisperConfig):
     model_type = "llava_phi3"
+    STORED_KEYS_IGNORED = ("train_llm", "aux_heads")
 
     def __init__(self, **kw):
         base = phi3_mini().to_dict()

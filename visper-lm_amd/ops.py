@@ -203,9 +203,9 @@ def rmsnorm_bwd_w(dy, x, rstd, out=None):
     nslab = (M + rpb - 1) // rpb
     pw = torch.empty(nslab, H, device=x.device, dtype=torch.float32)
     pb = torch.empty(nslab, H, device=x.device, dtype=torch.float32)
-    zero = _ZEROS_F32.get((M, x.device))
-    if zero is None:
-        zero = _ZEROS_F32[(M, x.device)] = torch.zeros(M, device=x.device, dtype=torch.float32)
+    zero = _ZEROS_F32.get(x.device)                     # ONE zeros buffer per device, grown to the largest M seen (ragged batches change M every step)
+    if zero is None or zero.numel() < M:
+        zero = _ZEROS_F32[x.device] = torch.zeros(max(M, 2 * (zero.numel() if zero is not None else 0)), device=x.device, dtype=torch.float32)
     _lib.call("vp_layernorm_bwd_wb_partial", M, H, _p(dy), _p(x), _p(zero), _p(rstd), _p(pw), _p(pb), ld, rpb, _stream())
     dw = torch.empty(H, device=x.device, dtype=torch.float32) if out is None else out
     _lib.call("vp_colsum_finish", nslab, H, _p(pw), _p(dw), 1.0, 0, _stream())
