@@ -266,6 +266,55 @@ def run_tiny_llama(arch="llama"):
     return model
 
 
+def run_tiny_ragged():
+    """Padded rows (VERDICT r3 next-6 follow-up).  A right-padded batch: sample 1 is 17 tokens shorter (attention_mask False on its tail) in one
+    run and carries NO <image> token in the other, so its tail of the spliced sequence is padding (ola_arch.py:337-338, 408-427).  The reference
+    does not mask padded QUERY rows anywhere, their hidden states are real numbers (position ids: the caller passes none, so the reference hands
+    `position_ids=None` on, ola_arch.py:439-440, and HF numbers every row of the padded tensor 0..S-1) and forward_emb_predictor feeds them to the
+    heads of the shorter sample (base_ola_vlm.py:413-443).  The fixture pins those rows: final hidden states of EVERY row of sample 1, every
+    layer's loss triple, and the gen / depth predictions per sample."""
+    B, T, col = 2, 59, 38
+    res = {}
+    for tag in ("short", "noimg"):
+        ids, labels, images, tg, td, ts = make_batch(B, T, col)
+        am = torch.ones_like(ids, dtype=torch.bool)
+        if tag == "short":
+            am[1, 42:] = False
+        else:
+            ids[1, col] = 7
+        model, shapes = _fresh_tiny_llama(B, TINY_LLAMA, "llama")
+        model._get_gen_feats = lambda pil, dev: tg
+        model._get_seg_targets = lambda pil, h: ts
+        model._get_dav2_feats = lambda pil, dev: ([(td, None)], torch.zeros(B, 336, 336))
+        captured = []
+        orig = model._emb_loss
+
+        def spy(preds, mask, tgt, scale, orig=orig):
+            r = orig(preds, mask, tgt, scale)
+            captured.append((tuple(preds.shape), [float(x) for x in r], preds.detach().float().reshape(preds.shape[0], -1)[:, ::max(1, preds[0].numel() // 509)].numpy().copy()))
+            return r
+        model._emb_loss = spy
+        mk = lambda: torch.ones(B).as_subclass(KeepMask)
+        with torch.no_grad():
+            out = model(input_ids=ids, attention_mask=am, labels=labels, images=images, pil_images=[None] * B,
+                        gen_mask=mk(), seg_mask=mk(), depth_mask=mk())
+        hs = out.hidden_states
+        res[f"{tag}_loss"] = np.float64(out.loss.item())
+        res[f"{tag}_layer_losses"] = np.array([c[1] for c in captured], dtype=np.float64)
+        res[f"{tag}_layer_shapes"] = json.dumps([c[0] for c in captured])
+        for j, c in enumerate(captured):
+            res[f"{tag}_pred{j}_sub"] = c[2]                                # [B, ~509 strided elements]: per sample
+        res[f"{tag}_hidden_last_sample1"] = hs[-1][1, :, ::3].detach().numpy().copy()       # every row (real and padded), every 3rd feature
+        res[f"{tag}_hidden2_sample1"] = hs[2][1, :, ::3].detach().numpy().copy()
+        res[f"{tag}_input_ids"] = ids.numpy()
+        res[f"{tag}_attention_mask"] = am.numpy()
+        res[f"{tag}_labels"] = labels.numpy()
+        print(f"tiny_ragged/{tag}: loss {res[f'{tag}_loss']:.6f}, S = {hs[-1].shape[1]}, layer losses\n", res[f"{tag}_layer_losses"])
+    res["cfg"] = json.dumps(TINY_LLAMA)
+    res["batch"] = json.dumps([B, T, col])
+    np.savez_compressed(os.path.join(OUT, "tiny_llama_ragged.npz"), **res)
+
+
 def run_tiny_ift(task_tokens=None):
     """IFT-stage golden: the reference's LlavaLlamaForCausalLM (llava_llama.py:50-119 + llava_arch.py:300-486, NTP loss
     only) with everything but the vision tower trainable (scripts/train/finetune.sh) -> loss + the norm and a subsample of EVERY
@@ -679,7 +728,7 @@ if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
     setup_reference()
-    which = sys.argv[1:] or ["units", "llama", "phi3", "ift", "ift_tok", "nt0", "data", "dino", "clipemb", "swin", "convnext"]
+    which = sys.argv[1:] or ["units", "llama", "phi3", "ift", "ift_tok", "nt0", "data", "dino", "clipemb", "swin", "convnext", "ragged"]
     if "units" in which:
         run_units()
     if "llama" in which:
@@ -702,3 +751,5 @@ if __name__ == "__main__":
         run_swin_teacher()
     if "convnext" in which:
         run_convnext()
+    if "ragged" in which:
+        run_tiny_ragged()

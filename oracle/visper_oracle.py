@@ -763,7 +763,10 @@ def forward(W, batch, cfg, rank=0, gathered=None, need_logits=True):
     feats = encode_images(batch["images"], W, cfg)
     pid, am, emb, labels = prepare_inputs_labels_for_multimodal(
         batch["input_ids"], batch.get("attention_mask"), batch.get("labels"), feats, W, cfg)
-    hidden, states = decoder_forward(emb, pid, am, W, cfg)
+    # the training caller passes no position_ids, so the reference drops the ones it built (`if _position_ids is None: position_ids = None`,
+    # ola_arch.py:439-440) and HF numbers EVERY row of the padded tensor 0..S-1 — padded rows included (they are real query rows whose states the
+    # shorter samples' heads read: pinned by tests/golden/tiny_llama_ragged.npz)
+    hidden, states = decoder_forward(emb, pid if batch.get("position_ids") is not None else None, am, W, cfg)
     logits, text_loss = ntp_loss(hidden, labels, W, cfg, keep_logits=need_logits)
     out = dict(text_loss=text_loss, logits=logits, labels=labels,
                inputs_embeds=emb, image_features=feats, hidden=hidden, layer_states=states,

@@ -332,9 +332,41 @@ def test_edge_sample_without_image():
     """ola_arch.py:344-355: a sample with no <image> token consumes an empty feature slot and carries no image / task rows."""
     def mutate(b):
         b["input_ids"][1, 38] = 7
-    # the text-only sample feeds ~600 rows of padding-position states into every head's cross-attention: the softmax gradients
-    # (to_q / to_kv) are the noisiest in bf16, hence the slightly wider bar
-    _edge_case({}, mutate, min_cos=0.90, tag="edge_no_image", max_norm=8e-2)
+    # the text-only sample feeds ~600 rows of padding-position states into every head's cross-attention.  (Rounds 1-3 ran this case with a 0.90
+    # cosine bar: the ORACLE numbered padded rows 0 instead of their row index — fixed in round 4 against tests/golden/tiny_llama_ragged.npz; measured
+    # now: 1 - cos 4.3e-4, norm 5.6e-3, the default bars hold.)
+    _edge_case({}, mutate, tag="edge_no_image")
+
+
+@pytest.mark.parametrize("tag", ["short", "noimg"])
+def test_padded_rows_match_reference_golden(tag):
+    """tests/golden/tiny_llama_ragged.npz = the REFERENCE on a right-padded batch (sample 1 shorter / without an image).  Padded query rows are
+    real rows in the reference (never masked, positions 0..S-1 over the padded tensor: ola_arch.py:439-440) and the shorter sample's heads read
+    them (base_ola_vlm.py:413-443), so the engine must reproduce their hidden states, not just the real rows': final hidden state of EVERY row
+    of sample 1, loss, and every layer's loss triple against the reference's own numbers (fp32 golden vs bf16 compute: bounds are the dtype's)."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from oracle import cases
+    from visper_lm_amd.config import VisperConfig
+    from visper_lm_amd.engine import Engine
+    ocfg, W, batch, _ = cases.tiny_llama_case()
+    g = cases.load_golden("tiny_llama_ragged.npz")
+    batch = dict(batch, input_ids=torch.from_numpy(g[f"{tag}_input_ids"]), attention_mask=torch.from_numpy(g[f"{tag}_attention_mask"]),
+                 labels=torch.from_numpy(g[f"{tag}_labels"]))
+    eng = Engine(VisperConfig(**vars(ocfg)))
+    eng.load_weights(W)
+    out = eng.train_step(_to_gpu_batch(batch))
+    n = int(out["plan"]["lens_host"][1])
+    hid = out["hidden"].float().cpu()[1, :, ::3]
+    ref = torch.from_numpy(g[f"{tag}_hidden_last_sample1"])
+    assert hid.shape == ref.shape and 0 < n < hid.shape[0]
+    check(f"ragged_golden_{tag}/loss_rel", rel(out["loss"], g[f"{tag}_loss"]), 1e-3)
+    check(f"ragged_golden_{tag}/hidden_real_rows_maxrel", max_rel(hid[:n], ref[:n]), 4e-2)
+    check(f"ragged_golden_{tag}/hidden_padded_rows_maxrel", max_rel(hid[n:], ref[n:]), 4e-2)
+    names = [("depth", 2), ("seg", 1), ("seg", 2), ("gen", 3)]
+    for i, key in enumerate(names):
+        mine = out["layer_losses"][key].float().cpu().numpy()
+        check(f"ragged_golden_{tag}/layer_loss/{key[0]}@{key[1]}", _trip_err(mine, g[f"{tag}_layer_losses"][i]), 1e-2)
 
 
 def test_edge_truncation():

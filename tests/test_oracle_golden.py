@@ -300,3 +300,26 @@ def test_swin_seg_teacher_matches_hf():
     assert tuple(tgt.shape) == tuple(g["target_shape"])
     _close(tgt[:, ::5, ::3, ::3].numpy(), g["target_sub"], 1e-3, 5e-5)
     _close(float(tgt.double().std()), g["target_std"], 1e-4, 1e-6)
+
+
+@pytest.mark.parametrize("tag", ["short", "noimg"])
+def test_padded_rows_match_reference(tag):
+    """tests/golden/tiny_llama_ragged.npz (oracle/gen_golden.py run_tiny_ragged): a right-padded batch through the REFERENCE.  Padded query rows
+    are never masked; with no position_ids from the caller the reference hands `position_ids=None` on (ola_arch.py:439-440) and HF numbers all rows
+    of the padded tensor 0..S-1, and forward_emb_predictor feeds those rows to the shorter sample's heads (base_ola_vlm.py:413-443).  The oracle
+    must reproduce the hidden states of EVERY row of the short sample, every layer's loss triple and the per-sample predictions."""
+    cfg, W, batch, _ = cases.tiny_llama_case()
+    g = cases.load_golden("tiny_llama_ragged.npz")
+    batch = dict(batch, input_ids=torch.from_numpy(g[f"{tag}_input_ids"]), attention_mask=torch.from_numpy(g[f"{tag}_attention_mask"]),
+                 labels=torch.from_numpy(g[f"{tag}_labels"]))
+    with torch.no_grad():
+        out = O.forward(W, batch, cfg, need_logits=False)
+    _close(float(out["loss"]), g[f"{tag}_loss"], 2e-5, 1e-6)
+    hs = out["layer_states"]
+    _close(hs[-1][1, :, ::3].numpy(), g[f"{tag}_hidden_last_sample1"], 1e-3, 2e-4)          # post-norm final state: real AND padded rows
+    _close(hs[1][1, :, ::3].numpy(), g[f"{tag}_hidden2_sample1"], 1e-3, 2e-4)               # hidden_states[2] = output of layer 2
+    shapes = json.loads(str(g[f"{tag}_layer_shapes"]))
+    names = [("depth", 2), ("seg", 1), ("seg", 2), ("gen", 3)]
+    assert len(shapes) == len(names)
+    for i, key in enumerate(names):
+        _close([float(x) for x in out["layer_losses"][key]], g[f"{tag}_layer_losses"][i], 2e-5, 1e-6)

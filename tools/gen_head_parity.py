@@ -34,7 +34,18 @@ def run(tag, mutate):
         cpu = [float(x) for x in rbf["layer_losses"][key]]
         e = lambda a: [abs(x - y) / max(abs(y), 1e-6) for x, y in zip(a, t32)]
         print(f"{tag} {key}: truth {[round(x, 5) for x in t32]} | HIP rel err {['%.1e' % x for x in e(hip)]} | bf16-CPU rel err {['%.1e' % x for x in e(cpu)]}")
-    for task in ("gen", "seg", "depth"):
+    hh, h32, hb = out["hidden"].float().cpu(), r32["hidden"].float(), rbf["hidden"].float()
+    lens = out["plan"]["lens_host"]
+    for b in range(hh.shape[0]):
+        n = int(lens[b])
+        for nm, sl in (("real rows", slice(0, n)), ("padded rows", slice(n, hh.shape[1]))):
+            if hh[b, sl].numel() == 0:
+                continue
+            ref = h32[b, sl]
+            rms = float(ref.pow(2).mean().sqrt())
+            print(f"{tag} hidden sample {b} {nm} ({ref.shape[0]} rows, rms {rms:.3f}): HIP rms err {float((hh[b, sl] - ref).pow(2).mean().sqrt()) / max(rms, 1e-9):.2e} | "
+                  f"bf16-CPU rms err {float((hb[b, sl] - ref).pow(2).mean().sqrt()) / max(rms, 1e-9):.2e}")
+    for task in ("gen", "depth"):
         p32 = r32[f"{task}_embs"][0]
         p32 = (p32[0] if isinstance(p32, (list, tuple)) else p32).float().reshape(-1)
         pb = rbf[f"{task}_embs"][0]
@@ -45,6 +56,10 @@ def run(tag, mutate):
             print(f"{tag} {task}: pred shapes differ {ph.shape} {p32.shape}")
             continue
         rms = float(p32.pow(2).mean().sqrt())
+        nb = hh.shape[0]
+        for b in range(nb):
+            sl = slice(b * p32.numel() // nb, (b + 1) * p32.numel() // nb)
+            print(f"{tag} {task} pred sample {b}: HIP rms err {float((ph[sl] - p32[sl]).pow(2).mean().sqrt()) / rms:.2e} | bf16-CPU {float((pb[sl] - p32[sl]).pow(2).mean().sqrt()) / rms:.2e}")
         for nm, x in (("HIP", ph), ("bf16-CPU", pb)):
             d = x - p32
             print(f"{tag} {task} pred ({p32.numel()} el, rms {rms:.3f}): {nm} rms err {float(d.pow(2).mean().sqrt()) / rms:.2e} max err {float(d.abs().max()) / rms:.2e} mean err {float(d.mean()) / rms:+.2e}")

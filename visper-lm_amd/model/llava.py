@@ -70,6 +70,8 @@ class LlavaPhi3Config(VisperConfig):
     def __init__(self, **kw):
         base = phi3_mini().to_dict()
         base.pop("model_type", None)                     # phi3_mini() tags its instance "ola_phi3": would shadow the class attribute
+        for k in self.STORED_KEYS_IGNORED:               # (the preset's PT-stage defaults, not a caller's choice)
+            base.pop(k, None)
         super().__init__(**_ift_kwargs({**base, **kw}))
 
 
