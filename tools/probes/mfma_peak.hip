@@ -5,12 +5,19 @@
 typedef __attribute__((ext_vector_type(8))) short bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
+// random bf16 in (-2, 2) (random sign, exponent 0x3e..0x3f, random mantissa) when seed0 != 0: data-dependent power is real (zeroed / constant
+// operands clock ~19 % higher: MI355X_MICROARCH.md), so the probe runs on random bits like the GEMM does
+__device__ inline short rnd_bf16(unsigned k, short keep) {
+  if (keep == 0) return 0;
+  k ^= k >> 16; k *= 0x7feb352du; k ^= k >> 15; k *= 0x846ca68bu; k ^= k >> 16;
+  return (short)(((k & 1u) << 15) | (0x3e80u + ((k >> 1) & 0xffu)) | ((k >> 9) & 0x7fu));
+}
 __global__ __launch_bounds__(512) void k16(float* out, int iters, bf16x8 a0, bf16x8 b0) {
   f32x4 acc[32];
   for (int i = 0; i < 32; ++i) acc[i] = f32x4{0, 0, 0, 0};
   bf16x8 a[8], b[4];
-  for (int i = 0; i < 8; ++i) { a[i] = a0; a[i][0] += threadIdx.x + i; }
-  for (int j = 0; j < 4; ++j) { b[j] = b0; b[j][1] += threadIdx.x + j; }
+  for (int i = 0; i < 8; ++i) { a[i] = a0; for (int e = 0; e < 8; ++e) a[i][e] = rnd_bf16(threadIdx.x * 131 + i * 17 + e, a0[e]); }
+  for (int j = 0; j < 4; ++j) { b[j] = b0; for (int e = 0; e < 8; ++e) b[j][e] = rnd_bf16(threadIdx.x * 257 + j * 29 + e + 7, b0[e]); }
   for (int it = 0; it < iters; ++it) {
 #pragma unroll
     for (int i = 0; i < 8; ++i)
@@ -25,8 +32,8 @@ __global__ __launch_bounds__(512) void k32(float* out, int iters, bf16x8 a0, bf1
   f32x16 acc[8];
   for (int i = 0; i < 8; ++i) for (int e = 0; e < 16; ++e) acc[i][e] = 0;
   bf16x8 a[4], b[2];
-  for (int i = 0; i < 4; ++i) { a[i] = a0; a[i][0] += threadIdx.x + i; }
-  for (int j = 0; j < 2; ++j) { b[j] = b0; b[j][1] += threadIdx.x + j; }
+  for (int i = 0; i < 4; ++i) { a[i] = a0; for (int e = 0; e < 8; ++e) a[i][e] = rnd_bf16(threadIdx.x * 131 + i * 17 + e, a0[e]); }
+  for (int j = 0; j < 2; ++j) { b[j] = b0; for (int e = 0; e < 8; ++e) b[j][e] = rnd_bf16(threadIdx.x * 257 + j * 29 + e + 7, b0[e]); }
   for (int it = 0; it < iters; ++it) {
 #pragma unroll
     for (int r = 0; r < 2; ++r)
@@ -44,7 +51,7 @@ int main() {
   bf16x8 a = {0x3f80, 0x3f00, 0x3e80, 0x3f80, 0x3f00, 0x3e80, 0x3f80, 0x3f00}, b = a;
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   for (int blocks : {256, 512}) {
-    const int iters = 4000;
+    const int iters = 40000;
     for (int which = 0; which < 2; ++which) {
       for (int rep = 0; rep < 2; ++rep) {
         hipEventRecord(e0);

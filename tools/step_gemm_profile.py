@@ -17,7 +17,7 @@ e0.record(); eng.train_step(batch); eng.optimizer_step(1e-3); e1.record(); torch
 prof, ops.GEMM_PROF = ops.GEMM_PROF, None
 agg = collections.defaultdict(lambda: [0, 0.0, 0.0])
 for a, b, fl, shp, _kind in prof:
-    r = agg[shp]; r[0] += 1; r[1] += a.elapsed_time(b); r[2] += fl
+    r = agg[(shp, _kind)]; r[0] += 1; r[1] += a.elapsed_time(b); r[2] += fl
 tot = sum(r[1] for r in agg.values())
 print(f"step {e0.elapsed_time(e1):.1f} ms, GEMM {tot:.1f} ms in {len(prof)} launches")
 for shp, (n, ms, fl) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:40]:

@@ -46,6 +46,24 @@ static __device__ __forceinline__ bf16x8 tr_join(s16x4 lo, s16x4 hi) {
   return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 }
 #define ATTN_LGKM(N) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory")
+// LDS-DMA through a buffer descriptor (`buffer_load ... lds`): wave-uniform descriptor (base of the tensor slice, num_records in BYTES: everything
+// past it reads as zeros, also when the scalar offset carries the position past the end — checked on gfx950 with tools/probes/buf_range_probe.hip),
+// ONE loop-invariant 32-bit lane offset per operand, the tile's row / head offset in the scalar offset, the LDS destination in m0: no 64-bit
+// address arithmetic and no row clamps per piece.
+typedef uint32_t fwdm_u32x4s __attribute__((ext_vector_type(4)));
+static __device__ __forceinline__ fwdm_u32x4s attn_make_rs(const void* base, long bytes) {
+  const uint64_t a = (uint64_t)(uintptr_t)base;
+  fwdm_u32x4s r;
+  r[0] = __builtin_amdgcn_readfirstlane((uint32_t)a);
+  r[1] = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32) & 0xffffu);
+  r[2] = __builtin_amdgcn_readfirstlane((uint32_t)bytes);
+  r[3] = 0x00020000u;
+  return r;
+}
+#define ATTN_DMA16(M0, VOFF, RS, SOFF)                                                                          \
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(M0), "v"(VOFF), "s"(RS), "s"(SOFF) : "memory")
+#define ATTN_DMA4(M0, VOFF, RS, SOFF)                                                                           \
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, %3 offen lds" ::"s"(M0), "v"(VOFF), "s"(RS), "s"(SOFF) : "memory")
 #define ATTN_PIN(F) asm volatile("" : "+v"(F))
 
 // store one row's 128 features (this lane: blocks d = 0..7, features d*16 + 4g + r) as bf16, optionally rotated back by RoPE^T:
@@ -130,33 +148,36 @@ void attn_bwd_dkdv128_kernel(AttnParams p) {
 
   // DMA geometry: instruction i of this wave fills rows (i*4 + wave)*4 .. +3 of a tile; lane -> (row, 16-byte slot).
   // Rows r and r+16 share the swizzle phase, so both instructions use the same source chunk.
-  // Everything derived from the lane id is RE-derived inside the loop behind an opaque asm: the register budget is full
-  // (dk/dv 128 + K/V fragments 64), and hipcc would otherwise spill these loop invariants to scratch and reload them with
-  // s_waitcnt vmcnt(0) -- which drains the DMA queue every iteration.
-  auto issue = [&](int t, int st, int ln) {
-    const int tc = min(t, nit - 1);                    // past the end: harmless re-fetch keeps the vmcnt bookkeeping uniform
-    const int hh = tc / ntq;
-    const int h = hk * rep + hh, q0 = qstart + (tc - hh * ntq) * 32;
-    bf16_t* sb = ring + st * DKDV128_STAGE;
-    const char* qb = (const char*)(p.q + (long)b * p.q_bs + (long)h * D);      // wave-uniform bases + 32-bit lane offsets
-    const char* gb = (const char*)(p.dout + (long)b * p.do_bs + (long)h * D);
-    const unsigned qts = (unsigned)p.q_ts, gts = (unsigned)p.do_ts;
+  // Pieces go through buffer descriptors (one per batch element, covering every head and row of q / dO / the (lse, delta) pairs: rows past Sq read
+  // as zeros) with the tile's row and head in the SCALAR offset; the lane offsets are re-derived from the lane id per call behind an opaque asm
+  // (32-bit, ~6 VALU): the register budget is full (dk/dv 128 + K/V fragments 64), and hipcc would otherwise spill loop invariants to scratch and
+  // reload them with s_waitcnt vmcnt(0) -- which drains the DMA queue every iteration.  The flattened (head, q tile) index is walked by two
+  // scalar counters instead of a division per tile.
+  const fwdm_u32x4s rsQ = attn_make_rs(p.q + (long)b * p.q_bs, (((long)p.Sq - 1) * p.q_ts + (long)p.Hq * D) * 2);
+  const fwdm_u32x4s rsG = attn_make_rs(p.dout + (long)b * p.do_bs, (((long)p.Sq - 1) * p.do_ts + (long)p.Hq * D) * 2);
+  const fwdm_u32x4s rsP = attn_make_rs(pairs + (long)b * p.Hq * p.Sq * 2, (long)p.Hq * p.Sq * 2 * 4);
+  const uint32_t ldsb = attn_lds_addr(attn_smem);
+  const uint32_t qts2 = __builtin_amdgcn_readfirstlane((uint32_t)(p.q_ts * 2)), gts2 = __builtin_amdgcn_readfirstlane((uint32_t)(p.do_ts * 2));
+  int ih = 0, iq = 0;                                  // (head within the group, q tile) of the NEXT tile to issue
+  auto issue = [&](int st, int ln) {                   // (past the end: a harmless re-fetch of the last tile keeps the vmcnt bookkeeping uniform)
+    const uint32_t h = (uint32_t)(hk * rep + ih), q0 = (uint32_t)(qstart + iq * 32);
+    const uint32_t soQ = q0 * qts2 + h * (uint32_t)(D * 2), soG = q0 * gts2 + h * (uint32_t)(D * 2);
+    const uint32_t m0s = ldsb + (uint32_t)(st * DKDV128_STAGE * 2);
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
       const int blk = i * NW + wave;                   // 4-row group of the tile this instruction fills
       const int drow = blk * 4 + (ln >> 4);
       int dch = ((ln & 15) ^ (drow & 15)) * 8;
-      if (D < 128 && dch >= D) dch = 0;                  // (a chunk no fragment read ever touches: keep its source inside the tensor)
-      const unsigned r = (unsigned)min(q0 + drow, p.Sq - 1);
-      ATTN_GLDS(qb + (size_t)((r * qts + dch) * 2u), sb + blk * 512, 16);
-      ATTN_GLDS(gb + (size_t)((r * gts + dch) * 2u), sb + 4096 + blk * 512, 16);
+      if (D < 128 && dch >= D) dch = 0;                  // (a chunk no fragment read ever touches: keep its source inside the head)
+      const uint32_t vq = (uint32_t)drow * qts2 + (uint32_t)dch * 2u, vg = (uint32_t)drow * gts2 + (uint32_t)dch * 2u;
+      ATTN_DMA16(m0s + (uint32_t)(blk * 1024), vq, rsQ, soQ);
+      ATTN_DMA16(m0s + (uint32_t)(8192 + blk * 1024), vg, rsG, soG);
     }
-    if (wave == 0) {
-      const long qi = min(q0 + (ln >> 1), p.Sq - 1);
-      ATTN_GLDS(pairs + (((long)b * p.Hq + h) * p.Sq + qi) * 2 + (ln & 1), sb + 8192, 4);
-    }
+    if (wave == 0) ATTN_DMA4(m0s + 16384u, (uint32_t)ln * 4u, rsP, (h * (uint32_t)p.Sq + q0) * 8u);
+    if (ih * ntq + iq + 1 < nit) { if (++iq == ntq) { iq = 0; ++ih; } }
   };
-  if (nit > 0) { issue(0, 0, lane); issue(1, 1, lane); issue(2, 2, lane); }
+  if (nit > 0) { issue(0, lane); issue(1, lane); issue(2, lane); }
+  int cq = 0;                                          // q tile (within its head) of the tile being consumed
   for (int it = 0; it < nit; ++it) {
     // tile `it` landed (this wave's part): at most the two younger stages may still be in flight
     if (wave == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (2 * NI + 1)) : "memory");
@@ -166,7 +187,7 @@ void attn_bwd_dkdv128_kernel(AttnParams p) {
     __builtin_amdgcn_sched_barrier(0);
     int ln = threadIdx.x & 63;
     asm volatile("" : "+v"(ln));                       // opaque: see the note above `issue`
-    issue(it + 3, (it + 3) & 3, ln);
+    issue((it + 3) & 3, ln);
     const int fr = ln & 15, g = ln >> 4;
     // LDS fragment addressing: the swizzle is an XOR on the chunk bits, so one base per read kind + compile-time XOR masks
     const int rbase = fr * 128 + ((g ^ fr) << 3);                         // row-wise: (row fr, chunk g) ^ (ks*4 chunks), + qt*16 rows
@@ -175,8 +196,8 @@ void attn_bwd_dkdv128_kernel(AttnParams p) {
     const bf16_t* Qs = ring + (it & 3) * DKDV128_STAGE;
     const bf16_t* dOs = Qs + 4096;
     const float* ld = (const float*)(Qs + 8192);
-    const int hh = it / ntq;
-    const int q0 = qstart + (it - hh * ntq) * 32;
+    const int q0 = qstart + cq * 32;
+    if (++cq == ntq) cq = 0;
     // wave-uniform skip: every query of this tile is below this wave's first key (causal) -> all p = 0
     const bool active = !CAUSAL || (q0 + 31 + off >= kw0);
     if (active) {
@@ -332,21 +353,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   int kstart = 0;
   if (p.window > 0) kstart = max(0, (q0 + off - p.window + 1)) & ~31;
   const int nit = kend > kstart ? (kend - kstart + 31) / 32 : 0;
-  const char* kb = (const char*)(p.k + (long)b * p.k_bs + (long)hk * D);
-  const char* vb = (const char*)(p.v + (long)b * p.v_bs + (long)hk * D);
+  // K / V pieces through buffer descriptors of this (batch, kv head) (rows past Skv read as zeros), the tile's row offset in the scalar offset
+  const fwdm_u32x4s rsK = attn_make_rs(p.k + (long)b * p.k_bs + (long)hk * D, (((long)p.Skv - 1) * p.k_ts + D) * 2);
+  const fwdm_u32x4s rsV = attn_make_rs(p.v + (long)b * p.v_bs + (long)hk * D, (((long)p.Skv - 1) * p.v_ts + D) * 2);
+  const uint32_t ldsb = attn_lds_addr(attn_smem);
+  const uint32_t kts2 = __builtin_amdgcn_readfirstlane((uint32_t)(p.k_ts * 2)), vts2 = __builtin_amdgcn_readfirstlane((uint32_t)(p.v_ts * 2));
 
   auto issue = [&](int t, int st, int ln) {            // lane-derived values are re-derived per call (see the dK/dV kernel)
-    const int k0 = kstart + min(t, nit - 1) * 32;
+    const uint32_t k0 = (uint32_t)(kstart + min(t, nit - 1) * 32);
     const int drow = wave * 4 + (ln >> 4);
     int dch = ((ln & 15) ^ (drow & 15)) * 8;
     if (D < 128 && dch >= D) dch = 0;                    // (never read: see attn_bwd_dkdv128_kernel)
-    bf16_t* sb = ring + st * DQ128_STAGE;
-    const unsigned r0 = (unsigned)min(k0 + drow, p.Skv - 1), r1 = (unsigned)min(k0 + drow + 16, p.Skv - 1);
-    const unsigned kts = (unsigned)p.k_ts, vts = (unsigned)p.v_ts;
-    ATTN_GLDS(kb + (size_t)((r0 * kts + dch) * 2u), sb + wave * 512, 16);
-    ATTN_GLDS(kb + (size_t)((r1 * kts + dch) * 2u), sb + (4 + wave) * 512, 16);
-    ATTN_GLDS(vb + (size_t)((r0 * vts + dch) * 2u), sb + 4096 + wave * 512, 16);
-    ATTN_GLDS(vb + (size_t)((r1 * vts + dch) * 2u), sb + 4096 + (4 + wave) * 512, 16);
+    const uint32_t vk = (uint32_t)drow * kts2 + (uint32_t)dch * 2u, vv = (uint32_t)drow * vts2 + (uint32_t)dch * 2u;
+    const uint32_t m0s = ldsb + (uint32_t)(st * DQ128_STAGE * 2 + wave * 1024);
+    ATTN_DMA16(m0s, vk, rsK, k0 * kts2);
+    ATTN_DMA16(m0s + 4096u, vk, rsK, (k0 + 16u) * kts2);
+    ATTN_DMA16(m0s + 8192u, vv, rsV, k0 * vts2);
+    ATTN_DMA16(m0s + 8192u + 4096u, vv, rsV, (k0 + 16u) * vts2);
   };
   if (nit > 0) { issue(0, 0, lane); issue(1, 1, lane); issue(2, 2, lane); }
   for (int it = 0; it < nit; ++it) {
@@ -464,7 +487,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 //   * a 1 KB K or V fragment feeds a 32x32x16 MFMA = 16 K MACs (the 16-row kernel: 8 K) -> half the LDS bytes per flop.
 // ================================================================================================
 typedef __attribute__((ext_vector_type(16))) float f32x16;
-typedef uint32_t fwdm_u32x4s __attribute__((ext_vector_type(4)));
 // ring: [K stage 0..3 (64 keys x 128 features, 16 KB each)] [V stage 0..3]: every K fragment address is one loop-invariant VGPR + a 16-bit
 // immediate (stage, key block), every V fragment address likewise (the loop is unrolled by four, so the stage is a literal)
 constexpr int FWDM_LDS = 8 * 64 * 128 * 2;            // bytes (128 KB)

@@ -159,7 +159,7 @@ class LazyRandomWeights:
 
 
 class Engine:
-    def __init__(self, cfg, device="cuda", lm_chunk_rows=8192):
+    def __init__(self, cfg, device="cuda", lm_chunk_rows=16384):
         if not torch.cuda.is_available():
             raise RuntimeError("visper_lm_amd.Engine needs a HIP device: there is no CPU fallback path")
         self.cfg = cfg
@@ -881,6 +881,26 @@ class Engine:
             states[L - 1] = hidden              # layer_states[-1] is the post-norm state (ola_llama.py:117-119)
         return dict(x=x, hidden=hidden, rstd_f=rstd_f, saved=saved, states=states)
 
+    def _lm_chunk(self, Mc, H):
+        """Rows per lm_head chunk: whole 256-row tiles, at most lm_chunk_rows (the bf16 logits of a chunk are the step's largest transient:
+        rows x V x 2 bytes), chosen so that the d_hidden GEMM — K = V is so long that one 256 x 256 tile takes milliseconds, and it has only
+        rows / 256 x H / 256 tiles — wastes the fewest persistent-grid rounds: 11 264 labelled rows as 2 x 5632 = 2 x (352 tiles = 1.4 rounds of
+        256 CUs -> 2) = 4 rounds, as one chunk = 704 tiles = 3 rounds (measured in the step: 9.7 -> 8.1 ms for that GEMM)."""
+        cus = 256
+        tn = max(1, (H + 255) // 256)
+        best = None
+        n0 = max(1, (Mc + self.lm_chunk_rows - 1) // self.lm_chunk_rows)
+        for n in range(n0, n0 + 4):
+            R = ((Mc + n - 1) // n + 255) // 256 * 256
+            rounds, r0 = 0, 0
+            while r0 < Mc:
+                rows = min(R, Mc - r0)
+                rounds += -(-(((rows + 255) // 256) * tn) // cus)
+                r0 += R
+            if best is None or rounds < best[0]:
+                best = (rounds, R)
+        return best[1]
+
     def _ntp(self, hidden, plan, compute_grads, out):
         """a7: lm_head + NTP loss (ola_llama.py:121-136), row-chunked; dlogits -> d_hidden in the same sweep.  Unless the caller wants the
         logits, only the rows that carry a label go through the two vocabulary-wide GEMMs and the cross-entropy (the others have zero loss
@@ -902,8 +922,7 @@ class Engine:
         d_hce = torch.empty(Mc, H, device=dev, dtype=BF16) if compute_grads else None
         row_loss = torch.empty(Mc, device=dev, dtype=F32)
         logits_keep = [] if self.keep_logits else None
-        nchunk = max(1, (Mc + self.lm_chunk_rows - 1) // self.lm_chunk_rows)
-        R = ((Mc + nchunk - 1) // nchunk + 255) // 256 * 256       # equal chunks of whole 256-row tiles (a short last chunk runs at 1.17 instead of 1.4 PF)
+        R = self._lm_chunk(Mc, H)
         for r0 in range(0, Mc, R):
             r1 = min(Mc, r0 + R)
             lg = ops.gemm(h_ce[r0:r1], fz["lm_head"])
