@@ -4,6 +4,15 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <utility>
+#include <type_traits>
+
+// compile-time loop: f(std::integral_constant<int, 0>{}), ..., f(<N-1>) — the index is a constant expression inside f (asm "n" operands,
+// if constexpr), which a `#pragma unroll` loop variable is only after the optimiser ran (and only if it did unroll)
+template <class F, int... I>
+__device__ __forceinline__ void vp_static_for_impl(F&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, class F>
+__device__ __forceinline__ void vp_static_for(F&& f) { vp_static_for_impl(static_cast<F&&>(f), std::make_integer_sequence<int, N>{}); }
 
 typedef uint16_t bf16_t;                                             // raw bf16 bits in memory
 typedef __attribute__((ext_vector_type(8))) short bf16x8;            // MFMA A/B fragment (4 VGPRs)

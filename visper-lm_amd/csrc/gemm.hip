@@ -20,10 +20,6 @@
 #include <utility>
 #include <type_traits>
 
-// compile-time loop: f(std::integral_constant<int, 0>{}), ..., f(<N-1>) — the index is a constant expression inside f (asm "n" operands,
-// if constexpr), which a `#pragma unroll` loop variable is only after the optimiser ran (and only if it did unroll)
-template <class F, int... I>
-__device__ __forceinline__ void vp_static_for_impl(F&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
 // 4-wave GEMM kernel: gap (of K-step 1) -> which of the 16 fragment reads of the next K-tile's K-step 0 sits there (-1: none)
 constexpr int vp_w4_rd_slot(int g) {
   constexpr int RG[16] = {13, 15, 18, 20, 22, 25, 27, 29, 32, 34, 36, 39, 41, 43, 46, 48};      // never a DMA (16 + 7k) / m0 (17 + 7k) / offset (19 + 7k) gap
@@ -33,8 +29,6 @@ constexpr int vp_w4_rd_slot(int g) {
 }
 // byte offset of B fragment r = 4 h + 2 s + jj from the lane's base row: rows 64 h + 32 s + 4 jj of 128 bytes
 constexpr int vp_w4_boff(int r) { return ((r >> 2) * 64 + ((r >> 1) & 1) * 32 + (r & 1) * 4) * 128; }
-template <int N, class F>
-__device__ __forceinline__ void vp_static_for(F&& f) { vp_static_for_impl(static_cast<F&&>(f), std::make_integer_sequence<int, N>{}); }
 
 enum { EPI_NONE = 0, EPI_GELU = 1, EPI_QUICK_GELU = 2, EPI_RELU = 3 };
 
