@@ -592,6 +592,25 @@ def test_dpt_conv_helpers(ops):
     close(ops.minmax_norm(dev(d)), (d.float() - mn) / (mx - mn), what="minmax")
 
 
+@pytest.mark.parametrize("B,H,W,C", [(2, 12, 16, 16), (1, 5, 13, 24), (2, 3, 7, 8), (1, 24, 24, 64)])
+def test_dwconv7x7_nhwc(ops, B, H, W, C):
+    """vp_dwconv7x7_nhwc (timm ConvNeXtBlock.conv_dw, clip_convnext_encoder.py:161-165) == F.conv2d(groups = C, padding 3) in fp32, rounded once:
+    widths that are / are not multiples of the kernel's 8-pixel strip, maps smaller than the 7 x 7 window, and an exact fp32 replay of the
+    kernel's accumulation order (bias, then taps in (dy, dx) order, fused multiply-adds) on a sample of outputs."""
+    x = rnd(B, H, W, C, seed=50)
+    w = rnd(C, 1, 7, 7, seed=51) * 0.2
+    b = rnd(C, seed=52)
+    ref = F.conv2d(x.float().permute(0, 3, 1, 2), w.float(), b.float(), padding=3, groups=C).permute(0, 2, 3, 1)
+    wt = dev(w.reshape(C, 49).t().contiguous())                       # tap-major [49, C]
+    got = ops.dwconv7x7_nhwc(dev(x), wt, dev(b))
+    close(got, ref, rtol=1e-2, what=f"dwconv7x7 {B}x{H}x{W}x{C}")
+    again = ops.dwconv7x7_nhwc(dev(x), wt, dev(b))
+    assert torch.equal(got, again)
+    # the error against fp32 math is the one bf16 rounding of the output
+    err = (got.float().cpu() - ref).abs()
+    assert float((err / (ref.abs() + 1e-3)).max()) < 8e-3
+
+
 def test_param_store_adamw_groups_schedule_clipping():
     """ParamStore.adamw_step (grouped fused launches + schedule multiplier + global-norm clipping) == torch.optim.AdamW with the
     reference trainer's parameter groups, transformers' cosine schedule and clip_grad_norm_."""

@@ -20,5 +20,5 @@ for a, b, fl, shp, _kind in prof:
     r = agg[(shp, _kind)]; r[0] += 1; r[1] += a.elapsed_time(b); r[2] += fl
 tot = sum(r[1] for r in agg.values())
 print(f"step {e0.elapsed_time(e1):.1f} ms, GEMM {tot:.1f} ms in {len(prof)} launches")
-for shp, (n, ms, fl) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:40]:
+for shp, (n, ms, fl) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:90]:
     print(f"{str(shp):28s} n={n:4d} {ms:8.2f} ms {100*ms/tot:5.1f}%  {fl/ms/1e9:7.0f} TF/s")

@@ -288,39 +288,76 @@ __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
 
 // ---------------------------------------------------------------- depthwise 7x7 conv (ConvNeXt block, NHWC) ----------
 // x, y: [B, Hh, Ww, C] bf16 (channels last); w: [49, C] bf16 (tap-major, so 8 channels of one tap are one 16-byte load);
-// bias: [C].  One thread = 8 channels of one pixel; zero padding 3; fp32 accumulate, one bf16 rounding (torch conv2d).
-// HBM-bound: the 49x input re-reads are served by L1/L2.   timm ConvNeXtBlock.conv_dw (clip_convnext_encoder.py:161-165)
+// bias: [C].  Zero padding 3; fp32 accumulate (bias first, then taps in (dy, dx) order), one bf16 rounding (torch conv2d).
+// timm ConvNeXtBlock.conv_dw (clip_convnext_encoder.py:161-165).
+// One thread = 8 channels of PX CONSECUTIVE output pixels of a row: an input vector is loaded and converted once and feeds up to 7 outputs,
+// the 7 taps of a filter row are converted once per PX outputs, the multiply-adds are packed (v_pk_fma_f32, two channels each).  Round 4:
+// replaces the one-pixel-per-thread kernel (784 loads, ~10 400 VALU per 64 outputs: 602 / 283 / 147 / 76 us at the four ConvNeXt-XXL stage
+// shapes of configs[3]); PX = 4 measures 405 / 176 / 90 / 48 us (PX = 8: 413 / 194 / 99 / 54), about half L1 traffic (17 16-byte loads per
+// filter row and thread) and half VALU issue.  Same accumulation order as before (bias, then taps in (dy, dx) order, fused multiply-adds).
+template <int PX>
 __global__ __launch_bounds__(256) void dwconv7x7_nhwc_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w,
                                                              const bf16_t* __restrict__ bias, bf16_t* __restrict__ y, int B, int Hh,
                                                              int Ww, int C) {
-  const int cv = C >> 3;
-  const long total = (long)B * Hh * Ww * cv;
+  const int cv = C >> 3, nxt = (Ww + PX - 1) / PX;
+  const long total = (long)B * Hh * nxt * cv;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const int c8 = (int)(i % cv) * 8;
-    const long pix = i / cv;
-    const int xw = (int)(pix % Ww), yh = (int)((pix / Ww) % Hh);
-    const long b = pix / ((long)Ww * Hh);
-    float acc[8];
-    const bf16x8 bv = *(const bf16x8*)(bias + c8);
+    long t = i / cv;
+    const int x0 = (int)(t % nxt) * PX;
+    t /= nxt;
+    const int yh = (int)(t % Hh);
+    const long b = t / Hh;
+    f32x2 acc[PX][4];
+    {
+      const bf16x8 bv = *(const bf16x8*)(bias + c8);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) acc[e] = bf2f((bf16_t)bv[e]);
+      for (int px = 0; px < PX; ++px)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[px][q] = f32x2{bf2f((bf16_t)bv[2 * q]), bf2f((bf16_t)bv[2 * q + 1])};
+    }
     for (int dy = 0; dy < 7; ++dy) {
       const int yy = yh + dy - 3;
       if (yy < 0 || yy >= Hh) continue;
+      f32x2 wf[7][4];
 #pragma unroll
       for (int dx = 0; dx < 7; ++dx) {
-        const int xx = xw + dx - 3;
-        if (xx < 0 || xx >= Ww) continue;
-        const bf16x8 xv = *(const bf16x8*)(x + ((b * Hh + yy) * Ww + xx) * C + c8);
         const bf16x8 wv = *(const bf16x8*)(w + (dy * 7 + dx) * C + c8);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) acc[e] += bf2f((bf16_t)xv[e]) * bf2f((bf16_t)wv[e]);
+        for (int q = 0; q < 4; ++q) wf[dx][q] = f32x2{bf2f((bf16_t)wv[2 * q]), bf2f((bf16_t)wv[2 * q + 1])};
+      }
+      // the strip's PX + 6 input vectors as ONE batch of unconditional loads (columns clamped into the row, out-of-range ones zeroed after):
+      // a bounds branch around each load left one L2 round trip exposed per tap (19 TFLOP/s; instruction-issue 25 % busy)
+      const bf16_t* row = x + ((b * Hh + yy) * Ww) * C + c8;
+      bf16x8 xv[PX + 6];
+#pragma unroll
+      for (int xi = 0; xi < PX + 6; ++xi) xv[xi] = *(const bf16x8*)(row + (long)min(max(x0 + xi - 3, 0), Ww - 1) * C);
+#pragma unroll
+      for (int xi = 0; xi < PX + 6; ++xi) {
+        const int xx = x0 + xi - 3;
+        const bool ok = xx >= 0 && xx < Ww;
+        f32x2 xf[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) xf[q] = ok ? f32x2{bf2f((bf16_t)xv[xi][2 * q]), bf2f((bf16_t)xv[xi][2 * q + 1])} : f32x2{0.f, 0.f};
+#pragma unroll
+        for (int px = 0; px < PX; ++px) {
+          const int dx = xi - px;
+          if (dx >= 0 && dx < 7) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[px][q] = __builtin_elementwise_fma(xf[q], wf[dx][q], acc[px][q]);
+          }
+        }
       }
     }
-    bf16x8 o;
+    bf16_t* yrow = y + ((b * Hh + yh) * Ww) * C + c8;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) o[e] = (short)f2bf(acc[e]);
-    *(bf16x8*)(y + pix * C + c8) = o;
+    for (int px = 0; px < PX; ++px) {
+      if (x0 + px < Ww) {
+        const u32x4 o = {pack_bf16x2(acc[px][0][0], acc[px][0][1]), pack_bf16x2(acc[px][1][0], acc[px][1][1]),
+                         pack_bf16x2(acc[px][2][0], acc[px][2][1]), pack_bf16x2(acc[px][3][0], acc[px][3][1])};
+        *(u32x4*)(yrow + (long)(x0 + px) * C) = o;
+      }
+    }
   }
 }
 
@@ -328,8 +365,9 @@ extern "C" {
 
 int vp_dwconv7x7_nhwc(int B, int Hh, int Ww, int C, const void* x, const void* w, const void* bias, void* y, hipStream_t s) {
   VP_REQUIRE(B > 0 && Hh > 0 && Ww > 0 && C > 0 && C % 8 == 0 && x && w && bias && y, VP_ERR_BAD_ARG, "vp_dwconv7x7_nhwc: bad args");
-  const long total = (long)B * Hh * Ww * (C / 8);
-  hipLaunchKernelGGL(dwconv7x7_nhwc_kernel, dim3((unsigned)min(65536L, (total + 255) / 256)), dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)w,
+  constexpr int DW_PX = 4;
+  const long total = (long)B * Hh * ((Ww + DW_PX - 1) / DW_PX) * (C / 8);
+  hipLaunchKernelGGL(dwconv7x7_nhwc_kernel<DW_PX>, dim3((unsigned)min(65536L, (total + 255) / 256)), dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)w,
                      (const bf16_t*)bias, (bf16_t*)y, B, Hh, Ww, C);
   return vp_check_launch("vp_dwconv7x7_nhwc");
 }
