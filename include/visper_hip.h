@@ -156,8 +156,8 @@ int vp_attn_bwd(int B, int Hq, int Hkv, int Sq, int Skv, int D, const void* q, l
                 int window, float scale, vp_stream_t stream);
 
 /* vp_attn_bwd with the RoPE backward of dq / dk fused into the stores (HF LlamaAttention.forward rotates q, k with
- * apply_rotary_pos_emb before SDPA, modeling_llama.py; autograd rotates dq / dk back).  D = 128, causal only.  rope_cos /
- * rope_sin: fp32 [positions, 64] as for vp_rope; rope_pos: int32 [B, S] position ids or NULL (position = row index).
+ * apply_rotary_pos_emb before SDPA, modeling_llama.py / modeling_phi3.py; autograd rotates dq / dk back).  D = 128 or 96, causal only.
+ * rope_cos / rope_sin: fp32 [positions, D / 2] as for vp_rope; rope_pos: int32 [B, S] position ids or NULL (position = row index).
  * Bit-identical to vp_attn_bwd followed by vp_rope(inverse = 1) on dq and dk. */
 int vp_attn_bwd_rope(int B, int Hq, int Hkv, int Sq, int Skv, int D, const void* q, long q_bs, long q_ts, const void* k, long k_bs,
                      long k_ts, const void* v, long v_bs, long v_ts, const void* o, long o_bs, long o_ts, const float* lse,

@@ -256,15 +256,17 @@ def test_gemm_tn_weight_gradient(ops, M, N, K):
         ops._lib.call("vp_gemm_tn_bf16", 200, 256, 64, dyg.data_ptr(), dyg.stride(0), xg.data_ptr(), N, out.data_ptr(), N, 1, 0, None)
 
 
-def test_attn_bwd_fused_rope(ops):
-    """dq / dk rotated back inside the D=128 backward kernels == vp_attn_bwd followed by vp_rope(inverse), bit for bit (GQA, ragged S)."""
-    B, Hq, Hkv, S, D = 2, 8, 2, 300, 128
+@pytest.mark.parametrize("D,theta", [(128, 500000.0), (96, 10000.0)])
+def test_attn_bwd_fused_rope(ops, D, theta):
+    """dq / dk rotated back inside the D = 128 (Llama) and D = 96 (Phi-3) backward kernels == vp_attn_bwd followed by vp_rope(inverse), bit for
+    bit (GQA, ragged S, explicit position ids)."""
+    B, Hq, Hkv, S = 2, 8, 2, 300
     qkv = dev(rnd(B, S, (Hq + 2 * Hkv) * D, seed=80))
     q = qkv[..., :Hq * D].unflatten(-1, (Hq, D)); k = qkv[..., Hq * D:(Hq + Hkv) * D].unflatten(-1, (Hkv, D))
     v = qkv[..., (Hq + Hkv) * D:].unflatten(-1, (Hkv, D))
     do = dev(rnd(B, S, Hq, D, seed=81))
     o, lse = ops.attn_fwd(q, k, v, True)
-    cos_t, sin_t = ops.rope_tables(S, D, 500000.0, "cuda")
+    cos_t, sin_t = ops.rope_tables(S, D, theta, "cuda")
     d1 = torch.zeros_like(qkv); d2 = torch.zeros_like(qkv)
     views = lambda d: (d[..., :Hq * D].unflatten(-1, (Hq, D)), d[..., Hq * D:(Hq + Hkv) * D].unflatten(-1, (Hkv, D)),
                        d[..., (Hq + Hkv) * D:].unflatten(-1, (Hkv, D)))

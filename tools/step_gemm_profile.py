@@ -4,10 +4,13 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import bench
 from visper_lm_amd import ops
-from visper_lm_amd.config import llama3_8b
+from visper_lm_amd import config as C
 from visper_lm_amd.engine import Engine
-cfg = llama3_8b(); eng = Engine(cfg); eng.init_random(0)
-batch = bench.make_batch(cfg, 8, 1449, 0, torch.device("cuda"))
+wl = sys.argv[1] if len(sys.argv) > 1 else "llama3_8b"          # llama3_8b | convnext | phi3
+cfg = {"llama3_8b": C.llama3_8b, "convnext": C.llama3_8b_convnext, "phi3": C.phi3_mini}[wl]()
+eng = Engine(cfg); eng.init_random(0)
+B, T = (4, 3497) if wl == "phi3" else (8, 1449)
+batch = bench.make_batch(cfg, B, T, 0, torch.device("cuda"))
 for _ in range(2):
     eng.train_step(batch); eng.optimizer_step(1e-3)
 torch.cuda.synchronize()

@@ -542,21 +542,16 @@ static int launch_bwd(const AttnParams& p_in, int causal, hipStream_t s) {
       (void)hipFuncSetAttribute((const void*)attn_bwd_dq128_kernel<false, false, D>, hipFuncAttributeMaxDynamicSharedMemorySize, DQ128_LDS);
       attr2 = true;
     }
-    if (p.rope_cos) {                                   // fused RoPE backward: its own instantiations (training: causal, D = 128 only)
-      if constexpr (D == 128) {
-        if (!causal) { vp_set_error("vp_attn_bwd_rope: causal attention only"); return VP_ERR_UNSUPPORTED_SHAPE; }
-        static bool attr3 = false;
-        if (!attr3) {
-          (void)hipFuncSetAttribute((const void*)attn_bwd_dkdv128_kernel<true, DKDV_KT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, DKDV128_LDS);
-          (void)hipFuncSetAttribute((const void*)attn_bwd_dq128_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, DQ128_LDS);
-          attr3 = true;
-        }
-        hipLaunchKernelGGL((attn_bwd_dq128_kernel<true, true>), g2, dim3(256), DQ128_LDS, s, p);
-        hipLaunchKernelGGL((attn_bwd_dkdv128_kernel<true, DKDV_KT, true>), g1, dim3(64 * (8 / DKDV_KT)), DKDV128_LDS, s, p);
-      } else {
-        vp_set_error("vp_attn_bwd_rope: head_dim 128 only");
-        return VP_ERR_UNSUPPORTED_SHAPE;
+    if (p.rope_cos) {                                   // fused RoPE backward: its own instantiations (training: causal only)
+      if (!causal) { vp_set_error("vp_attn_bwd_rope: causal attention only"); return VP_ERR_UNSUPPORTED_SHAPE; }
+      static bool attr3 = false;
+      if (!attr3) {
+        (void)hipFuncSetAttribute((const void*)attn_bwd_dkdv128_kernel<true, DKDV_KT, true, D>, hipFuncAttributeMaxDynamicSharedMemorySize, DKDV128_LDS);
+        (void)hipFuncSetAttribute((const void*)attn_bwd_dq128_kernel<true, true, D>, hipFuncAttributeMaxDynamicSharedMemorySize, DQ128_LDS);
+        attr3 = true;
       }
+      hipLaunchKernelGGL((attn_bwd_dq128_kernel<true, true, D>), g2, dim3(256), DQ128_LDS, s, p);
+      hipLaunchKernelGGL((attn_bwd_dkdv128_kernel<true, DKDV_KT, true, D>), g1, dim3(64 * (8 / DKDV_KT)), DKDV128_LDS, s, p);
     } else if (causal) {
       hipLaunchKernelGGL((attn_bwd_dq128_kernel<true, false, D>), g2, dim3(256), DQ128_LDS, s, p);
       hipLaunchKernelGGL((attn_bwd_dkdv128_kernel<true, DKDV_KT, false, D>), g1, dim3(64 * (8 / DKDV_KT)), DKDV128_LDS, s, p);
@@ -664,8 +659,8 @@ int vp_attn_bwd(int B, int Hq, int Hkv, int Sq, int Skv, int D, const void* q, l
 }
 
 // vp_attn_bwd with the RoPE backward of dq / dk fused into the stores (reference: HF LlamaAttention.forward applies apply_rotary_pos_emb
-// to q, k before SDPA -- modeling_llama.py; its autograd rotates dq / dk back).  D = 128, causal only.  rope_cos / rope_sin: fp32
-// [positions, 64] as for vp_rope; rope_pos: int32 [B, S] position ids or NULL (position = row index).  Same numbers as vp_attn_bwd
+// to q, k before SDPA -- modeling_llama.py / modeling_phi3.py; its autograd rotates dq / dk back).  D = 128 or 96 (Phi-3), causal only.
+// rope_cos / rope_sin: fp32 [positions, D / 2] as for vp_rope; rope_pos: int32 [B, S] position ids or NULL (position = row index).  Same numbers as vp_attn_bwd
 // followed by vp_rope(inverse = 1) on dq and dk.
 int vp_attn_bwd_rope(int B, int Hq, int Hkv, int Sq, int Skv, int D, const void* q, long q_bs, long q_ts, const void* k, long k_bs,
                      long k_ts, const void* v, long v_bs, long v_ts, const void* o, long o_bs, long o_ts, const float* lse,
@@ -675,7 +670,7 @@ int vp_attn_bwd_rope(int B, int Hq, int Hkv, int Sq, int Skv, int D, const void*
   int e = check_attn("vp_attn_bwd_rope", B, Hq, Hkv, Sq, Skv, D);
   if (e) return e;
   VP_REQUIRE(lse && delta && dout && dq && dk && dv && rope_cos && rope_sin, VP_ERR_BAD_ARG, "vp_attn_bwd_rope: null pointer");
-  VP_REQUIRE(D == 128 && causal, VP_ERR_UNSUPPORTED_SHAPE, "vp_attn_bwd_rope: head_dim 128, causal only (got %d, causal %d)", D, causal);
+  VP_REQUIRE((D == 128 || D == 96) && causal, VP_ERR_UNSUPPORTED_SHAPE, "vp_attn_bwd_rope: head_dim 128 or 96, causal only (got %d, causal %d)", D, causal);
   VP_REQUIRE(((((uintptr_t)rope_cos) | ((uintptr_t)rope_sin)) & 15) == 0, VP_ERR_BAD_ARG, "vp_attn_bwd_rope: tables must be 16-byte aligned");
   AttnParams p{};
   p.q = (const bf16_t*)q; p.k = (const bf16_t*)k; p.v = (const bf16_t*)v; p.o = (bf16_t*)o; p.lse = (float*)lse;
@@ -684,7 +679,7 @@ int vp_attn_bwd_rope(int B, int Hq, int Hkv, int Sq, int Skv, int D, const void*
   p.do_bs = do_bs; p.do_ts = do_ts; p.dq_bs = dq_bs; p.dq_ts = dq_ts; p.dk_bs = dk_bs; p.dk_ts = dk_ts; p.dv_bs = dv_bs; p.dv_ts = dv_ts;
   p.B = B; p.Hq = Hq; p.Hkv = Hkv; p.Sq = Sq; p.Skv = Skv; p.window = window; p.kv_len = kv_len; p.scale = scale;
   p.rope_cos = rope_cos; p.rope_sin = rope_sin; p.rope_pos = rope_pos;
-  return launch_bwd<128>(p, causal, s);
+  return D == 128 ? launch_bwd<128>(p, causal, s) : launch_bwd<96>(p, causal, s);
 }
 
 }  // extern "C"

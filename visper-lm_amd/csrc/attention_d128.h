@@ -66,11 +66,12 @@ static __device__ __forceinline__ fwdm_u32x4s attn_make_rs(const void* base, lon
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, %3 offen lds" ::"s"(M0), "v"(VOFF), "s"(RS), "s"(SOFF) : "memory")
 #define ATTN_PIN(F) asm volatile("" : "+v"(F))
 
-// store one row's 128 features (this lane: blocks d = 0..7, features d*16 + 4g + r) as bf16, optionally rotated back by RoPE^T:
-// x1 = feature f < 64, x2 = feature f + 64; out1 = bf(bf(x1 c) + bf(x2 s)), out2 = bf(bf(x2 c) + bf(-x1 s))  (vp_rope with inverse = 1)
+// store one row's D = 16 NDB features (this lane: blocks d = 0..NDB-1, features d*16 + 4g + r) as bf16, optionally rotated back by RoPE^T:
+// x1 = feature f < D/2, x2 = feature f + D/2; out1 = bf(bf(x1 c) + bf(x2 s)), out2 = bf(bf(x2 c) + bf(-x1 s))  (vp_rope with inverse = 1).
+// cs / sn: this row's D/2 cosines / sines (NDB = 8: the Llama shape; NDB = 6: Phi-3's D = 96, pairs 48 features apart)
 template <bool ROPE, int NDB = 8>
 static __device__ __forceinline__ void store_row128(bf16_t* dst, const f32x4 (&acc)[NDB], float scale, int g, const float* cs, const float* sn) {
-  static_assert(!ROPE || NDB == 8, "the fused RoPE^T store pairs feature f with f + 64");
+  static_assert(NDB % 2 == 0, "the fused RoPE^T store pairs feature f with f + D/2");
   if constexpr (!ROPE) {
 #pragma unroll
     for (int d = 0; d < NDB; ++d) {
@@ -80,19 +81,20 @@ static __device__ __forceinline__ void store_row128(bf16_t* dst, const f32x4 (&a
       *(bf16x4*)(dst + d * 16 + 4 * g) = a;
     }
   } else {
+    constexpr int HB = NDB / 2;
 #pragma unroll
-    for (int d = 0; d < 4; ++d) {
+    for (int d = 0; d < HB; ++d) {
       const f32x4 c4 = *(const f32x4*)(cs + d * 16 + 4 * g), s4 = *(const f32x4*)(sn + d * 16 + 4 * g);
       bf16x4 a, b;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float x1 = bfround(acc[d][r] * scale), x2 = bfround(acc[d + 4][r] * scale);
+        const float x1 = bfround(acc[d][r] * scale), x2 = bfround(acc[d + HB][r] * scale);
         const float ss = -s4[r];
         a[r] = (short)f2bf(bfround(x1 * c4[r]) + bfround(-x2 * ss));
         b[r] = (short)f2bf(bfround(x2 * c4[r]) + bfround(x1 * ss));
       }
       *(bf16x4*)(dst + d * 16 + 4 * g) = a;
-      *(bf16x4*)(dst + 64 + d * 16 + 4 * g) = b;
+      *(bf16x4*)(dst + HB * 16 + d * 16 + 4 * g) = b;
     }
   }
 }
@@ -199,11 +201,15 @@ void attn_bwd_dkdv128_kernel(AttnParams p) {
     const int q0 = qstart + cq * 32;
     if (++cq == ntq) cq = 0;
     // wave-uniform skip: every query of this tile is below this wave's first key (causal) -> all p = 0
-    const bool active = !CAUSAL || (q0 + 31 + off >= kw0);
+    // ... or (sliding window) every key of the wave is at or below the tile's FIRST query's lower bound
+    const bool active = (!CAUSAL || (q0 + 31 + off >= kw0)) && !(p.window > 0 && kw0 + 16 * KT - 1 <= q0 + off - p.window);
     if (active) {
       // s[kt][r]: query = q0 + 16qt + 4g + r, key = kw0 + 16kt + fr.  One 16-query half at a time: only the packed bf16
       // P / dS halves stay live across the two halves (register budget: dk/dv 128 + K/V fragments 64).
-      const bool need_mask = (q0 + 32 > p.Sq) || (kw0 + 16 * KT > kvlen) || (CAUSAL && (kw0 + 16 * KT - 1 > q0 + off)) || (p.window > 0);
+      // (sliding window: only a tile that touches the window's lower edge needs the per-element test: key > query + off - window holds for every
+      // pair as soon as the tile's first key is above its last query's bound; round 4: was `|| p.window > 0`, i.e. EVERY tile of a Phi-3 step)
+      const bool need_mask = (q0 + 32 > p.Sq) || (kw0 + 16 * KT > kvlen) || (CAUSAL && (kw0 + 16 * KT - 1 > q0 + off)) ||
+                             (p.window > 0 && kw0 <= q0 + 31 + off - p.window);
       u32x2 pk[KT][2], dsk[KT][2];
 #pragma unroll
       for (int qt = 0; qt < 2; ++qt) {
@@ -292,7 +298,7 @@ void attn_bwd_dkdv128_kernel(AttnParams p) {
     if (key < p.Skv) {
       bf16_t* dkp = p.dk + (long)b * p.dk_bs + (long)key * p.dk_ts + (long)hk * D;
       bf16_t* dvp = p.dv + (long)b * p.dv_bs + (long)key * p.dv_ts + (long)hk * D;
-      const long pp = ROPE ? (p.rope_pos ? (long)p.rope_pos[(long)b * p.Skv + key] : (long)key) * 64 : 0;
+      const long pp = ROPE ? (p.rope_pos ? (long)p.rope_pos[(long)b * p.Skv + key] : (long)key) * (D / 2) : 0;
       store_row128<ROPE, NDB>(dkp, dk[kt], p.scale, g, p.rope_cos + pp, p.rope_sin + pp);
       store_row128<false, NDB>(dvp, dv[kt], 1.f, g, nullptr, nullptr);
     }
@@ -401,9 +407,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const bf16_t* Ks = ring + (it & 3) * DQ128_STAGE;
     const bf16_t* Vs = Ks + 4096;
     const int k0 = kstart + it * 32;
-    const bool active = !CAUSAL || (k0 <= qw0 + 31 + off);
+    const bool active = (!CAUSAL || (k0 <= qw0 + 31 + off)) && !(p.window > 0 && k0 + 31 <= qw0 + off - p.window);
     if (active) {
-      const bool need_mask = (qw0 + 32 > p.Sq) || (k0 + 32 > kvlen) || (CAUSAL && (k0 + 31 > qw0 + off)) || (p.window > 0);
+      const bool need_mask = (qw0 + 32 > p.Sq) || (k0 + 32 > kvlen) || (CAUSAL && (k0 + 31 > qw0 + off)) ||
+                             (p.window > 0 && k0 <= qw0 + 31 + off - p.window);        // (window: see the dK/dV kernel)
       u32x2 dsk[2][2];                                 // [qt][kt] packed dS halves
       f32x4 st[2][2], dpt[2][2];                       // [kt][qt]
 #define DQ_MF(KT)                                                                                             \
@@ -482,7 +489,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int qrow = qw0 + qt * 16 + (lane & 15);
     if (qrow < p.Sq) {
       bf16_t* dqp = p.dq + (long)b * p.dq_bs + (long)qrow * p.dq_ts + (long)h * D;
-      const long pp = ROPE ? (p.rope_pos ? (long)p.rope_pos[(long)b * p.Sq + qrow] : (long)(qrow + p.Skv - p.Sq)) * 64 : 0;
+      const long pp = ROPE ? (p.rope_pos ? (long)p.rope_pos[(long)b * p.Sq + qrow] : (long)(qrow + p.Skv - p.Sq)) * (D / 2) : 0;
       store_row128<ROPE, NDB>(dqp, dq[qt], p.scale, lane >> 4, p.rope_cos + pp, p.rope_sin + pp);
     }
   }
@@ -671,7 +678,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     __builtin_amdgcn_sched_barrier(0);                                                                          \
     const int t3_ = min((IT) + 3, nit - 1);                                                                     \
     const int k0 = kstart + (IT) * 64;                                                                          \
-    const bool need_mask = (k0 + 64 > kvlen) || (CAUSAL && (k0 + 63 > qw0 + off)) || (p.window > 0);            \
+    const bool need_mask = (k0 + 64 > kvlen) || (CAUSAL && (k0 + 63 > qw0 + off)) || (p.window > 0 && k0 <= qw0 + 31 + off - p.window); \
     if (need_mask) {                                                                                            \
       int ln = threadIdx.x & 63;                                                                                \
       asm volatile("" : "+v"(ln));                                                                              \

@@ -1067,7 +1067,7 @@ class Engine:
             dqkv = torch.empty_like(qkv)
             q4, k4, v4 = self._qkv_views(qkv, B, S)
             dq4, dk4, dv4 = self._qkv_views(dqkv, B, S)
-            if hd == 128 and not os.environ.get("VP_NO_FUSED_ROPE"):     # RoPE^T of dq / dk fused into the attention-backward stores
+            if hd in (96, 128) and not os.environ.get("VP_NO_FUSED_ROPE"):     # RoPE^T of dq / dk fused into the attention-backward stores
                 ops.attn_bwd(q4, k4, v4, att, lse, d_att.view(B, S, nh, hd), causal=True, window=window, kv_len=kv_len,
                              dq=dq4, dk=dk4, dv=dv4, rope=(cos_t, sin_t))
             else:

@@ -458,7 +458,7 @@ def attn_bwd(q, k, v, o, lse, dout, causal, scale=None, window=0, kv_len=None, d
     delta = torch.empty(3, B, Hq, Sq, device=q.device, dtype=torch.float32)   # delta + (lse, delta) pairs
     qb, qt = _bshd(q); kb, kt = _bshd(k); vb, vt = _bshd(v); ob, ot = _bshd(o); gb, gt = _bshd(dout)
     dqb, dqt = _bshd(dq); dkb, dkt = _bshd(dk); dvb, dvt = _bshd(dv)
-    if rope is not None:                                  # (cos, sin[, pos]): dq / dk come out rotated back (D = 128, causal)
+    if rope is not None:                                  # (cos, sin[, pos]): dq / dk come out rotated back (D = 128 / 96, causal)
         cos_t, sin_t = rope[0], rope[1]
         pos = rope[2] if len(rope) > 2 else None
         _lib.call("vp_attn_bwd_rope", B, Hq, Hkv, Sq, Skv, D, _p(q), qb, qt, _p(k), kb, kt, _p(v), vb, vt, _p(o), ob, ot, _p(lse),
