@@ -204,91 +204,144 @@ void attn_bwd_dkdv128_kernel(AttnParams p) {
     // ... or (sliding window) every key of the wave is at or below the tile's FIRST query's lower bound
     const bool active = (!CAUSAL || (q0 + 31 + off >= kw0)) && !(p.window > 0 && kw0 + 16 * KT - 1 <= q0 + off - p.window);
     if (active) {
-      // s[kt][r]: query = q0 + 16qt + 4g + r, key = kw0 + 16kt + fr.  One 16-query half at a time: only the packed bf16
-      // P / dS halves stay live across the two halves (register budget: dk/dv 128 + K/V fragments 64).
+      // s[qt][kt][r]: query = q0 + 16qt + 4g + r, key = kw0 + 16kt + fr.  Per tile (two 16-query halves):
+      //   A  S / dP of half 0                                        (8 KT MFMAs)
+      //   B  S / dP of half 1  ||  softmax + dS arithmetic of half 0 (8 KT MFMAs over ~45 VALU, placed by sched_group_barrier)
+      //   C  softmax + dS arithmetic of half 1                       (VALU)
+      //   D  dV += dO^T P, dK += Q^T dS per feature block            (16 KT MFMAs, transposing reads one block ahead)
+      // ONE softmax code path: the mask is a v_cndmask per element against wave masks in SGPRs, all-ones in the (common) unmasked tile; only
+      // their computation sits behind the wave-uniform branch.  What does not work here (round 4, measured): a branch on need_mask per element
+      // fences the scheduler (a chain of 16 four-instruction blocks behind every MFMA burst: no overlap in B); two copies of the tile per mask
+      // mode turn all 128 dk / dv accumulators into phis (215 spilled VGPRs); two copies of the softmax arithmetic alone cost 25 VGPRs of phis
+      // = spilled K / V fragments, reloaded behind vmcnt(0), which drains the DMA ring; mask bounds kept live across the tile: 4 VGPRs too many.
       // (sliding window: only a tile that touches the window's lower edge needs the per-element test: key > query + off - window holds for every
-      // pair as soon as the tile's first key is above its last query's bound; round 4: was `|| p.window > 0`, i.e. EVERY tile of a Phi-3 step)
+      // pair as soon as the tile's first key is above its last query's bound)
       const bool need_mask = (q0 + 32 > p.Sq) || (kw0 + 16 * KT > kvlen) || (CAUSAL && (kw0 + 16 * KT - 1 > q0 + off)) ||
                              (p.window > 0 && kw0 <= q0 + 31 + off - p.window);
-      u32x2 pk[KT][2], dsk[KT][2];
+      const uint32_t qs_addr = attn_lds_addr(Qs);      // dO tile = +8192 bytes, rows +16 = +4096 bytes
+      {
+        f32x4 s[2][KT], dp[2][KT];
+        u32x2 pk[KT][2], dsk[KT][2];
+        auto mf = [&](int qt) __attribute__((always_inline)) {
 #pragma unroll
-      for (int qt = 0; qt < 2; ++qt) {
-        f32x4 s[KT], dp[KT];
+          for (int kt = 0; kt < KT; ++kt) { s[qt][kt] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[qt][kt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
-        for (int kt = 0; kt < KT; ++kt) { s[kt] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[kt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-        __builtin_amdgcn_s_setprio(1);
+          for (int ks = 0; ks < NKS; ++ks) {
+            const bf16x8 qa = *(const bf16x8*)(Qs + (rbase ^ (ks * 32)) + qt * 2048);
+            const bf16x8 da = *(const bf16x8*)(dOs + (rbase ^ (ks * 32)) + qt * 2048);
 #pragma unroll
-        for (int ks = 0; ks < NKS; ++ks) {
-          const bf16x8 qa = *(const bf16x8*)(Qs + (rbase ^ (ks * 32)) + qt * 2048);
-          const bf16x8 da = *(const bf16x8*)(dOs + (rbase ^ (ks * 32)) + qt * 2048);
+            for (int kt = 0; kt < KT; ++kt) {
+              s[qt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa, kf[kt][ks], s[qt][kt], 0, 0, 0);
+              dp[qt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(da, vf[kt][ks], dp[qt][kt], 0, 0, 0);
+            }
+          }
+        };
+        auto sm_p = [&](int qt) __attribute__((always_inline)) {
+          unsigned long long okm[KT][4];
+#pragma unroll
+          for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) okm[kt][r] = ~0ull;
+          if (need_mask) {
+            // bounds of this lane, derived HERE from an opaque lane id (kept live across the tile they cost 4 VGPRs -> K/V fragment spills):
+            // key = kw0 + 16kt + fr valid iff 16kt < m_kl; query = q0 + 16qt + 4g + r valid iff 16qt + r < m_ql;
+            // causal: key <= query + off iff 16kt - 16qt - r <= m_dq; window: key > query + off - window iff 16kt - 16qt - r > m_lo
+            int l2 = threadIdx.x & 63;
+            asm volatile("" : "+v"(l2));
+            const int fr2 = l2 & 15, g2 = l2 >> 4;
+            const int m_kl = kvlen - kw0 - fr2, m_ql = p.Sq - q0 - 4 * g2, m_dq = q0 + 4 * g2 + off - kw0 - fr2;
+            const int m_lo = p.window > 0 ? m_dq - p.window : -(1 << 30);
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                const int e = kt * 16 - qt * 16 - r;           // key - query, up to the lane's base
+                bool ok = (kt * 16 < m_kl) & (qt * 16 + r < m_ql) & (e > m_lo);
+                if (CAUSAL) ok = ok & (e <= m_dq);
+                okm[kt][r] = __builtin_amdgcn_ballot_w64(ok);
+              }
+          }
+          const f32x4 l0 = *(const f32x4*)(ld + (qt * 16 + 4 * g) * 2), l1 = *(const f32x4*)(ld + (qt * 16 + 4 * g) * 2 + 4);
+          const float lse_r[4] = {l0[0], l0[2], l1[0], l1[2]};
 #pragma unroll
           for (int kt = 0; kt < KT; ++kt) {
-            s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa, kf[kt][ks], s[kt], 0, 0, 0);
-            dp[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(da, vf[kt][ks], dp[kt], 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              float pv = fast_exp2(fmaf(s[qt][kt][r], c, -lse_r[r]));
+              asm("v_cndmask_b32 %0, 0, %0, %1" : "+v"(pv) : "s"(okm[kt][r]));
+              s[qt][kt][r] = pv;
+            }
+            pk[kt][qt] = u32x2{pack_bf16x2(s[qt][kt][0], s[qt][kt][1]), pack_bf16x2(s[qt][kt][2], s[qt][kt][3])};
           }
-          if (ks & 1) __builtin_amdgcn_sched_barrier(0);     // bound the scheduler's look-ahead: fragments for <= 2 k-steps live
+        };
+        auto sm_ds = [&](int qt) __attribute__((always_inline)) {
+          const f32x4 l0 = *(const f32x4*)(ld + (qt * 16 + 4 * g) * 2), l1 = *(const f32x4*)(ld + (qt * 16 + 4 * g) * 2 + 4);
+          const float del_r[4] = {l0[1], l0[3], l1[1], l1[3]};
+#pragma unroll
+          for (int kt = 0; kt < KT; ++kt) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dp[qt][kt][r] = s[qt][kt][r] * (dp[qt][kt][r] - del_r[r]);
+            dsk[kt][qt] = u32x2{pack_bf16x2(dp[qt][kt][0], dp[qt][kt][1]), pack_bf16x2(dp[qt][kt][2], dp[qt][kt][3])};
+          }
+        };
+        // ---- A: S / dP of query half 0;  B: S / dP of half 1 under the softmax + dS arithmetic of half 0 (one MFMA, one LDS read, a few VALU)
+        __builtin_amdgcn_s_setprio(1);
+        mf(0);
+        __builtin_amdgcn_sched_barrier(0);
+        mf(1);
+        sm_p(0);
+        sm_ds(0);
+#pragma unroll
+        for (int i = 0; i < 2 * KT * NKS; ++i) {
+          if (i < 2 * NKS) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
         }
         __builtin_amdgcn_s_setprio(0);
-        const f32x4 l0 = *(const f32x4*)(ld + (qt * 16 + 4 * g) * 2), l1 = *(const f32x4*)(ld + (qt * 16 + 4 * g) * 2 + 4);
-        const float lse_r[4] = {l0[0], l0[2], l1[0], l1[2]}, del_r[4] = {l0[1], l0[3], l1[1], l1[3]};
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- C, then D: transposing reads one feature block ahead of the MFMAs that consume them (counted lgkmcnt: the block's own 4 reads are
+        // the oldest)
+        sm_p(1);
+        sm_ds(1);
+        bf16x8 pf[KT], dsf[KT];
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt) {
+          pf[kt] = __builtin_bit_cast(bf16x8, u32x4{pk[kt][0][0], pk[kt][0][1], pk[kt][1][0], pk[kt][1][1]});
+          dsf[kt] = __builtin_bit_cast(bf16x8, u32x4{dsk[kt][0][0], dsk[kt][0][1], dsk[kt][1][0], dsk[kt][1][1]});
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);                  // MFMA bursts at raised priority: the co-resident block's VALU/LDS work yields (-3 %)
+        s16x4 al, ah, ql, qh;
+        {
+          const uint32_t ta_ = qs_addr + 2u * (uint32_t)tbase;
+          al = tr_read_asm<8192>(ta_); ah = tr_read_asm<12288>(ta_);
+          ql = tr_read_asm<0>(ta_); qh = tr_read_asm<4096>(ta_);
+        }
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            float pv = fast_exp2(fmaf(s[kt][r], c, -lse_r[r]));
-            if (need_mask) {
-              const int qg = q0 + qt * 16 + 4 * g + r, key = kw0 + kt * 16 + fr;
-              const bool ok = qg < p.Sq && key < kvlen && (!CAUSAL || key <= qg + off) && (p.window <= 0 || key > qg + off - p.window);
-              pv = ok ? pv : 0.f;
-            }
-            s[kt][r] = pv;
-            dp[kt][r] = pv * (dp[kt][r] - del_r[r]);
+        for (int d = 0; d < NDB; ++d) {
+          s16x4 nal = al, nah = ah, nql = ql, nqh = qh;
+          if (d + 1 < NDB) {
+            const uint32_t tn_ = qs_addr + 2u * (uint32_t)(tbase ^ ((d + 1) * 16));
+            nal = tr_read_asm<8192>(tn_); nah = tr_read_asm<12288>(tn_);
+            nql = tr_read_asm<0>(tn_); nqh = tr_read_asm<4096>(tn_);
+            ATTN_LGKM(6);
+          } else {
+            ATTN_LGKM(2);
           }
-          pk[kt][qt] = u32x2{pack_bf16x2(s[kt][0], s[kt][1]), pack_bf16x2(s[kt][2], s[kt][3])};
-          dsk[kt][qt] = u32x2{pack_bf16x2(dp[kt][0], dp[kt][1]), pack_bf16x2(dp[kt][2], dp[kt][3])};
+          bf16x8 ta = tr_join(al, ah);
+          ATTN_PIN(ta);
+#pragma unroll
+          for (int kt = 0; kt < KT; ++kt) dv[kt][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ta, pf[kt], dv[kt][d], 0, 0, 0);
+          if (d + 1 < NDB) { ATTN_LGKM(4); } else { ATTN_LGKM(0); }
+          bf16x8 tq = tr_join(ql, qh);
+          ATTN_PIN(tq);
+#pragma unroll
+          for (int kt = 0; kt < KT; ++kt) dk[kt][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tq, dsf[kt], dk[kt][d], 0, 0, 0);
+          al = nal; ah = nah; ql = nql; qh = nqh;
+          __builtin_amdgcn_sched_barrier(0);
         }
-        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(0);
       }
-      bf16x8 pf[KT], dsf[KT];
-#pragma unroll
-      for (int kt = 0; kt < KT; ++kt) {
-        pf[kt] = __builtin_bit_cast(bf16x8, u32x4{pk[kt][0][0], pk[kt][0][1], pk[kt][1][0], pk[kt][1][1]});
-        dsf[kt] = __builtin_bit_cast(bf16x8, u32x4{dsk[kt][0][0], dsk[kt][0][1], dsk[kt][1][0], dsk[kt][1][1]});
-      }
-      const uint32_t qs_addr = attn_lds_addr(Qs);      // dO tile = +8192 bytes, rows +16 = +4096 bytes
-      __builtin_amdgcn_s_setprio(1);                  // MFMA bursts at raised priority: the co-resident block's VALU/LDS work yields (-3 %)
-      // transposing reads one feature block ahead of the MFMAs that consume them (counted lgkmcnt: the block's own 4 reads are the oldest);
-      // measured 733 -> 698 us per call at the decoder shape
-      s16x4 al, ah, ql, qh;
-      {
-        const uint32_t ta_ = qs_addr + 2u * (uint32_t)tbase;
-        al = tr_read_asm<8192>(ta_); ah = tr_read_asm<12288>(ta_);
-        ql = tr_read_asm<0>(ta_); qh = tr_read_asm<4096>(ta_);
-      }
-#pragma unroll
-      for (int d = 0; d < NDB; ++d) {
-        s16x4 nal = al, nah = ah, nql = ql, nqh = qh;
-        if (d + 1 < NDB) {
-          const uint32_t tn_ = qs_addr + 2u * (uint32_t)(tbase ^ ((d + 1) * 16));
-          nal = tr_read_asm<8192>(tn_); nah = tr_read_asm<12288>(tn_);
-          nql = tr_read_asm<0>(tn_); nqh = tr_read_asm<4096>(tn_);
-          ATTN_LGKM(6);
-        } else {
-          ATTN_LGKM(2);
-        }
-        bf16x8 ta = tr_join(al, ah);
-        ATTN_PIN(ta);
-#pragma unroll
-        for (int kt = 0; kt < KT; ++kt) dv[kt][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ta, pf[kt], dv[kt][d], 0, 0, 0);
-        if (d + 1 < NDB) { ATTN_LGKM(4); } else { ATTN_LGKM(0); }
-        bf16x8 tq = tr_join(ql, qh);
-        ATTN_PIN(tq);
-#pragma unroll
-        for (int kt = 0; kt < KT; ++kt) dk[kt][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tq, dsf[kt], dk[kt][d], 0, 0, 0);
-        al = nal; ah = nah; ql = nql; qh = nqh;
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      __builtin_amdgcn_s_setprio(0);
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // trailing (dummy) DMAs must not outlive the block's LDS
