@@ -14,7 +14,7 @@ for (M, N, K) in SH:
     buf = (C.c_long * 2048)()
     lib.vp_debug_stamps.argtypes = [C.c_void_p]
     rc = lib.vp_debug_stamps(buf)
-    st = np.array(buf[:], dtype=np.int64).reshape(256, 8)
+    st = np.array(buf[:], dtype=np.int64).reshape(256, 8)[:min(256, (M // 256) * (N // 256))]      # only the blocks this launch ran
     t0 = st[:, 0].min()
     d = (st[:, :8] - t0) / 100.0   # us
     print(M, N, K, "rc", rc)
@@ -29,5 +29,5 @@ for (M, N, K) in SH:
     print(" shader clock during first K loop: %.0f MHz (cycles %.0f / %.1f us)" % ((cyc / us).mean(), cyc.mean(), us.mean()))
     print(" shader clock by xcd (MHz):", [int((cyc[x::8] / us[x::8]).mean()) for x in range(8)], " first K loop us by xcd:", [round(float(us[x::8].mean()), 1) for x in range(8)])
     e = np.sort(d[:, 5])
-    print(" block end times (us) pct 0/10/50/90/100: %.1f %.1f %.1f %.1f %.1f ; by xcd mean:" % (e[0], e[25], e[128], e[230], e[255]), [round(float(d[x::8, 5].mean()), 1) for x in range(8)])
+    print(" block end times (us) pct 0/10/50/90/100: %.1f %.1f %.1f %.1f %.1f ; by xcd mean:" % (e[0], e[len(e) // 10], e[len(e) // 2], e[len(e) * 9 // 10], e[-1]), [round(float(d[x::8, 5].mean()), 1) for x in range(8)])
     print(" end: mean %.1f max %.1f ; loopend spread %.1f..%.1f" % (d[:, 5].mean(), d[:, 5].max(), d[:, 2].min(), d[:, 2].max()))

@@ -437,6 +437,34 @@ __device__ __forceinline__ void epilogue_swz(const GemmArgs& p, bf16_t* wave_lds
   }
 }
 
+// Whole-line stores from the MFMA accumulator layout.  x / y = the 16 bytes lane (fr, g) holds of the left / right 64-byte half of row fr's
+// 128-byte line (16 rows per register).  z1 = what store 1 (rows 0..7 of the block, whole lines) takes from this lane, z2 = store 2 (rows 8..15):
+//   lanes fr < 8:  z1 = own x,             z2 = y of lane fr + 8        lanes fr >= 8:  z1 = y of lane fr - 8,   z2 = own x
+// One v_cndmask_b32_dpp (row_ror:8 on the y operand) per dword and store: 8 VALU per pair of stores.  (DPP reads of a VGPR written by the
+// VALU instruction in front need two wait states: the s_nop.)
+__device__ __forceinline__ void w4_rows8_swap(u32x4& z1, u32x4& z2, const u32x4& x, const u32x4& y) {
+  uint32_t a0, a1, a2, a3, b0, b1, b2, b3;
+  const unsigned long long lo8 = 0x00ff00ff00ff00ffull, hi8 = 0xff00ff00ff00ff00ull;
+  asm volatile(
+      "s_nop 1\n\t"
+      "s_mov_b64 vcc, %[mlo]\n\t"
+      "v_cndmask_b32_dpp %[a0], %[y0], %[x0], vcc row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+      "v_cndmask_b32_dpp %[a1], %[y1], %[x1], vcc row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+      "v_cndmask_b32_dpp %[a2], %[y2], %[x2], vcc row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+      "v_cndmask_b32_dpp %[a3], %[y3], %[x3], vcc row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+      "s_mov_b64 vcc, %[mhi]\n\t"
+      "v_cndmask_b32_dpp %[b0], %[y0], %[x0], vcc row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+      "v_cndmask_b32_dpp %[b1], %[y1], %[x1], vcc row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+      "v_cndmask_b32_dpp %[b2], %[y2], %[x2], vcc row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+      "v_cndmask_b32_dpp %[b3], %[y3], %[x3], vcc row_ror:8 row_mask:0xf bank_mask:0xf"
+      : [a0] "=&v"(a0), [a1] "=&v"(a1), [a2] "=&v"(a2), [a3] "=&v"(a3), [b0] "=&v"(b0), [b1] "=&v"(b1), [b2] "=&v"(b2), [b3] "=&v"(b3)
+      : [x0] "v"(x[0]), [x1] "v"(x[1]), [x2] "v"(x[2]), [x3] "v"(x[3]), [y0] "v"(y[0]), [y1] "v"(y[1]), [y2] "v"(y[2]), [y3] "v"(y[3]),
+        [mlo] "s"(lo8), [mhi] "s"(hi8)
+      : "vcc");
+  z1 = u32x4{a0, a1, a2, a3};
+  z2 = u32x4{b0, b1, b2, b3};
+}
+
 // Epilogue of the 4-wave kernel (decoder GEMMs: no bias, no activation; optional residual; fused SwiGLU forward / backward): STRAIGHT from the
 // accumulators to global memory, no LDS pass.  An MFMA result lane holds 4 consecutive columns of one token row; which weight row sits in which
 // MFMA row of which B fragment is the K loop's free choice, and it reads them so that the four B fragments (2 s + jj) of a 64-column half h hand
@@ -480,7 +508,8 @@ __device__ __forceinline__ void epilogue_w4(const GemmArgs& p, f32x4 (&acc)[2][8
     // SwiGLU backward: the accumulators are d(act); act block (64 h + 32 s + 8 g ..+7) <-> the 32 bytes (g8 | u8) at twice that column of the saved
     // gate_up (aux) and of d(gate_up) (C).  The saved rows of half h = 1 are fetched into the registers half h = 0 has just consumed.
     const __amdgpu_buffer_rsrc_t ars = tile_rs(p.aux, p.ldaux, 2L * ncol0), drs = tile_rs(p.C, p.ldc, 2L * ncol0);
-    const int aoff = (fr * p.ldaux + g * 16) * 2, astep = p.ldaux * 32, doff = (fr * p.ldc + g * 16) * 2, dstep = p.ldc * 32;
+    const int aoff = (fr * p.ldaux + g * 16) * 2, astep = p.ldaux * 32, dstep = p.ldc * 32;
+    const int doff1 = ((fr & 7) * p.ldc + g * 16 + ((fr & 8) ? 8 : 0)) * 2, doff2 = ((8 + (fr & 7)) * p.ldc + g * 16 + ((fr & 8) ? 0 : 8)) * 2;
     u32x4 gv[8][2], uv[8][2];
 #pragma unroll
     for (int i = 0; i < 8; ++i)
@@ -505,8 +534,12 @@ __device__ __forceinline__ void epilogue_w4(const GemmArgs& p, f32x4 (&acc)[2][8
             og[e] = (short)f2bf(dd * uu * sg * (1.f + gg * (1.f - sg)));
             ou[e] = (short)f2bf(dd * gg * sg);
           }
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, og), drs, doff + i * dstep, h * 256 + s2 * 128, 0);
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, ou), drs, doff + i * dstep, h * 256 + s2 * 128 + 16, 0);
+          // whole-line stores (see w4_rows8_swap): a row's 128-byte line of d(gate_up) is (og | ou) x 4 lanes g; rows 8..15 hand their ou up, take og's place
+          u32x4 z1, z2;
+          w4_rows8_swap(z1, z2, __builtin_bit_cast(u32x4, og), __builtin_bit_cast(u32x4, ou));
+          const int so = __builtin_amdgcn_readfirstlane(i * dstep + h * 256 + s2 * 128);
+          __builtin_amdgcn_raw_buffer_store_b128(z1, drs, doff1, so, 0);
+          __builtin_amdgcn_raw_buffer_store_b128(z2, drs, doff2, so, 0);
           if (h == 0) {
             gv[i][s2] = __builtin_amdgcn_raw_buffer_load_b128(ars, aoff + i * astep, 256 + s2 * 128, 0);
             uv[i][s2] = __builtin_amdgcn_raw_buffer_load_b128(ars, aoff + i * astep, 256 + s2 * 128 + 16, 0);
@@ -517,19 +550,28 @@ __device__ __forceinline__ void epilogue_w4(const GemmArgs& p, f32x4 (&acc)[2][8
     return;
   }
   const __amdgpu_buffer_rsrc_t crs = tile_rs(p.C, p.ldc, ncol0);
-  const int coff = (fr * p.ldc + g * 8) * 2, cstep = p.ldc * 32;
+  const int cstep = p.ldc * 32;
   if ((W4E_ONLY == 0 || W4E_ONLY == 2) && p.mode == 1) {
     // SwiGLU forward: C = gate_up (raw), C2 = act.  After the swap the even-g lanes hold pair g / 2, the odd-g lanes pair (g + 3) / 2 of the half.
+    // Whole-line stores (see w4_rows8_swap): gate_up rows from the (x, y) halves of one (h, i); an act row's 128-byte line is its h = 0 and h = 1
+    // halves, so both are computed before the pair of act stores.
     const int pq = (g & 1) ? (g + 3) >> 1 : g >> 1;
     const __amdgpu_buffer_rsrc_t ars = tile_rs(p.C2, p.ldc2, ncol0 >> 1);
-    const int aoff = (fr * p.ldc2 + pq * 8) * 2, astep = p.ldc2 * 32;
+    const bool hi8 = (fr & 8) != 0;
+    const int coff1 = ((fr & 7) * p.ldc + g * 8 + (hi8 ? 32 : 0)) * 2, coff2 = ((8 + (fr & 7)) * p.ldc + g * 8 + (hi8 ? 0 : 32)) * 2;
+    const int aoff1 = ((fr & 7) * p.ldc2 + pq * 8 + (hi8 ? 32 : 0)) * 2, aoff2 = ((8 + (fr & 7)) * p.ldc2 + pq * 8 + (hi8 ? 0 : 32)) * 2;
+    const int astep = p.ldc2 * 32;
 #pragma unroll
-    for (int h = 0; h < 2; ++h)
+    for (int i = 0; i < 8; ++i) {
+      u32x4 oh[2];
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
+      for (int h = 0; h < 2; ++h) {
         u32x4 x = pk(h, i, 0), y = pk(h, i, 1);
-        __builtin_amdgcn_raw_buffer_store_b128(x, crs, coff + i * cstep, h * 128, 0);
-        __builtin_amdgcn_raw_buffer_store_b128(y, crs, coff + i * cstep, h * 128 + 64, 0);
+        u32x4 z1, z2;
+        w4_rows8_swap(z1, z2, x, y);
+        const int so = __builtin_amdgcn_readfirstlane(i * cstep + h * 128);
+        __builtin_amdgcn_raw_buffer_store_b128(z1, crs, coff1, so, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(z2, crs, coff2, so, 0);
 #pragma unroll
         for (int d = 0; d < 4; ++d) {
           const auto r = __builtin_amdgcn_permlane16_swap(x[d], y[d], false, false);
@@ -539,13 +581,27 @@ __device__ __forceinline__ void epilogue_w4(const GemmArgs& p, f32x4 (&acc)[2][8
         bf16x8 o;
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[e] = (short)f2bf(bfround(silu(bf2f((bf16_t)gvv[e]))) * bf2f((bf16_t)uvv[e]));
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), ars, aoff + i * astep, h * 64, 0);
-        __builtin_amdgcn_sched_barrier(0);
+        oh[h] = __builtin_bit_cast(u32x4, o);
       }
+      u32x4 a1, a2;
+      w4_rows8_swap(a1, a2, oh[0], oh[1]);
+      const int sa = __builtin_amdgcn_readfirstlane(i * astep);
+      __builtin_amdgcn_raw_buffer_store_b128(a1, ars, aoff1, sa, 0);
+      __builtin_amdgcn_raw_buffer_store_b128(a2, ars, aoff2, sa, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
     return;
   }
-  // plain / residual: the residual / non-temporal choices are made once per tile, not per store
+  // plain / residual: the residual / non-temporal choices are made once per tile, not per store.
+  // FULL-LINE stores (round 4, tools/probes/store_pattern_probe.hip): a buffer_store_dwordx4 whose lanes cover 16 rows x 64 B moves 15.8 B/clk
+  // per CU, one that covers 8 rows x 128 B (whole cache lines) 52.9 B/clk.  The accumulator layout hands lane (fr, g) the 16 bytes at column
+  // 8 g of row fr for the left (x: B fragments 0, 1) and the right (y: fragments 2, 3) 64-byte half of the row's line.  The lanes of rows 8..15
+  // trade their x for the y of the lane 8 rows up (one DPP row_ror:8 inside each 16-lane row), so store 1 writes rows 0..7 and store 2 rows
+  // 8..15 of the 16-row block as whole lines: lane (fr, g) -> store 1: row fr & 7, byte column (fr & 8 ? 64 : 0) + 16 g; store 2: row 8 + (fr & 7),
+  // byte column (fr & 8 ? 0 : 64) + 16 g.  Pure data movement: results are bit-identical.
   if (W4E_ONLY > 1) return;
+  const bool hi8 = (fr & 8) != 0;
+  const int coff1 = ((fr & 7) * p.ldc + g * 8 + (hi8 ? 32 : 0)) * 2, coff2 = ((8 + (fr & 7)) * p.ldc + g * 8 + (hi8 ? 0 : 32)) * 2;
   auto body = [&](auto res_c, auto nt_c) __attribute__((always_inline)) {
     constexpr bool RES = decltype(res_c)::value, NT = decltype(nt_c)::value;
     u32x4 rv[8][2];
@@ -561,6 +617,7 @@ __device__ __forceinline__ void epilogue_w4(const GemmArgs& p, f32x4 (&acc)[2][8
     for (int h = 0; h < 2; ++h)
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
+        u32x4 xy[2];
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
           u32x4 v = pk(h, i, s2);
@@ -573,8 +630,17 @@ __device__ __forceinline__ void epilogue_w4(const GemmArgs& p, f32x4 (&acc)[2][8
             }
             if (h == 0) rv[i][s2] = __builtin_amdgcn_raw_buffer_load_b128(rrs, roff + i * rstep, 128 + s2 * 64, 0);
           }
-          if (NT) __builtin_amdgcn_raw_buffer_store_b128(v, crs, coff + i * cstep, h * 128 + s2 * 64, 2);
-          else __builtin_amdgcn_raw_buffer_store_b128(v, crs, coff + i * cstep, h * 128 + s2 * 64, 0);
+          xy[s2] = v;
+        }
+        u32x4 z1, z2;
+        w4_rows8_swap(z1, z2, xy[0], xy[1]);
+        const int so = __builtin_amdgcn_readfirstlane(i * cstep + h * 128);      // row block + half in the scalar offset: no address VALU per store
+        if (NT) {
+          __builtin_amdgcn_raw_buffer_store_b128(z1, crs, coff1, so, 2);
+          __builtin_amdgcn_raw_buffer_store_b128(z2, crs, coff2, so, 2);
+        } else {
+          __builtin_amdgcn_raw_buffer_store_b128(z1, crs, coff1, so, 0);
+          __builtin_amdgcn_raw_buffer_store_b128(z2, crs, coff2, so, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
       }
