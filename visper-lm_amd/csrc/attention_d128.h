@@ -822,9 +822,15 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #undef FWDM_DMA
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // trailing (dummy) DMAs must not outlive the block's LDS
   l += __shfl_xor(l, 32, 64);
-  if (qrow < p.Sq) {
+  // O leaves as WHOLE rows (round 4): the lane that owns a query holds its D features 4 at a time, and a row-per-lane store (16 dwordx2 per
+  // lane, 32 rows x 16 B per instruction) moves ~7 B/clk per CU while all 8 waves of the CU's one block wait for it (tools/probes/
+  // store_pattern_probe.hip: partial-line stores 15.8, whole-line stores 52.9 B/clk).  The finished ring is the staging buffer: every wave
+  // writes its 32 x D tile into a private 8 KB slice (8-byte unit u of row r at position u ^ r: conflict-free for the 16-lane write groups
+  // and for the row-wise reads), reads it back 4 rows per instruction and stores 16 bytes per lane: 4 whole rows per buffer instruction.
+  __builtin_amdgcn_s_barrier();                        // every wave is done reading K / V: the ring is free
+  {
     const float inv = l > 0.f ? 1.f / l : 0.f;
-    bf16_t* op = p.o + (long)b * p.o_bs + (long)qrow * p.o_ts + (long)h * D;
+    bf16_t* stg = (bf16_t*)attn_smem + wave * 4096;
 #pragma unroll
     for (int db = 0; db < NOB; ++db)
 #pragma unroll
@@ -832,9 +838,19 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         bf16x4 o;
 #pragma unroll
         for (int r = 0; r < 4; ++r) o[r] = (short)f2bf(oacc[db][4 * j + r] * inv);
-        *(bf16x4*)(op + db * 32 + 8 * j + 4 * hh) = o;
+        *(bf16x4*)(stg + ql * 128 + (((db * 8 + 2 * j + hh) ^ ql) << 2)) = o;
       }
-    if (p.lse && hh == 0) p.lse[((long)b * p.Hq + h) * p.Sq + qrow] = (l > 0.f) ? m + log2f(l) : -1e30f;
+    if (p.lse && hh == 0 && qrow < p.Sq) p.lse[((long)b * p.Hq + h) * p.Sq + qrow] = (l > 0.f) ? m + log2f(l) : -1e30f;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // wave-private slice: own writes visible to own reads
+    const int rr = lane >> 4, ch = lane & 15;
+    bf16_t* ob = p.o + (long)b * p.o_bs + (long)h * D + ch * 8;
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int r = it * 4 + rr;
+      const bf16x4 lo = *(const bf16x4*)(stg + r * 128 + (((2 * ch) ^ r) << 2));
+      const bf16x4 hi = *(const bf16x4*)(stg + r * 128 + (((2 * ch + 1) ^ r) << 2));
+      if (qw0 + r < p.Sq && ch * 8 < D)
+        *(bf16x8*)(ob + (long)(qw0 + r) * p.o_ts) = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    }
   }
 }
-
