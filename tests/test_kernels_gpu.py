@@ -231,6 +231,38 @@ def test_gemm_swiglu_fused(ops):
     close(dgu, _ileave(gr.grad, Fd), what="fused swiglu bwd")
 
 
+@pytest.mark.parametrize("M,N,K", [(4096, 6144, 256), (2048, 12288, 384)])
+def test_gemm_4wave_epilogues_whole_line_stores(ops, M, N, K):
+    """The 4-wave kernel's epilogues store whole 128-byte lines (rows 8..15 of a 16-row block trade halves with rows 0..7 by DPP): residual
+    epilogue bit-identical to the 8-phase kernel's, C and the residual as column slices of wider buffers whose base is only 16-byte aligned
+    (lines then straddle), nothing written outside the slice; fused SwiGLU forward / backward at shapes that ROUTE to the 4-wave kernel
+    (>= 192 tiles) against the GEMM + standalone SwiGLU kernels."""
+    a, w, r = rnd(M, K, seed=170), rnd(N, K, scale=0.1, seed=171), rnd(M, N, seed=172)
+    ag, wg, rg = dev(a), dev(w), dev(r)
+    assert torch.equal(ops.gemm(ag, wg, residual=rg, force_generic=8), ops.gemm(ag, wg, residual=rg, force_generic=7))
+    wide = torch.full((M, N + 512), 7.0, device="cuda", dtype=BF)
+    rwide = torch.zeros(M, N + 264, device="cuda", dtype=BF)
+    rwide[:, 8:8 + N] = rg
+    ops.gemm(ag, wg, residual=rwide[:, 8:8 + N], out=wide[:, 8:8 + N], force_generic=8)
+    assert torch.equal(wide[:, 8:8 + N], ops.gemm(ag, wg, residual=rg, force_generic=7))
+    assert float((wide[:, :8] - 7.0).abs().max()) == 0 and float((wide[:, 8 + N:] - 7.0).abs().max()) == 0
+    # fused SwiGLU on the 4-wave kernel: N = 2 F gate|up columns forward, F columns backward
+    Fd = N // 2
+    assert (M // 256) * (Fd // 256) >= 192                       # both directions route to gemm_nt_256w4
+    x, wgu, dy, wd = rnd(M, K, seed=173), rnd(N, K, seed=174) * 0.1, rnd(M, K, seed=175), rnd(K, Fd, seed=176) * 0.1
+    xg, dyg = dev(x), dev(dy)
+    wgu_i = ops.interleave_gate_up(dev(wgu))
+    wd_T = ops.transpose(dev(wd))                     # [Fd, K]
+    gu_ref = ops.gemm(xg, wgu_i, force_generic=7)
+    act_ref = ops.swiglu_fwd(gu_ref)
+    gu, act = ops.gemm_swiglu_fwd(xg, wgu_i)
+    assert torch.equal(gu, gu_ref) and torch.equal(act, act_ref)
+    dgu_ref = ops.swiglu_bwd(ops.gemm(dyg, wd_T, force_generic=7), gu_ref)
+    dgu = ops.gemm_swiglu_bwd(dyg, wd_T, gu_ref)
+    diff = (dgu.float() - dgu_ref.float()).abs()
+    assert float((diff > 0).float().mean()) < 1e-4 and float((diff / dgu_ref.float().abs().clamp_min(1e-3)).max()) < 1e-2
+
+
 @pytest.mark.parametrize("M,N,K", [(256, 256, 64), (512, 768, 192), (256, 1024, 4608), (4352, 4096, 256), (8192, 4096, 1024)])
 def test_gemm_tn_weight_gradient(ops, M, N, K):
     """dW = dY^T X straight from row-major activations == fp32 matmul of the same bf16 operands (fp32 output, strided operands,
