@@ -231,6 +231,27 @@ def test_gemm_swiglu_fused(ops):
     close(dgu, _ileave(gr.grad, Fd), what="fused swiglu bwd")
 
 
+@pytest.mark.parametrize("M,N,K", [(4616, 3072, 1024), (577, 1024, 4096), (300, 256, 128), (4608, 1536, 384), (18432, 1536, 256), (2000, 4096, 256)])
+def test_gemm_4wave_general_variant(ops, M, N, K):
+    """General variant of the 4-wave kernel (force code 14): bias / activation / residual epilogues and an M tail (ViT's M = 8 x 577, a single
+    partial row tile, tails that end inside the first / second wave row).  Bit-identical to the 8-phase kernel's epilogue (same rounding points:
+    acc + bias -> bf16 -> activation -> bf16 -> + residual -> bf16); rows past M of a longer output buffer are not written."""
+    a, w, b, r = rnd(M, K, seed=270), rnd(N, K, scale=0.1, seed=271), rnd(N, seed=272), rnd(M, N, seed=273)
+    ag, wg, bg, rg = dev(a), dev(w), dev(b), dev(r)
+    ref = a.float() @ w.float().t() + b.float()
+    close(ops.gemm(ag, wg, bias=bg, force_generic=14), ref, what=f"w4g bias {M}x{N}x{K}")
+    for kw in (dict(bias=bg), dict(bias=bg, residual=rg), dict(residual=rg), dict(), dict(bias=bg, epi=ops.EPI_GELU), dict(bias=bg, epi=ops.EPI_QUICK_GELU),
+               dict(bias=bg, epi=ops.EPI_RELU), dict(epi=ops.EPI_RELU)):
+        got, want = ops.gemm(ag, wg, force_generic=14, **kw), ops.gemm(ag, wg, force_generic=7, **kw)
+        assert torch.equal(got, want), (M, N, K, sorted(kw), float((got.float() - want.float()).abs().max()))
+    guard = torch.full((M + 300, N), 3.0, device="cuda", dtype=BF)
+    ops.gemm(ag, wg, bias=bg, residual=rg, out=guard[:M], force_generic=14)
+    assert torch.equal(guard[:M], ops.gemm(ag, wg, bias=bg, residual=rg, force_generic=7))
+    assert float((guard[M:] - 3.0).abs().max()) == 0
+    # the automatic choice takes it for these launches (and is the same result)
+    assert torch.equal(ops.gemm(ag, wg, bias=bg, epi=ops.EPI_QUICK_GELU), ops.gemm(ag, wg, bias=bg, epi=ops.EPI_QUICK_GELU, force_generic=7))
+
+
 @pytest.mark.parametrize("M,N,K", [(4096, 6144, 256), (2048, 12288, 384)])
 def test_gemm_4wave_epilogues_whole_line_stores(ops, M, N, K):
     """The 4-wave kernel's epilogues store whole 128-byte lines (rows 8..15 of a 16-row block trade halves with rows 0..7 by DPP): residual

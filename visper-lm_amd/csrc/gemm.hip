@@ -55,6 +55,9 @@ struct GemmArgs {
   // bf16 C tiles leave with non-temporal stores (set by the launcher for N <= 8192, the shapes where it measures +1...2 %: the output does not
   // evict the operand panels from the XCD's L2; hipBLASLt's kernels store C the same way.  Wider outputs measured -0.7 %.)
   int c_nt;
+  // general variant of the 4-wave kernel only (gemm_nt_256w4<false, 1>): optional fp32 per-row scale applied to the accumulator before the bias
+  // (RMSNorm's 1/rms when gamma is folded into the frozen weight, HF LlamaRMSNorm: modeling_llama.py)
+  const float* rowscale;
 };
 
 __device__ __forceinline__ float apply_epi(float v, int epi) {
@@ -64,6 +67,14 @@ __device__ __forceinline__ float apply_epi(float v, int epi) {
     case EPI_RELU: return fmaxf(v, 0.f);
     default: return v;
   }
+}
+
+template <int EPI>
+__device__ __forceinline__ float apply_epi_c(float v) {
+  if constexpr (EPI == EPI_GELU) return gelu_erf(v);
+  else if constexpr (EPI == EPI_QUICK_GELU) return quick_gelu(v);
+  else if constexpr (EPI == EPI_RELU) return fmaxf(v, 0.f);
+  else return v;
 }
 
 // Store 4 consecutive columns (n..n+3) of row m with the reference's rounding points:
@@ -474,6 +485,7 @@ __device__ __forceinline__ void w4_rows8_swap(u32x4& z1, u32x4& z2, const u32x4&
 // Rounding points as everywhere: accumulator -> bf16, (+ residual -> bf16) / (SwiGLU on bf16-rounded values): bit-identical to epilogue_swz.
 // SwiGLU forward: the (g8 | u8) column pairs of gate_up put the gate block in the even-g lanes and the up block in the odd-g lanes; one
 // v_permlane16_swap per dword (16-lane rows of two registers trade places) gives every lane a whole pair.
+template <bool GEN = false>
 __device__ __forceinline__ void epilogue_w4(const GemmArgs& p, f32x4 (&acc)[2][8][4], int mrow0, int ncol0, int lane) {
   int fr = lane & 15, g = lane >> 4;
   asm volatile("" : "+v"(fr), "+v"(g));      // opaque: keeps the lane offsets below from being hoisted out of the tile loop (and spilled across the K loop)
@@ -499,8 +511,103 @@ __device__ __forceinline__ void epilogue_w4(const GemmArgs& p, f32x4 (&acc)[2][8
   auto tile_rs = [&](const void* base, long ld, long col) __attribute__((always_inline)) -> __amdgpu_buffer_rsrc_t {
     const uint64_t b = (uint64_t)(uintptr_t)base + (uint64_t)(((long)mrow0 * ld + col) * 2);
     const uint64_t bu = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(b >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)b);
-    return __builtin_amdgcn_make_buffer_rsrc((void*)(uintptr_t)bu, 0, 0x7fffffff, 0x00020000);
+    // general variant: rows at and past M (the last row tile's tail) fall outside the descriptor: loads return 0, stores are dropped
+    int nrec = 0x7fffffff;
+    if constexpr (GEN) {
+      const int rows_left = min(128, p.M - mrow0);
+      nrec = __builtin_amdgcn_readfirstlane(rows_left > 0 ? (int)(((long)(rows_left - 1) * ld + 128) * 2) : 0);
+    }
+    return __builtin_amdgcn_make_buffer_rsrc((void*)(uintptr_t)bu, 0, nrec, 0x00020000);
   };
+  if constexpr (GEN) {
+    // General epilogue (round 4): fp32 accumulator (* row scale) + bias -> bf16 -> activation -> bf16 -> + residual -> bf16, the rounding points of
+    // store4 / HF's bf16 modules, on the whole-line store pattern of the lean path below.  Bias lives in 32 VGPRs per tile (the lane's 8 columns
+    // of each (h, s2) block), the activation is a template parameter (no per-element switch), residual rows are prefetched like the lean path's.
+    const bool hi8 = (fr & 8) != 0;
+    const __amdgpu_buffer_rsrc_t crs = tile_rs(p.C, p.ldc, ncol0);
+    const int cstep = p.ldc * 32;
+    const int coff1 = ((fr & 7) * p.ldc + g * 8 + (hi8 ? 32 : 0)) * 2, coff2 = ((8 + (fr & 7)) * p.ldc + g * 8 + (hi8 ? 0 : 32)) * 2;
+    auto bodyg = [&](auto epi_c, auto res_c) __attribute__((always_inline)) {
+      constexpr int EPI = decltype(epi_c)::value;
+      constexpr bool RES = decltype(res_c)::value;
+      float bf_[2][2][8];
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          u32x4 q = u32x4{0u, 0u, 0u, 0u};
+          if (p.bias) q = *(const u32x4*)(p.bias + ncol0 + 64 * h + 32 * s2 + 8 * g);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            bf_[h][s2][2 * e] = __builtin_bit_cast(float, q[e] << 16);
+            bf_[h][s2][2 * e + 1] = __builtin_bit_cast(float, q[e] & 0xffff0000u);
+          }
+        }
+      float rsv[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int row = mrow0 + 16 * i + fr;
+        rsv[i] = (p.rowscale && row < p.M) ? p.rowscale[row] : 1.f;
+      }
+      u32x4 rv[8][2];
+      const __amdgpu_buffer_rsrc_t rrs = tile_rs(RES ? (const void*)p.res : p.C, RES ? p.ldr : p.ldc, ncol0);
+      const int roff = (fr * p.ldr + g * 8) * 2, rstep = p.ldr * 32;
+      if (RES) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+          for (int s2 = 0; s2 < 2; ++s2) rv[i][s2] = __builtin_amdgcn_raw_buffer_load_b128(rrs, roff + i * rstep, s2 * 64, 0);
+      }
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          u32x4 xy[2];
+#pragma unroll
+          for (int s2 = 0; s2 < 2; ++s2) {
+            float a[8];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(a[e]) : "a"(acc[h][i][2 * s2][e]));
+              asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(a[4 + e]) : "a"(acc[h][i][2 * s2 + 1][e]));
+            }
+            u32x4 v;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              float x = a[e] * rsv[i] + bf_[h][s2][e];
+              if (EPI != EPI_NONE) x = apply_epi_c<EPI>(bfround(x));
+              a[e] = x;
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = pack_bf16x2(a[2 * e], a[2 * e + 1]);
+            if (RES) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                const float lo = __builtin_bit_cast(float, v[e] << 16) + __builtin_bit_cast(float, rv[i][s2][e] << 16);
+                const float hi = __builtin_bit_cast(float, v[e] & 0xffff0000u) + __builtin_bit_cast(float, rv[i][s2][e] & 0xffff0000u);
+                v[e] = pack_bf16x2(lo, hi);
+              }
+              if (h == 0) rv[i][s2] = __builtin_amdgcn_raw_buffer_load_b128(rrs, roff + i * rstep, 128 + s2 * 64, 0);
+            }
+            xy[s2] = v;
+          }
+          u32x4 z1, z2;
+          w4_rows8_swap(z1, z2, xy[0], xy[1]);
+          const int so = __builtin_amdgcn_readfirstlane(i * cstep + h * 128);
+          __builtin_amdgcn_raw_buffer_store_b128(z1, crs, coff1, so, 0);
+          __builtin_amdgcn_raw_buffer_store_b128(z2, crs, coff2, so, 0);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    using T_ = std::true_type; using F_ = std::false_type;
+    const int epi = p.epi & 0xff;
+    if (p.res != nullptr) bodyg(std::integral_constant<int, EPI_NONE>{}, T_{});       // (activation + residual: the launcher keeps those on the 8-phase kernel)
+    else if (epi == EPI_GELU) bodyg(std::integral_constant<int, EPI_GELU>{}, F_{});
+    else if (epi == EPI_QUICK_GELU) bodyg(std::integral_constant<int, EPI_QUICK_GELU>{}, F_{});
+    else if (epi == EPI_RELU) bodyg(std::integral_constant<int, EPI_RELU>{}, F_{});
+    else bodyg(std::integral_constant<int, EPI_NONE>{}, F_{});
+    return;
+  }
 #ifndef W4E_ONLY
 #define W4E_ONLY 0
 #endif
@@ -1312,7 +1419,9 @@ __global__ __launch_bounds__(512) void gemm_tn_256p8(GemmArgs p) {
 // kernel 1323, hipBLASLt 1163-1187); without the fragment reads 1050; without the DMA 1013; unswizzled (perfectly coalesced) DMA source addresses
 // change nothing (1047 vs 1052) — the pieces cost what they cost because DMA and reads share the CU's LDS / texture-address ports, not because
 // of their address pattern.  The ablation instantiations are gone again (they tripled the build time).
-template <bool OUT_F32>
+// VAR 1 (round 4, bf16 output only): the same K loop with the GENERAL epilogue (row scale, bias, activation, residual: epilogue_w4<true>) and
+// an M tail: the last row tile's A rows at and past M read as zeros through the panel's buffer descriptor, its C rows are dropped by theirs.
+template <bool OUT_F32, int VAR = 0>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void gemm_nt_256w4(GemmArgs p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   bf16_t* smem = (bf16_t*)smem_raw;                    // [buf 0: A 256x64 | B 256x64][buf 1][C staging 4 x 8 KB]
@@ -1320,7 +1429,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 1, wc = wave & 1;
   const int fr = lane & 15, g = lane >> 4;
-  const int tiles_m = p.M >> 8, tiles_n = p.N >> 8;
+  const int tiles_m = VAR == 1 ? (p.M + 255) >> 8 : p.M >> 8, tiles_n = p.N >> 8;
   const int ntiles = tiles_m * tiles_n;
   const int nt = p.K >> 6;                             // even, >= 2
 
@@ -1356,18 +1465,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   if ((p.dbg & 0x10000) && threadIdx.x == 0) vp_dbg_stamps[blockIdx.x * 8 + 0] = wall_clock64();
   // DMA stream state (wave-uniform): next K-tile to fetch = K-tile `kn` of tile `vn`; its byte offset along K is the soffset `kofs`
   typedef uint32_t u32x4s __attribute__((ext_vector_type(4)));
-  auto make_rs = [&](const bf16_t* base, long rows_ld) -> u32x4s {
+  auto make_rs = [&](const bf16_t* base, long rows_ld, int rows = 256) -> u32x4s {
     const uint64_t b = (uint64_t)(uintptr_t)base;
     u32x4s r;
     r[0] = __builtin_amdgcn_readfirstlane((uint32_t)b);
     r[1] = __builtin_amdgcn_readfirstlane((uint32_t)(b >> 32) & 0xffffu);
-    r[2] = __builtin_amdgcn_readfirstlane((uint32_t)(256u * (uint32_t)rows_ld * 2u));
+    r[2] = __builtin_amdgcn_readfirstlane((uint32_t)((uint32_t)rows * (uint32_t)rows_ld * 2u));
     r[3] = 0x00020000u;
     return r;
   };
   int vn = v, kn = 0;
   uint32_t kofs = 0, soff = 0;                         // kofs: byte offset of the stream's K-tile along K; soff: kofs + piece * step, walked by asm
-  u32x4s rsA = make_rs(p.A + (long)tc.m0 * p.lda, p.lda), rsB = make_rs(p.B + (long)tc.n0 * p.ldb, p.ldb);
+#define W4_AROWS(M0) (VAR == 1 ? min(256, p.M - (M0)) : 256)
+  u32x4s rsA = make_rs(p.A + (long)tc.m0 * p.lda, p.lda, W4_AROWS(tc.m0)), rsB = make_rs(p.B + (long)tc.n0 * p.ldb, p.ldb);
 #define W4_DMA(VOFF, RS) asm volatile("buffer_load_dwordx4 %0, %1, %2 offen lds" ::"v"(VOFF), "s"(RS), "s"(soff) : "memory")
 #define W4_SOFF0() asm volatile("s_mov_b32 %0, %1" : "=s"(soff) : "s"(kofs))                  /* first piece of an operand */
 #define W4_SOFFBUMP(STEP) asm volatile("s_add_u32 %0, %0, %1" : "+s"(soff) : "s"(STEP) : "scc")
@@ -1381,7 +1491,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       kofs = 0;                                                                                        \
       if (vn + (int)gridDim.x < ntiles) vn += gridDim.x;      /* else: harmless in-bounds re-fetch of the last tile */ \
       const TileCoord tn_ = TILE_OF(vn);                                                               \
-      rsA = make_rs(p.A + (long)tn_.m0 * p.lda, p.lda);                                                \
+      rsA = make_rs(p.A + (long)tn_.m0 * p.lda, p.lda, W4_AROWS(tn_.m0));                              \
       rsB = make_rs(p.B + (long)tn_.n0 * p.ldb, p.ldb);                                                \
     }                                                                                                  \
   }
@@ -1524,7 +1634,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const int vnext = v + gridDim.x;
     const int mr = tcur.m0 + wr * 128, nc = tcur.n0 + wc * 128;
     if (!OUT_F32) {
-      epilogue_w4(p, acc, mr, nc, lane);        // (the launcher sends bias / activation epilogues and unaligned C to the 8-phase kernel:
+      epilogue_w4<VAR == 1>(p, acc, mr, nc, lane);        // (the launcher sends bias / activation epilogues and unaligned C to the 8-phase kernel:
                                                        // the general epilogue's registers beside 256 accumulators made the allocator spill AGPRs)
     } else {
       float* c = (float*)p.C + (long)(mr + fr) * p.ldc + nc + g * 8;
@@ -1551,6 +1661,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   if ((p.dbg & 0x10000) && threadIdx.x == 0) vp_dbg_stamps[blockIdx.x * 8 + 5] = wall_clock64();
   if ((p.dbg & 0x10000) && threadIdx.x == 0 && false) vp_dbg_stamps[blockIdx.x * 8 + 0] = 0;
 #undef TILE_OF
+#undef W4_AROWS
 #undef W4_DMA
 #undef W4_M0SET
 #undef W4_M0BUMP
@@ -1746,7 +1857,7 @@ int vp_gemm_bf16(int M, int N, int K, const void* A, long lda, const void* B, lo
   VP_REQUIRE(lda >= K && ldb >= K && ldc >= N, VP_ERR_BAD_ARG, "vp_gemm_bf16: leading dims too small");
   VP_REQUIRE((epilogue & 0xff) >= 0 && (epilogue & 0xff) <= 3, VP_ERR_BAD_ARG, "vp_gemm_bf16: bad epilogue %d", epilogue);
   VP_REQUIRE(force_generic == 0 || force_generic == 1 || force_generic == 2 || force_generic == 3 || force_generic == 7 || force_generic == 8 ||
-                 force_generic == 13, VP_ERR_BAD_ARG, "vp_gemm_bf16: unknown kernel selector %d", force_generic);
+                 force_generic == 13 || force_generic == 14, VP_ERR_BAD_ARG, "vp_gemm_bf16: unknown kernel selector %d", force_generic);
   GemmArgs p{(const bf16_t*)A, (const bf16_t*)B, C, (const bf16_t*)bias, (const bf16_t*)residual, M, N, K,
              lda, ldb, ldc, ldr, epilogue, 0, 0, nullptr, 0, nullptr, 0};
   p.dbg = vp_gemm_dbg();
@@ -1776,6 +1887,28 @@ int vp_gemm_bf16(int M, int N, int K, const void* A, long lda, const void* B, lo
       const unsigned g4 = (unsigned)(big_tiles > 256 ? 256 : big_tiles);
       if (out_f32) hipLaunchKernelGGL(gemm_nt_256w4<true>, dim3(g4), dim3(256), 163840, stream, p);
       else hipLaunchKernelGGL(gemm_nt_256w4<false>, dim3(g4), dim3(256), 163840, stream, p);
+      return vp_check_launch("vp_gemm_bf16");
+    }
+  }
+  {
+    // General variant of the 4-wave kernel (round 4; force code 14; VP_GEMM_W4G=0 turns the automatic choice off): bias / activation / residual /
+    // row-scale epilogues and an M tail, for the tower, projector, head and DPT launches that used to fall to the 8-phase kernel.
+    static int w4g_env = -1;
+    if (w4g_env < 0) { const char* e = getenv("VP_GEMM_W4G"); w4g_env = e ? atoi(e) : 1; }
+    const int epi8 = epilogue & 0xff;
+    const bool w4g_ok = fast && !out_f32 && N % 256 == 0 && K % 128 == 0 && M >= 256 && (((uintptr_t)C) & 15) == 0 && ldc % 8 == 0 && ldc < (1L << 22) &&
+                        (!bias || (((uintptr_t)bias) & 15) == 0) && !(residual && epi8 != EPI_NONE) &&
+                        (!residual || (ldr % 8 == 0 && ldr < (1L << 22) && (((uintptr_t)residual) & 15) == 0));
+    // erf-GELU launches stay on the 8-phase kernel: ~50 VALU instructions per element at one wave per SIMD cost more than the K loop gains
+    // (ConvNeXt fc1 18432 x 6144 x 1536: 861 -> 800 TF/s; bias / residual launches: 1092 -> 1363, 1062 -> 1440, 892 -> 1101 TF/s)
+    if (w4g_ok && (force_generic == 14 || (force_generic == 0 && w4g_env == 1 && big_tiles >= 64 && epi8 != EPI_GELU))) {     // (tools/vit_w4_probe.py: ahead of the 128-tile kernel from 76 tiles on)
+      static bool attr_w4g = false;
+      if (!attr_w4g) {
+        (void)hipFuncSetAttribute((const void*)gemm_nt_256w4<false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
+        attr_w4g = true;
+      }
+      const unsigned g4 = (unsigned)(big_tiles > 256 ? 256 : big_tiles);
+      hipLaunchKernelGGL((gemm_nt_256w4<false, 1>), dim3(g4), dim3(256), 163840, stream, p);
       return vp_check_launch("vp_gemm_bf16");
     }
   }
