@@ -58,6 +58,15 @@ int vp_gemm_bf16(int M, int N, int K, const void* A, long lda, const void* B, lo
 int vp_gemm_bf16_swiglu(int mode, int M, int N, int K, const void* A, long lda, const void* B, long ldb, void* C, long ldc,
                         void* C2, long ldc2, const void* aux, long ldaux, vp_stream_t stream);
 
+/* QKV projection of a decoder layer with rotate-half RoPE in the GEMM epilogue (replaces: HF LlamaAttention.forward's q/k/v_proj followed by
+ * apply_rotary_pos_emb, reached from ola_vlm/model/language_model/ola_llama.py:105-115): C[M,N] = (row_scale (.) A) B^T with the columns
+ * < rope_cols (whole 128-wide heads: q and k of the fused qkv weight) rotated exactly as vp_gemm_bf16 + vp_rope would (same rounding points,
+ * bit-identical).  cos_t / sin_t: fp32 [S, 64]; pos: int32 [M] position ids or NULL (row % S).  row_scale: fp32 [M] or NULL; it multiplies the
+ * fp32 accumulator before the bf16 rounding (RMSNorm's 1/rms when gamma is folded into the frozen weight).  head_dim 128, N % 256 == 0,
+ * K % 128 == 0, M >= 256 (any M: the last row tile is range-checked), 16-byte aligned rows; otherwise VP_ERR_UNSUPPORTED_SHAPE. */
+int vp_gemm_bf16_rope(int M, int N, int K, const void* A, long lda, const void* B, long ldb, void* C, long ldc, const float* row_scale,
+                      int rope_cols, const float* cos_t, const float* sin_t, const int* pos, int S, vp_stream_t stream);
+
 /* Weight gradient without transposes: C[M,N] (+)= A[K,M]^T B[K,N], both operands contraction-major (autograd of nn.Linear,
  * grad_weight = grad_output.t() @ input: A = dY[tokens,out], B = X[tokens,in]).  Same 8-phase kernel structure with transposing
  * LDS reads.  M, N multiples of 256, K of 64, 16-byte aligned rows; else VP_ERR_UNSUPPORTED_SHAPE (the caller transposes and

@@ -187,6 +187,34 @@ def test_rope_fwd_and_inverse(ops):
     close(gd.reshape(B, S, nh, hd), qq.grad.transpose(1, 2), what="rope inverse")
 
 
+@pytest.mark.parametrize("B,S,nh,nkv,K", [(2, 256, 4, 2, 512), (3, 200, 6, 1, 256), (8, 2048, 32, 8, 128), (1, 300, 2, 2, 1024)])
+def test_gemm_rope_epilogue(ops, B, S, nh, nkv, K):
+    """vp_gemm_bf16_rope: the fused-QKV GEMM with RoPE of the q and k heads in its epilogue is bit-identical to vp_gemm_bf16 followed by vp_rope
+    (v columns untouched), with and without explicit position ids, on M tails (M = B S not a multiple of 256) and with a row scale (= the plain
+    GEMM of the row-scaled result: RMSNorm's 1/rms when gamma is folded into the weight)."""
+    hd = 128
+    M, N = B * S, (nh + 2 * nkv) * hd
+    assert ops.gemm_rope_ok(M, N, K, hd) == (((M + 255) // 256) * (N // 256) >= 64)      # the engine's routing predicate; the C entry takes every case here
+    a, w = dev(rnd(M, K, seed=300)), dev(rnd(N, K, scale=0.1, seed=301))
+    cs, sn = ops.rope_tables(S, hd, 500000.0, "cuda")
+    ref = ops.gemm(a, w, force_generic=7)
+    ops.rope_(ref, M, S, nh + nkv, hd, cs, sn)
+    got = ops.gemm_rope(a, w, S, (nh + nkv) * hd, cs, sn)
+    assert torch.equal(got, ref), float((got.float() - ref.float()).abs().max())
+    pos = torch.randint(0, S, (M,), dtype=torch.int32, device="cuda")
+    ref2 = ops.gemm(a, w, force_generic=7)
+    ops.rope_(ref2, M, S, nh + nkv, hd, cs, sn, pos=pos)
+    assert torch.equal(ops.gemm_rope(a, w, S, (nh + nkv) * hd, cs, sn, pos=pos), ref2)
+    # row scale: fp32 accumulator * scale -> bf16 (one rounding), then the rotation
+    rs = (torch.rand(M, device="cuda") + 0.5).float()
+    acc = ops.gemm(a, w, out_f32=True, force_generic=7)
+    ref3 = (acc * rs[:, None]).to(BF)
+    ops.rope_(ref3, M, S, nh + nkv, hd, cs, sn)
+    got3 = ops.gemm_rope(a, w, S, (nh + nkv) * hd, cs, sn, row_scale=rs)
+    d3 = (got3.float() - ref3.float()).abs()
+    assert float((d3 > 0).float().mean()) < 1e-3 and float((d3 / ref3.float().abs().clamp_min(1e-2)).max()) < 1e-2      # (fp32 output path sums in another order)
+
+
 def _ileave(t, Fd):
     """[gate | up] column halves -> the library's 8-wide chunk interleave (g0..7 | u0..7 | g8..15 | ...)."""
     g, u = t[..., :Fd], t[..., Fd:]

@@ -21,6 +21,7 @@ _SIGS = {
     "vp_device_info": [p, p, p],
     "vp_gemm_bf16": [i, i, i, p, l, p, l, p, l, p, p, l, i, i, i, p],
     "vp_gemm_bf16_swiglu": [i, i, i, i, p, l, p, l, p, l, p, l, p, l, p],
+    "vp_gemm_bf16_rope": [i, i, i, p, l, p, l, p, l, p, i, p, p, p, i, p],
     "vp_gemm_set_dynamic": [i],
     "vp_gemm_tn_bf16": [i, i, i, p, l, p, l, p, l, i, i, p],
     "vp_transpose_bf16": [i, i, p, l, p, l, p],

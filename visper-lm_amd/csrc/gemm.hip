@@ -58,6 +58,12 @@ struct GemmArgs {
   // general variant of the 4-wave kernel only (gemm_nt_256w4<false, 1>): optional fp32 per-row scale applied to the accumulator before the bias
   // (RMSNorm's 1/rms when gamma is folded into the frozen weight, HF LlamaRMSNorm: modeling_llama.py)
   const float* rowscale;
+  // general variant only: rotate-half RoPE (head_dim 128 = one wave sub-tile) on the columns < rope_cols of the bf16-rounded result, with the
+  // rounding points of rope_kernel (elementwise.hip); cos / sin fp32 [S, 64], position of row r = rope_pos ? rope_pos[r] : r % rope_S
+  const float* rope_cos;
+  const float* rope_sin;
+  const int* rope_pos;
+  int rope_S, rope_cols;
 };
 
 __device__ __forceinline__ float apply_epi(float v, int epi) {
@@ -527,6 +533,61 @@ __device__ __forceinline__ void epilogue_w4(const GemmArgs& p, f32x4 (&acc)[2][8
     const __amdgpu_buffer_rsrc_t crs = tile_rs(p.C, p.ldc, ncol0);
     const int cstep = p.ldc * 32;
     const int coff1 = ((fr & 7) * p.ldc + g * 8 + (hi8 ? 32 : 0)) * 2, coff2 = ((8 + (fr & 7)) * p.ldc + g * 8 + (hi8 ? 0 : 32)) * 2;
+    if (p.rope_cos) {
+      // QKV projection with RoPE in the epilogue (round 4): the wave's 128 columns are ONE head, and lane (fr, g) holds feature d = 32 s2 + 8 g + j
+      // in its h = 0 registers and d + 64 in its h = 1 registers, so the rotation pairs never leave the lane.  Both halves of a 16-row block are
+      // finished together (the loop over h is innermost here), rounding points as rope_kernel: bf(bf(x1 c) - bf(x2 s)), bf(bf(x2 c) + bf(x1 s)).
+      const bool do_rope = ncol0 < p.rope_cols;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int row = mrow0 + 16 * i + fr;
+        const int rowc = min(row, p.M - 1);
+        const float rs = p.rowscale ? p.rowscale[rowc] : 1.f;
+        const int pos = p.rope_pos ? p.rope_pos[rowc] : rowc % p.rope_S;
+        u32x4 v[2][2];
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          float a0[8], a1[8];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(a0[e]) : "a"(acc[0][i][2 * s2][e]));
+            asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(a0[4 + e]) : "a"(acc[0][i][2 * s2 + 1][e]));
+            asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(a1[e]) : "a"(acc[1][i][2 * s2][e]));
+            asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(a1[4 + e]) : "a"(acc[1][i][2 * s2 + 1][e]));
+          }
+          if (do_rope) {
+            const float* cp = p.rope_cos + (long)pos * 64 + 32 * s2 + 8 * g;
+            const float* sp = p.rope_sin + (long)pos * 64 + 32 * s2 + 8 * g;
+            const f32x4 c0 = *(const f32x4*)cp, c1 = *(const f32x4*)(cp + 4), s0 = *(const f32x4*)sp, s1 = *(const f32x4*)(sp + 4);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              const float x1 = bfround(a0[e] * rs), x2 = bfround(a1[e] * rs);
+              const float cc = e < 4 ? c0[e & 3] : c1[e & 3], ss = e < 4 ? s0[e & 3] : s1[e & 3];
+              a0[e] = bfround(x1 * cc) + bfround(-x2 * ss);
+              a1[e] = bfround(x2 * cc) + bfround(x1 * ss);
+            }
+          } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { a0[e] *= rs; a1[e] *= rs; }
+          }
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            v[0][s2][e] = pack_bf16x2(a0[2 * e], a0[2 * e + 1]);
+            v[1][s2][e] = pack_bf16x2(a1[2 * e], a1[2 * e + 1]);
+          }
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          u32x4 z1, z2;
+          w4_rows8_swap(z1, z2, v[h][0], v[h][1]);
+          const int so = __builtin_amdgcn_readfirstlane(i * cstep + h * 128);
+          __builtin_amdgcn_raw_buffer_store_b128(z1, crs, coff1, so, 0);
+          __builtin_amdgcn_raw_buffer_store_b128(z2, crs, coff2, so, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      return;
+    }
     auto bodyg = [&](auto epi_c, auto res_c) __attribute__((always_inline)) {
       constexpr int EPI = decltype(epi_c)::value;
       constexpr bool RES = decltype(res_c)::value;
@@ -1957,6 +2018,32 @@ int vp_gemm_bf16(int M, int N, int K, const void* A, long lda, const void* B, lo
     else hipLaunchKernelGGL(gemm_nt_generic<false>, dim3(grid), dim3(256), 0, stream, p);
   }
   return vp_check_launch("vp_gemm_bf16");
+}
+
+// QKV projection of a decoder layer with rotate-half RoPE in the epilogue (reference: HF LlamaAttention.forward, modeling_llama.py: q/k/v_proj, then
+// apply_rotary_pos_emb on q and k): C[M,N] = (row_scale (.) A) B^T, columns < rope_cols (whole 128-wide heads) rotated like vp_rope (same rounding
+// points: bit-identical to vp_gemm_bf16 followed by vp_rope).  row_scale (fp32 [M], may be NULL) multiplies the fp32 accumulator before the bf16
+// rounding: RMSNorm's 1/rms when gamma is folded into the frozen weight.  General variant of the one-wave-per-SIMD kernel only: head_dim 128,
+// N a multiple of 256, K of 128, M >= 256, 16-byte aligned rows; anything else is VP_ERR_UNSUPPORTED_SHAPE (the caller then runs the two calls).
+int vp_gemm_bf16_rope(int M, int N, int K, const void* A, long lda, const void* B, long ldb, void* C, long ldc, const float* row_scale,
+                      int rope_cols, const float* cos_t, const float* sin_t, const int* pos, int S, hipStream_t stream) {
+  VP_REQUIRE(M > 0 && N > 0 && K > 0 && A && B && C && cos_t && sin_t && S > 0, VP_ERR_BAD_ARG, "vp_gemm_bf16_rope: bad operands");
+  VP_REQUIRE(lda >= K && ldb >= K && ldc >= N && rope_cols >= 0 && rope_cols <= N, VP_ERR_BAD_ARG, "vp_gemm_bf16_rope: leading dims / rope_cols");
+  const long big_tiles = (long)((M + 255) / 256) * (N / 256);
+  VP_REQUIRE(N % 256 == 0 && K % 128 == 0 && M >= 256 && rope_cols % 128 == 0 && lda % 8 == 0 && ldb % 8 == 0 && ldc % 8 == 0 && ldc < (1L << 22) &&
+                 ((((uintptr_t)A) | ((uintptr_t)B) | ((uintptr_t)C) | ((uintptr_t)cos_t) | ((uintptr_t)sin_t)) & 15) == 0,
+             VP_ERR_UNSUPPORTED_SHAPE, "vp_gemm_bf16_rope: needs N %% 256 == 0, K %% 128 == 0, M >= 256, rope_cols %% 128 == 0, 16-byte aligned rows (got %d %d %d)", M, N, K);
+  GemmArgs p{(const bf16_t*)A, (const bf16_t*)B, C, nullptr, nullptr, M, N, K, lda, ldb, ldc, 0, EPI_NONE, 0, 0, nullptr, 0, nullptr, 0};
+  p.dbg = vp_gemm_dbg();
+  p.rowscale = row_scale;
+  p.rope_cos = cos_t; p.rope_sin = sin_t; p.rope_pos = pos; p.rope_S = S; p.rope_cols = rope_cols;
+  static bool attr_w4g = false;
+  if (!attr_w4g) {
+    (void)hipFuncSetAttribute((const void*)gemm_nt_256w4<false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
+    attr_w4g = true;
+  }
+  hipLaunchKernelGGL((gemm_nt_256w4<false, 1>), dim3((unsigned)(big_tiles > 256 ? 256 : big_tiles)), dim3(256), 163840, stream, p);
+  return vp_check_launch("vp_gemm_bf16_rope");
 }
 
 // Fused SwiGLU GEMMs for the decoder MLP (reference: HF LlamaMLP.forward, modeling_llama.py — down(act(gate(x)) * up(x)); the

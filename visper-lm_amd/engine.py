@@ -856,11 +856,15 @@ class Engine:
         il = self.gu_interleaved
         fuse = il and ops.swiglu_fusable(M, 2 * cfg.intermediate_size, cfg.hidden_size) and \
             ops.swiglu_fusable(M, cfg.intermediate_size, cfg.hidden_size)
+        fuse_rope = ops.gemm_rope_ok(M, (nh + 2 * nkv) * hd, cfg.hidden_size, hd) and cos_t.shape[-1] == 64
         for l in range(L):
             o = f"dec.{l}."
             xn, rstd1 = ops.rmsnorm_fwd(x, fz[o + "ln1"], cfg.rms_norm_eps)
-            qkv = ops.gemm(xn, fz[o + "wqkv"])
-            ops.rope_(qkv, M, S, nh + nkv, hd, cos_t, sin_t)
+            if fuse_rope:                                       # RoPE of q and k in the QKV GEMM's epilogue (bit-identical to gemm + rope_)
+                qkv = ops.gemm_rope(xn, fz[o + "wqkv"], S, (nh + nkv) * hd, cos_t, sin_t)
+            else:
+                qkv = ops.gemm(xn, fz[o + "wqkv"])
+                ops.rope_(qkv, M, S, nh + nkv, hd, cos_t, sin_t)
             q4, k4, v4 = self._qkv_views(qkv, B, S)
             att, lse = ops.attn_fwd(q4, k4, v4, causal=True, window=window, kv_len=kv_len)
             h1 = ops.gemm(att.view(M, nh * hd), fz[o + "wo"], residual=x)

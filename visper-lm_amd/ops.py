@@ -5,6 +5,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import os
 
 import torch
 
@@ -61,6 +62,28 @@ def gemm(a, w, bias=None, residual=None, epi=EPI_NONE, out=None, out_f32=False, 
     if GEMM_PROF is not None:
         e1.record()
         GEMM_PROF.append((e0, e1, 2.0 * M * N * K, (M, N, K), "nt_lean" if (bias is None and epi == 0) else "nt_epi"))
+    return out
+
+
+def gemm_rope_ok(M, N, K, head_dim):
+    """Shapes vp_gemm_bf16_rope accepts (general variant of the one-wave-per-SIMD kernel; enough tiles to be worth a persistent grid)."""
+    return head_dim == 128 and N % 256 == 0 and K % 128 == 0 and M >= 256 and ((M + 255) // 256) * (N // 256) >= 64 \
+        and os.environ.get("VP_GEMM_ROPE", "1") != "0"
+
+
+def gemm_rope(a, w, S, rope_cols, cos_t, sin_t, pos=None, row_scale=None):
+    """qkv = rope(a @ w^T) in one kernel: columns < rope_cols (q and k heads of 128) rotated as rope_() would (bit-identical)."""
+    M, K, lda = _rows2d(a)
+    N, K2, ldb = _rows2d(w)
+    assert K == K2 and a.dtype == BF16 and w.dtype == BF16 and cos_t.dtype == torch.float32 and cos_t.shape[-1] == 64
+    out = torch.empty(*a.shape[:-1], N, device=a.device, dtype=BF16)
+    if GEMM_PROF is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    _lib.call("vp_gemm_bf16_rope", M, N, K, _p(a), lda, _p(w), ldb, _p(out), N, _p(row_scale), rope_cols, _p(cos_t), _p(sin_t), _p(pos), S, _stream())
+    if GEMM_PROF is not None:
+        e1.record()
+        GEMM_PROF.append((e0, e1, 2.0 * M * N * K, (M, N, K), "nt_rope"))
     return out
 
 
