@@ -54,9 +54,22 @@ int vp_gemm_bf16(int M, int N, int K, const void* A, long lda, const void* B, lo
 /* Fused SwiGLU GEMMs for the decoder MLP (HF LlamaMLP.forward: down_proj(act_fn(gate_proj(x)) * up_proj(x))).  The fused
  * gate/up tensor keeps gate and up interleaved in 8-column chunks (g0..7 | u0..7 | g8..15 | ...), which is also the layout
  * vp_swiglu_fwd / vp_swiglu_bwd use.  mode 1: C[M,N] = A B^T (gate_up) and C2[M,N/2] = silu(gate)*up.  mode 2: d_act = A B^T
- * stays on chip, aux = gate_up[M,2N], C[M,2N] = d_gate_up.  M, N multiples of 256, K of 64; else VP_ERR_UNSUPPORTED_SHAPE. */
+ * stays on chip, aux = gate_up[M,2N], C[M,2N] = d_gate_up.  M, N multiples of 256, K of 64; else VP_ERR_UNSUPPORTED_SHAPE.
+ * mode 1 with aux != NULL: aux is an fp32 [M] row scale applied to the accumulators (gate_up = bf16(acc * scale): RMSNorm's 1/rms when
+ * gamma is folded into the frozen weight); one-wave-per-SIMD kernel only (K % 128 == 0, >= 192 tiles), else VP_ERR_UNSUPPORTED_SHAPE. */
 int vp_gemm_bf16_swiglu(int mode, int M, int N, int K, const void* A, long lda, const void* B, long ldb, void* C, long ldc,
                         void* C2, long ldc2, const void* aux, long ldaux, vp_stream_t stream);
+
+/* Residual GEMM that also emits the next RMSNorm's statistics (replaces: HF LlamaDecoderLayer.forward's `residual + o_proj(...)` /
+ * `residual + mlp(...)` followed by a separate pass over the stream for the norm, reached from ola_llama.py:105-115): C[M,N] = A B^T + residual
+ * exactly as vp_gemm_bf16, plus sumsq_part[M, N/16] (fp32): per-row sums of squares of the result (fp32, before the last bf16 rounding) over
+ * 16-column groups; vp_rstd_from_sumsq finishes them.  One-wave-per-SIMD kernel only: M, N multiples of 256, K of 128, 16-byte aligned
+ * rows; otherwise VP_ERR_UNSUPPORTED_SHAPE. */
+int vp_gemm_bf16_sumsq(int M, int N, int K, const void* A, long lda, const void* B, long ldb, void* C, long ldc, const void* residual, long ldr,
+                       float* sumsq_part, vp_stream_t stream);
+
+/* rstd[row] = rsqrt(sum_j part[row, j] / H + eps) (HF LlamaRMSNorm.forward's variance / rsqrt), fixed summation order.  nparts % 4 == 0. */
+int vp_rstd_from_sumsq(int M, int nparts, const float* part, int H, float eps, float* rstd, vp_stream_t stream);
 
 /* QKV projection of a decoder layer with rotate-half RoPE in the GEMM epilogue (replaces: HF LlamaAttention.forward's q/k/v_proj followed by
  * apply_rotary_pos_emb, reached from ola_vlm/model/language_model/ola_llama.py:105-115): C[M,N] = (row_scale (.) A) B^T with the columns

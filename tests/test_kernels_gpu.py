@@ -215,6 +215,47 @@ def test_gemm_rope_epilogue(ops, B, S, nh, nkv, K):
     assert float((d3 > 0).float().mean()) < 1e-3 and float((d3 / ref3.float().abs().clamp_min(1e-2)).max()) < 1e-2      # (fp32 output path sums in another order)
 
 
+@pytest.mark.parametrize("M,N,K", [(512, 512, 128), (4096, 4096, 256), (2048, 1024, 1024)])
+def test_gemm_sumsq_and_rstd(ops, M, N, K):
+    """vp_gemm_bf16_sumsq: the residual GEMM's output is bit-identical to vp_gemm_bf16's, and its per-16-column sums of squares finish
+    (vp_rstd_from_sumsq) to the rstd vp_rmsnorm_fwd computes from the stored row (up to the last bf16 rounding of the row: the partials are
+    taken in fp32 before it); two runs are bitwise identical."""
+    a, w, r = dev(rnd(M, K, seed=310)), dev(rnd(N, K, scale=0.1, seed=311)), dev(rnd(M, N, seed=312))
+    out, part = ops.gemm_sumsq(a, w, r)
+    assert torch.equal(out, ops.gemm(a, w, residual=r, force_generic=7))
+    assert part.shape == (M, N // 16)
+    ref_part = out.float().view(M, N // 16, 16).pow(2).sum(-1)
+    # layout: 16-column group j of the row = columns 128 (j // 8) + 64 ((j % 8) // 4) + 8 (j % 4) + {0..7} and + 32 + {0..7}
+    cols = torch.arange(N, device="cuda").view(N // 128, 2, 2, 4, 8)               # [block, h, s2, g, e]
+    grp = cols.permute(0, 1, 3, 2, 4).reshape(N // 16, 16)                          # [block, h, g] -> (s2, e)
+    ref_part = out.float()[:, grp].pow(2).sum(-1)
+    assert float(((part - ref_part).abs() / ref_part.clamp_min(1e-3)).max()) < 2e-2
+    eps = 1e-5
+    rstd = ops.rstd_from_sumsq(part, N, eps)
+    _, rstd_ref = ops.rmsnorm_fwd(out, torch.ones(N, device="cuda", dtype=BF), eps)
+    assert float(((rstd - rstd_ref).abs() / rstd_ref).max()) < 2e-3, float(((rstd - rstd_ref).abs() / rstd_ref).max())
+    out2, part2 = ops.gemm_sumsq(a, w, r)
+    assert torch.equal(part, part2) and torch.equal(rstd, ops.rstd_from_sumsq(part2, N, eps))
+
+
+def test_gemm_swiglu_row_scale(ops):
+    """Fused SwiGLU forward with an fp32 row scale on the accumulators (RMSNorm folded into the weight): gate_up = bf16(acc * scale), act from it."""
+    M, N, K = 4096, 6144, 256
+    x, wgu = dev(rnd(M, K, seed=320)), ops.interleave_gate_up(dev(rnd(N, K, seed=321) * 0.1))
+    rs = (torch.rand(M, device="cuda") + 0.5).float()
+    gu, act = ops.gemm_swiglu_fwd(x, wgu, row_scale=rs)
+    acc = ops.gemm(x, wgu, out_f32=True, force_generic=7)
+    gu_ref = (acc * rs[:, None]).to(BF)
+    d = (gu.float() - gu_ref.float()).abs()
+    assert float((d > 0).float().mean()) < 1e-3 and float((d / gu_ref.float().abs().clamp_min(1e-2)).max()) < 1e-2
+    assert torch.equal(act, ops.swiglu_fwd(gu))
+    gu1, act1 = ops.gemm_swiglu_fwd(x, wgu, row_scale=torch.ones(M, device="cuda"))
+    gu0, act0 = ops.gemm_swiglu_fwd(x, wgu)
+    assert torch.equal(gu1, gu0) and torch.equal(act1, act0)
+    with pytest.raises(Exception):                             # not a one-wave-per-SIMD shape: refused, never silently unscaled
+        ops.gemm_swiglu_fwd(x[:256], wgu[:256], row_scale=rs[:256])
+
+
 def _ileave(t, Fd):
     """[gate | up] column halves -> the library's 8-wide chunk interleave (g0..7 | u0..7 | g8..15 | ...)."""
     g, u = t[..., :Fd], t[..., Fd:]

@@ -22,6 +22,8 @@ _SIGS = {
     "vp_gemm_bf16": [i, i, i, p, l, p, l, p, l, p, p, l, i, i, i, p],
     "vp_gemm_bf16_swiglu": [i, i, i, i, p, l, p, l, p, l, p, l, p, l, p],
     "vp_gemm_bf16_rope": [i, i, i, p, l, p, l, p, l, p, i, p, p, p, i, p],
+    "vp_gemm_bf16_sumsq": [i, i, i, p, l, p, l, p, l, p, l, p, p],
+    "vp_rstd_from_sumsq": [i, i, p, i, f, p, p],
     "vp_gemm_set_dynamic": [i],
     "vp_gemm_tn_bf16": [i, i, i, p, l, p, l, p, l, i, i, p],
     "vp_transpose_bf16": [i, i, p, l, p, l, p],

@@ -60,6 +60,9 @@ struct GemmArgs {
   const float* rowscale;
   // general variant only: rotate-half RoPE (head_dim 128 = one wave sub-tile) on the columns < rope_cols of the bf16-rounded result, with the
   // rounding points of rope_kernel (elementwise.hip); cos / sin fp32 [S, 64], position of row r = rope_pos ? rope_pos[r] : r % rope_S
+  // lean variant, residual epilogue only: per-row sum of squares of the stored row (fp32, before the last bf16 rounding) over this wave's 128 columns,
+  // written to sumsq_part[row * (N / 16) + 16-column block]: the next RMSNorm's statistics without another pass over the residual stream
+  float* sumsq_part;
   const float* rope_cos;
   const float* rope_sin;
   const int* rope_pos;
@@ -491,8 +494,9 @@ __device__ __forceinline__ void w4_rows8_swap(u32x4& z1, u32x4& z2, const u32x4&
 // Rounding points as everywhere: accumulator -> bf16, (+ residual -> bf16) / (SwiGLU on bf16-rounded values): bit-identical to epilogue_swz.
 // SwiGLU forward: the (g8 | u8) column pairs of gate_up put the gate block in the even-g lanes and the up block in the odd-g lanes; one
 // v_permlane16_swap per dword (16-lane rows of two registers trade places) gives every lane a whole pair.
-template <bool GEN = false>
+template <int EV = 0>      // 0: lean (decoder GEMMs) | 1: general (bias / activation / residual / RoPE, M tail) | 2: lean + RMSNorm-fold features
 __device__ __forceinline__ void epilogue_w4(const GemmArgs& p, f32x4 (&acc)[2][8][4], int mrow0, int ncol0, int lane) {
+  constexpr bool GEN = EV == 1, FOLD = EV == 2;
   int fr = lane & 15, g = lane >> 4;
   asm volatile("" : "+v"(fr), "+v"(g));      // opaque: keeps the lane offsets below from being hoisted out of the tile loop (and spilled across the K loop)
   auto pk = [&](int h, int i, int s2) __attribute__((always_inline)) -> u32x4 {
@@ -672,7 +676,7 @@ __device__ __forceinline__ void epilogue_w4(const GemmArgs& p, f32x4 (&acc)[2][8
 #ifndef W4E_ONLY
 #define W4E_ONLY 0
 #endif
-  if ((W4E_ONLY == 0 || W4E_ONLY == 3) && p.mode == 2) {
+  if (!FOLD && (W4E_ONLY == 0 || W4E_ONLY == 3) && p.mode == 2) {
     // SwiGLU backward: the accumulators are d(act); act block (64 h + 32 s + 8 g ..+7) <-> the 32 bytes (g8 | u8) at twice that column of the saved
     // gate_up (aux) and of d(gate_up) (C).  The saved rows of half h = 1 are fetched into the registers half h = 0 has just consumed.
     const __amdgpu_buffer_rsrc_t ars = tile_rs(p.aux, p.ldaux, 2L * ncol0), drs = tile_rs(p.C, p.ldc, 2L * ncol0);
@@ -720,6 +724,27 @@ __device__ __forceinline__ void epilogue_w4(const GemmArgs& p, f32x4 (&acc)[2][8
   const __amdgpu_buffer_rsrc_t crs = tile_rs(p.C, p.ldc, ncol0);
   const int cstep = p.ldc * 32;
   if ((W4E_ONLY == 0 || W4E_ONLY == 2) && p.mode == 1) {
+    auto fwd_body = [&](auto rs_c) __attribute__((always_inline)) {
+    constexpr bool RS = decltype(rs_c)::value;        // fp32 row scale on the accumulators (RMSNorm folded into the weight): gate_up = bf16(acc * scale)
+    float rsv[8];
+    if (RS) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) rsv[i] = p.rowscale[mrow0 + 16 * i + fr];
+    }
+    auto pks = [&](int h, int i, int s2) __attribute__((always_inline)) -> u32x4 {
+      if (!RS) return pk(h, i, s2);
+      f32x4 a, b;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float x, y;
+        asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(x) : "a"(acc[h][i][2 * s2][e]));
+        asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(y) : "a"(acc[h][i][2 * s2 + 1][e]));
+        a[e] = x * rsv[i]; b[e] = y * rsv[i];
+      }
+      u32x4 v;
+      v[0] = pack_bf16x2(a[0], a[1]); v[1] = pack_bf16x2(a[2], a[3]); v[2] = pack_bf16x2(b[0], b[1]); v[3] = pack_bf16x2(b[2], b[3]);
+      return v;
+    };
     // SwiGLU forward: C = gate_up (raw), C2 = act.  After the swap the even-g lanes hold pair g / 2, the odd-g lanes pair (g + 3) / 2 of the half.
     // Whole-line stores (see w4_rows8_swap): gate_up rows from the (x, y) halves of one (h, i); an act row's 128-byte line is its h = 0 and h = 1
     // halves, so both are computed before the pair of act stores.
@@ -734,7 +759,7 @@ __device__ __forceinline__ void epilogue_w4(const GemmArgs& p, f32x4 (&acc)[2][8
       u32x4 oh[2];
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
-        u32x4 x = pk(h, i, 0), y = pk(h, i, 1);
+        u32x4 x = pks(h, i, 0), y = pks(h, i, 1);
         u32x4 z1, z2;
         w4_rows8_swap(z1, z2, x, y);
         const int so = __builtin_amdgcn_readfirstlane(i * cstep + h * 128);
@@ -758,6 +783,8 @@ __device__ __forceinline__ void epilogue_w4(const GemmArgs& p, f32x4 (&acc)[2][8
       __builtin_amdgcn_raw_buffer_store_b128(a2, ars, aoff2, sa, 0);
       __builtin_amdgcn_sched_barrier(0);
     }
+    };
+    if constexpr (FOLD) fwd_body(std::true_type{}); else fwd_body(std::false_type{});
     return;
   }
   // plain / residual: the residual / non-temporal choices are made once per tile, not per store.
@@ -770,8 +797,20 @@ __device__ __forceinline__ void epilogue_w4(const GemmArgs& p, f32x4 (&acc)[2][8
   if (W4E_ONLY > 1) return;
   const bool hi8 = (fr & 8) != 0;
   const int coff1 = ((fr & 7) * p.ldc + g * 8 + (hi8 ? 32 : 0)) * 2, coff2 = ((8 + (fr & 7)) * p.ldc + g * 8 + (hi8 ? 0 : 32)) * 2;
-  auto body = [&](auto res_c, auto nt_c) __attribute__((always_inline)) {
-    constexpr bool RES = decltype(res_c)::value, NT = decltype(nt_c)::value;
+  auto body = [&](auto res_c, auto nt_c, auto ssq_c) __attribute__((always_inline)) {
+    constexpr bool RES = decltype(res_c)::value, NT = decltype(nt_c)::value, SSQ = decltype(ssq_c)::value;
+    // SSQ: one fp32 partial per (row, 64-column half h, lane g) = 16 columns, stored as soon as the (h, i) block is done (a value that lived across the
+    // whole epilogue made the allocator move the accumulator chain out of the AGPRs: 150-190 spilled tuples), N / 16 partials per row, through a buffer
+    // descriptor based at this wave's first row / first partial (scalar (i, h) offset: no 64-bit address arithmetic)
+    const int npr = p.N >> 4;
+    __amdgpu_buffer_rsrc_t srs = crs;
+    int ssoff = 0;
+    if (SSQ) {
+      const uint64_t b = (uint64_t)(uintptr_t)p.sumsq_part + (uint64_t)(((long)mrow0 * npr + (ncol0 >> 4)) * 4);
+      const uint64_t bu = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(b >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)b);
+      srs = __builtin_amdgcn_make_buffer_rsrc((void*)(uintptr_t)bu, 0, 0x7fffffff, 0x00020000);
+      ssoff = (fr * npr + g) * 4;
+    }
     u32x4 rv[8][2];
     const __amdgpu_buffer_rsrc_t rrs = tile_rs(RES ? (const void*)p.res : p.C, RES ? p.ldr : p.ldc, ncol0);
     const int roff = (fr * p.ldr + g * 8) * 2, rstep = p.ldr * 32;
@@ -786,6 +825,7 @@ __device__ __forceinline__ void epilogue_w4(const GemmArgs& p, f32x4 (&acc)[2][8
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         u32x4 xy[2];
+        float sq = 0.f;
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
           u32x4 v = pk(h, i, s2);
@@ -795,6 +835,7 @@ __device__ __forceinline__ void epilogue_w4(const GemmArgs& p, f32x4 (&acc)[2][8
               const float lo = __builtin_bit_cast(float, v[e] << 16) + __builtin_bit_cast(float, rv[i][s2][e] << 16);
               const float hi = __builtin_bit_cast(float, v[e] & 0xffff0000u) + __builtin_bit_cast(float, rv[i][s2][e] & 0xffff0000u);
               v[e] = pack_bf16x2(lo, hi);
+              if (SSQ) sq = fmaf(lo, lo, fmaf(hi, hi, sq));
             }
             if (h == 0) rv[i][s2] = __builtin_amdgcn_raw_buffer_load_b128(rrs, roff + i * rstep, 128 + s2 * 64, 0);
           }
@@ -810,12 +851,17 @@ __device__ __forceinline__ void epilogue_w4(const GemmArgs& p, f32x4 (&acc)[2][8
           __builtin_amdgcn_raw_buffer_store_b128(z1, crs, coff1, so, 0);
           __builtin_amdgcn_raw_buffer_store_b128(z2, crs, coff2, so, 0);
         }
+        if (SSQ) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, sq), srs, ssoff, __builtin_amdgcn_readfirstlane((i * 16 * npr + h * 4) * 4), 0);
         __builtin_amdgcn_sched_barrier(0);
       }
   };
   using T_ = std::true_type; using F_ = std::false_type;
-  if (p.res != nullptr) { if (p.c_nt) body(T_{}, T_{}); else body(T_{}, F_{}); }
-  else { if (p.c_nt) body(F_{}, T_{}); else body(F_{}, F_{}); }
+  if constexpr (FOLD) {
+    if (p.c_nt) body(T_{}, T_{}, T_{}); else body(T_{}, F_{}, T_{});      // (the launcher sends residual + sumsq launches only)
+  } else {
+    if (p.res != nullptr) { if (p.c_nt) body(T_{}, T_{}, F_{}); else body(T_{}, F_{}, F_{}); }
+    else { if (p.c_nt) body(F_{}, T_{}, F_{}); else body(F_{}, F_{}, F_{}); }
+  }
 }
 
 template <bool OUT_F32>
@@ -1695,7 +1741,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const int vnext = v + gridDim.x;
     const int mr = tcur.m0 + wr * 128, nc = tcur.n0 + wc * 128;
     if (!OUT_F32) {
-      epilogue_w4<VAR == 1>(p, acc, mr, nc, lane);        // (the launcher sends bias / activation epilogues and unaligned C to the 8-phase kernel:
+      epilogue_w4<VAR>(p, acc, mr, nc, lane);        // (the launcher sends bias / activation epilogues and unaligned C to the 8-phase kernel:
                                                        // the general epilogue's registers beside 256 accumulators made the allocator spill AGPRs)
     } else {
       float* c = (float*)p.C + (long)(mr + fr) * p.ldc + nc + g * 8;
@@ -2020,6 +2066,31 @@ int vp_gemm_bf16(int M, int N, int K, const void* A, long lda, const void* B, lo
   return vp_check_launch("vp_gemm_bf16");
 }
 
+// Residual GEMM that also emits the statistics of the next RMSNorm (reference: HF LlamaDecoderLayer.forward, modeling_llama.py: residual +
+// o_proj(...) / residual + mlp(...), each followed by an RMSNorm): C[M,N] = A B^T + residual (bf16, as vp_gemm_bf16) and
+// sumsq_part[M, N / 16] (fp32) = per-row sums of squares of the result over 16-column groups (vp_rstd_from_sumsq adds them in a fixed order).
+// Lean one-wave-per-SIMD kernel only: M, N multiples of 256, K of 128, 16-byte aligned rows; else VP_ERR_UNSUPPORTED_SHAPE.
+int vp_gemm_bf16_sumsq(int M, int N, int K, const void* A, long lda, const void* B, long ldb, void* C, long ldc, const void* residual, long ldr,
+                       float* sumsq_part, hipStream_t stream) {
+  VP_REQUIRE(M > 0 && N > 0 && K > 0 && A && B && C && residual && sumsq_part, VP_ERR_BAD_ARG, "vp_gemm_bf16_sumsq: bad operands");
+  VP_REQUIRE(lda >= K && ldb >= K && ldc >= N && ldr >= N, VP_ERR_BAD_ARG, "vp_gemm_bf16_sumsq: leading dims too small");
+  VP_REQUIRE(M % 256 == 0 && N % 256 == 0 && K % 128 == 0 && lda % 8 == 0 && ldb % 8 == 0 && ldc % 8 == 0 && ldr % 8 == 0 && ldc < (1L << 22) &&
+                 ldr < (1L << 22) && ((((uintptr_t)A) | ((uintptr_t)B) | ((uintptr_t)C) | ((uintptr_t)residual)) & 15) == 0,
+             VP_ERR_UNSUPPORTED_SHAPE, "vp_gemm_bf16_sumsq: needs M, N %% 256 == 0, K %% 128 == 0, 16-byte aligned rows (got %d %d %d)", M, N, K);
+  GemmArgs p{(const bf16_t*)A, (const bf16_t*)B, C, nullptr, (const bf16_t*)residual, M, N, K, lda, ldb, ldc, ldr, EPI_NONE, 0, 0, nullptr, 0, nullptr, 0};
+  p.dbg = vp_gemm_dbg();
+  p.sumsq_part = sumsq_part;
+  p.c_nt = (N <= 8192 && vp_c_nt_enabled()) ? 1 : 0;
+  static bool attr_w4 = false;
+  if (!attr_w4) {
+    (void)hipFuncSetAttribute((const void*)gemm_nt_256w4<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
+    attr_w4 = true;
+  }
+  const long big_tiles = (long)(M / 256) * (N / 256);
+  hipLaunchKernelGGL((gemm_nt_256w4<false, 2>), dim3((unsigned)(big_tiles > 256 ? 256 : big_tiles)), dim3(256), 163840, stream, p);
+  return vp_check_launch("vp_gemm_bf16_sumsq");
+}
+
 // QKV projection of a decoder layer with rotate-half RoPE in the epilogue (reference: HF LlamaAttention.forward, modeling_llama.py: q/k/v_proj, then
 // apply_rotary_pos_emb on q and k): C[M,N] = (row_scale (.) A) B^T, columns < rope_cols (whole 128-wide heads) rotated like vp_rope (same rounding
 // points: bit-identical to vp_gemm_bf16 followed by vp_rope).  row_scale (fp32 [M], may be NULL) multiplies the fp32 accumulator before the bf16
@@ -2049,6 +2120,7 @@ int vp_gemm_bf16_rope(int M, int N, int K, const void* A, long lda, const void* 
 // Fused SwiGLU GEMMs for the decoder MLP (reference: HF LlamaMLP.forward, modeling_llama.py — down(act(gate(x)) * up(x)); the
 // fused gate/up weight keeps its columns interleaved in 8-wide chunks: g0..7 | u0..7 | g8..15 | ...).
 //   mode 1 (forward):  C[M,N] = A[M,K] B[N,K]^T (gate_up), C2[M,N/2] = silu(gate) * up         (aux unused)
+//                      aux (optional) = fp32 [M] row scale on the accumulators: gate_up = bf16(acc * scale) (RMSNorm folded into the weight)
 //   mode 2 (backward): d_act[M,N] = A B^T stays on chip; aux = gate_up[M,2N]; C[M,2N] = d_gate_up  (C2 unused)
 // Only the 8-phase kernel implements these epilogues: M, N multiples of 256, K a multiple of 64, 16-byte aligned rows.
 int vp_gemm_bf16_swiglu(int mode, int M, int N, int K, const void* A, long lda, const void* B, long ldb, void* C, long ldc,
@@ -2068,6 +2140,10 @@ int vp_gemm_bf16_swiglu(int mode, int M, int N, int K, const void* A, long lda, 
                "vp_gemm_bf16_swiglu: backward operands");
   GemmArgs p{(const bf16_t*)A, (const bf16_t*)B, C, nullptr, nullptr, M, N, K, lda, ldb, ldc, 0, EPI_NONE, 0,
              mode, C2, ldc2, (const bf16_t*)aux, ldaux};
+  if (mode == 1 && aux) {                              // forward: aux = fp32 [M] row scale (one-wave-per-SIMD kernel only, checked below)
+    p.rowscale = (const float*)aux;
+    p.aux = nullptr;
+  }
   const long big_tiles = (long)(M / 256) * (N / 256);
   {
     static int w4_env = -1;
@@ -2078,10 +2154,18 @@ int vp_gemm_bf16_swiglu(int mode, int M, int N, int K, const void* A, long lda, 
         (void)hipFuncSetAttribute((const void*)gemm_nt_256w4<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
         attr_w4 = true;
       }
-      hipLaunchKernelGGL(gemm_nt_256w4<false>, dim3((unsigned)(big_tiles > 256 ? 256 : big_tiles)), dim3(256), 163840, stream, p);
+      if (p.rowscale) {
+        static bool attr_w4f = false;
+        if (!attr_w4f) {
+          (void)hipFuncSetAttribute((const void*)gemm_nt_256w4<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
+          attr_w4f = true;
+        }
+        hipLaunchKernelGGL((gemm_nt_256w4<false, 2>), dim3((unsigned)(big_tiles > 256 ? 256 : big_tiles)), dim3(256), 163840, stream, p);
+      } else hipLaunchKernelGGL(gemm_nt_256w4<false>, dim3((unsigned)(big_tiles > 256 ? 256 : big_tiles)), dim3(256), 163840, stream, p);
       return vp_check_launch("vp_gemm_bf16_swiglu");
     }
   }
+  VP_REQUIRE(!p.rowscale, VP_ERR_UNSUPPORTED_SHAPE, "vp_gemm_bf16_swiglu: the row scale exists on the one-wave-per-SIMD kernel only (K %% 128 == 0, >= 192 tiles; got %d %d %d)", M, N, K);
   static bool attr_p8 = false;
   if (!attr_p8) {
     (void)hipFuncSetAttribute((const void*)gemm_nt_256p8<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);

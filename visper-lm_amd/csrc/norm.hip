@@ -94,6 +94,22 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const bf16_t* __restri
   }
 }
 
+// one wave per row: lanes stride over the row's partials (float4 each), then the fixed xor tree of wave_sum: deterministic
+__global__ __launch_bounds__(256) void rstd_from_sumsq_kernel(const float* __restrict__ part, float* __restrict__ rstd, int M, int nparts,
+                                                              float inv_h, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const f32x4* p4 = (const f32x4*)(part + (long)row * nparts);
+  float s = 0.f;
+  for (int j = lane; j < (nparts >> 2); j += 64) {
+    const f32x4 v = p4[j];
+    s += (v[0] + v[1]) + (v[2] + v[3]);
+  }
+  s = wave_sum(s);
+  if (lane == 0) rstd[row] = rsqrtf(s * inv_h + eps);
+}
+
 // ---------------------------------------------------------------- LayerNorm --------------------
 template <int NCH>
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w,
@@ -245,6 +261,14 @@ int vp_rmsnorm_bwd(int M, int H, const void* dy, const void* x, const void* w, c
   NORM_DISPATCH(rmsnorm_bwd_kernel, H, dim3((M + 3) / 4), dim3(256), 0, s, (const bf16_t*)dy, (const bf16_t*)x,
                      (const bf16_t*)w, rstd, (const bf16_t*)dres, (bf16_t*)dx, M, H, ld);
   return vp_check_launch("vp_rmsnorm_bwd");
+}
+
+// rstd[row] = rsqrt(sum_j part[row, j] / H + eps): finishes the per-16-column sums of squares vp_gemm_bf16_sumsq emitted (nparts = N / 16), in a
+// fixed order (deterministic).  Reference: HF LlamaRMSNorm.forward (variance = hidden.pow(2).mean(-1); rsqrt(variance + eps)).
+int vp_rstd_from_sumsq(int M, int nparts, const float* part, int H, float eps, float* rstd, hipStream_t s) {
+  VP_REQUIRE(M > 0 && nparts > 0 && nparts % 4 == 0 && H > 0 && part && rstd, VP_ERR_BAD_ARG, "vp_rstd_from_sumsq: bad args");
+  hipLaunchKernelGGL(rstd_from_sumsq_kernel, dim3((M + 3) / 4), dim3(256), 0, s, part, rstd, M, nparts, 1.f / (float)H, eps);
+  return vp_check_launch("vp_rstd_from_sumsq");
 }
 
 int vp_layernorm_fwd(int M, int H, const void* x, long ldx, const void* w, const void* b, float eps, void* y, long ldy,

@@ -178,6 +178,14 @@ class Engine:
     def _load_frozen_decoder(self, W, d):
         """PT stage: the LLM is frozen -> bf16 kernel-ready copies, q/k/v and gate/up fused, plus pre-transposed dgrad copies."""
         cfg, fz = self.cfg, self.fz
+        # RMSNorm fold (frozen LLM only; VP_FOLD_NORM=0 turns it off): y = W (gamma (.) x / rms) = (W diag(gamma)) x / rms.  The kernel-side decoder
+        # weights are derived copies already (fused qkv, interleaved gate|up, pre-transposed dgrad copies), so gamma goes into them for free, the
+        # norms keep gamma = 1, and where every GEMM of a layer is a one-wave-per-SIMD launch (ops.fold_norm_ok) the normalisation itself
+        # disappears: 1/rms is a row scale in the consumer's epilogue, the sums of squares come out of the producer's residual epilogue.
+        # Reference: HF LlamaRMSNorm / LlamaDecoderLayer (modeling_llama.py), reached from ola_llama.py:105-115.
+        # Only where the fast path can exist (head_dim 128: RoPE in the QKV epilogue); Phi-3 (D = 96) keeps gamma in its norms.
+        self.fold_norm = os.environ.get("VP_FOLD_NORM", "1") != "0" and cfg.head_dim == 128 and cfg.hidden_size % 256 == 0
+        fz["ones_h"] = torch.ones(cfg.hidden_size, device=self.dev, dtype=BF16)
         fz["embed"] = d(W["model.embed_tokens.weight"])
         fz["norm"] = d(W["model.norm.weight"])
         fz["lm_head"] = d(W["lm_head.weight"])
@@ -190,14 +198,21 @@ class Engine:
             else:
                 wqkv = torch.cat([W[p + f"self_attn.{x}_proj.weight"] for x in "qkv"], 0)
                 wgu = torch.cat([W[p + "mlp.gate_proj.weight"], W[p + "mlp.up_proj.weight"]], 0)
+            if self.fold_norm:                                   # gamma of the two RMSNorms into the (derived, frozen) consumer weights: see _decoder_fwd
+                g1, g2 = W[p + "input_layernorm.weight"], W[p + "post_attention_layernorm.weight"]
+                wqkv = wqkv.to(self.dev).float() * g1.to(self.dev).float()[None, :]
+                wgu = wgu.to(self.dev).float() * g2.to(self.dev).float()[None, :]
             fz[o + "wqkv"] = d(wqkv)
             fz[o + "wgu"] = ops.interleave_gate_up(d(wgu))      # gate / up rows interleaved in 8-row chunks (fused SwiGLU epilogues)
             fz[o + "wo"] = d(W[p + "self_attn.o_proj.weight"])
             fz[o + "wd"] = d(W[p + "mlp.down_proj.weight"])
             for k in ("wqkv", "wgu", "wo", "wd"):
                 fz[o + k + "_T"] = _tp(fz[o + k])
-            fz[o + "ln1"] = d(W[p + "input_layernorm.weight"])
-            fz[o + "ln2"] = d(W[p + "post_attention_layernorm.weight"])
+            if self.fold_norm:
+                fz[o + "ln1"] = fz[o + "ln2"] = fz["ones_h"]
+            else:
+                fz[o + "ln1"] = d(W[p + "input_layernorm.weight"])
+                fz[o + "ln2"] = d(W[p + "post_attention_layernorm.weight"])
 
     # ------------------------------------------------------------------------------------------ weights
     def load_weights(self, W):
@@ -857,8 +872,36 @@ class Engine:
         fuse = il and ops.swiglu_fusable(M, 2 * cfg.intermediate_size, cfg.hidden_size) and \
             ops.swiglu_fusable(M, cfg.intermediate_size, cfg.hidden_size)
         fuse_rope = ops.gemm_rope_ok(M, (nh + 2 * nkv) * hd, cfg.hidden_size, hd) and cos_t.shape[-1] == 64
+        fold = getattr(self, "fold_norm", False) and not self.train_llm and fuse and fuse_rope and \
+            ops.fold_norm_ok(M, cfg.hidden_size, cfg.intermediate_size, hd, (nh + 2 * nkv) * hd)
+        H, eps = cfg.hidden_size, cfg.rms_norm_eps
+        rstd1 = None
         for l in range(L):
             o = f"dec.{l}."
+            if fold:
+                # no normalised copy of the stream: 1/rms rides in the consuming GEMM's epilogue (gamma is in its weight), the statistics of the next
+                # norm come out of the residual GEMM that writes the stream (layer 0's from one pass over the spliced embeddings)
+                if rstd1 is None:
+                    _, rstd1 = ops.rmsnorm_fwd(x, fz["ones_h"], eps)
+                qkv = ops.gemm_rope(x, fz[o + "wqkv"], S, (nh + nkv) * hd, cos_t, sin_t, row_scale=rstd1)
+                q4, k4, v4 = self._qkv_views(qkv, B, S)
+                att, lse = ops.attn_fwd(q4, k4, v4, causal=True, window=window, kv_len=kv_len)
+                h1, part = ops.gemm_sumsq(att.view(M, nh * hd), fz[o + "wo"], x)
+                rstd2 = ops.rstd_from_sumsq(part, H, eps)
+                gu, act = ops.gemm_swiglu_fwd(h1, fz[o + "wgu"], row_scale=rstd2)
+                if l == L - 1:
+                    xo = ops.gemm(act, fz[o + "wd"], residual=h1)
+                    rnext = None
+                else:
+                    xo, part = ops.gemm_sumsq(act, fz[o + "wd"], h1)
+                    rnext = ops.rstd_from_sumsq(part, H, eps)
+                del part
+                if compute_grads:
+                    saved.append((x, rstd1, qkv, att, lse, h1, rstd2, gu))
+                if l in self.tapped and l != L - 1:
+                    states[l] = xo
+                x, rstd1 = xo, rnext
+                continue
             xn, rstd1 = ops.rmsnorm_fwd(x, fz[o + "ln1"], cfg.rms_norm_eps)
             if fuse_rope:                                       # RoPE of q and k in the QKV GEMM's epilogue (bit-identical to gemm + rope_)
                 qkv = ops.gemm_rope(xn, fz[o + "wqkv"], S, (nh + nkv) * hd, cos_t, sin_t)

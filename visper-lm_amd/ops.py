@@ -87,6 +87,38 @@ def gemm_rope(a, w, S, rope_cols, cos_t, sin_t, pos=None, row_scale=None):
     return out
 
 
+def fold_norm_ok(M, H, I, head_dim, nqkv):
+    """Shapes for which a decoder layer can run with RMSNorm folded away (gamma in the frozen weights, 1/rms as a row scale in the consuming
+    GEMM's epilogue, sums of squares from the producing residual GEMM's epilogue): every GEMM involved must be a one-wave-per-SIMD launch."""
+    return (gemm_rope_ok(M, nqkv, H, head_dim) and M % 256 == 0 and H % 256 == 0 and I % 128 == 0 and (M // 256) * (2 * I // 256) >= 192
+            and os.environ.get("VP_GEMM_W4", "1") == "1" and os.environ.get("VP_FOLD_NORM", "1") != "0")
+
+
+def gemm_sumsq(a, w, residual):
+    """out = a @ w^T + residual and the per-row sum-of-squares partials [M, N/16] of out (vp_gemm_bf16_sumsq)."""
+    M, K, lda = _rows2d(a)
+    N, K2, ldb = _rows2d(w)
+    assert K == K2 and a.dtype == BF16 and w.dtype == BF16
+    out = torch.empty(*a.shape[:-1], N, device=a.device, dtype=BF16)
+    part = torch.empty(M, N // 16, device=a.device, dtype=torch.float32)
+    _, _, ldr = _rows2d(residual)
+    if GEMM_PROF is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    _lib.call("vp_gemm_bf16_sumsq", M, N, K, _p(a), lda, _p(w), ldb, _p(out), N, _p(residual), ldr, _p(part), _stream())
+    if GEMM_PROF is not None:
+        e1.record()
+        GEMM_PROF.append((e0, e1, 2.0 * M * N * K, (M, N, K), "nt_lean"))
+    return out, part
+
+
+def rstd_from_sumsq(part, H, eps):
+    M, nparts = part.shape
+    rstd = torch.empty(M, device=part.device, dtype=torch.float32)
+    _lib.call("vp_rstd_from_sumsq", M, nparts, _p(part), H, float(eps), _p(rstd), _stream())
+    return rstd
+
+
 def swiglu_fusable(M, N, K):
     """Shapes the fused SwiGLU GEMM epilogues accept (vp_gemm_bf16_swiglu: 8-phase kernel, interior tiles only)."""
     return M % 256 == 0 and N % 256 == 0 and K % 64 == 0
@@ -103,8 +135,8 @@ def interleave_gate_up(w_gate_up):
     return torch.stack([g.reshape(F // 8, 8, *rest), u.reshape(F // 8, 8, *rest)], 1).reshape(F2, *rest).contiguous()
 
 
-def gemm_swiglu_fwd(a, w_gu):
-    """gate_up = a @ w_gu^T (chunk-interleaved), act = silu(gate) * up, in one kernel.  Returns (gate_up, act)."""
+def gemm_swiglu_fwd(a, w_gu, row_scale=None):
+    """gate_up = (row_scale * a) @ w_gu^T (chunk-interleaved), act = silu(gate) * up, in one kernel.  Returns (gate_up, act)."""
     M, K, lda = _rows2d(a)
     N, K2, ldb = _rows2d(w_gu)
     assert K == K2 and swiglu_fusable(M, N, K)
@@ -113,7 +145,7 @@ def gemm_swiglu_fwd(a, w_gu):
     if GEMM_PROF is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    _lib.call("vp_gemm_bf16_swiglu", 1, M, N, K, _p(a), lda, _p(w_gu), ldb, _p(gu), N, _p(act), N // 2, None, 0, _stream())
+    _lib.call("vp_gemm_bf16_swiglu", 1, M, N, K, _p(a), lda, _p(w_gu), ldb, _p(gu), N, _p(act), N // 2, _p(row_scale), 0, _stream())
     if GEMM_PROF is not None:
         e1.record()
         GEMM_PROF.append((e0, e1, 2.0 * M * N * K, (M, N, K), "nt_lean"))
