@@ -826,22 +826,60 @@ class Engine:
 
         dec = self._decoder_fwd(x, plan, compute_grads)
         out["hidden"] = self.present(dec["hidden"], plan)
-        text_loss, d_hidden = self._ntp(dec["hidden"], plan, compute_grads, out)
-        task_loss, d_state = self._heads(dec["states"], plan, batch, compute_grads, out)
-        if compute_grads and self.world > 1:
-            self._reducer().start_early()                    # heads + logit scales: overlap with the decoder backward
-        loss = text_loss.clone()
-        for task in ("seg", "depth", "gen"):                                 # sum order: ola_llama.py:143-144
-            if task in task_loss:
-                loss = loss + task_loss[task]
-                out[f"{task}_loss"] = task_loss[task]
-        out["loss"] = loss
+        # The distillation heads (a8..a14: ~300 small launches, few tiles each) depend only on the tapped layer states, and nothing needs their
+        # result before the decoder backward reaches the topmost tapped layer.  They run on a SIDE STREAM, forked here and joined there
+        # (_join_heads), so their workgroups fill the CUs the persistent GEMMs of lm_head / the upper layers' backward leave idle in their
+        # XCD tails and dispatch gaps instead of owning the chip for ~13 ms.  Same kernels, same inputs, no atomics: results are bit-identical
+        # to the serial order (VP_HEADS_STREAM=0).  The reference runs them serially inside forward (base_ola_vlm.py:445-534).
+        fork = compute_grads and len(self.tasks) > 0 and os.environ.get("VP_HEADS_STREAM", "1") != "0"
+        self._heads_join = None
+        if fork:
+            main = torch.cuda.current_stream()
+            if getattr(self, "_side", None) is None:
+                # lowest priority the device offers (VP_HEADS_PRIO overrides): the GEMM stream's workgroups go first, the heads take what is idle
+                lo_pri = torch.cuda.Stream.priority_range()[0]
+                self._side = torch.cuda.Stream(device=self.dev, priority=int(os.environ.get("VP_HEADS_PRIO", lo_pri)))
+            ev = torch.cuda.Event()
+            ev.record(main)
+            self._side.wait_event(ev)
+            with torch.cuda.stream(self._side):
+                task_loss, d_state = self._heads(dec["states"], plan, batch, compute_grads, out)
+                if self.world > 1:
+                    self._reducer().start_early()                # heads + logit scales: overlap with the decoder backward
+                self._heads_join = torch.cuda.Event()
+                self._heads_join.record(self._side)
+            for t in d_state.values():
+                t.record_stream(main)
+            text_loss, d_hidden = self._ntp(dec["hidden"], plan, compute_grads, out)
+        else:
+            text_loss, d_hidden = self._ntp(dec["hidden"], plan, compute_grads, out)
+            task_loss, d_state = self._heads(dec["states"], plan, batch, compute_grads, out)
+            if compute_grads and self.world > 1:
+                self._reducer().start_early()                    # heads + logit scales: overlap with the decoder backward
+
+        def total():
+            loss = text_loss.clone()
+            for task in ("seg", "depth", "gen"):                             # sum order: ola_llama.py:143-144
+                if task in task_loss:
+                    loss = loss + task_loss[task]
+                    out[f"{task}_loss"] = task_loss[task]
+            out["loss"] = loss
         if not compute_grads:
+            total()
             return out
         dx = self._decoder_bwd(d_hidden, dec, d_state, plan)
+        self._join_heads()
+        total()
         out["d_inputs_embeds"] = self.present(dx, plan)
         self._splice_bwd(dx, plan, feats, z1, a1)
         return out
+
+    def _join_heads(self):
+        """The current stream waits (on the GPU; the host does not block) for the side stream's heads: called in front of the first use of their
+        results (d_state in the decoder backward) and once more at its end."""
+        if getattr(self, "_heads_join", None) is not None:
+            torch.cuda.current_stream().wait_event(self._heads_join)
+            self._heads_join = None
 
     def _attn_window(self):
         """kernels keep keys with q - key < window; transformers 4.41.1 (the reference's pin) keeps q - key <= sliding_window"""
@@ -1077,6 +1115,7 @@ class Engine:
         window = self._attn_window()
         x, rstd_f, saved = dec["x"], dec["rstd_f"], dec["saved"]
         if (L - 1) in d_state:
+            self._join_heads()
             ops.add(d_hidden, d_state[L - 1], out=d_hidden)
         train_llm = self.train_llm
         if train_llm:
@@ -1090,6 +1129,7 @@ class Engine:
             o = f"dec.{l}."
             x_in, rstd1, qkv, att, lse, h1, rstd2, gu = saved[l]
             if l in d_state and l != L - 1:
+                self._join_heads()
                 ops.add(dx, d_state[l], out=dx)
             pl = f"model.layers.{l}."
             if self.gu_interleaved and ops.swiglu_fusable(M, cfg.intermediate_size, cfg.hidden_size) and gu.is_contiguous():
