@@ -516,8 +516,10 @@ def main():
         lab = ids.clone()
         lab[:, :cfg.num_sys_tokens + 7] = -100
         b["input_ids"], b["labels"] = ids, lab
+        b["images_resident"] = True                 # the image / target pool above was written to HBM before the first step was enqueued
         fresh.append(b)
 
+    torch.cuda.synchronize(dev)                      # (images_resident: the pool is in HBM before any step is enqueued)
     from visper_lm_amd import optim
     total_steps = 2181                                  # LLaVA-558K / global batch 256 (scripts/train/pretrain.sh), 3 % warm-up, cosine
     n_warm = optim.warmup_steps(total_steps, 0.03)

@@ -164,6 +164,33 @@ def test_as_released_mask_zeroing(tiny):
             assert float(eng.ps.g(k).abs().sum()) == 0.0, k
 
 
+def test_side_stream_schedule_is_bit_identical(tiny, monkeypatch):
+    """The heads run on a side stream (forked after the decoder forward, joined in the decoder backward) and, for a batch flagged
+    `images_resident`, so does the frozen tower (no dependency on the current stream).  Scheduling only: loss, layer losses and every gradient are
+    bitwise those of the serial order (VP_HEADS_STREAM=0 / VP_TOWER_STREAM=0), also over back-to-back steps with the host running ahead."""
+    eng, gb = tiny["eng"], _to_gpu_batch(tiny["batch"])
+    torch.cuda.synchronize()
+
+    def run(resident, n=3):
+        res = []
+        for _ in range(n):                                   # no sync between steps: step t+1's tower may run under step t's backward
+            out = eng.train_step({**gb, "images_resident": resident})
+            res.append((out["loss"].clone(), {k: v.clone() for k, v in out["layer_losses"].items()}, eng.ps.grad.clone()))
+        torch.cuda.synchronize()
+        return res
+
+    monkeypatch.setenv("VP_HEADS_STREAM", "0")
+    monkeypatch.setenv("VP_TOWER_STREAM", "0")
+    serial = run(False, 1)[0]
+    monkeypatch.setenv("VP_HEADS_STREAM", "1")
+    monkeypatch.setenv("VP_TOWER_STREAM", "1")
+    for resident in (False, True):
+        for loss, ll, grad in run(resident):
+            assert torch.equal(loss, serial[0])
+            assert all(torch.equal(ll[k], serial[1][k]) for k in serial[1])
+            assert torch.equal(grad, serial[2])
+
+
 def test_optimizer_step_reduces_loss(tiny):
     from visper_lm_amd.engine import Engine
     eng = Engine(tiny["cfg"])

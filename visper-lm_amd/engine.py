@@ -758,12 +758,34 @@ class Engine:
         return plan
 
     # ------------------------------------------------------------------------------------------ embed
-    def _embed(self, images, plan):
+    def _side_stream(self):
+        if getattr(self, "_side", None) is None:
+            # lowest priority the device offers (VP_HEADS_PRIO overrides; gfx950 / ROCm 7: range (0, -1), no measurable difference between them)
+            lo_pri = torch.cuda.Stream.priority_range()[0]
+            self._side = torch.cuda.Stream(device=self.dev, priority=int(os.environ.get("VP_HEADS_PRIO", lo_pri)))
+        return self._side
+
+    def _embed(self, images, plan, images_resident=False):
         """CLIP tower -> mlp2x_gelu projector -> task-token rows -> splice gather.  Returns x [B*S,H] and the projector
-        activations its backward needs."""
+        activations its backward needs.
+        images_resident: the caller states that `images` was fully written before any work still pending on the current stream was enqueued (bench.py:
+        synthetic batches resident in HBM; a dataloader that copies to the device on its own stream).  The frozen tower then runs on the side
+        stream WITHOUT waiting for the current stream: it depends on nothing but the images and the frozen weights, so when the host runs ahead
+        its ~160 small launches execute under the previous step's decoder backward (in its XCD tails and dispatch gaps) instead of at the head of
+        this step with the chip to themselves.  Every step still runs its own tower pass; only its place in the GPU's schedule moves.
+        VP_TOWER_STREAM=0: on the current stream, as before."""
         cfg, fz, ps, dev = self.cfg, self.fz, self.ps, self.dev
         H = cfg.hidden_size
-        feats = self.vit_forward(images)                                           # [n_img*576, C]
+        if images_resident and os.environ.get("VP_TOWER_STREAM", "1") != "0":
+            main, side = torch.cuda.current_stream(), self._side_stream()
+            with torch.cuda.stream(side):
+                feats = self.vit_forward(images)
+                ev = torch.cuda.Event()
+                ev.record(side)
+            main.wait_event(ev)
+            feats.record_stream(main)
+        else:
+            feats = self.vit_forward(images)                                       # [n_img*576, C]
         z1 = ops.gemm(feats, ps.w("model.mm_projector.0.weight"), bias=ps.w("model.mm_projector.0.bias"))
         a1 = ops.act_fwd(z1, ops.EPI_GELU)
         img = ops.gemm(a1, ps.w("model.mm_projector.2.weight"), bias=ps.w("model.mm_projector.2.bias"))
@@ -820,7 +842,7 @@ class Engine:
         out = {"plan": plan}
 
         # ---- vision tower + projector + splice (a1..a5)
-        x, feats, z1, a1, img = self._embed(batch["images"], plan)
+        x, feats, z1, a1, img = self._embed(batch["images"], plan, images_resident=bool(batch.get("images_resident", False)))
         out["image_features"] = img
         out["inputs_embeds"] = self.present(x, plan)
 
@@ -835,19 +857,16 @@ class Engine:
         self._heads_join = None
         if fork:
             main = torch.cuda.current_stream()
-            if getattr(self, "_side", None) is None:
-                # lowest priority the device offers (VP_HEADS_PRIO overrides): the GEMM stream's workgroups go first, the heads take what is idle
-                lo_pri = torch.cuda.Stream.priority_range()[0]
-                self._side = torch.cuda.Stream(device=self.dev, priority=int(os.environ.get("VP_HEADS_PRIO", lo_pri)))
+            side = self._side_stream()
             ev = torch.cuda.Event()
             ev.record(main)
-            self._side.wait_event(ev)
-            with torch.cuda.stream(self._side):
+            side.wait_event(ev)
+            with torch.cuda.stream(side):
                 task_loss, d_state = self._heads(dec["states"], plan, batch, compute_grads, out)
                 if self.world > 1:
                     self._reducer().start_early()                # heads + logit scales: overlap with the decoder backward
                 self._heads_join = torch.cuda.Event()
-                self._heads_join.record(self._side)
+                self._heads_join.record(side)
             for t in d_state.values():
                 t.record_stream(main)
             text_loss, d_hidden = self._ntp(dec["hidden"], plan, compute_grads, out)
