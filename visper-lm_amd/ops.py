@@ -108,7 +108,7 @@ def gemm_sumsq(a, w, residual):
     _lib.call("vp_gemm_bf16_sumsq", M, N, K, _p(a), lda, _p(w), ldb, _p(out), N, _p(residual), ldr, _p(part), _stream())
     if GEMM_PROF is not None:
         e1.record()
-        GEMM_PROF.append((e0, e1, 2.0 * M * N * K, (M, N, K), "nt_lean"))
+        GEMM_PROF.append((e0, e1, 2.0 * M * N * K, (M, N, K), "nt_fold"))
     return out, part
 
 
@@ -148,7 +148,7 @@ def gemm_swiglu_fwd(a, w_gu, row_scale=None):
     _lib.call("vp_gemm_bf16_swiglu", 1, M, N, K, _p(a), lda, _p(w_gu), ldb, _p(gu), N, _p(act), N // 2, _p(row_scale), 0, _stream())
     if GEMM_PROF is not None:
         e1.record()
-        GEMM_PROF.append((e0, e1, 2.0 * M * N * K, (M, N, K), "nt_lean"))
+        GEMM_PROF.append((e0, e1, 2.0 * M * N * K, (M, N, K), "nt_lean" if row_scale is None else "nt_fold"))
     return gu, act
 
 
