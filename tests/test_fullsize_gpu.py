@@ -1,6 +1,7 @@
 """Parity at BASELINE.json's full sizes (configs[1]: B=8, S=2048, Llama-3-8B dims) through size-independent properties: the oracle
 cannot run these shapes in seconds, so kernels are checked on row samples against fp32 math, by linearity / determinism, and the
 fused kernels against their unfused compositions."""
+import os
 import pytest
 import torch
 
@@ -166,6 +167,55 @@ def test_config3_convnext_full_step_is_deterministic_and_finite():
     cfg = llama3_8b_convnext()
     out = _two_steps_bitwise(cfg, 8, 1449, 2048)
     assert tuple(out["image_features"].shape)[-1] == 4096
+
+
+@pytest.mark.parametrize("stage", ["ift", "pt"])
+def test_overlapped_steps_equal_synchronised_steps_full_width(stage):
+    """Side-stream schedule at full width (2 decoder layers): with the host running ahead, step t+1's frozen tower (and step t's heads) execute beside
+    the main stream's kernels — in the IFT stage beside the decoder FORWARD and its low-register RMSNorm / element-wise kernels.  Regression test of the
+    round-4 fault (a 4-wave GEMM wave that did not own its SIMD's register file produced NaNs next to a foreign wave): six back-to-back steps without
+    any synchronisation give bitwise the losses of the same six steps with a device synchronise after each."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+    import bench
+    from visper_lm_amd.config import llama3_8b
+    from visper_lm_amd.engine import Engine
+    T = 1473 if stage == "ift" else 1449
+
+    def run(sync):
+        cfg = llama3_8b(aux_mode="", num_task_tokens=0, train_llm=True) if stage == "ift" else llama3_8b()
+        cfg.num_hidden_layers = 2
+        cfg.depth_decoder = stage == "pt"
+        if stage == "pt":
+            cfg.image_gen["img_layer_indices"] = "2"; cfg.image_depth["depth_layer_indices"] = "2"; cfg.image_seg["seg_layer_indices"] = "2"
+        eng = Engine(cfg, device=torch.device("cuda:0"))
+        eng.set_distributed(0, 1, transport="torch")
+        eng.init_random(seed=0)
+        pool = [bench.make_batch(cfg, 8, T, 1000 * j, torch.device("cuda:0")) for j in range(2)]
+        torch.cuda.synchronize()
+        gi = torch.Generator().manual_seed(99)
+        losses = []
+        for it in range(6):
+            b = dict(pool[it % 2])
+            ids = torch.randint(0, 1000, (8, T), generator=gi)
+            ids[:, cfg.num_sys_tokens] = -200
+            lab = ids.clone()
+            lab[:, :cfg.num_sys_tokens + 7] = -100
+            b["input_ids"], b["labels"], b["images_resident"] = ids, lab, True
+            out = eng.train_step(b)
+            losses.append(out["loss"].clone())
+            eng.optimizer_step(lr=1e-3, lr_mult=1.0)
+            if sync:
+                torch.cuda.synchronize()
+        torch.cuda.synchronize()
+        res = torch.cat([l.reshape(1) for l in losses]).cpu()
+        del eng, pool
+        torch.cuda.empty_cache()
+        return res
+
+    a, b_ = run(True), run(False)
+    assert torch.isfinite(a).all() and torch.isfinite(b_).all(), (a, b_)
+    assert torch.equal(a, b_), (a, b_)
 
 
 def test_attention_d128_generic_forward_matches_default():
