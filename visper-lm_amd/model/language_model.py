@@ -389,7 +389,14 @@ class _OlaCausalLMBase(OlaLlavaMetaForCausalLM, BaseOLA_VLM, EngineModule):
         eng = self._get_engine()
         dev = eng.dev
         B = input_ids.shape[0]
-        batch = dict(input_ids=input_ids, attention_mask=attention_mask, labels=labels, images=images.to(dev))
+        if images.device != dev and labels is not None:
+            # host images (a collator that leaves them on the CPU): copy AND encode them on the engine's side stream — neither depends on the
+            # work still queued on the current stream, so the frozen tower of this batch runs beside the previous step's backward (engine._embed)
+            with torch.cuda.stream(eng._side_stream()):
+                images = images.to(dev, non_blocking=True)
+            batch = dict(input_ids=input_ids, attention_mask=attention_mask, labels=labels, images=images, images_resident=True)
+        else:
+            batch = dict(input_ids=input_ids, attention_mask=attention_mask, labels=labels, images=images.to(dev))
         for task, tg in self._collect_targets(pil_images, kwargs, B, dev).items():
             batch[f"{task}_target"] = tg
             m = {"gen": gen_mask, "seg": seg_mask, "depth": depth_mask}[task]
