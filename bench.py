@@ -621,6 +621,24 @@ def main():
                        "frac": round(sum(f for _, f in fam) / max(sum(t for t, _ in fam), 1e-9) / 1e9 / PEAK_BF16_TF, 4)},
             "schedule": "heads + DPT decoder and (images resident) the frozen tower run on a side stream beside these launches: their HIP-event "
                         "durations include whatever CU-time the side stream took"}
+    # The same launches with the step on ONE stream (3 extra steps outside the timed region, world 1 only): what the kernel does when nothing shares
+    # the chip with it — the figure the earlier rounds' `frac` was.
+    if dist is None and not args.no_probes and os.environ.get("VP_HEADS_STREAM", "1") != "0":
+        keep = {k: os.environ.get(k) for k in ("VP_HEADS_STREAM", "VP_TOWER_STREAM")}
+        os.environ["VP_HEADS_STREAM"], os.environ["VP_TOWER_STREAM"] = "0", "0"
+        try:
+            el_s, _, prof_s = timed_leg(1, 3, profile=True)
+            big_s = [(e0.elapsed_time(e1), f) for e0, e1, f, shp, kind in prof_s if is_dom(shp, kind)]
+            ms_s, fl_s = sum(t for t, _ in big_s), sum(f for _, f in big_s)
+            roof["one_stream_schedule"] = {"ms_per_step": round(el_s / 3 * 1e3, 2), "avg_launch_ms": round(ms_s / max(len(big_s), 1), 4),
+                                           "achieved": round(fl_s / max(ms_s, 1e-9) / 1e9, 1), "frac": round(fl_s / max(ms_s, 1e-9) / 1e9 / PEAK_BF16_TF, 4),
+                                           "what": "VP_HEADS_STREAM=0 VP_TOWER_STREAM=0, 3 steps after the timed region"}
+        finally:
+            for k, v in keep.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
     # whole-step fraction of the bf16 MFMA peak, priced on the FLOPs this rank EXECUTED (every GEMM launch's 2MNK as recorded live — the
     # lm_head GEMMs only cover the labelled rows — plus the causal decoder attention at S^2/2, backward 2x forward, and the ViT attention);
     # the nominal BASELINE.md table figure (lm_head over every row) is kept beside it
