@@ -633,6 +633,8 @@ def main():
             roof["one_stream_schedule"] = {"ms_per_step": round(el_s / 3 * 1e3, 2), "avg_launch_ms": round(ms_s / max(len(big_s), 1), 4),
                                            "achieved": round(fl_s / max(ms_s, 1e-9) / 1e9, 1), "frac": round(fl_s / max(ms_s, 1e-9) / 1e9 / PEAK_BF16_TF, 4),
                                            "what": "VP_HEADS_STREAM=0 VP_TOWER_STREAM=0, 3 steps after the timed region"}
+        except Exception as e:                       # (a measurement aid must not take the line down)
+            roof["one_stream_schedule"] = {"error": repr(e)[:200]}
         finally:
             for k, v in keep.items():
                 if v is None:
