@@ -571,6 +571,8 @@ def main():
     S = out["plan"]["S"]
     n_valid_rows = out["plan"]["n_valid"]
     loss = float(out["loss"])
+    if loss != loss or abs(loss) == float("inf"):
+        raise SystemExit(f"bench.py: non-finite loss ({loss}) after the timed steps — the measurement is void")
     ms = dt / args.steps * 1e3
     value = args.batch * world * args.steps / dt
 
