@@ -6,7 +6,7 @@ out=$root/gpurun_out/pmc_$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 CTR="SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VALU SQ_ACTIVE_INST_ANY"
-BENCH_ONLY=k256p8 timeout 600 rocprofv3 --kernel-trace --pmc $CTR --output-format csv -d /tmp/pmc_gemm -- python $root/tools/gemm_bench.py 16384x4096x4096 16384x28672x4096 16384x4096x14336 > $out/gemm.log 2>&1
+BENCH_ONLY=${PMC_GEMM_VARIANT:-k256w4} timeout 600 rocprofv3 --kernel-trace --pmc $CTR --output-format csv -d /tmp/pmc_gemm -- python $root/tools/gemm_bench.py 16384x4096x4096 16384x28672x4096 16384x4096x14336 > $out/gemm.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --pmc $CTR --output-format csv -d /tmp/pmc_attn -- python $root/tools/attn_bench.py > $out/attn.log 2>&1
 for d in gemm attn; do
   f=$(find /tmp/pmc_$d -name "*counter_collection.csv" | head -1)
