@@ -46,7 +46,9 @@ int vp_device_info(int* cu_count, int* wave_size, long* lds_bytes_per_cu);
  * large problems, 128x128 otherwise, bounds-checked generic kernel when K%64 != 0 or rows are not 16-B aligned),
  * 1 = generic, 2 = 128-tile, 3 = the simple persistent 256-tile kernel (kept as the A/B reference), 7 = 8-phase,
  * 8 = the one-wave-per-SIMD 256-tile kernel (the auto choice for aligned large problems), 13 = 4-phase variant of the 8-phase
- * kernel.  Every code computes the same result (the tests compare them bit for bit); any other value is VP_ERR_BAD_ARG. */
+ * kernel, 14 = the one-wave-per-SIMD kernel's general variant (bias / activation / residual epilogues, any M >= 256; the auto choice
+ * for such launches from 64 tiles on, erf-GELU excepted).  Every code computes the same result (the tests compare them bit for bit);
+ * any other value is VP_ERR_BAD_ARG. */
 int vp_gemm_bf16(int M, int N, int K, const void* A, long lda, const void* B, long ldb, void* C, long ldc,
                  const void* bias, const void* residual, long ldr, int epilogue, int out_f32, int force_generic,
                  vp_stream_t stream);

@@ -43,7 +43,8 @@ def _rows2d(t):
 def gemm(a, w, bias=None, residual=None, epi=EPI_NONE, out=None, out_f32=False, force_generic=False):
     """out[M,N] = epi(a[M,K] @ w[N,K]^T + bias) + residual.
     force_generic: 0 auto | 1 bounds-checked generic kernel | 2 the 128-tile kernel | 3 the simple persistent 256-tile kernel |
-    7 the 8-phase kernel (the auto choice for large problems)."""
+    7 the 8-phase kernel | 8 the one-wave-per-SIMD kernel (the auto choice for aligned large problems) | 14 its general variant (bias /
+    activation / residual epilogues, M tail)."""
     M, K, lda = _rows2d(a)
     N, K2, ldb = _rows2d(w)
     assert K == K2, (a.shape, w.shape)
