@@ -430,6 +430,9 @@ def main():
     ap.add_argument("--transports", default="both", choices=["both", "torch", "native"],
                     help="N > 1: which DP transports to time (the JSON line's value is the first one's; the other is reported under multi_gpu)")
     ap.add_argument("--lr", type=float, default=1e-3)
+    ap.add_argument("--reference-outputs", action="store_true",
+                    help="materialise what the reference's forward returns every step (logits of all B x S rows + every layer state: the mirror's "
+                         "config.reference_outputs=True default) instead of the lean training mode (loss only, lm_head on labelled rows)")
     ap.add_argument("--same-batch", action="store_true", help="A/B aid: replay one batch (splice-plan cache hit) instead of a fresh one per step")
     ap.add_argument("--force-dist", action="store_true", help="initialise the RCCL process group even with one rank (test hook)")
     args = ap.parse_args()
@@ -500,6 +503,7 @@ def main():
             legs = [os.environ["VP_COMM"]] + [t for t in ("torch", "native") if t != os.environ["VP_COMM"]]
         if shared:
             legs = ["torch"]                            # the one-GPU test hook runs over gloo: no RCCL communicator to build
+    eng.keep_logits = eng.keep_states = bool(args.reference_outputs)
     eng.set_distributed(rank, world, transport=legs[0])
     eng.init_random(seed=0)                       # identical weights on every rank
     # A FRESH batch every step, as a dataloader delivers it (ola_vlm_train.py:882-925): new input_ids / labels each step, so the host
@@ -670,6 +674,9 @@ def main():
                           "depth_decoder": bool(cfg.depth_decoder), "fresh_batch_per_step": not args.same_batch,
                           "peak_mem_gb": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 1),
                           "lm_head_rows": f"{n_valid_rows} labelled of {args.batch * S} (rows with label -100 skip lm_head + CE: zero loss, zero d_logits)",
+                          "outputs": ("reference (bf16 logits of all B x S rows + all L + 1 layer states materialised every step)" if args.reference_outputs
+                                      else "lean: loss + per-layer losses only (the mirror's config.reference_outputs=False; the reference-outputs mode "
+                                           "also sends the unlabelled rows through lm_head: --reference-outputs)"),
                           "valid": args.layers is None},
                "roofline": roof, **({"multi_gpu": diag} if diag is not None else {})}
 

@@ -42,12 +42,12 @@ int vp_device_info(int* cu_count, int* wave_size, long* lds_bytes_per_cu);
  * (HF modeling_llama.py), CLIP q,k,v,out,fc1,fc2 (HF modeling_clip.py), lm_head (ola_llama.py:121),
  * mm_projector (multimodal_projector/builder.py:53-60), resampler proj_in/to_q/to_kv/to_out/FF/proj_out
  * (multimodal_projector/resampler.py:9-16,40-44,186-190), depth MLPs (aux_heads/da_v2_head.py:439-442).
- * out_f32=1 writes fp32 (used for weight gradients). force_generic: 0 = auto (256x256 8-phase ping-pong kernel for
- * large problems, 128x128 otherwise, bounds-checked generic kernel when K%64 != 0 or rows are not 16-B aligned),
- * 1 = generic, 2 = 128-tile, 3 = the simple persistent 256-tile kernel (kept as the A/B reference), 7 = 8-phase,
- * 8 = the one-wave-per-SIMD 256-tile kernel (the auto choice for aligned large problems), 13 = 4-phase variant of the 8-phase
- * kernel, 14 = the one-wave-per-SIMD kernel's general variant (bias / activation / residual epilogues, any M >= 256; the auto choice
- * for such launches from 64 tiles on, erf-GELU excepted).  Every code computes the same result (the tests compare them bit for bit);
+ * out_f32=1 writes fp32 (used for weight gradients). force_generic: 0 = auto: the one-wave-per-SIMD 256x256 kernel (code 8) for aligned
+ * large problems without bias / activation (M, N multiples of 256, K of 128), its general variant (code 14: bias / activation / residual
+ * epilogues, any M >= 256) for such launches from 64 tiles on (erf-GELU launches stay on the 8-phase kernel), the 128x128 kernel for small
+ * problems, the bounds-checked generic kernel when K%64 != 0 or rows are not 16-B aligned.  1 = generic, 2 = 128-tile, 3 = the simple
+ * persistent 256-tile kernel (kept as the A/B reference), 7 = the 256x256 8-phase ping-pong kernel (the auto choice of rounds 1-2),
+ * 8 / 14 = see above, 13 = 4-phase variant of the 8-phase kernel.  Every code computes the same result (the tests compare them bit for bit);
  * any other value is VP_ERR_BAD_ARG. */
 int vp_gemm_bf16(int M, int N, int K, const void* A, long lda, const void* B, long ldb, void* C, long ldc,
                  const void* bias, const void* residual, long ldr, int epilogue, int out_f32, int force_generic,

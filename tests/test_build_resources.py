@@ -1,0 +1,43 @@
+"""What the hand-scheduled kernels assume about their own register allocation, checked on the BUILT library's code-object metadata (CPU test).
+
+ADVICE r4 (medium): `gemm_nt_256w4` is written as the only wave on its SIMD; with fewer than 512 registers a low-register wave of a kernel on another
+stream can be placed beside it (round 4: sporadic NaNs).  The kernel claims the whole file through an asm clobber of v255 — a compiler or flag change
+that drops it must fail here, not in a training run."""
+import os
+import sys
+
+import pytest
+
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "tools"))
+import kernel_resources as kr  # noqa: E402
+
+SO = os.path.join(os.path.dirname(__file__), "..", "visper-lm_amd", "libvisper_hip.so")
+
+
+@pytest.fixture(scope="module")
+def kernels():
+    if not os.path.exists(SO):
+        pytest.skip("library not built")
+    k = kr.kernels(SO)
+    assert len(k) > 50, "could not read the code objects' metadata"
+    return k
+
+
+def test_one_wave_per_simd_kernels_own_the_whole_register_file(kernels):
+    w4 = {n: d for n, d in kernels.items() if "gemm_nt_256w4" in n}
+    assert len(w4) >= 4
+    for n, d in w4.items():
+        assert d["vgpr_count"] == 512 and d["agpr_count"] == 256, (n, d)
+        assert d.get("vgpr_spill_count", 0) == 0 and d.get("private_segment_fixed_size", 0) == 0, (n, d)
+    # the one-wave-per-SIMD attention backward kernels (round 5) are written the same way
+    for n, d in kernels.items():
+        if "attn_bwd_dkdv64w" in n or "attn_bwd_dq64w" in n:
+            assert d["vgpr_count"] == 512, (n, d)
+            assert d.get("vgpr_spill_count", 0) == 0 and d.get("private_segment_fixed_size", 0) == 0, (n, d)
+
+
+def test_dma_ring_kernels_do_not_spill(kernels):
+    """a scratch reload inside a kernel that keeps an LDS-DMA ring in flight is followed by s_waitcnt vmcnt(0): it drains the ring every iteration"""
+    for n, d in kernels.items():
+        if any(t in n for t in ("attn_bwd_dkdv128", "attn_bwd_dq128", "attn_fwd128m", "attn_bwd_dkdv64w", "attn_bwd_dq64w")):
+            assert d.get("vgpr_spill_count", 0) == 0 and d.get("private_segment_fixed_size", 0) == 0, (n, d)

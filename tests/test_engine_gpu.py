@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 import torch
 
-from parity import check, max_rel, grad_err
+from parity import check, log, max_rel, grad_err, scalar_grad_yardstick, scalar_grad_bound
 
 pytestmark = pytest.mark.gpu
 BF = torch.bfloat16
@@ -30,8 +30,11 @@ def _bf16_cpu_layer_dev(O, ocfg, W, batch, ref32):
     return {key: _trip_err([float(x) for x in refb["layer_losses"][key]], [float(x) for x in trip]) for key, trip in ref32["layer_losses"].items()}
 
 
+LAYER_LOSS_CAP = 1.2e-2       # the fixed bound of rounds 1-3: a noisy CPU bf16 run can never loosen the bar past it
+
+
 def _layer_loss_bound(dev):
-    return max(1e-3, 1.5 * dev)
+    return min(LAYER_LOSS_CAP, max(1e-3, 1.5 * dev))
 
 
 def _to_gpu_batch(batch):
@@ -100,7 +103,7 @@ def test_losses_match_oracle_and_reference_golden(tiny):
         mine = out["layer_losses"][key].float().cpu().numpy()
         theirs = np.array([float(x) for x in ref["layer_losses"][key]])
         dev = tiny["cpu_dev"][key]                                       # the reference-style bf16 CPU path's own distance from fp32 truth
-        check(f"tiny/layer_loss/{key[0]}@{key[1]}_INFO_bf16_cpu_path_vs_fp32_truth", dev, float("inf"))
+        log(f"tiny/layer_loss/{key[0]}@{key[1]}_INFO_bf16_cpu_path_vs_fp32_truth", dev)
         check(f"tiny/layer_loss/{key[0]}@{key[1]}_vs_oracle", _trip_err(mine, theirs), _layer_loss_bound(dev))
         check(f"tiny/layer_loss/{key[0]}@{key[1]}_vs_reference_golden", _trip_err(mine, g["keep_layer_losses"][i]), 1e-2)
 
@@ -227,13 +230,19 @@ def test_phi3_path_matches_oracle_and_reference_golden():
         mine = out["layer_losses"][key].float().cpu().numpy()
         check(f"tiny_phi3/layer_loss/{key[0]}@{key[1]}_vs_reference_golden", _trip_err(mine, g["keep_layer_losses"][i]), 1e-2)
     none_ref = set(json.loads(str(g["keep_grad_none"])))
+    # logit scales: |g| ~ 1e-6 (a sum of a few signed terms): absolute bound tied to what the bf16 CPU path itself deviates by
+    scal = [k for k in eng.ps.index if eng.ps.g(k).numel() == 1 and k not in none_ref]
+    yard = scalar_grad_yardstick(O, ocfg, W, batch, scal)
     for k in eng.ps.index:
         got = float(eng.ps.g(k).float().norm())
         ref = 0.0 if k in none_ref else float(g[f"keep_gradnorm::{k}"])
         if ref == 0.0:
             assert got == 0.0, k
+        elif k in yard:
+            log(f"tiny_phi3/gradnorm/{k}_INFO_bf16_cpu_path_abs_dev", yard[k][1])
+            check(f"tiny_phi3/gradnorm/{k}_abs", abs(got - ref), scalar_grad_bound(ref, yard[k][1], 0.3))
         else:
-            check(f"tiny_phi3/gradnorm/{k}_rel", abs(got - ref) / ref, 0.3 if eng.ps.g(k).numel() == 1 else 5e-2)
+            check(f"tiny_phi3/gradnorm/{k}_rel", abs(got - ref) / ref, 5e-2)
 
 
 def test_convnext_tower_matches_oracle():
@@ -325,7 +334,7 @@ def _edge_case(ocfg_kw, mutate, min_cos=0.985, tag="edge", max_norm=3e-2):
     cpu_dev = _bf16_cpu_layer_dev(O, ocfg, W, batch, ref)
     for key, trip in ref["layer_losses"].items():
         mine = out["layer_losses"][key].float().cpu().numpy()
-        check(f"{tag}/layer_loss/{key[0]}@{key[1]}_INFO_bf16_cpu_path_vs_fp32_truth", cpu_dev[key], float("inf"))
+        log(f"{tag}/layer_loss/{key[0]}@{key[1]}_INFO_bf16_cpu_path_vs_fp32_truth", cpu_dev[key])
         check(f"{tag}/layer_loss/{key[0]}@{key[1]}", _trip_err(mine, [float(x) for x in trip]), _layer_loss_bound(cpu_dev[key]))
     for k in eng.ps.index:
         got = eng.ps.g(k).detach().float().cpu()

@@ -436,6 +436,37 @@ def test_gemm_dynamic_tile_scheduling(ops):
     assert torch.equal(ops.gemm(a, w), ref)
 
 
+def test_w4_gemm_beside_small_kernels_on_a_second_stream(ops):
+    """every instantiation of the one-wave-per-SIMD GEMM (lean / general / RMSNorm-fold epilogues) must give bit-identical results
+    while a second stream keeps low-register kernels (element-wise, norm, fill: the kind that was placed beside a 464-register wave in round 4)
+    and a collective-like CU hog flowing through the chip."""
+    M, N, K = 8192, 4096, 1024
+    a, w = dev(rnd(M, K, seed=190)), dev(rnd(N, K, scale=0.1, seed=191))
+    bias, res = dev(rnd(N, seed=192)), dev(rnd(M, N, seed=193))
+    Mt = M - 100                                                      # general variant's M tail
+    solo = (ops.gemm(a, w), ops.gemm(a, w, bias=bias, residual=res, epi=ops.EPI_QUICK_GELU, force_generic=14),
+            ops.gemm(a[:Mt], w, bias=bias, force_generic=14), *ops.gemm_sumsq(a, w, res))
+    torch.cuda.synchronize()
+    side, stop = torch.cuda.Stream(), torch.cuda.Event()
+    sm = dev(rnd(96, 4096, seed=194))
+    ones = torch.ones(4096, device="cuda", dtype=torch.bfloat16)
+    small = torch.empty(64 * 1024, device="cuda", dtype=torch.float32)
+    for rnd_ in range(6):
+        with torch.cuda.stream(side):
+            for _ in range(60):                                       # ~600 small launches queued beside the GEMMs of this round
+                ops.add(sm, sm)
+                ops.rmsnorm_fwd(sm, ones, 1e-5)
+                ops.act_fwd(sm, ops.EPI_GELU)
+                ops.zero_(small)
+            if rnd_ & 1:
+                ops._lib.call("vp_debug_occupy", 16, 2000000, torch.cuda.current_stream().cuda_stream)
+        got = (ops.gemm(a, w), ops.gemm(a, w, bias=bias, residual=res, epi=ops.EPI_QUICK_GELU, force_generic=14),
+               ops.gemm(a[:Mt], w, bias=bias, force_generic=14), *ops.gemm_sumsq(a, w, res))
+        for i, (g_, s_) in enumerate(zip(got, solo)):
+            assert torch.equal(g_, s_), f"round {rnd_}, output {i}: differs from the solo launch"
+    torch.cuda.synchronize()
+
+
 @pytest.mark.parametrize("kind", [1, 3])
 def test_act(ops, kind):
     x, d = rnd(40, 64, seed=22), rnd(40, 64, seed=23)

@@ -595,20 +595,24 @@ struct ElPlan {
 // that used it has finished: each launch records a fence event behind itself (el_slot_done) and eviction waits for it on the host (the rare
 // path; ~never blocks, that launch is >= 31 other streams' launches old).  A destroyed stream whose handle value is reused simply finds its
 // old set again — harmless for the same reason (every launch leaves its counters zeroed).
-struct ElSlot { hipStream_t stream; hipEvent_t fence; unsigned long tick; bool used; };
+struct ElSlot { hipStream_t stream; hipEvent_t fence; unsigned long tick; bool used; int busy; bool pinned; };
 static std::mutex g_slot_mu;
 static ElSlot g_slots[N_SLOTS];
 static unsigned long g_slot_tick = 0;
+// A set is HELD (busy > 0) from el_slot_for until the fence behind its launch is recorded (el_slot_done), so a second thread can never evict it
+// in that window and wait on a stale / never-recorded event; a set whose last launch was captured into a graph is pinned for good
+// (no host-visible fence exists for replays).  -2: every set is held or pinned.
 int el_slot_for(hipStream_t s) {
   std::lock_guard<std::mutex> lk(g_slot_mu);
-  int free_id = -1, lru = 0;
+  int free_id = -1, lru = -1;
   for (int i = 0; i < N_SLOTS; ++i) {
-    if (g_slots[i].used && g_slots[i].stream == s) { g_slots[i].tick = ++g_slot_tick; return i; }
+    if (g_slots[i].used && g_slots[i].stream == s) { g_slots[i].tick = ++g_slot_tick; ++g_slots[i].busy; return i; }
     if (!g_slots[i].used && free_id < 0) free_id = i;
-    if (g_slots[i].used && g_slots[i].tick < g_slots[lru].tick) lru = i;
+    if (g_slots[i].used && g_slots[i].busy == 0 && !g_slots[i].pinned && (lru < 0 || g_slots[i].tick < g_slots[lru].tick)) lru = i;
   }
   int id = free_id;
   if (id < 0) {                                                    // evict: wait until the set's last launch is done, then hand it on
+    if (lru < 0) return -2;
     id = lru;
     if (g_slots[id].fence && hipEventSynchronize(g_slots[id].fence) != hipSuccess) (void)hipGetLastError();
   } else if (hipEventCreateWithFlags(&g_slots[id].fence, hipEventDisableTiming) != hipSuccess) {
@@ -616,16 +620,23 @@ int el_slot_for(hipStream_t s) {
     (void)hipGetLastError();
     return -1;
   }
-  g_slots[id].stream = s; g_slots[id].used = true; g_slots[id].tick = ++g_slot_tick;
+  g_slots[id].stream = s; g_slots[id].used = true; g_slots[id].tick = ++g_slot_tick; g_slots[id].busy = 1; g_slots[id].pinned = false;
   return id;
 }
-void el_slot_done(int id, hipStream_t s) {                          // fence behind the launch that just used set `id`
+void el_slot_done(int id, hipStream_t s, bool launched) {           // fence behind the launch that just used set `id`, then release the hold
   std::lock_guard<std::mutex> lk(g_slot_mu);
-  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-  if (hipStreamIsCapturing(s, &cap) != hipSuccess) { (void)hipGetLastError(); return; }
-  if (cap != hipStreamCaptureStatusNone) return;                   // inside a graph capture: no host-visible fence (the graph's stream orders replays)
-  if (g_slots[id].fence && hipEventRecord(g_slots[id].fence, s) != hipSuccess) (void)hipGetLastError();
+  if (launched) {
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &cap) != hipSuccess) { (void)hipGetLastError(); cap = hipStreamCaptureStatusNone; }
+    if (cap != hipStreamCaptureStatusNone) g_slots[id].pinned = true;      // inside a graph capture: replays own this set from now on
+    else if (g_slots[id].fence && hipEventRecord(g_slots[id].fence, s) != hipSuccess) (void)hipGetLastError();
+  }
+  if (g_slots[id].busy > 0) --g_slots[id].busy;
 }
+struct ElSlotHold {                                                 // releases the hold on every exit path of the launcher
+  int id; hipStream_t s; bool launched;
+  ~ElSlotHold() { if (id >= 0) el_slot_done(id, s, launched); }
+};
 
 ElPlan el_plan(int B, int Bw, long D) {
   ElPlan p;
@@ -689,7 +700,9 @@ int vp_emb_loss_fwd_multi(int ntask, int B, int Bw, const long* D, int rank, con
              "vp_emb_loss_fwd: need 0<B<=64, B<=Bw<=1024 (got B=%d Bw=%d)", B, Bw);
   VP_REQUIRE(rank >= 0 && (long)(rank + 1) * B <= Bw, VP_ERR_BAD_ARG, "vp_emb_loss_fwd: rank/B/Bw mismatch");
   const int slot = el_slot_for(s);
-  VP_REQUIRE(slot >= 0, VP_ERR_HIP, "vp_emb_loss_fwd: could not create the fence event of a ticket-counter set");
+  VP_REQUIRE(slot >= 0, VP_ERR_HIP, slot == -2 ? "vp_emb_loss_fwd: all %d ticket-counter sets are in use by concurrent launches / captured graphs"
+                                               : "vp_emb_loss_fwd: could not create the fence event of a ticket-counter set (of %d)", N_SLOTS);
+  ElSlotHold hold{slot, s, false};
   ElMulti m;
   ElPlan p0 = el_plan(B, Bw, D[0] > 0 ? D[0] : 8);
   int gx = 0;
@@ -717,7 +730,7 @@ int vp_emb_loss_fwd_multi(int ntask, int B, int Bw, const long* D, int rank, con
   else if (p0.npb == 1) el_launch<1>(p0.ng, grid, s, m);
   else if (p0.npb == 2) el_launch<2>(p0.ng, grid, s, m);
   else el_launch<4>(p0.ng, grid, s, m);
-  el_slot_done(slot, s);
+  hold.launched = true;
   return vp_check_launch("vp_emb_loss_fwd");
 }
 

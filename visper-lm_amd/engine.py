@@ -174,6 +174,7 @@ class Engine:
         self._red = None
         self.comm = None       # parallel.NativeComm when the C ABI's own communicator carries the collectives (set_distributed)
         self.keep_logits = False
+        self.keep_states = False      # True: train_step also returns every decoder-layer state (HF `hidden_states`: embeddings, layer outputs, final norm)
 
     def _load_frozen_decoder(self, W, d):
         """PT stage: the LLM is frozen -> bf16 kernel-ready copies, q/k/v and gate/up fused, plus pre-transposed dgrad copies."""
@@ -848,6 +849,8 @@ class Engine:
 
         dec = self._decoder_fwd(x, plan, compute_grads)
         out["hidden"] = self.present(dec["hidden"], plan)
+        if dec["hidden_states"] is not None:             # (embeddings, layer 1 .. L-1 outputs, norm(layer L output)): ola_llama.py:113,181
+            out["hidden_states"] = (out["inputs_embeds"],) + tuple(self.present(t, plan) for t in dec["hidden_states"][1:-1]) + (out["hidden"],)
         # The distillation heads (a8..a14: ~300 small launches, few tiles each) depend only on the tapped layer states, and nothing needs their
         # result before the decoder backward reaches the topmost tapped layer.  They run on a SIDE STREAM, forked here and joined there
         # (_join_heads), so their workgroups fill the CUs the persistent GEMMs of lm_head / the upper layers' backward leave idle in their
@@ -867,8 +870,24 @@ class Engine:
                     self._reducer().start_early()                # heads + logit scales: overlap with the decoder backward
                 self._heads_join = torch.cuda.Event()
                 self._heads_join.record(side)
-            for t in d_state.values():
-                t.record_stream(main)
+            # Everything _heads allocated on the side stream and handed on (layer-state gradients, per-task / per-layer losses, embeddings, depth
+            # maps) is READ on the main stream (total(), the caller).  Tell the allocator: otherwise a caller that drops `out` early returns those
+            # blocks to the side stream's pool while main-stream reads are still queued, and the next step's side-stream tower may reuse them
+            # first.
+            def _rs(v):
+                if torch.is_tensor(v):
+                    if v.is_cuda:
+                        v.record_stream(main)
+                elif isinstance(v, dict):
+                    for x in v.values():
+                        _rs(x)
+                elif isinstance(v, (list, tuple)):
+                    for x in v:
+                        _rs(x)
+            _rs(d_state)
+            _rs(task_loss)
+            for k in ("layer_losses", "embs", "depth_preds", "depth_feats"):
+                _rs(out.get(k))
             text_loss, d_hidden = self._ntp(dec["hidden"], plan, compute_grads, out)
         else:
             text_loss, d_hidden = self._ntp(dec["hidden"], plan, compute_grads, out)
@@ -933,8 +952,11 @@ class Engine:
             ops.fold_norm_ok(M, cfg.hidden_size, cfg.intermediate_size, hd, (nh + 2 * nkv) * hd)
         H, eps = cfg.hidden_size, cfg.rms_norm_eps
         rstd1 = None
+        hs = [] if self.keep_states else None            # HF all_hidden_states: the input of every layer, then the post-norm final state
         for l in range(L):
             o = f"dec.{l}."
+            if hs is not None:
+                hs.append(x)
             if fold:
                 # no normalised copy of the stream: 1/rms rides in the consuming GEMM's epilogue (gamma is in its weight), the statistics of the next
                 # norm come out of the residual GEMM that writes the stream (layer 0's from one pass over the spliced embeddings)
@@ -983,7 +1005,9 @@ class Engine:
         hidden, rstd_f = ops.rmsnorm_fwd(x, fz["norm"], cfg.rms_norm_eps)
         if (L - 1) in self.tapped:
             states[L - 1] = hidden              # layer_states[-1] is the post-norm state (ola_llama.py:117-119)
-        return dict(x=x, hidden=hidden, rstd_f=rstd_f, saved=saved, states=states)
+        if hs is not None:
+            hs.append(hidden)
+        return dict(x=x, hidden=hidden, rstd_f=rstd_f, saved=saved, states=states, hidden_states=hs)
 
     def _lm_chunk(self, Mc, H):
         """Rows per lm_head chunk: whole 256-row tiles, at most lm_chunk_rows (the bf16 logits of a chunk are the step's largest transient:

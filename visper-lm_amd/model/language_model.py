@@ -71,6 +71,28 @@ class OlaLlavaPhi3Model(OlaLlavaMetaModel, ParamTree):
     config_class = OlaLlavaPhi3Config
 
 
+def _run_engine(module, eng, batch, labels, output_hidden_states, kwargs, force_states=True):
+    """One engine step behind the reference's `forward` contract (shared by the PT and IFT mirrors): returns (loss, engine outputs,
+    logits, hidden_states).  Reference: logits fp32 [B, S, V] always, every decoder-layer state (ola_llama.py:113-122, 181)."""
+    ref_out = bool(getattr(module.config, "reference_outputs", True))
+    eng.keep_logits = labels is None or ref_out or bool(kwargs.get("output_logits", False))
+    eng.keep_states = (ref_out and force_states) or bool(output_hidden_states)
+    try:
+        if labels is not None:
+            loss = _VisperStep.apply(module, batch, *module._trainable_params)
+        else:
+            module._last = eng.train_step(batch, compute_grads=False)
+            loss = None
+    finally:
+        eng.keep_logits, eng.keep_states = False, False
+    out = module._last
+    logits = out.get("logits")
+    if logits is not None and ref_out:
+        logits = logits.float()                                      # ola_llama.py:122
+    hidden_states = out.get("hidden_states") or (out["inputs_embeds"], out["hidden"])
+    return loss, out, logits, hidden_states
+
+
 class _VisperStep(torch.autograd.Function):
     """One fused forward+backward on the engine; backward hands the already-computed gradients to autograd."""
 
@@ -381,8 +403,12 @@ class _OlaCausalLMBase(OlaLlavaMetaForCausalLM, BaseOLA_VLM, EngineModule):
     def forward(self, input_ids=None, attention_mask=None, position_ids=None, past_key_values=None, inputs_embeds=None,
                 labels=None, use_cache=None, output_attentions=None, output_hidden_states=None, images=None,
                 image_sizes=None, return_dict=None, pil_images=None, gen_mask=None, seg_mask=None, depth_mask=None, **kwargs):
-        """ola_llama.py:190-244 signature.  Extra kwargs: gen_target / depth_target / seg_target (precomputed frozen-teacher
-        features), output_logits=True to materialise `logits`."""
+        """ola_llama.py:190-244 signature, ola_llama.py:170-188 outputs.  Extra kwargs: gen_target / depth_target / seg_target (precomputed
+        frozen-teacher features).  With `config.reference_outputs` (default True) the call returns what the reference returns: fp32
+        `logits` [B, S, V] always (ola_llama.py:121-122) and all L + 1 `hidden_states` (`output_hidden_states=True` is forced at :113);
+        `return_dict=False` gives the reference's tuple.  `config.reference_outputs = False` is the lean mode for training loops that only read
+        `loss`: lm_head + CE run on labelled rows only, `logits` is None unless `output_logits=True` / `labels is None`, and `hidden_states`
+        = (inputs_embeds, final state) unless `output_hidden_states=True`."""
         if inputs_embeds is not None or past_key_values is not None or use_cache:
             raise NotImplementedError("the MI355X path covers the training forward (input_ids + images); generation is out of scope")
         self._sync_trainable()
@@ -401,18 +427,15 @@ class _OlaCausalLMBase(OlaLlavaMetaForCausalLM, BaseOLA_VLM, EngineModule):
             batch[f"{task}_target"] = tg
             m = {"gen": gen_mask, "seg": seg_mask, "depth": depth_mask}[task]
             batch[f"{task}_mask"] = torch.ones(B, device=dev) if m is None else m
-        eng.keep_logits = bool(kwargs.get("output_logits", False))
-        if labels is not None:
-            loss = _VisperStep.apply(self, batch, *self._trainable_params)
-        else:
-            self._last = eng.train_step(batch, compute_grads=False)
-            loss = None
-        out = self._last
+        loss, out, logits, hidden_states = _run_engine(self, eng, batch, labels, output_hidden_states, kwargs)
         embs = out.get("embs", {})
-        return OlaCausalLLMOutputWithPast(loss=loss, logits=out.get("logits"), hidden_states=(out["hidden"],),
-                                          image_embs=embs.get("gen", []), seg_embs=embs.get("seg", []),
-                                          depth_embs=out.get("depth_feats") or embs.get("depth", []),
-                                          depth_preds=out.get("depth_preds", []))     # filled when config.depth_decoder
+        res = OlaCausalLLMOutputWithPast(loss=loss, logits=logits, hidden_states=hidden_states,
+                                         image_embs=embs.get("gen", []), seg_embs=embs.get("seg", []),
+                                         depth_embs=out.get("depth_feats") or embs.get("depth", []),
+                                         depth_preds=out.get("depth_preds", []))     # filled when config.depth_decoder
+        if return_dict is not None and not return_dict:             # ola_llama.py:170-172: (loss,) + (logits,) + outputs[1:]
+            return tuple(v for v in (loss, logits, hidden_states) if v is not None)
+        return res
 
     _forward = forward
 

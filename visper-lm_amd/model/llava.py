@@ -16,7 +16,7 @@ import torch
 
 from ..config import VisperConfig, phi3_mini
 from .builders import ParamTree
-from .language_model import EngineModule, _ModelOutput, _VisperStep
+from .language_model import EngineModule, _ModelOutput, _VisperStep, _run_engine
 from .ola_arch import OlaLlavaMetaForCausalLM, OlaLlavaMetaModel
 
 
@@ -121,8 +121,8 @@ class _LlavaCausalLMBase(LlavaMetaForCausalLM, EngineModule):
     def forward(self, input_ids=None, attention_mask=None, position_ids=None, past_key_values=None, inputs_embeds=None,
                 labels=None, use_cache=None, output_attentions=None, output_hidden_states=None, images=None, image_sizes=None,
                 return_dict=None, **kwargs):
-        """llava_llama.py:73-119 signature -> CausalLMOutputWithPast.  Extra kwarg: output_logits=True materialises `logits`
-        (the reference always returns the full fp32 logits; the fused lm_head + CE path never builds them unless asked)."""
+        """llava_llama.py:73-119 signature -> CausalLMOutputWithPast.  Outputs as language_model._run_engine: the reference's (fp32 logits
+        always, hidden states on request) unless `config.reference_outputs = False` (lean mode: labelled rows only through lm_head + CE)."""
         if inputs_embeds is not None or past_key_values is not None or use_cache:
             raise NotImplementedError("the MI355X path covers the training forward (input_ids + images); generation is out of scope")
         self._sync_trainable()
@@ -137,14 +137,10 @@ class _LlavaCausalLMBase(LlavaMetaForCausalLM, EngineModule):
             side = self.config.cnx_image if self.config.is_convnext else self.config.vit_image
             images = torch.zeros(input_ids.shape[0], 3, side, side, device=eng.dev, dtype=torch.bfloat16)
         batch = dict(input_ids=input_ids, attention_mask=attention_mask, labels=labels, images=images.to(eng.dev))
-        eng.keep_logits = bool(kwargs.get("output_logits", False))
-        if labels is not None:
-            loss = _VisperStep.apply(self, batch, *self._trainable_params)
-        else:
-            self._last = eng.train_step(batch, compute_grads=False)
-            loss = None
-        out = self._last
-        return CausalLMOutputWithPast(loss=loss, logits=out.get("logits"), hidden_states=(out["hidden"],))
+        loss, out, logits, hidden_states = _run_engine(self, eng, batch, labels, output_hidden_states, kwargs, force_states=False)   # HF LlamaForCausalLM: states on request
+        if return_dict is not None and not return_dict:             # llava_llama.py -> HF LlamaForCausalLM: (loss,) + (logits,) + outputs[1:]
+            return tuple(v for v in (loss, logits, hidden_states) if v is not None)
+        return CausalLMOutputWithPast(loss=loss, logits=logits, hidden_states=hidden_states)
 
 
 class LlavaLlamaForCausalLM(_LlavaCausalLMBase):
