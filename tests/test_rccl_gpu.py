@@ -146,9 +146,11 @@ NATIVE2 = r'''
 import os, sys, torch, torch.distributed as dist
 sys.path.insert(0, os.environ["VP_ROOT"])
 rank = int(os.environ["RANK"])
-torch.cuda.set_device(0)                               # BOTH ranks on the one test GPU: RCCL must refuse (or serve) this without hanging
-dist.init_process_group("gloo", rank=rank, world_size=2)   # only carries rank 0's unique id to rank 1
-from visper_lm_amd.parallel import NativeComm
+multi = os.environ.get("VP_TEST_MULTI_DEVICE") == "1"      # >= 2 devices on the box: one device per rank, success REQUIRED
+torch.cuda.set_device(rank if multi else 0)               # one device: BOTH ranks on it — RCCL must refuse (or serve) this without hanging
+dist.init_process_group("nccl" if multi else "gloo", rank=rank, world_size=2,
+                        **({"device_id": torch.device("cuda", rank)} if multi else {}))   # gloo only carries rank 0's unique id to rank 1
+from visper_lm_amd.parallel import NativeComm, GradReducer, all_gather_rows
 try:
     c = NativeComm(rank=rank, world=2)                 # vp_comm_unique_id -> broadcast -> vp_comm_init (collective)
     g = torch.full((1024,), float(rank + 1), device="cuda")
@@ -157,6 +159,26 @@ try:
     t = torch.full((2, 8), float(rank), device="cuda").to(torch.bfloat16)
     out = c.allgather(t); torch.cuda.synchronize()
     assert out.shape == (4, 8) and float(out[0, 0]) == 0.0 and float(out[2, 0]) == 1.0
+    if multi:
+        # the native transport against the torch.distributed (nccl = RCCL) leg, bit for bit, on gradient-shaped data through the engine's
+        # own GradReducer (bf16 buckets, early + late pieces) and the target all-gather
+        gen = torch.Generator(device="cuda").manual_seed(100 + rank)
+        base = torch.randn(3_000_000, device="cuda", generator=gen)
+        res = {}
+        for name, comm in (("torch", None), ("native", c)):
+            buf = base.clone()
+            r = GradReducer(buf, split=1_000_064, comm=comm, reduce_dtype=torch.bfloat16)
+            r.start_early(); r.finish(); torch.cuda.synchronize()
+            res[name] = buf
+        assert torch.equal(res["torch"], res["native"]), "all-reduced gradients differ between the torch and the native transport"
+        other = [torch.empty_like(res["native"]) for _ in range(2)]
+        dist.all_gather(other, res["native"])
+        assert torch.equal(other[0], other[1]), "all-reduced gradients differ across ranks"
+        tg = torch.randn(8, 4096, device="cuda", generator=gen).to(torch.bfloat16)
+        a, b = all_gather_rows(tg, None), all_gather_rows(tg, c)
+        torch.cuda.synchronize()
+        assert a.shape == (16, 4096) and torch.equal(a, b) and torch.equal(b[rank * 8:(rank + 1) * 8], tg)
+        print(f"NATIVE2_RANK{rank}_BITWISE_OK")
     c.close()
     print(f"NATIVE2_RANK{rank}_RAN")
 except RuntimeError as e:                              # the C ABI's error path: an int code turned into RuntimeError by _lib.call
@@ -165,18 +187,23 @@ dist.destroy_process_group()
 '''
 
 
+def _multi_device():
+    return torch.cuda.is_available() and torch.cuda.device_count() >= 2
+
+
 def test_native_comm_two_processes_no_hang():
-    """vp_comm_init with world 2 across two PROCESSES.  The test box has one GPU, so both ranks sit on device 0: RCCL
-    either refuses the duplicate device (-> the ABI's error code -> RuntimeError, the documented error path) or serves it; what must not
-    happen is a hang or a crash.  Both outcomes are printed; the first real N > 1 run of the native transport is the driver's 8-GPU bench
-    (bench.py reports it next to the torch.distributed transport, behind a watchdog)."""
+    """vp_comm_init with world 2 across two PROCESSES.  On a box with >= 2 devices: one device per rank over RCCL, success
+    REQUIRED, and the native transport's all-reduced gradients / gathered targets must equal the torch.distributed leg's bit for bit and be
+    identical on both ranks.  On the one-GPU test box both ranks sit on device 0: RCCL either refuses the duplicate device (-> the ABI's error
+    code -> RuntimeError, the documented error path) or serves it; what must not happen is a hang or a crash."""
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
+    multi = _multi_device()
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     procs = []
     for r in range(2):
         env = dict(os.environ, VP_ROOT=root, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29621", RANK=str(r),
-                   WORLD_SIZE="2", NCCL_DEBUG="WARN")
+                   WORLD_SIZE="2", NCCL_DEBUG="WARN", VP_TEST_MULTI_DEVICE="1" if multi else "0")
         procs.append(subprocess.Popen([sys.executable, "-c", NATIVE2], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
     outs = []
     for p in procs:
@@ -189,4 +216,81 @@ def test_native_comm_two_processes_no_hang():
         outs.append((p.returncode, o, e))
     for r, (rc, o, e) in enumerate(outs):
         print(f"rank {r}: rc={rc} {o.strip()[-300:]}")
-        assert f"NATIVE2_RANK{r}_RAN" in o or f"NATIVE2_RANK{r}_REFUSED" in o, (rc, o[-1500:], e[-1500:])
+        if multi:
+            assert f"NATIVE2_RANK{r}_RAN" in o and f"NATIVE2_RANK{r}_BITWISE_OK" in o, (rc, o[-1500:], e[-1500:])
+        else:
+            assert f"NATIVE2_RANK{r}_RAN" in o or f"NATIVE2_RANK{r}_REFUSED" in o, (rc, o[-1500:], e[-1500:])
+
+
+def test_bench_two_ranks_native_leg_is_the_headline_on_a_multi_gpu_box():
+    """`python bench.py --gpus 2 --layers 4` the way a user types it.  With >= 2 devices: one device per rank over RCCL, BOTH transports must
+    complete, the native (vp_comm_*) leg is the headline, every communicator saw two ranks, all-reduced gradients and gathered targets are
+    bit-identical across ranks on both legs.  With one device: the same command on the shared-GPU hook (gloo), control flow only."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import json
+    multi = _multi_device()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "VP_TEST_SHARED_GPU")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    if not multi:
+        env["VP_TEST_SHARED_GPU"] = "1"
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--layers", "4", "--batch", "2",
+           "--no-cpu-baseline", "--no-probes"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=1500, cwd=root, env=env)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{") and '"metric"' in l]
+    assert r.returncode == 0 and len(lines) == 1, r.stdout[-1500:] + r.stderr[-2500:]
+    res = json.loads(lines[0])
+    mg = res["multi_gpu"]
+    assert res["n_gpus"] == 2 and res["config"]["global_batch"] == 4 and mg["torch_world_size"] == 2
+    if multi:
+        assert mg["torch_backend"] == "nccl" and mg["headline_transport"] == "native", mg
+        assert mg["n_ranks_seen"] == {"torch.distributed": 2, "vp_comm_info": 2}, mg["n_ranks_seen"]
+        for leg in ("torch", "native"):
+            assert "error" not in mg[leg], mg[leg]
+            assert mg[leg]["grad_checksum_identical_across_ranks"] and mg[leg].get("target_checksum_identical_across_ranks", True), mg[leg]
+        assert mg["torch"]["grad_checksum"] == mg["native"]["grad_checksum"], "the two transports reduce the same gradient to different bits"
+
+
+def test_collective_on_the_comm_stream_beside_a_dynamic_gemm():
+    """a vp_comm collective on the communicator's side stream BESIDE a many-round one-wave-per-SIMD GEMM with per-XCD dynamic
+    tile claims (vp_gemm_set_dynamic(1): what world > 1 switches on) — a self all-reduce at world 1, so it runs on any box.  The GEMM result
+    must be bit-identical to the launch without the collective, round after round, and the reduced buffer intact."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = r"""
+import os, sys, torch
+sys.path.insert(0, os.environ["VP_ROOT"])
+torch.cuda.set_device(0)
+from visper_lm_amd import ops
+from visper_lm_amd.parallel import NativeComm
+M, N, K = 16384, 4096, 1024                            # 1024 tiles = 4 rounds of the persistent grid
+g = torch.Generator(device="cuda").manual_seed(5)
+a = torch.randn(M, K, device="cuda", generator=g).to(torch.bfloat16)
+w = (torch.randn(N, K, device="cuda", generator=g) * 0.1).to(torch.bfloat16)
+res = torch.randn(M, N, device="cuda", generator=g).to(torch.bfloat16)
+ref = ops.gemm(a, w); ref_r = ops.gemm(a, w, residual=res)
+torch.cuda.synchronize()
+c = NativeComm(rank=0, world=1)
+buf = torch.randn(32 * 1024 * 1024, device="cuda", generator=g).to(torch.bfloat16)       # 64 MB bucket
+keep = buf.clone()
+prev = ops._lib.raw("vp_gemm_set_dynamic", 1)
+try:
+    for it in range(6):
+        c.allreduce_async(buf)                         # side stream, fenced behind the compute stream's work so far
+        o1 = ops.gemm(a, w); o2 = ops.gemm(a, w, residual=res)
+        c.allreduce_async(buf)
+        o3 = ops.gemm(a, w)
+        c.wait()
+        assert torch.equal(o1, ref) and torch.equal(o2, ref_r) and torch.equal(o3, ref), f"round {it}"
+    torch.cuda.synchronize()
+    assert torch.equal(buf, keep)                      # world 1: the sum over one rank
+finally:
+    ops._lib.raw("vp_gemm_set_dynamic", prev)
+c.close()
+print("COMM_BESIDE_GEMM_OK")
+"""
+    env = dict(os.environ, VP_ROOT=root, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-c", script], env=env, capture_output=True, text=True, timeout=600)
+    assert "COMM_BESIDE_GEMM_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
