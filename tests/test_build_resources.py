@@ -41,3 +41,16 @@ def test_dma_ring_kernels_do_not_spill(kernels):
     for n, d in kernels.items():
         if any(t in n for t in ("attn_bwd_dkdv128", "attn_bwd_dq128", "attn_fwd128m", "attn_bwd_dkdv64w", "attn_bwd_dq64w")):
             assert d.get("vgpr_spill_count", 0) == 0 and d.get("private_segment_fixed_size", 0) == 0, (n, d)
+
+
+def test_asm_owned_registers_are_never_touched_by_the_compiler():
+    """csrc/attention_bwd64.h names v64..v255 and every AGPR literally inside asm statements; tools/audit_asm_owned.py compiles attention.hip to ISA
+    and checks that no compiler-generated instruction uses them while they are live, that nothing spills inside the streams and that no scalar
+    load sits inside the counted-lgkmcnt regions (needs hipcc: ~1 min)."""
+    import shutil
+    import audit_asm_owned as au
+    if not (shutil.which("hipcc") or os.path.exists(au.HIPCC)):
+        pytest.skip("needs hipcc")
+    n, problems = au.audit(au.isa())
+    assert n >= 12, n
+    assert not problems, problems[:10]

@@ -465,6 +465,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(AttnParams p) {
 }
 
 #include "attention_d128.h"
+#include "attention_bwd64.h"
 
 // ================================================================================================
 // C ABI
@@ -526,6 +527,12 @@ static int launch_fwd(const AttnParams& p_in, int causal, hipStream_t s) {
   }
   return vp_check_launch("vp_attn_fwd");
 }
+static bool vp_bwd64_enabled() {                       // the one-wave-per-SIMD backward (D = 128 / 96) is the default since round 5; VP_ATTN_BWD64=0: round 4's kernels
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("VP_ATTN_BWD64"); v = e ? atoi(e) : 1; }
+  return v != 0;
+}
+
 template <int D>
 static int launch_bwd(const AttnParams& p_in, int causal, hipStream_t s) {
   AttnParams p = p_in;
@@ -533,6 +540,28 @@ static int launch_bwd(const AttnParams& p_in, int causal, hipStream_t s) {
   const dim3 g1 = p.order ? dim3(p.Hkv, (p.Skv + 127) / 128, p.B) : dim3(p.Hkv, p.B, (p.Skv + 127) / 128);
   const dim3 g2 = p.order ? dim3(p.Hq, (p.Sq + 127) / 128, p.B) : dim3(p.Hq, p.B, (p.Sq + 127) / 128);
   if constexpr (D == 128 || D == 96) {
+    if (vp_bwd64_enabled()) {                           // round 5: one wave per SIMD, 64 rows per wave, 32x32x16 MFMAs (attention_bwd64.h)
+      if (p.rope_cos && !causal) { vp_set_error("vp_attn_bwd_rope: causal attention only"); return VP_ERR_UNSUPPORTED_SHAPE; }
+      const int nkb = (p.Skv + 255) / 256, nqb = (p.Sq + 255) / 256;
+      const dim3 h1 = p.order ? dim3(p.Hkv, nkb, p.B) : dim3(p.Hkv, p.B, nkb);
+      const dim3 h2 = p.order ? dim3(p.Hq, nqb, p.B) : dim3(p.Hq, p.B, nqb);
+#define VP_B64_LAUNCH(C_, R_)                                                                                                        \
+  {                                                                                                                                  \
+    static bool a_ = false;                                                                                                          \
+    if (!a_) {                                                                                                                       \
+      (void)hipFuncSetAttribute((const void*)attn_bwd_dq64w_kernel<C_, R_, D>, hipFuncAttributeMaxDynamicSharedMemorySize, B64_DQ_LDS);   \
+      (void)hipFuncSetAttribute((const void*)attn_bwd_dkdv64w_kernel<C_, R_, D>, hipFuncAttributeMaxDynamicSharedMemorySize, B64_KV_LDS); \
+      a_ = true;                                                                                                                     \
+    }                                                                                                                                \
+    hipLaunchKernelGGL((attn_bwd_dq64w_kernel<C_, R_, D>), h2, dim3(256), B64_DQ_LDS, s, p);     /* first: writes the statistics planes */ \
+    hipLaunchKernelGGL((attn_bwd_dkdv64w_kernel<C_, R_, D>), h1, dim3(256), B64_KV_LDS, s, p);                                       \
+  }
+      if (p.rope_cos) VP_B64_LAUNCH(true, true)
+      else if (causal) VP_B64_LAUNCH(true, false)
+      else VP_B64_LAUNCH(false, false)
+#undef VP_B64_LAUNCH
+      return vp_check_launch("vp_attn_bwd");
+    }
     // the LDS-DMA ring kernels (attention_d128.h): dQ first — it also writes the (lse, delta) pairs the dK/dV kernel streams
     static bool attr2 = false;
     if (!attr2) {
