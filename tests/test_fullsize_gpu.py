@@ -290,6 +290,7 @@ def test_config1_real_step_vs_reference_style_bf16_cpu_path():
     torch.cuda.synchronize()
     assert out["plan"]["S"] == 2048 and out["plan"]["n_valid"] == B * (T - 1 - (ns + 6))
     mine = dict(loss=float(out["loss"]), text=float(out["text_loss"]), layers={k: v.float().cpu().tolist() for k, v in out["layer_losses"].items()})
+    hip_states = {l: t.detach().float().cpu() for l, t in out["layer_states"].items()}         # what the HIP heads actually read (bf16 values)
     gn = float(eng.ps.grad.norm())
     assert gn > 0 and gn == gn
     Wc = {k: v.detach().cpu() for k, v in W.items()}
@@ -305,6 +306,35 @@ def test_config1_real_step_vs_reference_style_bf16_cpu_path():
     check("config1_vs_bf16_cpu_path/loss_rel", rel(mine["loss"], ref["loss"]), 1e-3)
     check("config1_vs_bf16_cpu_path/text_loss_rel", rel(mine["text"], ref["text_loss"]), 1e-3)
     assert sorted(ref["layer_losses"]) == sorted(mine["layers"]) == [("depth", 17), ("gen", 19), ("seg", 17)]
+    # ---- which side is nearer the truth at FULL size?  The heads + _emb_loss of every distillation layer are re-run on the CPU
+    # from the HIP step's OWN tapped layer states (so the decoder's bf16 noise is common to all three): (a) fp32 arithmetic on the bf16-rounded
+    # weights = truth, (b) the reference-style bf16 path (bf16 weights / activations / normalisation / logits: ola_utils.py:114-115,
+    # base_ola_vlm.py:306-316).  The HIP terms (fp32 normalisation, DESIGN deviation ii) are held to max(1e-3, 1.5 x the bf16 path's own deviation
+    # from truth) — measured, they meet north_star's 1e-3 outright, so that is the bound; the comparison with the full bf16 CPU forward stays as a
+    # cross-check at the old bounds (it measures the REFERENCE path's deviation: see the INFO lines).
+    from parity import log
+    spec = {"depth": ("image_depth", "depth_layer_indices", "depth_logit_scale"), "seg": ("image_seg", "seg_layer_indices", "seg_logit_scale"),
+            "gen": ("image_gen", "img_layer_indices", "gen_logit_scale")}
+
+    def heads_from(states, dtype):
+        Wd = {k: (v.to(dtype) if v.dim() > 0 else v.float()) for k, v in Wc.items()}
+        res = {}
+        with torch.no_grad():
+            for task, (cname, ikey, sname) in spec.items():
+                for i, idx in enumerate(O.layer_indices(getattr(ocfg, cname)[ikey])):
+                    pred, _ = O.head_forward(states[idx].to(dtype), task, i, Wd, ocfg)
+                    res[(task, idx)] = [float(x) for x in O.emb_loss(pred, batch[f"{task}_mask"].float(), batch[f"{task}_target"].to(dtype), Wd.get(sname),
+                                                                      ocfg.contrastive_loss_weight)]
+        return res
+    t0 = time.time()
+    truth = heads_from(hip_states, torch.float32)
+    refb = heads_from(hip_states, BF)
+    print(f"[parity] config1: heads + _emb_loss from the HIP layer states, fp32 and bf16 on the CPU: {time.time() - t0:.1f} s")
     for key, trip in ref["layer_losses"].items():
-        for j, (nm, bound) in enumerate((("emb", 1e-2), ("sl1", 1e-3), ("con", 1e-2))):
-            check(f"config1_vs_bf16_cpu_path/layer_loss/{key[0]}@{key[1]}/{nm}_rel", rel(mine["layers"][key][j], trip[j]), bound)
+        for j, (nm, old_bound) in enumerate((("emb", 1e-2), ("sl1", 1e-3), ("con", 1e-2))):
+            hip_dev, ref_dev = rel(mine["layers"][key][j], truth[key][j]), rel(refb[key][j], truth[key][j])
+            log(f"config1_heads_from_hip_states/{key[0]}@{key[1]}/{nm}_INFO_bf16_cpu_path_vs_fp32_truth", ref_dev)
+            # measured (round 5, B = 8, D up to 884 736): HIP vs truth <= 1.6e-4 on every term (depth / seg: ~1e-6) while the bf16 CPU path sits
+            # 2.3e-3 .. 5.0e-3 from the same truth: the 5e-3 "gap" of the line below is the reference path's own bf16 normalisation
+            check(f"config1_heads_from_hip_states/{key[0]}@{key[1]}/{nm}_hip_vs_fp32_truth", hip_dev, 1e-3)
+            check(f"config1_vs_bf16_cpu_path/layer_loss/{key[0]}@{key[1]}/{nm}_rel", rel(mine["layers"][key][j], trip[j]), old_bound)

@@ -527,10 +527,12 @@ static int launch_fwd(const AttnParams& p_in, int causal, hipStream_t s) {
   }
   return vp_check_launch("vp_attn_fwd");
 }
-static bool vp_bwd64_enabled() {                       // the one-wave-per-SIMD backward (D = 128 / 96) is the default since round 5; VP_ATTN_BWD64=0: round 4's kernels
+// VP_ATTN_BWD64: 1 (default) = the one-wave-per-SIMD backward kernels of round 5 (attention_bwd64.h); 2 = round 5's dK/dV kernel behind round 4's
+// dQ kernel (which then writes the statistics planes); 0 = round 4's kernels
+static int vp_bwd64_mode() {
   static int v = -1;
   if (v < 0) { const char* e = getenv("VP_ATTN_BWD64"); v = e ? atoi(e) : 1; }
-  return v != 0;
+  return v;
 }
 
 template <int D>
@@ -540,11 +542,20 @@ static int launch_bwd(const AttnParams& p_in, int causal, hipStream_t s) {
   const dim3 g1 = p.order ? dim3(p.Hkv, (p.Skv + 127) / 128, p.B) : dim3(p.Hkv, p.B, (p.Skv + 127) / 128);
   const dim3 g2 = p.order ? dim3(p.Hq, (p.Sq + 127) / 128, p.B) : dim3(p.Hq, p.B, (p.Sq + 127) / 128);
   if constexpr (D == 128 || D == 96) {
-    if (vp_bwd64_enabled()) {                           // round 5: one wave per SIMD, 64 rows per wave, 32x32x16 MFMAs (attention_bwd64.h)
+    if (vp_bwd64_mode() != 0) {                         // round 5: one wave per SIMD, 64 rows per wave, 32x32x16 MFMAs (attention_bwd64.h)
       if (p.rope_cos && !causal) { vp_set_error("vp_attn_bwd_rope: causal attention only"); return VP_ERR_UNSUPPORTED_SHAPE; }
       const int nkb = (p.Skv + 255) / 256, nqb = (p.Sq + 255) / 256;
       const dim3 h1 = p.order ? dim3(p.Hkv, nkb, p.B) : dim3(p.Hkv, p.B, nkb);
       const dim3 h2 = p.order ? dim3(p.Hq, nqb, p.B) : dim3(p.Hq, p.B, nqb);
+      const bool old_dq = vp_bwd64_mode() == 2;
+      if (old_dq) p.stat_planes = 1;
+      static bool attr_o = false;
+      if (old_dq && !attr_o) {
+        (void)hipFuncSetAttribute((const void*)attn_bwd_dq128_kernel<true, false, D>, hipFuncAttributeMaxDynamicSharedMemorySize, DQ128_LDS);
+        (void)hipFuncSetAttribute((const void*)attn_bwd_dq128_kernel<false, false, D>, hipFuncAttributeMaxDynamicSharedMemorySize, DQ128_LDS);
+        (void)hipFuncSetAttribute((const void*)attn_bwd_dq128_kernel<true, true, D>, hipFuncAttributeMaxDynamicSharedMemorySize, DQ128_LDS);
+        attr_o = true;
+      }
 #define VP_B64_LAUNCH(C_, R_)                                                                                                        \
   {                                                                                                                                  \
     static bool a_ = false;                                                                                                          \
@@ -553,7 +564,8 @@ static int launch_bwd(const AttnParams& p_in, int causal, hipStream_t s) {
       (void)hipFuncSetAttribute((const void*)attn_bwd_dkdv64w_kernel<C_, R_, D>, hipFuncAttributeMaxDynamicSharedMemorySize, B64_KV_LDS); \
       a_ = true;                                                                                                                     \
     }                                                                                                                                \
-    hipLaunchKernelGGL((attn_bwd_dq64w_kernel<C_, R_, D>), h2, dim3(256), B64_DQ_LDS, s, p);     /* first: writes the statistics planes */ \
+    if (old_dq) hipLaunchKernelGGL((attn_bwd_dq128_kernel<C_, R_, D>), g2, dim3(256), DQ128_LDS, s, p);                              \
+    else hipLaunchKernelGGL((attn_bwd_dq64w_kernel<C_, R_, D>), h2, dim3(256), B64_DQ_LDS, s, p);     /* first: writes the statistics planes */ \
     hipLaunchKernelGGL((attn_bwd_dkdv64w_kernel<C_, R_, D>), h1, dim3(256), B64_KV_LDS, s, p);                                       \
   }
       if (p.rope_cos) VP_B64_LAUNCH(true, true)

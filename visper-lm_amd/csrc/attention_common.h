@@ -48,6 +48,9 @@ struct AttnParams {
   // 1 = (head, tile, batch) with `batch` slowest: one batch's heads and tiles run together, so an XCD's resident blocks share ONE
   // (batch, kv-head) K/V set (1 MB at S=2048) instead of eight (8 MB > the 4 MB L2)
   int order;
+  // 1: the dQ kernel writes the per-row statistics as two planes (-lse / c at delta[0 .. rows), -delta at delta[rows .. 2 rows)) for the round-5 dK/dV
+  // kernel (attention_bwd64.h) instead of round 4's interleaved (lse, delta) pairs
+  int stat_planes;
 };
 #define VP_BY(P) ((P).order ? (int)blockIdx.z : (int)blockIdx.y)      /* batch index */
 #define VP_BZ(P) ((P).order ? (int)blockIdx.y : (int)blockIdx.z)      /* tile index */

@@ -411,8 +411,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     part += __shfl_xor(part, 32, 64);
     dlt[qt] = part;
     if ((lane >> 4) == 0 && qw0 + qt * 16 + (lane & 15) < p.Sq) {
-      p.delta[sidx] = part;
-      *(float2*)(p.delta + (long)p.B * p.Hq * p.Sq + 2 * sidx) = float2{lse[qt], part};
+      if (p.stat_planes) {                               // round-5 dK/dV kernel: planes (-lse / c, -delta)
+        p.delta[sidx] = -lse[qt] / c;
+        p.delta[(long)p.B * p.Hq * p.Sq + sidx] = -part;
+      } else {
+        p.delta[sidx] = part;
+        *(float2*)(p.delta + (long)p.B * p.Hq * p.Sq + 2 * sidx) = float2{lse[qt], part};
+      }
     }
   }
   f32x4 dq[2][NDB];

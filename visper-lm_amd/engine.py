@@ -849,6 +849,7 @@ class Engine:
 
         dec = self._decoder_fwd(x, plan, compute_grads)
         out["hidden"] = self.present(dec["hidden"], plan)
+        out["layer_states"] = {l: self.present(t, plan) for l, t in dec["states"].items()}      # the tapped states the heads read (views when right-padded)
         if dec["hidden_states"] is not None:             # (embeddings, layer 1 .. L-1 outputs, norm(layer L output)): ola_llama.py:113,181
             out["hidden_states"] = (out["inputs_embeds"],) + tuple(self.present(t, plan) for t in dec["hidden_states"][1:-1]) + (out["hidden"],)
         # The distillation heads (a8..a14: ~300 small launches, few tiles each) depend only on the tapped layer states, and nothing needs their
