@@ -970,6 +970,20 @@ def test_attention_forward_variants_by_env():
         assert r.returncode == 0 and " passed" in r.stdout, (env, r.stdout[-1500:], r.stderr[-500:])
 
 
+def test_attention_backward_variants_by_env():
+    """VP_ATTN_BWD64 (read once per process -> child processes): 1 = round 5's one-wave-per-SIMD dQ + dK/dV kernels (attention_bwd64.h), 2 = round 4's
+    dQ kernel (writing the statistics planes) in front of round 5's dK/dV kernel, 0 = round 4's pair.  Every backward test of this file (edges, GQA,
+    kv_len, windows, D = 96, fused RoPE^T) must pass under each, whichever is the default."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for mode in ("0", "1", "2"):
+        r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-k",
+                            "test_attention_d128_dma_kernels_edges or test_attention_fwd_bwd or test_attention_fused_qkv_views_and_kvlen or test_attention_sliding_window "
+                            "or test_attention_d96_fused_qkv_views_fwd_bwd or test_attn_bwd_fused_rope or test_attention_d128_rescale_branch_mid_sequence"],
+                           capture_output=True, text=True, timeout=900, cwd=root, env=dict(os.environ, VP_ATTN_BWD64=mode))
+        assert r.returncode == 0 and " passed" in r.stdout, (mode, r.stdout[-1500:], r.stderr[-500:])
+
+
 def test_attention_with_additive_biases(ops):
     """vp_attn_fwd_bias (Swin window attention): per-head relative-position bias + per-window shift mask (-100 entries, HF
     modeling_swin.py get_attn_mask), 144-token windows, D = 32, batch = images x windows."""

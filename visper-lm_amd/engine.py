@@ -184,8 +184,9 @@ class Engine:
         # norms keep gamma = 1, and where every GEMM of a layer is a one-wave-per-SIMD launch (ops.fold_norm_ok) the normalisation itself
         # disappears: 1/rms is a row scale in the consumer's epilogue, the sums of squares come out of the producer's residual epilogue.
         # Reference: HF LlamaRMSNorm / LlamaDecoderLayer (modeling_llama.py), reached from ola_llama.py:105-115.
-        # Only where the fast path can exist (head_dim 128: RoPE in the QKV epilogue); Phi-3 (D = 96) keeps gamma in its norms.
-        self.fold_norm = os.environ.get("VP_FOLD_NORM", "1") != "0" and cfg.head_dim == 128 and cfg.hidden_size % 256 == 0
+        # Only where the fast path can exist: head_dim 128 (Llama: RoPE in the QKV epilogue as well) and 96 (Phi-3, round 5: 1/rms as the QKV GEMM's row
+        # scale with rope_cols = 0, the rotation stays its own kernel: a 96-wide head straddles the kernel's 128-column wave sub-tiles).
+        self.fold_norm = os.environ.get("VP_FOLD_NORM", "1") != "0" and cfg.head_dim in (96, 128) and cfg.hidden_size % 256 == 0
         fz["ones_h"] = torch.ones(cfg.hidden_size, device=self.dev, dtype=BF16)
         fz["embed"] = d(W["model.embed_tokens.weight"])
         fz["norm"] = d(W["model.norm.weight"])
@@ -949,7 +950,7 @@ class Engine:
         fuse = il and ops.swiglu_fusable(M, 2 * cfg.intermediate_size, cfg.hidden_size) and \
             ops.swiglu_fusable(M, cfg.intermediate_size, cfg.hidden_size)
         fuse_rope = ops.gemm_rope_ok(M, (nh + 2 * nkv) * hd, cfg.hidden_size, hd) and cos_t.shape[-1] == 64
-        fold = getattr(self, "fold_norm", False) and not self.train_llm and fuse and fuse_rope and \
+        fold = getattr(self, "fold_norm", False) and not self.train_llm and fuse and (fuse_rope or hd == 96) and \
             ops.fold_norm_ok(M, cfg.hidden_size, cfg.intermediate_size, hd, (nh + 2 * nkv) * hd)
         H, eps = cfg.hidden_size, cfg.rms_norm_eps
         rstd1 = None
@@ -963,7 +964,11 @@ class Engine:
                 # norm come out of the residual GEMM that writes the stream (layer 0's from one pass over the spliced embeddings)
                 if rstd1 is None:
                     _, rstd1 = ops.rmsnorm_fwd(x, fz["ones_h"], eps)
-                qkv = ops.gemm_rope(x, fz[o + "wqkv"], S, (nh + nkv) * hd, cos_t, sin_t, row_scale=rstd1)
+                if fuse_rope:
+                    qkv = ops.gemm_rope(x, fz[o + "wqkv"], S, (nh + nkv) * hd, cos_t, sin_t, row_scale=rstd1)
+                else:                                       # D = 96: row-scaled GEMM (rope_cols = 0), then the rotation kernel
+                    qkv = ops.gemm_rope(x, fz[o + "wqkv"], S, 0, cos_t, sin_t, row_scale=rstd1)
+                    ops.rope_(qkv, M, S, nh + nkv, hd, cos_t, sin_t)
                 q4, k4, v4 = self._qkv_views(qkv, B, S)
                 att, lse = ops.attn_fwd(q4, k4, v4, causal=True, window=window, kv_len=kv_len)
                 h1, part = ops.gemm_sumsq(att.view(M, nh * hd), fz[o + "wo"], x)

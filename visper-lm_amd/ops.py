@@ -66,17 +66,21 @@ def gemm(a, w, bias=None, residual=None, epi=EPI_NONE, out=None, out_f32=False, 
     return out
 
 
+def gemm_rowscale_ok(M, N, K):
+    """Shapes vp_gemm_bf16_rope accepts as a plain row-scaled GEMM (rope_cols = 0): the general variant of the one-wave-per-SIMD kernel."""
+    return N % 256 == 0 and K % 128 == 0 and M >= 256 and ((M + 255) // 256) * (N // 256) >= 64 and os.environ.get("VP_GEMM_ROPE", "1") != "0"
+
+
 def gemm_rope_ok(M, N, K, head_dim):
-    """Shapes vp_gemm_bf16_rope accepts (general variant of the one-wave-per-SIMD kernel; enough tiles to be worth a persistent grid)."""
-    return head_dim == 128 and N % 256 == 0 and K % 128 == 0 and M >= 256 and ((M + 255) // 256) * (N // 256) >= 64 \
-        and os.environ.get("VP_GEMM_ROPE", "1") != "0"
+    """Shapes vp_gemm_bf16_rope accepts WITH the rotation in its epilogue (whole 128-wide heads per wave sub-tile)."""
+    return head_dim == 128 and gemm_rowscale_ok(M, N, K)
 
 
 def gemm_rope(a, w, S, rope_cols, cos_t, sin_t, pos=None, row_scale=None):
     """qkv = rope(a @ w^T) in one kernel: columns < rope_cols (q and k heads of 128) rotated as rope_() would (bit-identical)."""
     M, K, lda = _rows2d(a)
     N, K2, ldb = _rows2d(w)
-    assert K == K2 and a.dtype == BF16 and w.dtype == BF16 and cos_t.dtype == torch.float32 and cos_t.shape[-1] == 64
+    assert K == K2 and a.dtype == BF16 and w.dtype == BF16 and cos_t.dtype == torch.float32 and (rope_cols == 0 or cos_t.shape[-1] == 64)
     out = torch.empty(*a.shape[:-1], N, device=a.device, dtype=BF16)
     if GEMM_PROF is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -91,7 +95,7 @@ def gemm_rope(a, w, S, rope_cols, cos_t, sin_t, pos=None, row_scale=None):
 def fold_norm_ok(M, H, I, head_dim, nqkv):
     """Shapes for which a decoder layer can run with RMSNorm folded away (gamma in the frozen weights, 1/rms as a row scale in the consuming
     GEMM's epilogue, sums of squares from the producing residual GEMM's epilogue): every GEMM involved must be a one-wave-per-SIMD launch."""
-    return (gemm_rope_ok(M, nqkv, H, head_dim) and M % 256 == 0 and H % 256 == 0 and I % 128 == 0 and (M // 256) * (2 * I // 256) >= 192
+    return (gemm_rowscale_ok(M, nqkv, H) and head_dim in (96, 128) and M % 256 == 0 and H % 256 == 0 and I % 128 == 0 and (M // 256) * (2 * I // 256) >= 192
             and os.environ.get("VP_GEMM_W4", "1") == "1" and os.environ.get("VP_FOLD_NORM", "1") != "0")
 
 
