@@ -175,6 +175,55 @@ def test_fullwidth_llama_step_all_heads_vs_fp32_oracle():
     assert got["S"] == 127 + 576 + 24
 
 
+def test_fold_norm_step_matches_unfolded_step(monkeypatch):
+    """DESIGN section 2, deviation (v): which rounding points the decoder's RMSNorms take depends on the SHAPE — the fold (gamma in the
+    derived weights, 1/rms as a row scale of the QKV / SwiGLU epilogues, sums of squares out of the residual GEMMs) needs tokens % 256 == 0 and
+    one-wave-per-SIMD GEMM shapes, every other batch takes HF's rounding points.  Both must describe the same step: full-width Llama layers at a
+    shape that folds (B = 2, S = 768 -> 1536 tokens), once with the fold and once with VP_FOLD_NORM=0, same weights and batch: losses, layer losses,
+    hidden states and every gradient agree to bf16-rounding level (the other full-width tests of this file have S = 727: un-folded by shape)."""
+    from visper_lm_amd.config import llama3_8b
+    cfg = llama3_8b(num_hidden_layers=2, vit_layers=4)
+    cfg.image_seg = dict(cfg.image_seg, seg_layer_indices="1")
+    cfg.image_depth = dict(cfg.image_depth, depth_layer_indices="2")
+    cfg.image_gen = dict(cfg.image_gen, img_layer_indices="2")
+    from visper_lm_amd.engine import Engine
+    W, batch = _weights(cfg), _batch(cfg, 2, 169)
+
+    def run(fold):
+        monkeypatch.setenv("VP_FOLD_NORM", "1" if fold else "0")
+        eng = Engine(cfg)
+        eng.load_weights(W)
+        out = eng.train_step(_gpu(batch))
+        torch.cuda.synchronize()
+        assert out["plan"]["S"] == 768 and eng.last_fold == fold, (out["plan"]["S"], eng.last_fold)
+        res = dict(loss=float(out["loss"]), text_loss=float(out["text_loss"]), hidden=out["hidden"].float().cpu(),
+                   layer_losses={k: v.float().cpu() for k, v in out["layer_losses"].items()},
+                   grads={k: eng.ps.g(k).detach().float().cpu().clone() for k in eng.ps.index})
+        del eng, out
+        torch.cuda.empty_cache()
+        return res
+    a, b = run(True), run(False)
+    check("fold_vs_unfolded/loss_rel", rel(a["loss"], b["loss"]), 1e-3)
+    check("fold_vs_unfolded/text_loss_rel", rel(a["text_loss"], b["text_loss"]), 1e-3)
+    for key, trip in b["layer_losses"].items():
+        for j, nm in enumerate(("emb", "sl1", "con")):
+            if abs(float(trip[j])) > 1e-9:
+                check(f"fold_vs_unfolded/layer_loss/{key[0]}@{key[1]}/{nm}_rel", rel(a["layer_losses"][key][j], trip[j]), 5e-3)
+    check("fold_vs_unfolded/hidden_frob", _frob(a["hidden"], b["hidden"]), 2e-2)
+    # gradients: the depth head (ReLU gates + LayerNorm backward) amplifies ANY bf16 rounding difference of its input state — the reference-style
+    # bf16 CPU path sits 4.6e-2 from fp32 truth on the same parameters (TIGHT above) — so it gets that yardstick; everything else is tight
+    worst = {"depth_head": (0.0, ""), "rest": (0.0, "")}
+    for k, gb in b["grads"].items():
+        if gb.numel() > 1 and float(gb.abs().max()) > 0:
+            c, _ = grad_err(a["grads"][k], gb)
+            grp = "depth_head" if "depth" in k else "rest"
+            if c > worst[grp][0]:
+                worst[grp] = (c, k)
+    print("[parity] fold_vs_unfolded worst gradients:", worst)
+    check("fold_vs_unfolded/worst_grad_one_minus_cos/rest", worst["rest"][0], 5e-3)
+    check("fold_vs_unfolded/worst_grad_one_minus_cos/depth_head", worst["depth_head"][0], 7e-2)
+
+
 def _mem_available_gb():
     try:
         for line in open("/proc/meminfo"):

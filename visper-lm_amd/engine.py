@@ -954,6 +954,7 @@ class Engine:
         fuse_rope = ops.gemm_rope_ok(M, (nh + 2 * nkv) * hd, cfg.hidden_size, hd) and cos_t.shape[-1] == 64
         fold = getattr(self, "fold_norm", False) and not self.train_llm and fuse and (fuse_rope or hd == 96) and \
             ops.fold_norm_ok(M, cfg.hidden_size, cfg.intermediate_size, hd, (nh + 2 * nkv) * hd)
+        self.last_fold = bool(fold)                      # (which set of rounding points the last step took: DESIGN section 2, deviation v)
         H, eps = cfg.hidden_size, cfg.rms_norm_eps
         rstd1 = None
         hs = [] if self.keep_states else None            # HF all_hidden_states: the input of every layer, then the post-norm final state
