@@ -1574,6 +1574,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   int v = blockIdx.x;
   TileCoord tc = TILE_OF(v);
   if ((p.dbg & 0x10000) && threadIdx.x == 0) vp_dbg_stamps[blockIdx.x * 8 + 0] = wall_clock64();
+  if ((p.dbg & 0x80000) && (blockIdx.x & 3)) return;     // (measurement aid, tools/gemm_epilogue_probe.py: a quarter of the CUs work, the rest leave — results are wrong)
   // DMA stream state (wave-uniform): next K-tile to fetch = K-tile `kn` of tile `vn`; its byte offset along K is the soffset `kofs`
   typedef uint32_t u32x4s __attribute__((ext_vector_type(4)));
   auto make_rs = [&](const bf16_t* base, long rows_ld, int rows = 256) -> u32x4s {
@@ -2144,6 +2145,7 @@ int vp_gemm_bf16_swiglu(int mode, int M, int N, int K, const void* A, long lda, 
                "vp_gemm_bf16_swiglu: backward operands");
   GemmArgs p{(const bf16_t*)A, (const bf16_t*)B, C, nullptr, nullptr, M, N, K, lda, ldb, ldc, 0, EPI_NONE, 0,
              mode, C2, ldc2, (const bf16_t*)aux, ldaux};
+  p.dbg = vp_gemm_dbg();
   if (mode == 1 && aux) {                              // forward: aux = fp32 [M] row scale (one-wave-per-SIMD kernel only, checked below)
     p.rowscale = (const float*)aux;
     p.aux = nullptr;
