@@ -14,11 +14,21 @@ from visper_lm_amd import ops, _lib
 dev = torch.device("cuda")
 
 
-def probe(name, M, N, K, fn, n=40, quarter=False):
+def probe(name, M, N, K, fn, n=40, quarter=False, extra=0):
+    _lib.call("vp_debug_gemm_flags", extra)
     for _ in range(n - 1):
         fn()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    _lib.call("vp_debug_gemm_flags", 0x10000 | (0x80000 if quarter else 0))
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record()
+    for _ in range(20):
+        fn()
+    ev1.record(); torch.cuda.synchronize()
+    if extra:
+        name += f" [flags {extra:#x}: {ev0.elapsed_time(ev1) * 50:.0f} us per launch back to back]"
+    else:
+        name += f" [{ev0.elapsed_time(ev1) * 50:.0f} us per launch back to back]"
+    _lib.call("vp_debug_gemm_flags", extra | 0x10000 | (0x80000 if quarter else 0))
     try:
         e0.record(); fn(); e1.record()
         torch.cuda.synchronize()
