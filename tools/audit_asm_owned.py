@@ -26,7 +26,7 @@ def isa():
 
 def audit(text):
     """AGPRs: never outside asm.  VGPRs above v63: not between the first asm statement that WRITES one of them (a literal register goes live) and the
-    last barrier of the kernel (dK/dV: the epilogue behind it only reads accumulators through asm) / the end of the kernel (dQ: persistent)."""
+    last barrier of the kernel (the epilogue behind it only reads accumulators through asm)."""
     problems, seen = [], 0
     for m in re.finditer(r"^(_Z\d+attn_bwd_(?:dq|dkdv)64w_kernel\w+):.*?^\s*s_endpgm", text, re.S | re.M):
         name, lines = m.group(1), m.group(0).splitlines()
@@ -42,8 +42,7 @@ def audit(text):
                 if t.startswith("s_barrier"):
                     last_bar = ln
                     first_bar = ln if first_bar is None else first_bar
-                if live is None and re.match(r"(v_mov_b32 v(6[4-9]|[7-9]\d|1\d\d|2\d\d)\b|(ds_read\w*|buffer_load_dwordx4) v\[(6[4-9]|[7-9]\d|1\d\d|2\d\d):"
-                                             r"|buffer_load_dwordx4 a\[)", t):
+                if live is None and re.match(r"(v_mov_b32 v(6[4-9]|[7-9]\d|1\d\d|2\d\d)\b|ds_read\w* v\[(6[4-9]|[7-9]\d|1\d\d|2\d\d):)", t):
                     live = ln
         in_asm = False
         for ln, line in enumerate(lines):
@@ -61,12 +60,11 @@ def audit(text):
                 problems.append(f"{name}:{ln}: compiler instruction touches an AGPR: {code}")
             if code.startswith("scratch_") and first_bar is not None and first_bar < ln < last_bar:
                 problems.append(f"{name}:{ln}: scratch access between the barriers (the streams' loops): {code}")
-            # (the dQ kernel is persistent: its epilogue sits INSIDE the item loop, with the next item's fragments already in their registers)
-            if live is not None and live <= ln and (ln <= last_bar or "dq64w" in name):
+            if live is not None and live <= ln <= last_bar:
                 hi = [int(r) for r in re.findall(r"\bv(\d+)\b", code)] + [int(b_) for _, b_ in re.findall(r"\bv\[(\d+):(\d+)\]", code)]
                 if hi and max(hi) > 63:
                     problems.append(f"{name}:{ln}: compiler instruction uses v{max(hi)} while asm-owned registers are live: {code}")
-                if first_bar is not None and first_bar < ln <= last_bar and code.startswith(("s_load_", "s_buffer_load")):
+                if first_bar is not None and ln > first_bar and code.startswith(("s_load_", "s_buffer_load")):
                     problems.append(f"{name}:{ln}: scalar memory load inside the counted-lgkmcnt region: {code}")
     return seen, problems
 

@@ -547,18 +547,6 @@ static int launch_bwd(const AttnParams& p_in, int causal, hipStream_t s) {
       const int nkb = (p.Skv + 255) / 256, nqb = (p.Sq + 255) / 256;
       const dim3 h1 = p.order ? dim3(p.Hkv, nkb, p.B) : dim3(p.Hkv, p.B, nkb);
       const dim3 h2 = p.order ? dim3(p.Hq, nqb, p.B) : dim3(p.Hq, p.B, nqb);
-      // the one-wave-per-SIMD dQ kernel walks its (head, batch, query block) items with a persistent grid: one block per CU (VP_ATTN_DQ_GRID = blocks,
-      // 0 = one block per item)
-      static const int dq_grid = [] {
-        const char* e = getenv("VP_ATTN_DQ_GRID");
-        if (e) return atoi(e);
-        int dev = 0, cus = 256;
-        (void)hipGetDevice(&dev);
-        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        return cus;
-      }();
-      const int dq_items = p.Hq * p.B * nqb;
-      const int h2p = dq_grid > 0 ? (dq_items < dq_grid ? dq_items : dq_grid) : dq_items;
       const bool old_dq = vp_bwd64_mode() == 2;
       if (old_dq) p.stat_planes = 1;
       static bool attr_o = false;
@@ -577,7 +565,7 @@ static int launch_bwd(const AttnParams& p_in, int causal, hipStream_t s) {
       a_ = true;                                                                                                                     \
     }                                                                                                                                \
     if (old_dq) hipLaunchKernelGGL((attn_bwd_dq128_kernel<C_, R_, D>), g2, dim3(256), DQ128_LDS, s, p);                              \
-    else hipLaunchKernelGGL((attn_bwd_dq64w_kernel<C_, R_, D>), dim3(h2p), dim3(256), B64_DQ_LDS, s, p); /* first: writes the statistics planes */ \
+    else hipLaunchKernelGGL((attn_bwd_dq64w_kernel<C_, R_, D>), h2, dim3(256), B64_DQ_LDS, s, p);     /* first: writes the statistics planes */ \
     hipLaunchKernelGGL((attn_bwd_dkdv64w_kernel<C_, R_, D>), h1, dim3(256), B64_KV_LDS, s, p);                                       \
   }
       if (p.rope_cos) VP_B64_LAUNCH(true, true)

@@ -233,20 +233,91 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1), amdg
   static_assert(D == 128 || D == 96, "D");
   constexpr int NKS = D / 16, NOB = D / 32, NOPS = 2 * NOB;
   constexpr int A_ACC = 0, A_QF = 128, A_DOF = 192, V_SE = 64, V_SO = 96, V_DP = 128, V_ND = 160, V_KFR = 192, V_VFR = 208, V_TR = 224, V_PK = 236;
-  constexpr int V_OR = 192;                              // O rows of the item whose loads are in flight: (qb, ks) at 192 + 32 qb + 4 ks (dead loop registers)
-  constexpr int N_ITEM_VM = 12 + 3 * 2 * NKS + 2;        // vector-memory operations of one item's loads: 12 LDS-DMA pieces, Q / dO / O fragments, 2 lse
-  static_assert(N_ITEM_VM <= 63, "vmcnt is a 6-bit counter");
   extern __shared__ __attribute__((aligned(16))) unsigned char attn_smem[];
   asm volatile("" ::: "v255", "a255");                   // the wave owns its SIMD's whole register file (see gemm_nt_256w4)
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int ql = lane & 31, hh = lane >> 5;
   const int nqb = (p.Sq + 255) >> 8;
+  const int qblk = nqb - 1 - VP_BZ(p);                 // z is the slowest dispatch index: heavy (late) causal blocks first
+  const int hx = blockIdx.x;
+  const int h = (p.Hq & 7) == 0 ? (hx & 7) * (p.Hq >> 3) + (hx >> 3) : hx;     // whole GQA groups per XCD
+  const int b = VP_BY(p), hk = h / (p.Hq / p.Hkv);
+  const int q0 = qblk * 256, qw0 = q0 + wave * 64;
+  const int kvlen = p.kv_len ? min(p.kv_len[b], p.Skv) : p.Skv;
   const int off = p.Skv - p.Sq, Sq = p.Sq, window = p.window;
   const float c = p.scale * LOG2E;
   const long nrows = (long)p.B * p.Hq * p.Sq;
-  const int nhb = p.Hq * p.B, nitems = nhb * nqb, rep = p.Hq / p.Hkv;
 
-  // ---- LDS-DMA lane addresses (item-invariant); K / V pieces go through buffer descriptors of the item's (batch, kv head); rows past Skv read as zeros
+  // ---- Q / dO fragments (B operands: lane = query, features 16 ks + 8 hh .. + 7) straight into their AGPRs (buffer loads with an AGPR destination:
+  // no pressure on the compiler's 64 VGPRs), delta = rowsum(dO o O) from the loaded dO fragments, -lse; the two statistics planes
+  float nlse[2], npart[2];
+  {
+    const fwdm_u32x4s rsQh = attn_make_rs(p.q + (long)b * p.q_bs + (long)h * D, (((long)Sq - 1) * p.q_ts + D) * 2);
+    const fwdm_u32x4s rsGh = attn_make_rs(p.dout + (long)b * p.do_bs + (long)h * D, (((long)Sq - 1) * p.do_ts + D) * 2);
+    uint32_t voq[2], vog[2];
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+      const int qrc = min(qw0 + 32 * qb + ql, Sq - 1);  // clamped (unconditional loads); rows >= Sq are never stored
+      voq[qb] = (uint32_t)qrc * (uint32_t)(p.q_ts * 2) + 16u * (uint32_t)hh;
+      vog[qb] = (uint32_t)qrc * (uint32_t)(p.do_ts * 2) + 16u * (uint32_t)hh;
+    }
+    asm volatile("s_nop 4" ::: "memory");               // (descriptor SGPRs fresh from v_readfirstlane)
+    vp_static_for<2 * NKS>([&](auto i_) __attribute__((always_inline)) {
+      constexpr int qb = decltype(i_)::value / NKS, ks = decltype(i_)::value % NKS;
+      b64_use(voq, vog, rsQh, rsGh);
+      asm volatile("buffer_load_dwordx4 a[%c2:%c3], %0, %1, 0 offen offset:%c4" ::"v"(voq[qb]), "s"(rsQh), "n"(A_QF + 32 * qb + 4 * ks),
+                   "n"(A_QF + 32 * qb + 4 * ks + 3), "n"(32 * ks) : "memory");
+      asm volatile("buffer_load_dwordx4 a[%c2:%c3], %0, %1, 0 offen offset:%c4" ::"v"(vog[qb]), "s"(rsGh), "n"(A_DOF + 32 * qb + 4 * ks),
+                   "n"(A_DOF + 32 * qb + 4 * ks + 3), "n"(32 * ks) : "memory");
+    });
+  }
+  // the O rows (compiler loads, one q block at a time: 32 registers) fly together with the fragment loads; one wait for everything
+  vp_static_for<2>([&](auto qb_) __attribute__((always_inline)) {
+    constexpr int qb = decltype(qb_)::value;
+    const int qrow = qw0 + 32 * qb + ql;
+    const int qrc = min(qrow, Sq - 1);
+    const bf16_t* op_ = p.o + (long)b * p.o_bs + (long)qrc * p.o_ts + (long)h * D;
+    const long sidx = ((long)b * p.Hq + h) * Sq + qrc;
+    bf16x8 ov[NKS];
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) ov[ks] = *(const bf16x8*)(op_ + ks * 16 + hh * 8);
+    const float lse = p.lse[sidx];
+    B64_VMCNT(0);
+    float part = 0.f;
+    vp_static_for<NKS>([&](auto ks_) __attribute__((always_inline)) {
+      constexpr int ks = decltype(ks_)::value;
+      b64_use(ov, part);
+      const bf16x8 g8 = __builtin_bit_cast(bf16x8, b64_aread<A_DOF + 32 * qb + 4 * ks>());
+#pragma unroll
+      for (int e = 0; e < 8; ++e) part = fmaf(bf2f((bf16_t)g8[e]), bf2f((bf16_t)ov[ks][e]), part);
+    });
+    part += __shfl_xor(part, 32, 64);
+    nlse[qb] = -lse;
+    npart[qb] = -part;
+    if (hh == 0 && qrow < Sq) {
+      p.delta[sidx] = -lse / c;                        // plane 0: -lse / c   (S' = S - lse / c, P = exp2(c S'))
+      p.delta[nrows + sidx] = -part;                   // plane 1: -delta
+    }
+  });
+  vp_static_for<2 * NOB * 16>([&](auto i_) __attribute__((always_inline)) {
+    constexpr int i = decltype(i_)::value;
+    R_AZERO(A_ACC + 64 * (i / (NOB * 16)) + (i % (NOB * 16)));
+  });
+
+  int kend = kvlen;
+  if (CAUSAL) kend = min(kend, q0 + 256 + off);
+  int kstart = 0;
+  if (window > 0) kstart = max(0, (q0 + off - window + 1)) & ~31;
+  const int nit = (B64_ABL & 8) ? 0 : (kend > kstart ? (kend - kstart + 31) / 32 : 0);      // (ablation 8: prologue + epilogue only)
+  // tiles this WAVE computes: [first_w, last_w]; the others only keep the block's barrier / DMA cadence
+  int last_w = CAUSAL ? min(nit - 1, (qw0 + 63 + off - kstart) >> 5) : nit - 1;
+  int first_w = 0;
+  if (window > 0) first_w = max(0, (qw0 + off - window + 1 - kstart) >> 5);
+  if (last_w < first_w || qw0 >= Sq) { last_w = -1; first_w = nit; }
+
+  // ---- LDS-DMA: K / V pieces through buffer descriptors of this (batch, kv head); rows past Skv read as zeros
+  const fwdm_u32x4s rsK = attn_make_rs(p.k + (long)b * p.k_bs + (long)hk * D, (((long)p.Skv - 1) * p.k_ts + D) * 2);
+  const fwdm_u32x4s rsV = attn_make_rs(p.v + (long)b * p.v_bs + (long)hk * D, (((long)p.Skv - 1) * p.v_ts + D) * 2);
   const uint32_t ldsb = attn_lds_addr(attn_smem);
   const uint32_t kts2 = __builtin_amdgcn_readfirstlane((uint32_t)(p.k_ts * 2)), vts2 = __builtin_amdgcn_readfirstlane((uint32_t)(p.v_ts * 2));
   uint32_t vK, vV;
@@ -257,78 +328,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1), amdg
     asm volatile("" : "+v"(vK), "+v"(vV));
   }
   const uint32_t m0w = __builtin_amdgcn_readfirstlane(ldsb + (uint32_t)wave * (uint32_t)B64_PIECE);
-
-  // ---- the item (one q head x 256 queries) this block works on.  The grid is PERSISTENT (<= one block per CU: a wave owns its SIMD's register file, so
-  // a second block could never overlap the first one's loads): block g walks items g, g + G, ...; item t -> (query block nqb - 1 - t / (Hq B): heavy
-  // causal blocks first, batch, head); with Hq B a multiple of G every block gets one item of every weight.  The NEXT item's fragments (Q, dO -> their
-  // AGPRs, O rows -> v[192:255], lse) and its first three K / V tiles (LDS-DMA) are issued behind the loop, under the epilogue's table loads,
-  // accumulator reads and stores.
-  int h, b, qw0, kvlen, kstart, nit, first_w, last_w;
-  fwdm_u32x4s rsK, rsV;
-  float lse_n[2];
-  auto set_item = [&](int t) __attribute__((always_inline)) {
-    const int z = t / nhb, r = t - z * nhb, y = r / p.Hq, hx = r - y * p.Hq;
-    h = __builtin_amdgcn_readfirstlane((p.Hq & 7) == 0 ? (hx & 7) * (p.Hq >> 3) + (hx >> 3) : hx);     // whole GQA groups per XCD (G is a multiple of 8)
-    b = __builtin_amdgcn_readfirstlane(y);
-    const int hk = h / rep;
-    const int q0 = __builtin_amdgcn_readfirstlane((nqb - 1 - z) * 256);
-    qw0 = q0 + wave * 64;
-    kvlen = p.kv_len ? min(p.kv_len[b], p.Skv) : p.Skv;
-    int kend = kvlen;
-    if (CAUSAL) kend = min(kend, q0 + 256 + off);
-    kstart = 0;
-    if (window > 0) kstart = max(0, (q0 + off - window + 1)) & ~31;
-    nit = (B64_ABL & 8) ? 0 : (kend > kstart ? (kend - kstart + 31) / 32 : 0);      // (ablation 8: prologue + epilogue only)
-    // tiles this WAVE computes: [first_w, last_w]; the others only keep the block's barrier / DMA cadence
-    last_w = CAUSAL ? min(nit - 1, (qw0 + 63 + off - kstart) >> 5) : nit - 1;
-    first_w = 0;
-    if (window > 0) first_w = max(0, (qw0 + off - window + 1 - kstart) >> 5);
-    if (last_w < first_w || qw0 >= Sq) { last_w = -1; first_w = nit; }
-    rsK = attn_make_rs(p.k + (long)b * p.k_bs + (long)hk * D, (((long)p.Skv - 1) * p.k_ts + D) * 2);
-    rsV = attn_make_rs(p.v + (long)b * p.v_bs + (long)hk * D, (((long)p.Skv - 1) * p.v_ts + D) * 2);
-  };
   // piece PC of tile T into stage ST: 0 / 1 = K token groups wave, wave + 4; 2 / 3 = V likewise
 #define DQ_DMA(T, ST, PC)                                                                                       \
   {                                                                                                             \
-    const uint32_t row_ = (uint32_t)(kstart + max(min((T), nit - 1), 0) * 32 + 4 * wave + (((PC) & 1) ? 16 : 0)); \
+    const uint32_t row_ = (uint32_t)(kstart + min((T), nit - 1) * 32 + 4 * wave + (((PC) & 1) ? 16 : 0));       \
     const uint32_t so_ = row_ * (((PC) & 2) ? vts2 : kts2);                                                     \
     const uint32_t m0_ = m0w + (uint32_t)((ST) * B64_DQ_STAGE + (((PC) & 1) ? 4 * B64_PIECE : 0) + (((PC) & 2) ? B64_TILE : 0)); \
     if ((PC) & 2) B64_DMA16(m0_, vV, rsV, so_); else B64_DMA16(m0_, vK, rsK, so_);                            \
   }
 #define DQ_DMA4(T, ST) { DQ_DMA(T, ST, 0) DQ_DMA(T, ST, 1) DQ_DMA(T, ST, 2) DQ_DMA(T, ST, 3) }
-  // All vector-memory loads of the current item (N_ITEM_VM operations): the first three K / V tiles, the Q / dO fragments (B operands: lane = query,
-  // features 16 ks + 8 hh .. + 7) straight into their AGPRs and the O rows into v[192:255] (buffer loads with literal destinations: no pressure on
-  // the compiler's 64 VGPRs), lse.  LDS must be free (a barrier behind the previous item's last fragment read).
-  auto issue_item = [&]() __attribute__((always_inline)) {
-    DQ_DMA4(0, 0) DQ_DMA4(1, 1) DQ_DMA4(2, 2)
-    int ln_ = threadIdx.x & 63;
-    asm volatile("" : "+v"(ln_));
-    const int ql_ = ln_ & 31, hh_ = ln_ >> 5;
-    const fwdm_u32x4s rsQh = attn_make_rs(p.q + (long)b * p.q_bs + (long)h * D, (((long)Sq - 1) * p.q_ts + D) * 2);
-    const fwdm_u32x4s rsGh = attn_make_rs(p.dout + (long)b * p.do_bs + (long)h * D, (((long)Sq - 1) * p.do_ts + D) * 2);
-    const fwdm_u32x4s rsOh = attn_make_rs(p.o + (long)b * p.o_bs + (long)h * D, (((long)Sq - 1) * p.o_ts + D) * 2);
-    uint32_t voq[2], vog[2], voo[2];
-#pragma unroll
-    for (int qb = 0; qb < 2; ++qb) {
-      const int qrc = min(qw0 + 32 * qb + ql_, Sq - 1);  // clamped (unconditional loads); rows >= Sq are never stored
-      voq[qb] = (uint32_t)qrc * (uint32_t)(p.q_ts * 2) + 16u * (uint32_t)hh_;
-      vog[qb] = (uint32_t)qrc * (uint32_t)(p.do_ts * 2) + 16u * (uint32_t)hh_;
-      voo[qb] = (uint32_t)qrc * (uint32_t)(p.o_ts * 2) + 16u * (uint32_t)hh_;
-    }
-    asm volatile("s_nop 4" ::: "memory");               // (descriptor SGPRs fresh from v_readfirstlane)
-    vp_static_for<2 * NKS>([&](auto i_) __attribute__((always_inline)) {
-      constexpr int qb = decltype(i_)::value / NKS, ks = decltype(i_)::value % NKS;
-      b64_use(voq, vog, voo, rsQh, rsGh, rsOh);
-      asm volatile("buffer_load_dwordx4 a[%c2:%c3], %0, %1, 0 offen offset:%c4" ::"v"(voq[qb]), "s"(rsQh), "n"(A_QF + 32 * qb + 4 * ks),
-                   "n"(A_QF + 32 * qb + 4 * ks + 3), "n"(32 * ks) : "memory");
-      asm volatile("buffer_load_dwordx4 a[%c2:%c3], %0, %1, 0 offen offset:%c4" ::"v"(vog[qb]), "s"(rsGh), "n"(A_DOF + 32 * qb + 4 * ks),
-                   "n"(A_DOF + 32 * qb + 4 * ks + 3), "n"(32 * ks) : "memory");
-      asm volatile("buffer_load_dwordx4 v[%c2:%c3], %0, %1, 0 offen offset:%c4" ::"v"(voo[qb]), "s"(rsOh), "n"(V_OR + 32 * qb + 4 * ks),
-                   "n"(V_OR + 32 * qb + 4 * ks + 3), "n"(32 * ks) : "memory");
-    });
-#pragma unroll
-    for (int qb = 0; qb < 2; ++qb) lse_n[qb] = p.lse[((long)b * p.Hq + h) * Sq + min(qw0 + 32 * qb + ql_, Sq - 1)];
-  };
 
   // ---- fragment addresses (loop-invariant; stage / tensor / k-step in the immediate)
   uint32_t rowa[4], tra[NOB];
@@ -366,6 +374,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1), amdg
     } else { DQ_VRD((G) - (2 * NOPS - 3), ((ST) + 1) & 3); }                                                    \
   }
 
+  if constexpr (ROPE) asm volatile("" ::"s"(p.rope_cos), "s"(p.rope_sin), "s"(p.rope_pos));      // (the epilogue's kernel arguments: loaded here, not inside the stream)
+  // from here on v64..v255 are asm-owned (tools/audit_asm_owned.py): the constant -delta blocks first
+  B64_FENCE();
+  vp_static_for<32>([&](auto i_) __attribute__((always_inline)) {
+    constexpr int i = decltype(i_)::value;
+    b64_use(npart);
+    R_VMOV(V_ND + i, npart[i >> 4]);
+  });
+  if (nit > 0) {
+    DQ_DMA4(0, 0) DQ_DMA4(1, 1) DQ_DMA4(2, 2)
+    B64_VMCNT(8);                                       // tile 0 landed (this wave's part)
+    B64_BAR();
+  }
+  // head: tiles below this wave's window only keep the cadence (barrier i: tile i + 1 landed for everybody, stage (i - 1) & 3 free)
+  for (int it = 0; it < min(first_w, nit); ++it) {
+    B64_FENCE();
+    B64_VMCNT(4);
+    B64_BAR();
+    DQ_DMA4(it + 3, (it + 3) & 3)
+  }
+  B64_FENCE();
   // S^T of the wave's first tile and the first V rows (a run-time stage only here -> one copy per stage)
 #define DQ_FIRST(SN, ST)                                                                                        \
   {                                                                                                             \
@@ -382,6 +411,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1), amdg
       }                                                                                                         \
     });                                                                                                         \
   }
+  B64_LGKM(0);                                          // (no scalar load of the prologue may be in flight inside the counted-lgkmcnt stream)
+  if (last_w >= 0) {
+    const int fs_ = first_w & 3;
+    if (fs_ == 0) DQ_FIRST(V_SE, 0) else if (fs_ == 1) DQ_FIRST(V_SO, 1) else if (fs_ == 2) DQ_FIRST(V_SE, 2) else DQ_FIRST(V_SO, 3)
+  }
+
   // exponentials of elements 2 X, 2 X + 1 of the tile's 32 (element e = register e & 15 of q block e >> 4: v[SC + e])
 #define DQ_EXPV(SC, X)                                                                                          \
   {                                                                                                             \
@@ -470,134 +505,61 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1), amdg
     });                                                                                                         \
   }
 
-  if constexpr (ROPE) asm volatile("" ::"s"(p.rope_cos), "s"(p.rope_sin), "s"(p.rope_pos));      // (the epilogue's kernel arguments: loaded here, not inside the stream)
-  // from here on v64..v255 and every AGPR are asm-owned (tools/audit_asm_owned.py)
+  if (last_w >= 0) {
+    int it = first_w;
+    // the ring stage must be a literal: enter the 4-way unrolled loop at the right phase
+    switch (it & 3) {
+      case 1: goto dq_l1;
+      case 2: goto dq_l2;
+      case 3: goto dq_l3;
+      default: break;
+    }
+    for (;;) {
+      DQ_ITER(it, 0, V_SE, V_SO)
+      if (++it > last_w) break;
+    dq_l1:
+      DQ_ITER(it, 1, V_SO, V_SE)
+      if (++it > last_w) break;
+    dq_l2:
+      DQ_ITER(it, 2, V_SE, V_SO)
+      if (++it > last_w) break;
+    dq_l3:
+      DQ_ITER(it, 3, V_SO, V_SE)
+      if (++it > last_w) break;
+    }
+    B64_LGKM(0);                                        // (the stream's last reads: V rows of a tile this wave does not compute)
+  }
+  // tail: tiles above this wave's diagonal that the block's other waves still need
   B64_FENCE();
-  int item = blockIdx.x;
-  set_item(item);
-  issue_item();
-  for (;;) {
+  for (int it = max(last_w + 1, min(first_w, nit)); it < nit; ++it) {
     B64_FENCE();
-    B64_VMCNT(0);                                       // this item's fragments, O rows, lse and first three tiles landed (this wave's pieces)
-    // ---- delta = rowsum(dO o O) from the fragment registers, -lse; the two statistics planes the dK/dV kernel streams
-    float nlse[2], npart[2];
-    {
-      int ln_ = threadIdx.x & 63;
-      asm volatile("" : "+v"(ln_));
-      const int ql_ = ln_ & 31, hh_ = ln_ >> 5;
-      vp_static_for<2>([&](auto qb_) __attribute__((always_inline)) {
-        constexpr int qb = decltype(qb_)::value;
-        b64_use(nlse, npart, lse_n, ql_, hh_);
-        const int qrow = qw0 + 32 * qb + ql_;
-        const long sidx = ((long)b * p.Hq + h) * Sq + min(qrow, Sq - 1);
-        float part = 0.f;
-        vp_static_for<NKS>([&](auto ks_) __attribute__((always_inline)) {
-          constexpr int ks = decltype(ks_)::value;
-          b64_use(part);
-          const bf16x8 g8 = __builtin_bit_cast(bf16x8, b64_aread<A_DOF + 32 * qb + 4 * ks>());
-          const bf16x8 o8 = __builtin_bit_cast(bf16x8, b64_vread<V_OR + 32 * qb + 4 * ks>());
+    B64_VMCNT(4);
+    B64_BAR();
+    DQ_DMA4(it + 3, (it + 3) & 3)
+  }
+  // epilogue: the RoPE tables of both rows first (they fly while the trailing DMAs drain), then the accumulators.  Every lane-derived value is
+  // re-derived HERE from an opaque lane id: kept live across the loops (the compiler hoists address arithmetic) they do not fit its 64 registers
+  // and are reloaded from scratch inside the loop (a VMEM load whose wait drains the DMA ring).
+  B64_FENCE();
+  int ln_ = threadIdx.x & 63;
+  asm volatile("" : "+v"(ln_));
+  const int ql_ = ln_ & 31, hh_ = ln_ >> 5;
+  if constexpr (ROPE) {
+    uint32_t vo[2];
 #pragma unroll
-          for (int e = 0; e < 8; ++e) part = fmaf(bf2f((bf16_t)g8[e]), bf2f((bf16_t)o8[e]), part);
-        });
-        part += __shfl_xor(part, 32, 64);
-        nlse[qb] = -lse_n[qb];
-        npart[qb] = -part;
-        if (hh_ == 0 && qrow < Sq) {
-          p.delta[sidx] = -lse_n[qb] / c;                  // plane 0: -lse / c   (S' = S - lse / c, P = exp2(c S'))
-          p.delta[nrows + sidx] = -part;                   // plane 1: -delta
-        }
-      });
+    for (int qb = 0; qb < 2; ++qb) {
+      const int qrc = min(qw0 + 32 * qb + ql_, Sq - 1);
+      const long pp = (p.rope_pos ? (long)p.rope_pos[(long)b * Sq + qrc] : (long)(qrc + off)) * (D / 2);
+      vo[qb] = (uint32_t)(pp * 4 + 16 * hh_);
     }
-    vp_static_for<2 * NOB * 16>([&](auto i_) __attribute__((always_inline)) {
-      constexpr int i = decltype(i_)::value;
-      R_AZERO(A_ACC + 64 * (i / (NOB * 16)) + (i % (NOB * 16)));
-    });
-    B64_FENCE();
-    vp_static_for<32>([&](auto i_) __attribute__((always_inline)) {      // the constant -delta blocks
-      constexpr int i = decltype(i_)::value;
-      b64_use(npart);
-      R_VMOV(V_ND + i, npart[i >> 4]);
-    });
-    B64_BAR();                                          // tiles 0..2 landed for everybody (every wave waited for its own pieces)
-    // head: tiles below this wave's window only keep the cadence (barrier i: tile i + 1 landed for everybody, stage (i - 1) & 3 free)
-    for (int it = 0; it < min(first_w, nit); ++it) {
-      B64_FENCE();
-      B64_VMCNT(4);
-      B64_BAR();
-      DQ_DMA4(it + 3, (it + 3) & 3)
-    }
-    B64_FENCE();
-    B64_LGKM(0);                                        // (no scalar load may be in flight inside the counted-lgkmcnt stream)
-    if (last_w >= 0) {
-      const int fs_ = first_w & 3;
-      if (fs_ == 0) DQ_FIRST(V_SE, 0) else if (fs_ == 1) DQ_FIRST(V_SO, 1) else if (fs_ == 2) DQ_FIRST(V_SE, 2) else DQ_FIRST(V_SO, 3)
-      int it = first_w;
-      // the ring stage must be a literal: enter the 4-way unrolled loop at the right phase
-      switch (it & 3) {
-        case 1: goto dq_l1;
-        case 2: goto dq_l2;
-        case 3: goto dq_l3;
-        default: break;
-      }
-      for (;;) {
-        DQ_ITER(it, 0, V_SE, V_SO)
-        if (++it > last_w) break;
-      dq_l1:
-        DQ_ITER(it, 1, V_SO, V_SE)
-        if (++it > last_w) break;
-      dq_l2:
-        DQ_ITER(it, 2, V_SE, V_SO)
-        if (++it > last_w) break;
-      dq_l3:
-        DQ_ITER(it, 3, V_SO, V_SE)
-        if (++it > last_w) break;
-      }
-      B64_LGKM(0);                                      // (the stream's last reads: V rows of a tile this wave does not compute)
-    }
-    // tail: tiles above this wave's diagonal that the block's other waves still need
-    B64_FENCE();
-    for (int it = max(last_w + 1, min(first_w, nit)); it < nit; ++it) {
-      B64_FENCE();
-      B64_VMCNT(4);
-      B64_BAR();
-      DQ_DMA4(it + 3, (it + 3) & 3)
-    }
-    // ---- epilogue: the RoPE tables of both rows, then the NEXT item's loads, then the accumulators.  Every lane-derived value is re-derived HERE
-    // from an opaque lane id: kept live across the loops (the compiler hoists address arithmetic) they do not fit its 64 registers and are reloaded
-    // from scratch inside the loop (a VMEM load whose wait drains the DMA ring).
-    B64_FENCE();
-    B64_VMCNT(0);                                       // the trailing (dummy) DMAs landed ...
-    B64_BAR();                                          // ... and every wave is behind its last fragment read: the LDS stages are free
-    int ln_ = threadIdx.x & 63;
-    asm volatile("" : "+v"(ln_));
-    const int ql_ = ln_ & 31, hh_ = ln_ >> 5;
-    const int h_c = h, b_c = b, qw0_c = qw0;
-    if constexpr (ROPE) {
-      uint32_t vo[2];
-#pragma unroll
-      for (int qb = 0; qb < 2; ++qb) {
-        const int qrc = min(qw0_c + 32 * qb + ql_, Sq - 1);
-        const long pp = (p.rope_pos ? (long)p.rope_pos[(long)b_c * Sq + qrc] : (long)(qrc + off)) * (D / 2);
-        vo[qb] = (uint32_t)(pp * 4 + 16 * hh_);
-      }
-      b64_rope_issue<NOB>(p.rope_cos, p.rope_sin, vo);
-    }
-    item += gridDim.x;
-    const bool more = item < nitems;
-    if (more) {
-      set_item(item);
-      issue_item();
-      B64_VMCNT(N_ITEM_VM);                             // the tables landed; the next item's loads fly under the stores
-    } else {
-      B64_VMCNT(0);
-    }
-    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // the last MFMAs' results are visible to v_accvgpr_read
-    {
-      const int qrow0 = qw0_c + ql_, qrow1 = qw0_c + 32 + ql_;
-      if (qrow0 < Sq) b64_store_row<ROPE, NOB, A_ACC, 0>(p.dq + (long)b_c * p.dq_bs + (long)qrow0 * p.dq_ts + (long)h_c * D, p.scale, hh_);
-      if (qrow1 < Sq) b64_store_row<ROPE, NOB, A_ACC + 64, 1>(p.dq + (long)b_c * p.dq_bs + (long)qrow1 * p.dq_ts + (long)h_c * D, p.scale, hh_);
-    }
-    if (!more) break;
+    b64_rope_issue<NOB>(p.rope_cos, p.rope_sin, vo);
+  }
+  B64_VMCNT(0);                                         // the tables landed; trailing (dummy) DMAs must not outlive the block's LDS
+  asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");    // the last MFMAs' results are visible to v_accvgpr_read
+  {
+    const int qrow0 = qw0 + ql_, qrow1 = qw0 + 32 + ql_;
+    if (qrow0 < Sq) b64_store_row<ROPE, NOB, A_ACC, 0>(p.dq + (long)b * p.dq_bs + (long)qrow0 * p.dq_ts + (long)h * D, p.scale, hh_);
+    if (qrow1 < Sq) b64_store_row<ROPE, NOB, A_ACC + 64, 1>(p.dq + (long)b * p.dq_bs + (long)qrow1 * p.dq_ts + (long)h * D, p.scale, hh_);
   }
 #undef DQ_DMA
 #undef DQ_DMA4
