@@ -34,7 +34,8 @@
 constexpr int B64_PIECE = 1040;                       // bytes: 4 tokens x 256 B + 16 B of padding
 constexpr int B64_TILE = 8 * B64_PIECE;               // 32 tokens
 constexpr int B64_DQ_STAGE = 2 * B64_TILE;            // K tile | V tile
-constexpr int B64_DQ_LDS = 4 * B64_DQ_STAGE;          // 66560 bytes
+constexpr int B64_DQ_RING = 4 * B64_DQ_STAGE;          // 66560 bytes
+constexpr int B64_DQ_LDS = B64_DQ_RING + 4 * 8192;       // + one 8 KB staging slice per wave for the whole-line dQ stores
 constexpr int B64_KV_STAGE = 2 * B64_TILE + 256;      // Q tile | dO tile | 32 lse' | 32 delta'
 constexpr int B64_KV_RING = 4 * B64_KV_STAGE;         // 67584 bytes
 constexpr int B64_KV_LDS = B64_KV_RING + 64 * B64_PIECE;      // + the block's 256 V rows (66560 bytes): 134144
@@ -182,9 +183,15 @@ static __device__ __forceinline__ f32x4 b64_vread() {                 // v[R .. 
                : "=v"(v[0]), "=v"(v[1]), "=v"(v[2]), "=v"(v[3]) : "n"(R), "n"(R + 1), "n"(R + 2), "n"(R + 3) : B64_OWNED);
   return v;
 }
-template <bool ROPE, int NOB, int A0, int ROW>
-static __device__ __forceinline__ void b64_store_row(bf16_t* dst, float scale, int hh) {
+// LDS = true: the row goes into a wave-private staging slice instead (32 rows x 128 features, 8-byte unit w of row r at position w ^ r: conflict-free
+// for these 16-lane write groups and for b64_flush_rows' row-wise reads); dst = the slice, ql = the lane's row in it.  A row-per-lane global store
+// (32 rows x 8 bytes per instruction) moves ~7 B/clk per CU, whole cache lines 53 (tools/probes/store_pattern_probe.hip, the forward's store path).
+template <bool ROPE, int NOB, int A0, int ROW, bool LDS = false>
+static __device__ __forceinline__ void b64_store_row(bf16_t* dst, float scale, int hh, int ql = 0) {
   constexpr int NG = NOB * 4;                           // 8-feature groups; group u = registers A0 + 4 u .. + 3 = features 8 u + 4 hh + e
+  auto put = [&](int f, bf16x4 v) __attribute__((always_inline)) {
+    if constexpr (LDS) *(bf16x4*)(dst + ql * 128 + (((f >> 2) ^ ql) << 2)) = v; else *(bf16x4*)(dst + f) = v;
+  };
   if constexpr (!ROPE) {
     vp_static_for<NG>([&](auto u_) __attribute__((always_inline)) {
       constexpr int u = decltype(u_)::value;
@@ -192,7 +199,7 @@ static __device__ __forceinline__ void b64_store_row(bf16_t* dst, float scale, i
       bf16x4 a;
 #pragma unroll
       for (int e = 0; e < 4; ++e) a[e] = (short)f2bf(x[e] * scale);
-      *(bf16x4*)(dst + 8 * u + 4 * hh) = a;
+      put(8 * u + 4 * hh, a);
     });
   } else {
     vp_static_for<NG / 2>([&](auto u_) __attribute__((always_inline)) {
@@ -208,10 +215,26 @@ static __device__ __forceinline__ void b64_store_row(bf16_t* dst, float scale, i
         a[e] = (short)f2bf(bfround(x1 * c4[e]) + bfround(-x2 * ss));
         b[e] = (short)f2bf(bfround(x2 * c4[e]) + bfround(x1 * ss));
       }
-      *(bf16x4*)(dst + f) = a;
-      *(bf16x4*)(dst + 4 * NG + f) = b;                 // + D / 2 features
+      put(f, a);
+      put(4 * NG + f, b);                               // + D / 2 features
     });
   }
+}
+
+// a staged 32-row block -> global memory as WHOLE rows: 4 rows x 16 bytes per lane per instruction.  gbase = row 0 / feature 0 of the block,
+// ts = the row stride in elements, rows_valid = rows of the block that exist (may be <= 0)
+template <int D>
+static __device__ __forceinline__ void b64_flush_rows(const bf16_t* stg, bf16_t* gbase, long ts, int rows_valid, int lane) {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // wave-private slice: own writes visible to own reads
+  const int rr = lane >> 4, ch = lane & 15;
+#pragma unroll
+  for (int t4 = 0; t4 < 8; ++t4) {
+    const int r = t4 * 4 + rr;
+    const bf16x4 lo = *(const bf16x4*)(stg + r * 128 + (((2 * ch) ^ r) << 2));
+    const bf16x4 hi = *(const bf16x4*)(stg + r * 128 + (((2 * ch + 1) ^ r) << 2));
+    if (r < rows_valid && ch * 8 < D) *(bf16x8*)(gbase + (long)r * ts + ch * 8) = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (the slice is rewritten by the next block)
 }
 
 // ================================================================================================
@@ -556,10 +579,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1), amdg
   }
   B64_VMCNT(0);                                         // the tables landed; trailing (dummy) DMAs must not outlive the block's LDS
   asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");    // the last MFMAs' results are visible to v_accvgpr_read
-  {
-    const int qrow0 = qw0 + ql_, qrow1 = qw0 + 32 + ql_;
-    if (qrow0 < Sq) b64_store_row<ROPE, NOB, A_ACC, 0>(p.dq + (long)b * p.dq_bs + (long)qrow0 * p.dq_ts + (long)h * D, p.scale, hh_);
-    if (qrow1 < Sq) b64_store_row<ROPE, NOB, A_ACC + 64, 1>(p.dq + (long)b * p.dq_bs + (long)qrow1 * p.dq_ts + (long)h * D, p.scale, hh_);
+  {   // whole-line stores through the wave's staging slice behind the ring (one 32-query block at a time)
+    bf16_t* stg = (bf16_t*)(attn_smem + B64_DQ_RING) + wave * 4096;
+    bf16_t* g0 = p.dq + (long)b * p.dq_bs + (long)qw0 * p.dq_ts + (long)h * D;
+    b64_store_row<ROPE, NOB, A_ACC, 0, true>(stg, p.scale, hh_, ql_);
+    b64_flush_rows<D>(stg, g0, p.dq_ts, Sq - qw0, ln_);
+    b64_store_row<ROPE, NOB, A_ACC + 64, 1, true>(stg, p.scale, hh_, ql_);
+    b64_flush_rows<D>(stg, g0 + 32 * (long)p.dq_ts, p.dq_ts, Sq - qw0 - 32, ln_);
   }
 #undef DQ_DMA
 #undef DQ_DMA4
@@ -930,18 +956,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1), amdg
     }
     b64_rope_issue<NOB>(p.rope_cos, p.rope_sin, vo);
   }
-  B64_VMCNT(0);                                         // the tables landed; trailing (dummy) DMAs must not outlive the block's LDS
+  B64_VMCNT(0);                                         // the tables landed; trailing (dummy) DMAs landed too ...
+  B64_BAR();                                            // ... for every wave, and every wave is behind its last fragment read: the ring is free
   asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");    // the last MFMAs' results are visible to v_accvgpr_read
-  {
-    const int key0 = kw0 + kl_, key1 = kw0 + 32 + kl_;
-    if (key0 < p.Skv) {
-      b64_store_row<ROPE, NOB, A_DK, 0>(p.dk + (long)b * p.dk_bs + (long)key0 * p.dk_ts + (long)hk * D, p.scale, hh_);
-      b64_store_row<false, NOB, A_DV, 0>(p.dv + (long)b * p.dv_bs + (long)key0 * p.dv_ts + (long)hk * D, 1.f, hh_);
-    }
-    if (key1 < p.Skv) {
-      b64_store_row<ROPE, NOB, A_DK + 64, 1>(p.dk + (long)b * p.dk_bs + (long)key1 * p.dk_ts + (long)hk * D, p.scale, hh_);
-      b64_store_row<false, NOB, A_DV + 64, 1>(p.dv + (long)b * p.dv_bs + (long)key1 * p.dv_ts + (long)hk * D, 1.f, hh_);
-    }
+  {   // whole-line stores through a wave-private staging slice in the (finished) ring, one 32-key block of dK / dV at a time
+    bf16_t* stg = (bf16_t*)attn_smem + wave * 4096;
+    bf16_t* gk = p.dk + (long)b * p.dk_bs + (long)kw0 * p.dk_ts + (long)hk * D;
+    bf16_t* gv = p.dv + (long)b * p.dv_bs + (long)kw0 * p.dv_ts + (long)hk * D;
+    b64_store_row<ROPE, NOB, A_DK, 0, true>(stg, p.scale, hh_, kl_);
+    b64_flush_rows<D>(stg, gk, p.dk_ts, p.Skv - kw0, ln_);
+    b64_store_row<false, NOB, A_DV, 0, true>(stg, 1.f, hh_, kl_);
+    b64_flush_rows<D>(stg, gv, p.dv_ts, p.Skv - kw0, ln_);
+    b64_store_row<ROPE, NOB, A_DK + 64, 1, true>(stg, p.scale, hh_, kl_);
+    b64_flush_rows<D>(stg, gk + 32 * (long)p.dk_ts, p.dk_ts, p.Skv - kw0 - 32, ln_);
+    b64_store_row<false, NOB, A_DV + 64, 1, true>(stg, 1.f, hh_, kl_);
+    b64_flush_rows<D>(stg, gv + 32 * (long)p.dv_ts, p.dv_ts, p.Skv - kw0 - 32, ln_);
   }
 #undef KV_PIECE
 #undef KV_ADVANCE
