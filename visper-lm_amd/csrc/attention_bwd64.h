@@ -121,6 +121,7 @@ constexpr int B64_KV_LDS = B64_KV_RING + 64 * B64_PIECE;      // + the block's 2
 #define R_EXP(R) asm volatile("v_exp_f32 v%c0, v%c0" ::"n"(R))
 #define R_CVT(RD, R0, R1) asm volatile("v_cvt_pk_bf16_f32 v%c0, v%c1, v%c2" ::"n"(RD), "n"(R0), "n"(R1))
 #endif
+#define R_FMAL(R, A, RL) asm volatile("v_fma_f32 v%c0, v%c0, %1, v%c2" ::"n"(R), "v"(A), "n"(RL))     /* vR = vR * A + v[RL] (a literal register) */
 #define R_VMOV(R, X) asm volatile("v_mov_b32 v%c0, %1" ::"n"(R), "v"(X))
 #define R_AWRITE(R, X) asm volatile("v_accvgpr_write_b32 a%c0, %1" ::"n"(R), "v"(X))
 #define R_AZERO(R) asm volatile("v_accvgpr_write_b32 a%c0, 0" ::"n"(R))
@@ -249,13 +250,13 @@ static __device__ __forceinline__ void b64_flush_rows(const bf16_t* stg, bf16_t*
 //   a[128:191] Q fragments (qb, ks) at 128 + 32 qb + 4 ks;  a[192:255] dO fragments at 192 + 32 qb + 4 ks
 //   v[64:95] S^T of even tiles (16 qb), v[96:127] of odd tiles, v[128:159] dP^T, v[160:191] the constant -delta blocks
 //   v[192:207] K row fragments (ring of 4), v[208:223] V row fragments, v[224:235] transposed-K operands (ring of 3: lo | hi),
-//   v[236:251] packed dS: (qb, t) at 236 + 8 qb + 4 t,  v252 scratch of the mask statement
+//   v[236:251] packed dS: (qb, t) at 236 + 8 qb + 4 t,  v252 scratch of the mask statement,  v253 / v254 -lse of the two q blocks
 // ================================================================================================
 template <bool CAUSAL, bool ROPE, int D>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1), amdgpu_num_vgpr(64))) void attn_bwd_dq64w_kernel(AttnParams p) {
   static_assert(D == 128 || D == 96, "D");
   constexpr int NKS = D / 16, NOB = D / 32, NOPS = 2 * NOB;
-  constexpr int A_ACC = 0, A_QF = 128, A_DOF = 192, V_SE = 64, V_SO = 96, V_DP = 128, V_ND = 160, V_KFR = 192, V_VFR = 208, V_TR = 224, V_PK = 236;
+  constexpr int A_ACC = 0, A_QF = 128, A_DOF = 192, V_SE = 64, V_SO = 96, V_DP = 128, V_ND = 160, V_KFR = 192, V_VFR = 208, V_TR = 224, V_PK = 236, V_NL = 253;
   extern __shared__ __attribute__((aligned(16))) unsigned char attn_smem[];
   asm volatile("" ::: "v255", "a255");                   // the wave owns its SIMD's whole register file (see gemm_nt_256w4)
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -337,6 +338,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1), amdg
   int first_w = 0;
   if (window > 0) first_w = max(0, (qw0 + off - window + 1 - kstart) >> 5);
   if (last_w < first_w || qw0 >= Sq) { last_w = -1; first_w = nit; }
+  // The ring stage is a literal of the four-way unrolled loop, so the wave enters it at a multiple of four: up to three tiles below a sliding window's
+  // lower edge are computed fully masked (P = 0, dS = 0: they add nothing) instead of entering the loop at an arbitrary phase — the goto-entered loop
+  // was irreducible and the compiler's dispatcher for it cost ~25 scalar instructions and several branches in EVERY iteration of every launch.
+  else first_w &= ~3;
 
   // ---- LDS-DMA: K / V pieces through buffer descriptors of this (batch, kv head); rows past Skv read as zeros
   const fwdm_u32x4s rsK = attn_make_rs(p.k + (long)b * p.k_bs + (long)hk * D, (((long)p.Skv - 1) * p.k_ts + D) * 2);
@@ -405,6 +410,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1), amdg
     b64_use(npart);
     R_VMOV(V_ND + i, npart[i >> 4]);
   });
+  // -lse of the wave's two q blocks in literal registers as well: as compiler values they were spilled under the prologue's pressure and reloaded
+  // from scratch at the loop's entry (behind the first LDS-DMA pieces: a vmcnt(0) that drains the ring once per block)
+  R_VMOV(V_NL, nlse[0]);
+  R_VMOV(V_NL + 1, nlse[1]);
   if (nit > 0) {
     DQ_DMA4(0, 0) DQ_DMA4(1, 1) DQ_DMA4(2, 2)
     B64_VMCNT(8);                                       // tile 0 landed (this wave's part)
@@ -435,16 +444,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1), amdg
     });                                                                                                         \
   }
   B64_LGKM(0);                                          // (no scalar load of the prologue may be in flight inside the counted-lgkmcnt stream)
-  if (last_w >= 0) {
-    const int fs_ = first_w & 3;
-    if (fs_ == 0) DQ_FIRST(V_SE, 0) else if (fs_ == 1) DQ_FIRST(V_SO, 1) else if (fs_ == 2) DQ_FIRST(V_SE, 2) else DQ_FIRST(V_SO, 3)
-  }
+  if (last_w >= 0) DQ_FIRST(V_SE, 0)
 
   // exponentials of elements 2 X, 2 X + 1 of the tile's 32 (element e = register e & 15 of q block e >> 4: v[SC + e])
 #define DQ_EXPV(SC, X)                                                                                          \
   {                                                                                                             \
-    R_FMA(SC + 2 * (X), cc, nlse[(2 * (X)) >> 4]);                                                              \
-    R_FMA(SC + 2 * (X) + 1, cc, nlse[(2 * (X) + 1) >> 4]);                                                      \
+    R_FMAL(SC + 2 * (X), cc, V_NL + ((2 * (X)) >> 4));                                                          \
+    R_FMAL(SC + 2 * (X) + 1, cc, V_NL + ((2 * (X) + 1) >> 4));                                                  \
     R_EXP(SC + 2 * (X));                                                                                        \
     R_EXP(SC + 2 * (X) + 1);                                                                                    \
   }
@@ -489,7 +495,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1), amdg
     /* ---- A: dP^T = V dO^T (C = -delta) under this tile's exponentials; barrier in the middle; K rows of the next tile behind it */ \
     vp_static_for<NKS>([&](auto ks_) __attribute__((always_inline)) {                                           \
       constexpr int ks = decltype(ks_)::value;                                                                  \
-      b64_use(rowa, cc, nlse);                                                                                  \
+      b64_use(rowa, cc);                                                                                  \
       if constexpr (ks == NKS - 4) { B64_VMCNT(4); B64_BAR(); }      /* tile IT + 1 landed for everybody; stage (IT - 1) & 3 is free */ \
       if constexpr (ks + 3 < NKS) { DQ_VRD(ks + 3, ST); } else { DQ_KRD(ks + 3 - NKS, ((ST) + 1) & 3); }        \
       B64_LGKM(3);                                                                                              \
@@ -529,24 +535,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1), amdg
   }
 
   if (last_w >= 0) {
-    int it = first_w;
-    // the ring stage must be a literal: enter the 4-way unrolled loop at the right phase
-    switch (it & 3) {
-      case 1: goto dq_l1;
-      case 2: goto dq_l2;
-      case 3: goto dq_l3;
-      default: break;
-    }
+    int it = first_w;                                   // a multiple of four: tile `it` sits in stage 0
     for (;;) {
       DQ_ITER(it, 0, V_SE, V_SO)
       if (++it > last_w) break;
-    dq_l1:
       DQ_ITER(it, 1, V_SO, V_SE)
       if (++it > last_w) break;
-    dq_l2:
       DQ_ITER(it, 2, V_SE, V_SO)
       if (++it > last_w) break;
-    dq_l3:
       DQ_ITER(it, 3, V_SO, V_SE)
       if (++it > last_w) break;
     }
