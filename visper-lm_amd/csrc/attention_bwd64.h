@@ -686,12 +686,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1), amdg
     if constexpr ((PC) == 3) B64_DMA16(m0w + (uint32_t)((ST) * B64_KV_STAGE + B64_TILE + 4 * B64_PIECE), vG, rsG, soG + 16u * gts2); \
     if constexpr ((PC) == 4) { if (wave == 0) B64_DMA4(stP0 + (uint32_t)((ST) * B64_KV_STAGE), vP, rsP, soP); } \
   }
-#define KV_ADVANCE()                                                                                            \
+#define KV_ADVANCE()             /* (selects, no branches: this sits in the tile loop's issue stream) */         \
   {                                                                                                             \
-    if (++nissued < nit) {                                                                                      \
-      if (++iq == ntq) { iq = 0; soQ += backQ; soG += backG; soP += backP; }                                    \
-      else { soQ += 32u * qts2; soG += 32u * gts2; soP += 128u; }                                               \
-    } else { nissued = nit; }                                                                                   \
+    const bool adv_ = nissued + 1 < nit, wrap_ = iq + 1 == ntq;                                                 \
+    nissued = min(nissued + 1, nit);                                                                            \
+    soQ += adv_ ? (wrap_ ? backQ : 32u * qts2) : 0u;                                                            \
+    soG += adv_ ? (wrap_ ? backG : 32u * gts2) : 0u;                                                            \
+    soP += adv_ ? (wrap_ ? backP : 128u) : 0u;                                                                  \
+    iq = adv_ ? (wrap_ ? 0 : iq + 1) : iq;                                                                      \
   }
 #define KV_ISSUE(ST) { KV_PIECE(ST, 0) KV_PIECE(ST, 1) KV_PIECE(ST, 2) KV_PIECE(ST, 3) KV_PIECE(ST, 4) KV_ADVANCE() }
 
@@ -897,7 +899,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1), amdg
     });                                                                                                         \
   }
   // One iteration: the wave computes the tile (cold start of the stream if the previous iteration skipped), or only keeps the block's cadence.
-  bool warm = false;
+  // (the flag lives in an SGPR written by asm: as a C++ bool the compiler specialised every unrolled iteration on it — a flag machine of ~100 scalar
+  // instructions and ~25 branches per iteration)
+  int warm;
+  asm volatile("s_mov_b32 %0, 0" : "=s"(warm));
 #define KV_ITER(ST)                                                                                             \
   {                                                                                                             \
     B64_FENCE();                                                                                                \
@@ -905,16 +910,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1), amdg
     if (++cq == ntq) cq = 0;                                                                                    \
     /* wave-uniform skip: every query of this tile is below this wave's first key (causal), or every key of the wave is at or below the window's \
        lower bound of the tile's first query, or the wave's keys are all padding */                            \
-    const bool active = (!CAUSAL || (q0 + 31 + off >= kw0)) && !(window > 0 && kw0 + 63 <= q0 + off - window) && kw0 < kvlen; \
+    const bool active = (it + (ST) < nit) && (!CAUSAL || (q0 + 31 + off >= kw0)) && !(window > 0 && kw0 + 63 <= q0 + off - window) && kw0 < kvlen; \
     if (active) {                                                                                               \
       const bool need_mask = (q0 + 32 > Sq) || (kw0 + 64 > kvlen) || (CAUSAL && (kw0 + 63 > q0 + off)) ||       \
                              (window > 0 && kw0 <= q0 + 31 + off - window);                                     \
       if (!warm) KV_COLD(ST)                                                                                    \
       KV_TILE(ST)                                                                                               \
-      warm = true;                                                                                              \
+      asm volatile("s_mov_b32 %0, 1" : "=s"(warm));                                                             \
     } else {                                                                                                    \
       if (warm) B64_LGKM(0);                        /* (the previous tile's read-ahead of this one) */           \
-      warm = false;                                                                                             \
+      asm volatile("s_mov_b32 %0, 0" : "=s"(warm));                                                             \
       if (wave == 0) { B64_VMCNT(5); } else { B64_VMCNT(4); }                                                   \
       B64_BAR();                                                                                                \
       KV_ISSUE(((ST) + 3) & 3)                                                                                  \
@@ -923,15 +928,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1), amdg
   if (nit > 0) {
     if (wave == 0) { B64_VMCNT(10); } else { B64_VMCNT(8); }      // tile 0 landed (this wave's part; the V rows and K fragments are older)
     B64_BAR();
-    for (int it = 0;;) {
+    // whole groups of four iterations (the ring stage is a literal): up to three trailing iterations past the last tile only keep the cadence (a
+    // barrier and a re-fetch of the last tile each) — no exits in the middle of the unrolled body, which the compiler turned into a flag machine
+    for (int it = 0; it < nit; it += 4) {
       KV_ITER(0)
-      if (++it >= nit) break;
       KV_ITER(1)
-      if (++it >= nit) break;
       KV_ITER(2)
-      if (++it >= nit) break;
       KV_ITER(3)
-      if (++it >= nit) break;
     }
     B64_LGKM(0);
   }
