@@ -284,6 +284,31 @@ __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
     if (shadow) shadow[i] = f2bf(pi);
   }
 }
+// four parameters per thread and non-temporal streams (round 5): every buffer is read and written exactly once per step (the IFT stage moves 30 bytes
+// for each of 8 G parameters).  Same arithmetic per element as adamw_kernel: bit-identical.  n4 = n / 4 elements of 16-byte aligned buffers.
+__global__ void adamw4_kernel(f32x4* __restrict__ p, const f32x4* __restrict__ g, f32x4* __restrict__ m, f32x4* __restrict__ v,
+                              bf16x4* __restrict__ shadow, long n4, float lr, float b1, float b2, float eps, float wd, float bc1,
+                              float bc2_sqrt, float gscale) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    const f32x4 g4 = __builtin_nontemporal_load(g + i), m4 = __builtin_nontemporal_load(m + i), v4 = __builtin_nontemporal_load(v + i);
+    f32x4 p4 = __builtin_nontemporal_load(p + i), mo, vo;
+    bf16x4 s4;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float gr = g4[e] * gscale;
+      float pi = p4[e] * (1.f - lr * wd);
+      const float mi = b1 * m4[e] + (1.f - b1) * gr;
+      const float vi = b2 * v4[e] + (1.f - b2) * gr * gr;
+      pi -= (lr / bc1) * mi / (sqrtf(vi) / bc2_sqrt + eps);
+      p4[e] = pi; mo[e] = mi; vo[e] = vi;
+      s4[e] = (short)f2bf(pi);
+    }
+    __builtin_nontemporal_store(p4, p + i);
+    __builtin_nontemporal_store(mo, m + i);
+    __builtin_nontemporal_store(vo, v + i);
+    if (shadow) shadow[i] = s4;                        // (read by the next step's GEMMs: ordinary store)
+  }
+}
 
 
 // ---------------------------------------------------------------- depthwise 7x7 conv (ConvNeXt block, NHWC) ----------
@@ -501,6 +526,17 @@ int vp_adamw(long n, float* p, const float* g, float* m, float* v, void* bf16_sh
   VP_REQUIRE(n > 0 && step >= 1, VP_ERR_BAD_ARG, "vp_adamw: bad args");
   const float bc1 = 1.f - powf(beta1, (float)step);
   const float bc2s = sqrtf(1.f - powf(beta2, (float)step));
+  const long n4 = n >> 2;
+  const bool vec = n4 > 0 && ((((uintptr_t)p) | ((uintptr_t)g) | ((uintptr_t)m) | ((uintptr_t)v)) & 15) == 0 && (((uintptr_t)bf16_shadow) & 7) == 0;
+  if (vec) {
+    hipLaunchKernelGGL(adamw4_kernel, dim3((unsigned)min((long)4096, (n4 + 255) / 256)), dim3(256), 0, s, (f32x4*)p, (const f32x4*)g, (f32x4*)m, (f32x4*)v,
+                       (bf16x4*)bf16_shadow, n4, lr, beta1, beta2, eps, weight_decay, bc1, bc2s, grad_scale);
+    const long done = n4 << 2;
+    if (done < n)                                       // the last n & 3 elements
+      hipLaunchKernelGGL(adamw_kernel, dim3(1), dim3(64), 0, s, p + done, g + done, m + done, v + done,
+                         bf16_shadow ? (bf16_t*)bf16_shadow + done : nullptr, n - done, lr, beta1, beta2, eps, weight_decay, bc1, bc2s, grad_scale);
+    return vp_check_launch("vp_adamw");
+  }
   hipLaunchKernelGGL(adamw_kernel, GRID_FOR(n), dim3(256), 0, s, p, g, m, v, (bf16_t*)bf16_shadow, n, lr, beta1, beta2, eps,
                      weight_decay, bc1, bc2s, grad_scale);
   return vp_check_launch("vp_adamw");
