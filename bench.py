@@ -60,11 +60,13 @@ def _cpu_model():
 
 def cpu_baseline(cfg, dev):
     """The CPU oracle (a port of the reference's PyTorch path; oracle/visper_oracle.py) timed on this box's host cores on a BOUNDED
-    sample of the same workload: REAL fwd + bwd steps of the whole path at configs[0] shapes (B=2 images, text 128 -> S=727: full
-    CLIP-ViT-L tower, projector fwd/bwd, splice, full-width Llama-3-8B decoder layers fwd + dgrad, lm_head + CE at V=128256, all three
-    distillation heads fwd/bwd + losses), run with 2 and with 4 decoder layers; the step is scaled ONLY in layer count:
-    T(32) = T(4) + 28 * (T(4) - T(2)) / 2.  bf16 like the reference's CPU path.  Thread count: the fastest of {16, 64, all cores} on one
-    decoder layer (all three numbers are reported; on a 256-thread host the GEMMs of a 1454-token batch stop scaling long before 256)."""
+    sample of the same workload: REAL, WHOLE fwd + bwd steps of the PT path at configs[0] shapes with the headline's architecture at FULL
+    depth (B = 2 images, text 128 -> S = 727: full CLIP-ViT-L tower, projector fwd/bwd, splice, all 32 full-width Llama-3-8B decoder layers
+    fwd + dgrad, lm_head + CE at V = 128256, the three distillation heads d18 / s18 / g20 fwd/bwd + losses), bf16 like the reference's CPU
+    path.  One warm-up step, then the MEDIAN of two timed steps; nothing is extrapolated.  Fixed thread count (16, or every core of a
+    smaller host): on the pool's 256-thread EPYC 9575F hosts the GEMMs of a 1454-token batch run fastest there (rounds 3-5 probed 16 / 64 /
+    256 threads in every run: 0.28 / 0.50 / 8.7 s per decoder layer forward) and a per-run choice was one source of the 2x run-to-run
+    spread of the earlier, layer-extrapolated figure."""
     from oracle import visper_oracle as O
     from visper_lm_amd.config import llama3_8b
     from visper_lm_amd.engine import is_trainable
@@ -72,32 +74,29 @@ def cpu_baseline(cfg, dev):
     ncpu = os.cpu_count() or 1
     dt = torch.bfloat16
     B, T = 2, 128
+    th = min(ncpu, int(os.environ.get("VP_CPU_BASELINE_THREADS", "16")))
+    torch.set_num_threads(th)
+    c = llama3_8b(num_hidden_layers=cfg.num_hidden_layers)
+    c.image_seg, c.image_depth, c.image_gen = dict(cfg.image_seg), dict(cfg.image_depth), dict(cfg.image_gen)
+    gen = torch.Generator(device=dev).manual_seed(1)
+    W = {}
+    for k, shp in param_shapes(c, vit_nested=True).items():
+        if k.startswith("da_v2_head."):
+            continue
+        w = init_value(k, shp, gen, dev, dt if len(shp) else torch.float32).cpu()      # generated on the GPU, copied once
+        W[k] = w.requires_grad_(True) if is_trainable(k) else w
+    g = torch.Generator().manual_seed(2)
+    ids = torch.randint(0, 1000, (B, T), generator=g)
+    ids[:, c.num_sys_tokens] = -200
+    lab = ids.clone()
+    lab[:, :c.num_sys_tokens + 7] = -100
+    rn = lambda *s_: torch.randn(*s_, generator=g).to(dt)
+    batch = dict(input_ids=ids, labels=lab, attention_mask=torch.ones_like(ids, dtype=torch.bool), images=rn(B, 3, 336, 336),
+                 gen_target=rn(B, 1, 1024), gen_mask=torch.ones(B), depth_target=rn(B, 576, 1024), depth_mask=torch.ones(B),
+                 seg_target=rn(B, 1536, 24, 24), seg_mask=torch.ones(B))
+    ocfg = O.make_config(**{k: v for k, v in c.to_dict().items() if k in vars(O.make_config())})
 
-    def case(L):
-        c = llama3_8b(num_hidden_layers=L)
-        c.image_seg = dict(c.image_seg, seg_layer_indices=str(L - 1))
-        c.image_depth = dict(c.image_depth, depth_layer_indices=str(L))
-        c.image_gen = dict(c.image_gen, img_layer_indices=str(L))
-        gen = torch.Generator(device=dev).manual_seed(1)
-        W = {}
-        for k, shp in param_shapes(c, vit_nested=True).items():
-            if k.startswith("da_v2_head."):
-                continue
-            w = init_value(k, shp, gen, dev, dt if len(shp) else torch.float32).cpu()      # generated on the GPU, copied once
-            W[k] = w.requires_grad_(True) if is_trainable(k) else w
-        g = torch.Generator().manual_seed(2)
-        ids = torch.randint(0, 1000, (B, T), generator=g)
-        ids[:, c.num_sys_tokens] = -200
-        lab = ids.clone()
-        lab[:, :c.num_sys_tokens + 7] = -100
-        rn = lambda *s_: torch.randn(*s_, generator=g).to(dt)
-        batch = dict(input_ids=ids, labels=lab, attention_mask=torch.ones_like(ids, dtype=torch.bool), images=rn(B, 3, 336, 336),
-                     gen_target=rn(B, 1, 1024), gen_mask=torch.ones(B), depth_target=rn(B, 576, 1024), depth_mask=torch.ones(B),
-                     seg_target=rn(B, 1536, 24, 24), seg_mask=torch.ones(B))
-        ocfg = O.make_config(**{k: v for k, v in c.to_dict().items() if k in vars(O.make_config())})
-        return W, batch, ocfg
-
-    def timed_step(W, batch, ocfg):
+    def timed_step():
         t0 = time.time()
         out = O.forward(W, batch, ocfg, need_logits=False)
         out["loss"].backward()
@@ -106,31 +105,55 @@ def cpu_baseline(cfg, dev):
             w.grad = None
         return el, float(out["loss"])
 
-    # thread probe on one decoder layer (forward): 16 / 64 / all
-    W2, b2, c2 = case(2)
-    one = O.make_config(**{**vars(c2), "num_hidden_layers": 1})
-    xp = torch.randn(B, 727, cfg.hidden_size).to(dt)
-    probe = {}
-    for th in sorted({min(ncpu, 16), min(ncpu, 64), ncpu}):
-        torch.set_num_threads(th)
-        with torch.no_grad():
-            O.decoder_forward(xp, None, None, W2, one)
-            t0 = time.time(); O.decoder_forward(xp, None, None, W2, one); probe[th] = round(time.time() - t0, 3)
-    th = min(probe, key=probe.get)
-    torch.set_num_threads(th)
-    timed_step(W2, b2, c2)                                     # warm-up (allocator, oneDNN primitive caches)
-    t2, _ = timed_step(W2, b2, c2)
-    del W2
-    W4, b4, c4 = case(4)
-    t4, loss4 = timed_step(W4, b4, c4)
-    del W4
-    per_layer = max((t4 - t2) / 2.0, 1e-6)
-    step = t4 + (cfg.num_hidden_layers - 4) * per_layer
+    t_warm, _ = timed_step()                                   # warm-up (allocator, oneDNN primitive caches)
+    runs = [timed_step() for _ in range(2)]
+    ts = sorted(t for t, _ in runs)
+    step = 0.5 * (ts[0] + ts[1])
     return {"value": round(B / step, 5), "unit": "images/s", "cores": th, "host_cpus": ncpu, "cpu_model": _cpu_model(), "dtype": "bf16",
-            "kind": "port", "threads_probe_s_per_layer_fwd": {str(k): v for k, v in probe.items()},
-            "sample": (f"oracle bf16, {th} threads ({_cpu_model()}, {ncpu} logical CPUs): real fwd+bwd steps of the whole PT path at configs[0] "
-                       f"shapes (B=2, text 128 -> S=727, ViT-L full, 3 heads, V=128256) with 2 decoder layers {t2:.2f}s and 4 layers {t4:.2f}s "
-                       f"(loss {loss4:.4f}); scaled in layer count only: T(32) = {t4:.2f} + 28 x {per_layer:.3f} = {step:.1f}s/step")}
+            "kind": "port", "extrapolated": False, "step_s": [round(t, 2) for t, _ in runs], "warmup_step_s": round(t_warm, 2),
+            "sample": (f"oracle bf16, {th} threads ({_cpu_model()}, {ncpu} logical CPUs): whole fwd+bwd steps of the PT path at configs[0] shapes "
+                       f"(B=2, text 128 -> S=727, ViT-L full, ALL {c.num_hidden_layers} decoder layers, 3 heads, V=128256); 1 warm-up step "
+                       f"({t_warm:.1f}s), median of 2 timed steps {runs[0][0]:.1f}s / {runs[1][0]:.1f}s (loss {runs[1][1]:.4f}); nothing extrapolated")}
+
+
+def run_extras(args, headline_ms, step_tf_hint=None):
+    """Secondary legs of the default line, each a FRESH process of this script started after the headline's timed region (this process has
+    freed the GPU by then): W = 2 warm-up + K = --extras-steps timed steps between the same barrier + synchronize fences, every other probe
+    off.  engine_direct = Engine.train_step / optimizer_step without the model class (rounds 1-5's headline); reference_outputs = the model
+    class with its contract default config.reference_outputs=True (fp32 logits of all B x S rows + all L + 1 layer states, ola_llama.py:113-122);
+    configs[4] / configs[3] = the other two single-GPU configurations of BASELINE.json through the model class."""
+    import subprocess
+    base = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", str(args.extras_steps), "--warmup", "2", "--no-probes",
+            "--no-cpu-baseline", "--no-extras", "--lr", str(args.lr)] + (["--no-depth-decoder"] if args.no_depth_decoder else [])
+    legs = [("engine_direct", ["--api", "engine"]), ("reference_outputs", ["--api", "model", "--reference-outputs"]),
+            ("configs[4]_phi3", ["--api", "model", "--workload", "phi3"]), ("configs[3]_convnext", ["--api", "model", "--workload", "convnext"])]
+    only = os.environ.get("VP_BENCH_EXTRAS")
+    out = {"what": run_extras.__doc__.split("\n")[0].strip() + " ... (bench.py run_extras)", "steps": args.extras_steps, "warmup": 2}
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    for tag, extra in legs:
+        if only and tag not in only.split(","):
+            continue
+        t0 = time.time()
+        try:
+            pr = subprocess.run(base + extra, capture_output=True, text=True, cwd=ROOT, env=env,
+                                timeout=float(os.environ.get("VP_BENCH_EXTRA_TIMEOUT", "900")))
+            lines = [ln for ln in pr.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln]
+            if not lines:
+                raise RuntimeError(f"no result line (exit code {pr.returncode}): {(pr.stderr or pr.stdout)[-300:]}")
+            r = json.loads(lines[-1])
+            rf, cf = r["roofline"], r["config"]
+            out[tag] = {"ms_per_step": r["ms_per_step"], "images_per_s": r["value"], "step_frac_of_peak_executed_flops": rf.get("step_frac_of_peak"),
+                        "executed_tflop_per_step": rf.get("executed_tflop_per_step"), "gemm_frac": rf.get("frac"),
+                        "gemm_family_frac": rf.get("family", {}).get("frac"), "loss": cf.get("loss"), "api": cf.get("api"), "seq_len": cf.get("seq_len"),
+                        "per_gpu_batch": cf.get("per_gpu_batch"), "peak_mem_gb": cf.get("peak_mem_gb"), "lm_head_rows": cf.get("lm_head_rows"),
+                        "outputs": cf.get("outputs", "")[:60], "workload": cf.get("workload"), "process_wall_s": round(time.time() - t0, 1)}
+            if tag in ("engine_direct", "reference_outputs"):
+                out[tag]["delta_ms_vs_headline"] = round(r["ms_per_step"] - headline_ms, 2)
+        except Exception as e:                              # noqa: BLE001  (a secondary leg must never cost the headline line)
+            out[tag] = {"error": f"{type(e).__name__}: {e}"[:400]}
+    return out
 
 
 def clock_probe(dev, n=120):
@@ -145,16 +168,18 @@ def clock_probe(dev, n=120):
     a = torch.randn(M, K, device=dev, dtype=torch.bfloat16)
     w = torch.randn(N, K, device=dev, dtype=torch.bfloat16) * 0.02
     o = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
-    for _ in range(n - 1):
-        ops.gemm(a, w, out=o)
-    _lib.call("vp_debug_gemm_flags", 0x10000)
-    try:
-        ops.gemm(a, w, out=o)
-        torch.cuda.synchronize()
-    finally:
-        _lib.call("vp_debug_gemm_flags", 0)
-    buf = (C.c_long * 2048)()
-    _lib.call("vp_debug_stamps", buf)
+    # (the in-kernel stamps exist in the -DVP_DEBUG build of the library only: the probe's launches go to libvisper_hip_debug.so, same kernels)
+    with _lib.debug_library():
+        for _ in range(n - 1):
+            ops.gemm(a, w, out=o)
+        _lib.call("vp_debug_gemm_flags", 0x10000)
+        try:
+            ops.gemm(a, w, out=o)
+            torch.cuda.synchronize()
+        finally:
+            _lib.call("vp_debug_gemm_flags", 0)
+        buf = (C.c_long * 2048)()
+        _lib.call("vp_debug_stamps", buf)
     st = np.array(buf[:], dtype=np.int64).reshape(256, 8)
     us = (st[:, 2] - st[:, 1]) / 100.0                          # wall clock ticks are 10 ns
     cyc = (st[:, 7] - st[:, 6]).astype(np.float64)
@@ -433,6 +458,15 @@ def main():
     ap.add_argument("--reference-outputs", action="store_true",
                     help="materialise what the reference's forward returns every step (logits of all B x S rows + every layer state: the mirror's "
                          "config.reference_outputs=True default) instead of the lean training mode (loss only, lm_head on labelled rows)")
+    ap.add_argument("--api", default="model", choices=["model", "engine"],
+                    help="model (default) = the drop-in boundary north_star names: every step is `out = model(**batch); out.loss.backward(); "
+                         "model.optimizer_step(lr)` through the reference-named class (OlaLlavaLlamaForCausalLM / OlaLlavaPhi3ForCausalLM / "
+                         "LlavaLlamaForCausalLM: ola_vlm_train.py:1297-1327 -> ola_llama.py:190-244); engine = Engine.train_step + "
+                         "Engine.optimizer_step called directly (what rounds 1-5 timed; reported beside the headline under `extras`)")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the secondary legs of the default line (engine-direct, reference outputs, configs[4] phi3, configs[3] convnext: each a "
+                         "fresh process of this script after the timed region, a few steps between the same fences)")
+    ap.add_argument("--extras-steps", type=int, default=3)
     ap.add_argument("--same-batch", action="store_true", help="A/B aid: replay one batch (splice-plan cache hit) instead of a fresh one per step")
     ap.add_argument("--force-dist", action="store_true", help="initialise the RCCL process group even with one rank (test hook)")
     args = ap.parse_args()
@@ -495,7 +529,26 @@ def main():
         cfg.image_gen["img_layer_indices"] = str(min(20, args.layers))
         cfg.image_depth["depth_layer_indices"] = str(min(18, args.layers))
         cfg.image_seg["seg_layer_indices"] = str(min(18, args.layers))
-    eng = Engine(cfg, device=dev)
+    model = None
+    if args.api == "model":
+        # the reference-named module owns the parameters; its engine is built from the module's state_dict (EngineModule._get_engine)
+        from visper_lm_amd import model as M_
+        if args.workload == "ift":
+            mcls, ccls = M_.LlavaLlamaForCausalLM, M_.LlavaConfig
+        elif args.workload == "phi3":
+            mcls, ccls = M_.OlaLlavaPhi3ForCausalLM, M_.OlaLlavaPhi3Config
+        else:
+            mcls, ccls = M_.OlaLlavaLlamaForCausalLM, M_.OlaLlavaLlamaConfig
+        cd = cfg.to_dict()
+        for k in getattr(ccls, "STORED_KEYS_IGNORED", ()):
+            cd.pop(k, None)
+        mcfg = ccls(**cd)
+        mcfg.reference_outputs = bool(args.reference_outputs)
+        model = mcls(mcfg, device=dev, init="random", seed=0)
+        eng = model._get_engine()
+        cfg = eng.cfg
+    else:
+        eng = Engine(cfg, device=dev)
     legs = ["torch"]
     if world > 1:
         legs = {"both": ["torch", "native"], "torch": ["torch"], "native": ["native"]}[args.transports]
@@ -503,9 +556,10 @@ def main():
             legs = [os.environ["VP_COMM"]] + [t for t in ("torch", "native") if t != os.environ["VP_COMM"]]
         if shared:
             legs = ["torch"]                            # the one-GPU test hook runs over gloo: no RCCL communicator to build
-    eng.keep_logits = eng.keep_states = bool(args.reference_outputs)
     eng.set_distributed(rank, world, transport=legs[0])
-    eng.init_random(seed=0)                       # identical weights on every rank
+    if model is None:
+        eng.keep_logits = eng.keep_states = bool(args.reference_outputs)
+        eng.init_random(seed=0)                   # identical weights on every rank
     # A FRESH batch every step, as a dataloader delivers it (ola_vlm_train.py:882-925): new input_ids / labels each step, so the host
     # splice plan (ola_arch.py:256-444 restated in splice.host_plan), its H2D copy and the head tables are paid inside the timed
     # region; images / teacher targets rotate through 4 distinct sets already resident in HBM.
@@ -530,8 +584,20 @@ def main():
     it = [0]
 
     def step():
-        out = eng.train_step(fresh[it[0] % n_total] if not args.same_batch else fresh[0])
-        eng.optimizer_step(lr=args.lr, lr_mult=optim.cosine_with_warmup(it[0], total_steps, n_warm))   # wd 0, no clipping: pretrain.sh
+        b = fresh[it[0] % n_total] if not args.same_batch else fresh[0]
+        lr_mult = optim.cosine_with_warmup(it[0], total_steps, n_warm)
+        if model is None:
+            out = eng.train_step(b)
+            eng.optimizer_step(lr=args.lr, lr_mult=lr_mult)                  # wd 0, no clipping: pretrain.sh
+        else:
+            # what the reference's trainer does per micro-batch (HF Trainer.training_step under ola_vlm_train.py:1297-1327): forward through
+            # the model class, backward through autograd, optimizer, zero_grad
+            res = model(**b)
+            res.loss.backward()
+            model.optimizer_step(lr=args.lr, lr_mult=lr_mult)
+            model.zero_grad(set_to_none=True)
+            out = model._last
+            out["loss"] = res.loss.detach()
         it[0] += 1
         return out
 
@@ -674,9 +740,13 @@ def main():
                           "depth_decoder": bool(cfg.depth_decoder), "fresh_batch_per_step": not args.same_batch,
                           "peak_mem_gb": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 1),
                           "lm_head_rows": f"{n_valid_rows} labelled of {args.batch * S} (rows with label -100 skip lm_head + CE: zero loss, zero d_logits)",
-                          "outputs": ("reference (bf16 logits of all B x S rows + all L + 1 layer states materialised every step)" if args.reference_outputs
-                                      else "lean: loss + per-layer losses only (the mirror's config.reference_outputs=False; the reference-outputs mode "
-                                           "also sends the unlabelled rows through lm_head: --reference-outputs)"),
+                          "api": ("model: out = %s(**batch); out.loss.backward(); model.optimizer_step(lr); model.zero_grad() "
+                                  "(the drop-in boundary: ola_vlm_train.py:1297-1327 -> ola_llama.py:190-244)" % type(model).__name__) if model is not None
+                                 else "engine: Engine.train_step(batch) + Engine.optimizer_step(lr) called directly",
+                          "outputs": ("reference (fp32 logits of all B x S rows + all L + 1 layer states returned every step: the model class's contract "
+                                      "default config.reference_outputs=True)" if args.reference_outputs
+                                      else "lean: loss + per-layer losses + embeddings (config.reference_outputs=False: no logits tensor, lm_head + CE on "
+                                           "labelled rows only; the contract-default mode is timed under extras.reference_outputs)"),
                           "valid": args.layers is None},
                "roofline": roof, **({"multi_gpu": diag} if diag is not None else {})}
 
@@ -715,10 +785,15 @@ def main():
                 roof["frac_at_sustained_clock"] = round(achieved / (PEAK_BF16_TF * ck["shader_clock_mhz"] / ck["nominal_mhz"]), 4)
             except Exception as e:                      # noqa: BLE001
                 roof["clock"] = {"error": f"{type(e).__name__}: {e}"[:300]}
-        if world == 1 and not args.no_cpu_baseline and args.workload == "llama3_8b":
-            del eng, fresh, pool
+        if world == 1 and args.workload == "llama3_8b" and (not args.no_extras or not args.no_cpu_baseline):
+            del eng, fresh, pool, model, out
+            import gc
+            gc.collect()
             torch.cuda.empty_cache()
-            res["cpu_baseline"] = cpu_baseline(cfg, dev)
+            if not args.no_extras and args.layers is None:
+                res["extras"] = run_extras(args, res["ms_per_step"])
+            if not args.no_cpu_baseline:
+                res["cpu_baseline"] = cpu_baseline(cfg, dev)
         print(json.dumps(res), flush=True)
     if dist is not None:
         dist.barrier()

@@ -8,7 +8,9 @@
  *
  * Conventions
  *  - plain pointers + sizes; all tensors are device pointers owned by the caller (PyTorch caching
- *    allocator); the library never allocates, frees or retains device memory.
+ *    allocator); the library never allocates, frees or retains device memory — also not for its own bookkeeping: the two kernels that need
+ *    device-side counters (dynamic GEMM tile claims, the distillation loss's reduction tree) take them as caller-owned blocks
+ *    (`sched_ws`, `counters`).  Only the vp_comm_* communicator object holds state.
  *  - bf16 tensors are `void*` (raw uint16 bit patterns); fp32 are `float*`; ld* = leading dimension in
  *    ELEMENTS; every call is asynchronous on `stream` (a hipStream_t passed as void*).
  *  - return 0 on success, negative VP_ERR_* otherwise; vp_last_error_string() (thread-local) explains.
@@ -50,8 +52,16 @@ int vp_device_info(int* cu_count, int* wave_size, long* lds_bytes_per_cu);
  * 8 / 14 = see above, 13 = 4-phase variant of the 8-phase kernel.  Every code computes the same result (the tests compare them bit for bit);
  * any other value is VP_ERR_BAD_ARG. */
 int vp_gemm_bf16(int M, int N, int K, const void* A, long lda, const void* B, long ldb, void* C, long ldc,
-                 const void* bias, const void* residual, long ldr, int epilogue, int out_f32, int force_generic,
+                 const void* bias, const void* residual, long ldr, int epilogue, int out_f32, int force_generic, int* sched_ws,
                  vp_stream_t stream);
+
+/* sched_ws (vp_gemm_bf16, vp_gemm_bf16_swiglu, vp_gemm_tn_bf16): NULL = the persistent kernels walk their tiles statically (single GPU:
+ * nothing else runs beside the GEMMs).  Non-NULL = vp_gemm_sched_workspace_bytes() bytes of CALLER-OWNED device memory, zeroed once by the
+ * caller: the persistent 8-phase kernels then claim their tiles from per-XCD counters in it, so a CU held by a concurrent kernel (an RCCL
+ * collective) only costs its own share instead of stalling the static grid (the reference leaves this to DeepSpeed's stream overlap,
+ * scripts/zero2.json "overlap_comm").  A launch leaves the block zeroed again: one block serves every launch of one stream; launches that may
+ * overlap (different streams) need different blocks.  The library keeps no pointer after the call returns. */
+long vp_gemm_sched_workspace_bytes(void);
 
 /* Fused SwiGLU GEMMs for the decoder MLP (HF LlamaMLP.forward: down_proj(act_fn(gate_proj(x)) * up_proj(x))).  The fused
  * gate/up tensor keeps gate and up interleaved in 8-column chunks (g0..7 | u0..7 | g8..15 | ...), which is also the layout
@@ -60,7 +70,7 @@ int vp_gemm_bf16(int M, int N, int K, const void* A, long lda, const void* B, lo
  * mode 1 with aux != NULL: aux is an fp32 [M] row scale applied to the accumulators (gate_up = bf16(acc * scale): RMSNorm's 1/rms when
  * gamma is folded into the frozen weight); one-wave-per-SIMD kernel only (K % 128 == 0, >= 192 tiles), else VP_ERR_UNSUPPORTED_SHAPE. */
 int vp_gemm_bf16_swiglu(int mode, int M, int N, int K, const void* A, long lda, const void* B, long ldb, void* C, long ldc,
-                        void* C2, long ldc2, const void* aux, long ldaux, vp_stream_t stream);
+                        void* C2, long ldc2, const void* aux, long ldaux, int* sched_ws, vp_stream_t stream);
 
 /* Residual GEMM that also emits the next RMSNorm's statistics (replaces: HF LlamaDecoderLayer.forward's `residual + o_proj(...)` /
  * `residual + mlp(...)` followed by a separate pass over the stream for the norm, reached from ola_llama.py:105-115): C[M,N] = A B^T + residual
@@ -87,13 +97,8 @@ int vp_gemm_bf16_rope(int M, int N, int K, const void* A, long lda, const void* 
  * LDS reads.  M, N multiples of 256, K of 64, 16-byte aligned rows; else VP_ERR_UNSUPPORTED_SHAPE (the caller transposes and
  * uses vp_gemm_bf16).  out_f32=1 writes fp32; accumulate=1 (fp32 only) adds into C (chunked lm_head gradient). */
 int vp_gemm_tn_bf16(int M, int N, int K, const void* A, long lda, const void* B, long ldb, void* C, long ldc, int out_f32,
-                    int accumulate, vp_stream_t stream);
+                    int accumulate, int* sched_ws, vp_stream_t stream);
 
-/* Dynamic tile scheduling of the persistent GEMM kernel (per-XCD claim counters): switch it on when collectives (RCCL) run
- * concurrently with the GEMMs -- a CU held by another kernel then costs its own share instead of stalling the static grid
- * (Engine.set_distributed does this for world > 1; the reference leaves this to DeepSpeed's stream overlap,
- * scripts/zero2.json "overlap_comm").  Returns the previous setting.  Off by default. */
-int vp_gemm_set_dynamic(int on);
 /* (measurement / development entry points — vp_debug_* — are NOT part of this ABI: include/visper_hip_debug.h, built with -DVP_DEBUG) */
 
 int vp_transpose_bf16(int rows, int cols, const void* in, long ld_in, void* out, long ld_out, vp_stream_t stream);
@@ -145,6 +150,10 @@ int vp_gather_sum_rows(long n_out, int cnt, int H, const void* src, long lds, in
 
 int vp_cast_f32_to_bf16(long n, const float* x, void* y, vp_stream_t stream);
 int vp_cast_bf16_to_f32(long n, const void* x, float* y, int accumulate, vp_stream_t stream);
+/* dst[idx[r], :] = (float)src[r, :] for n rows of H bf16 (idx NULL: row r; idx < 0: row skipped): the bf16 lm_head logits of a row chunk widened
+ * into their rows of the fp32 [B*S, V] `logits` the reference's forward returns (ola_llama.py:121-122 `logits = self.lm_head(hidden_states);
+ * logits = logits.float()`).  H % 8 == 0, lds % 8 == 0, ldd % 4 == 0, 16-byte aligned bases. */
+int vp_scatter_rows_bf16_to_f32(long n, int H, const void* src, long lds, const int* idx, float* dst, long ldd, vp_stream_t stream);
 int vp_sum_f32(long n, const float* x, float* out, float scale, vp_stream_t stream);
 /* out[0] = sum x[i]^2 (global gradient norm for clip_grad_norm_ semantics); part = workspace of vp_sumsq_nblk(n) floats */
 int vp_sumsq_nblk(long n);
@@ -197,20 +206,22 @@ int vp_ce_fwd_bwd(long rows, int V, void* logits, long ld, const long* labels, f
 /* vp_emb_loss_fwd: ONE launch (streaming MFMA/dot2 pass + deterministic last-block tree + the B x Bw softmax); out3 = {emb_loss, sl1,
  * contrastive} exactly as _emb_loss returns them (not yet multiplied by the task weight); coef (2B + B*Bw + 1 floats) carries the
  * backward coefficients and d loss / d logit_scale in its last slot.  workspace: vp_emb_loss_workspace(B, Bw, D) floats, uninitialised.
+ * counters: vp_emb_loss_counter_bytes() bytes of CALLER-OWNED device memory holding the tree's ticket counters, zeroed once by the caller;
+ * every launch leaves the block zeroed, so one block serves all launches of one stream; launches that may overlap (different streams) need
+ * different blocks.  The library owns no device memory and keeps no pointer after the call returns.
  * 0 < B <= 64 local predictions, B <= Bw <= 1024 gathered targets (rank-ordered, rank r's rows at r*B), D % 8 == 0; pred [B,D] and
- * tgt_all [Bw,D] bf16 row-major, 16-byte aligned.  logit_scale NULL = no contrastive term.  Every distinct stream gets its own ticket
- * counters (32 sets, re-assigned least-recently-used once more than 32 streams have called), so calls on different streams may overlap
- * freely; calls on one stream are ordered by it. */
+ * tgt_all [Bw,D] bf16 row-major, 16-byte aligned.  logit_scale NULL = no contrastive term. */
+long vp_emb_loss_counter_bytes(void);
 long vp_emb_loss_workspace(int B, int Bw, long D);
 int vp_emb_loss_fwd(int B, int Bw, long D, int rank, const void* pred, const void* tgt_all, const float* mask,
-                    const float* logit_scale, float w_contrastive, float* out3, float* coef, float* workspace,
+                    const float* logit_scale, float w_contrastive, float* out3, float* coef, float* workspace, unsigned* counters,
                     vp_stream_t stream);
 /* The same for `ntask` (<= 8) distillation heads in ONE launch each way (blockIdx.z = head): the heads of a step share B, Bw and rank and
  * differ in D, pointers, workspace and contrastive weight (host arrays of length ntask).  The reference calls _emb_loss once per head and
  * layer (base_ola_vlm.py:445-534). */
 int vp_emb_loss_fwd_multi(int ntask, int B, int Bw, const long* D, int rank, const void* const* pred, const void* const* tgt_all,
                           const float* const* mask, const float* const* logit_scale, const float* w_contrastive, float* const* out3,
-                          float* const* coef, float* const* workspace, vp_stream_t stream);
+                          float* const* coef, float* const* workspace, unsigned* counters, vp_stream_t stream);
 int vp_emb_loss_bwd_multi(int ntask, int B, int Bw, const long* D, int rank, const void* const* pred, const void* const* tgt_all,
                           const float* const* coef, const float* grad_out, void* const* dpred, vp_stream_t stream);
 int vp_emb_loss_bwd(int B, int Bw, long D, int rank, const void* pred, const void* tgt_all, const float* coef,

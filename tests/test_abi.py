@@ -42,18 +42,22 @@ def test_debug_entry_points_are_outside_the_product_abi():
     assert dbg == set(_lib._DEBUG_SIGS) and all(n.startswith("vp_debug_") for n in dbg)
     assert not (dbg & set(_lib.EXPORTS))
     lib = _lib.load()
-    have = [hasattr(lib, n) for n in sorted(dbg)]
-    assert all(have) or not any(have), dict(zip(sorted(dbg), have))         # a build has all of them (VP_DEBUG=1) or none (sealed)
+    if not os.environ.get("VP_LIB_PATH"):
+        assert not any(hasattr(lib, n) for n in dbg), "the product library must be the sealed build (make: no -DVP_DEBUG)"
+        with _lib.debug_library() as dl:                                   # the -DVP_DEBUG build of the same sources carries all of them
+            assert all(hasattr(dl, n) for n in dbg) and all(hasattr(dl, n) for n in _lib.EXPORTS)
+        assert _lib.load() is lib                                          # ... and the product library is back afterwards
 
 
 def test_bad_arguments_return_codes_not_crashes():
     from visper_lm_amd import _lib
     lib = _lib.load()
     assert lib.vp_emb_loss_workspace(8, 64, 884736) > 0 and lib.vp_emb_loss_workspace(0, 0, 0) == 0
-    rc = lib.vp_emb_loss_fwd(0, 0, 0, 0, None, None, None, None, ctypes.c_float(0.3), None, None, None, None)
+    rc = lib.vp_emb_loss_fwd(0, 0, 0, 0, None, None, None, None, ctypes.c_float(0.3), None, None, None, None, None)
     assert rc == -2 and b"vp_emb_loss_fwd" in lib.vp_last_error_string()
     rc = lib.vp_comm_allreduce_async(None, None, 0, 0, None)
     assert rc == -1 and b"vp_comm_allreduce_async" in lib.vp_last_error_string()
     assert lib.vp_comm_unique_id_bytes() == 128
-    rc = lib.vp_gemm_bf16(0, 0, 0, None, 0, None, 0, None, 0, None, None, 0, 0, 0, 0, None)
+    assert lib.vp_gemm_sched_workspace_bytes() == 64 and lib.vp_emb_loss_counter_bytes() == 8 * 1025 * 4          # caller-owned counter blocks
+    rc = lib.vp_gemm_bf16(0, 0, 0, None, 0, None, 0, None, 0, None, None, 0, 0, 0, 0, None, None)
     assert rc < 0

@@ -37,6 +37,17 @@ def test_one_wave_per_simd_kernels_own_the_whole_register_file(kernels):
             assert d.get("vgpr_spill_count", 0) <= 16, (n, d)
 
 
+def test_register_resident_row_kernels_do_not_go_to_scratch(kernels):
+    """only attention.hip / gemm.hip are built with -amdgpu-spill-vgpr-to-agpr=0 now; the cross-entropy kernel that keeps its row in
+    registers (128 data VGPRs under launch_bounds(512)) and the 4-wide AdamW must not touch scratch (a spill may use a free AGPR)."""
+    hit = 0
+    for n, d in kernels.items():
+        if "ce_fwd_bwd_reg_kernel" in n or "adamw4_kernel" in n:
+            hit += 1
+            assert d.get("private_segment_fixed_size", 0) == 0, (n, d)
+    assert hit >= 2, hit
+
+
 def test_dma_ring_kernels_do_not_spill(kernels):
     """a scratch reload inside a kernel that keeps an LDS-DMA ring in flight is followed by s_waitcnt vmcnt(0): it drains the ring every iteration"""
     for n, d in kernels.items():
@@ -52,6 +63,7 @@ def test_asm_owned_registers_are_never_touched_by_the_compiler():
     import audit_asm_owned as au
     if not (shutil.which("hipcc") or os.path.exists(au.HIPCC)):
         pytest.skip("needs hipcc")
-    n, problems = au.audit(au.isa())
-    assert n >= 12, n
-    assert not problems, problems[:10]
+    for dbg in (False, True):                      # the sealed product build AND the -DVP_DEBUG build
+        n, problems = au.audit(au.isa(debug=dbg))
+        assert n >= 12, (dbg, n)
+        assert not problems, (dbg, problems[:10])

@@ -118,17 +118,32 @@ def test_hidden_states_and_logits(tiny):
 
 
 def test_labelled_row_compaction_is_exact(tiny):
-    """Without keep_logits only the rows that carry a label go through lm_head + cross-entropy: same loss, bit-identical gradients."""
+    """Only the rows that carry a label go through lm_head + cross-entropy + the d_hidden GEMM (with or without keep_logits; the label-less rows
+    take a forward-only lm_head pass when the logits are wanted): same loss, bit-identical gradients AND bit-identical fp32 logits as sending
+    every row through all three, literally as ola_llama.py:121-136 does (Engine.lm_head_all_rows)."""
     eng = tiny["eng"]
+    batch = _to_gpu_batch(tiny["batch"])
+    plan = eng.build_plan(tiny["batch"]["input_ids"], tiny["batch"]["attention_mask"], tiny["batch"]["labels"])
+    assert 0 < plan["n_valid"] < plan["B"] * plan["S"]                      # the compacted path really runs
+    eng.lm_head_all_rows = True
+    try:
+        full = eng.train_step(batch)
+        torch.cuda.synchronize()
+        gfull = {k: eng.ps.g(k).detach().float().cpu().clone() for k in eng.ps.index}
+    finally:
+        eng.lm_head_all_rows = False
+    assert full["logits"].dtype == torch.float32 and tiny["out"]["logits"].dtype == torch.float32
+    assert torch.equal(full["logits"], tiny["out"]["logits"])                # compacted + forward-only rows == all rows, bit for bit
+    assert torch.equal(full["text_loss"], tiny["out"]["text_loss"]) or rel(full["text_loss"], tiny["out"]["text_loss"]) < 1e-6
+    for k in eng.ps.index:
+        assert torch.equal(gfull[k], tiny["grads"][k]), k
     eng.keep_logits = False
     try:
-        out = eng.train_step(_to_gpu_batch(tiny["batch"]))
+        out = eng.train_step(batch)
         torch.cuda.synchronize()
     finally:
         eng.keep_logits = True
     assert "logits" not in out
-    plan = eng.build_plan(tiny["batch"]["input_ids"], tiny["batch"]["attention_mask"], tiny["batch"]["labels"])
-    assert 0 < plan["n_valid"] < plan["B"] * plan["S"]                      # the compacted path really ran
     check("tiny/compact/text_loss_rel", rel(out["text_loss"], tiny["out"]["text_loss"]), 1e-6)
     check("tiny/compact/loss_rel", rel(out["loss"], tiny["out"]["loss"]), 1e-6)
     for k in eng.ps.index:

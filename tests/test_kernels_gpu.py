@@ -375,7 +375,7 @@ def test_gemm_tn_weight_gradient(ops, M, N, K):
     ops.gemm_tn(dyg, xg, out=out)
     assert float((out - old).abs().max()) <= 1e-5 * scale * max(1.0, K / 256) ** 0.5
     with pytest.raises(RuntimeError):
-        ops._lib.call("vp_gemm_tn_bf16", 200, 256, 64, dyg.data_ptr(), dyg.stride(0), xg.data_ptr(), N, out.data_ptr(), N, 1, 0, None)
+        ops._lib.call("vp_gemm_tn_bf16", 200, 256, 64, dyg.data_ptr(), dyg.stride(0), xg.data_ptr(), N, out.data_ptr(), N, 1, 0, None, None)
 
 
 @pytest.mark.parametrize("D,theta", [(128, 500000.0), (96, 10000.0)])
@@ -419,20 +419,21 @@ def test_gemm_dynamic_tile_scheduling(ops):
     gu_ref, act_ref = ops.gemm_swiglu_fwd(x2, wgu)
     dyt, xt = dev(rnd(512, 4352, seed=94)), dev(rnd(512, 4096, seed=95))       # TN weight gradient, 17 x 16 tiles
     tn_ref = ops.gemm_tn(dyt, xt)
-    prev = ops._lib.raw("vp_gemm_set_dynamic", 1)
+    prev = ops.set_dynamic(True)               # counter blocks: caller-owned, one zeroed block per stream (ops._sched)
     try:
         for it in range(4):
             if it == 2:
                 side = torch.cuda.Stream()
                 with torch.cuda.stream(side):
-                    ops._lib.call("vp_debug_occupy", 24, 3000000, torch.cuda.current_stream().cuda_stream)
+                    with ops._lib.debug_library():             # the stand-in collective lives in the -DVP_DEBUG build only
+                        ops._lib.call("vp_debug_occupy", 24, 3000000, torch.cuda.current_stream().cuda_stream)
             assert torch.equal(ops.gemm(a, w), ref)
             gu, act = ops.gemm_swiglu_fwd(x2, wgu)
             assert torch.equal(gu, gu_ref) and torch.equal(act, act_ref)
             assert torch.equal(ops.gemm_tn(dyt, xt), tn_ref)
         torch.cuda.synchronize()
     finally:
-        ops._lib.raw("vp_gemm_set_dynamic", prev)
+        ops.set_dynamic(prev)
     assert torch.equal(ops.gemm(a, w), ref)
 
 
@@ -459,7 +460,8 @@ def test_w4_gemm_beside_small_kernels_on_a_second_stream(ops):
                 ops.act_fwd(sm, ops.EPI_GELU)
                 ops.zero_(small)
             if rnd_ & 1:
-                ops._lib.call("vp_debug_occupy", 16, 2000000, torch.cuda.current_stream().cuda_stream)
+                with ops._lib.debug_library():
+                    ops._lib.call("vp_debug_occupy", 16, 2000000, torch.cuda.current_stream().cuda_stream)
         got = (ops.gemm(a, w), ops.gemm(a, w, bias=bias, residual=res, epi=ops.EPI_QUICK_GELU, force_generic=14),
                ops.gemm(a[:Mt], w, bias=bias, force_generic=14), *ops.gemm_sumsq(a, w, res))
         for i, (g_, s_) in enumerate(zip(got, solo)):
@@ -488,6 +490,26 @@ def test_add_colsum_cast(ops):
     ref = dst.clone().float().cpu(); ref[:, 16:80] += src.float().cpu()
     ops.add2d_(dst[:, 16:80], src)
     close(dst, ref, what="add2d")
+
+
+def test_scatter_rows_bf16_to_f32(ops):
+    """vp_scatter_rows_bf16_to_f32: bf16 rows widened into chosen rows of an fp32 matrix (the reference's `logits.float()`, ola_llama.py:122);
+    skipped rows (idx < 0) and rows nobody writes stay untouched; idx = None is the row-for-row cast.  Exact (a widening)."""
+    src = rnd(37, 1000, seed=301)
+    idx = torch.randperm(64, generator=torch.Generator().manual_seed(5))[:37].to(torch.int32)
+    idx[5] = -1
+    dst = torch.full((64, 1000), 7.0, device="cuda")
+    ops.scatter_rows_to_f32(dev(src), dev(idx), dst)
+    ref = torch.full((64, 1000), 7.0)
+    for r in range(37):
+        if idx[r] >= 0:
+            ref[idx[r]] = src[r].float()
+    assert torch.equal(dst.cpu(), ref)
+    d2 = torch.empty(40, 1000, device="cuda")
+    ops.scatter_rows_to_f32(dev(src), None, d2[2:39])                      # row-for-row into a slice
+    assert torch.equal(d2[2:39].cpu(), src.float())
+    with pytest.raises(RuntimeError):
+        ops.scatter_rows_to_f32(dev(rnd(4, 12, seed=302)), None, torch.empty(4, 12, device="cuda"))      # H % 8 != 0
 
 
 def test_gather_and_gather_sum(ops):
@@ -665,8 +687,9 @@ def test_emb_loss_full_size_world8(ops):
 
 
 def test_emb_loss_concurrent_streams(ops):
-    """the loss forward's ticket counters are per DISTINCT stream (a registry, not a hash of the stream pointer), so launches
-    that overlap on several streams never share tickets.  12 streams (more than the old 8 hash slots) run the single-launch forward
+    """The loss forward's ticket counters live in a CALLER-owned block (include/visper_hip.h `counters`; round 6: the library owns no device
+    memory); ops._loss_counters keeps one zeroed block per stream, so launches that overlap on several streams never share tickets.
+    12 streams run the single-launch forward
     concurrently, 6 rounds each on its own data; every result must equal the bits of the same call made alone on the default stream, and
     a later default-stream call must still be exact (no counter left armed)."""
     B, Bw, D = 8, 16, 576 * 256
@@ -691,9 +714,9 @@ def test_emb_loss_concurrent_streams(ops):
 
 
 def test_emb_loss_more_streams_than_counter_sets(ops):
-    """the registry of per-stream ticket-counter sets (32) must not fill up for good.  40 distinct streams — more than there are sets,
-    some created and dropped in between — call the loss twice each; the least recently used set is re-assigned behind a fence event.  Every
-    result must equal the bits of the same call on the default stream, also when earlier streams come back after their set was handed on."""
+    """ADVICE r3 (the library-side registry of 32 counter sets is gone in round 6: the block is the caller's): 40 distinct streams, some created
+    and dropped in between, call the loss twice each, every one with its own caller-owned counter block.  Every result must equal the bits of the
+    same call on the default stream, also when earlier streams come back."""
     B, Bw, D = 8, 8, 576 * 64
     g = torch.Generator(device="cuda").manual_seed(10)
     pred = (torch.randn(B, D, device="cuda", generator=g) * 1.1).to(torch.bfloat16)

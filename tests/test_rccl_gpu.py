@@ -254,7 +254,7 @@ def test_bench_two_ranks_native_leg_is_the_headline_on_a_multi_gpu_box():
 
 def test_collective_on_the_comm_stream_beside_a_dynamic_gemm():
     """a vp_comm collective on the communicator's side stream BESIDE a many-round one-wave-per-SIMD GEMM with per-XCD dynamic
-    tile claims (vp_gemm_set_dynamic(1): what world > 1 switches on) — a self all-reduce at world 1, so it runs on any box.  The GEMM result
+    tile claims (ops.set_dynamic(True): what world > 1 switches on; the counter blocks are caller-owned) — a self all-reduce at world 1, so it runs on any box.  The GEMM result
     must be bit-identical to the launch without the collective, round after round, and the reduced buffer intact."""
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
@@ -275,7 +275,7 @@ torch.cuda.synchronize()
 c = NativeComm(rank=0, world=1)
 buf = torch.randn(32 * 1024 * 1024, device="cuda", generator=g).to(torch.bfloat16)       # 64 MB bucket
 keep = buf.clone()
-prev = ops._lib.raw("vp_gemm_set_dynamic", 1)
+prev = ops.set_dynamic(True)
 try:
     for it in range(6):
         c.allreduce_async(buf)                         # side stream, fenced behind the compute stream's work so far
@@ -287,7 +287,7 @@ try:
     torch.cuda.synchronize()
     assert torch.equal(buf, keep)                      # world 1: the sum over one rank
 finally:
-    ops._lib.raw("vp_gemm_set_dynamic", prev)
+    ops.set_dynamic(prev)
 c.close()
 print("COMM_BESIDE_GEMM_OK")
 """

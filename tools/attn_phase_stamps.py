@@ -5,6 +5,7 @@ import os, sys, ctypes as C
 os.environ["VP_ATTN_DBG"] = "1"
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, numpy as np
+os.environ.setdefault("VP_LIB_PATH", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "visper-lm_amd", "libvisper_hip_debug.so"))   # vp_debug_* live in the -DVP_DEBUG build
 from visper_lm_amd import ops, _lib
 B, Hq, Hkv, S, D = 8, 32, 8, 2048, 128
 qkv = torch.randn(B, S, (Hq + 2 * Hkv) * D, device="cuda", dtype=torch.bfloat16)

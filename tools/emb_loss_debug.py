@@ -2,6 +2,7 @@
 import math, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+os.environ.setdefault("VP_LIB_PATH", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "visper-lm_amd", "libvisper_hip_debug.so"))   # vp_debug_* live in the -DVP_DEBUG build
 from visper_lm_amd import ops, _lib
 import ctypes as C
 
@@ -33,7 +34,7 @@ for (B, world, rank, D) in ((2, 4, 2, 2304), (8, 1, 0, 1024), (3, 1, 0, 40960), 
         ws = torch.full((nws,), float("nan"), device="cuda")
         coef = torch.empty(2 * B + B * Bw + 1, device="cuda")
         out3 = torch.empty(3, device="cuda")
-        _lib.call("vp_emb_loss_fwd", B, Bw, D, rank, ops._p(pred), ops._p(tgt), ops._p(mask), ops._p(ls), 0.3, ops._p(out3), ops._p(coef), ops._p(ws), ops._stream())
+        _lib.call("vp_emb_loss_fwd", B, Bw, D, rank, ops._p(pred), ops._p(tgt), ops._p(mask), ops._p(ls), 0.3, ops._p(out3), ops._p(coef), ops._p(ws), ops._loss_counters(), ops._stream())
         torch.cuda.synchronize()
         fin = ws[njc * nblk * ns + njc * ngrp * ns:]
         if fin.numel() < B * Bw + Bw + 2 * B:          # LDS-resident finalize: the sums never reach the workspace

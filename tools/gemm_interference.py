@@ -3,6 +3,7 @@
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+os.environ.setdefault("VP_LIB_PATH", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "visper-lm_amd", "libvisper_hip_debug.so"))   # vp_debug_* live in the -DVP_DEBUG build
 from visper_lm_amd import ops
 
 M, N, K = 16384, 4096, 4096
@@ -29,9 +30,9 @@ def run(blocks, n=12):
 
 
 for dyn in (0, 1):
-    ops._lib.raw("vp_gemm_set_dynamic", dyn)
+    ops.set_dynamic(bool(dyn))
     base = run(0)
     for blocks in (8, 16, 32):
         ms = run(blocks)
         print(f"dynamic={dyn} occupied CUs={blocks:3d}: {ms:.3f} ms per GEMM ({ms / base:.2f}x of the undisturbed {base:.3f} ms)", flush=True)
-ops._lib.raw("vp_gemm_set_dynamic", 0)
+ops.set_dynamic(False)

@@ -2,6 +2,7 @@ import os, sys, ctypes as C
 sys.path.insert(0, "/root/repo")
 os.environ["VP_GEMM_DBG"] = str(0x10000 + int(sys.argv[1]) if len(sys.argv) > 1 else 0x10000)
 import torch, numpy as np
+os.environ.setdefault("VP_LIB_PATH", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "visper-lm_amd", "libvisper_hip_debug.so"))   # vp_debug_* live in the -DVP_DEBUG build
 from visper_lm_amd import ops, _lib
 lib = _lib.load()
 SH = [tuple(int(x) for x in a.split("x")) for a in os.environ.get("STAMP_SHAPES", "16384x28672x4096").split(",")]

@@ -167,6 +167,7 @@ static __device__ __forceinline__ f32x4 b64_aread() {
 template <int NOB>
 static __device__ __forceinline__ void b64_rope_issue(const float* cs, const float* sn, const uint32_t (&voff)[2]) {
   const fwdm_u32x4s rsC = attn_make_rs(cs, 0x7fffffff), rsS = attn_make_rs(sn, 0x7fffffff);
+  B64_FENCE();                                // voff (and anything else live here) cannot sit in v64..v191: the loads below overwrite them
   asm volatile("s_nop 4" ::: "memory");
   vp_static_for<2 * 2 * NOB>([&](auto i_) __attribute__((always_inline)) {
     constexpr int r = decltype(i_)::value / (2 * NOB), u = decltype(i_)::value % (2 * NOB);

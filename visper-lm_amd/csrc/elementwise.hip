@@ -233,6 +233,27 @@ __global__ void cast_bf16_to_f32_kernel(const bf16_t* __restrict__ x, float* __r
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
     y[i] = accumulate ? y[i] + bf2f(x[i]) : bf2f(x[i]);
 }
+// dst[idx[r], :] = float(src[r, :])  (idx NULL: r; idx < 0 skips the row): bf16 logits of a row chunk widened into their rows of the fp32
+// [B*S, V] tensor the reference's forward returns (ola_llama.py:121-122 `logits.float()`).  One wave per row, 16-byte loads, write-once
+// (non-temporal) 2 x 16-byte stores.  H % 8 == 0.
+__global__ __launch_bounds__(256) void scatter_rows_bf16_to_f32_kernel(const bf16_t* __restrict__ src, long lds, const int* __restrict__ idx,
+                                                                       float* __restrict__ dst, long ldd, long n, int H) {
+  const int lane = threadIdx.x & 63;
+  for (long r = blockIdx.x * 4L + (threadIdx.x >> 6); r < n; r += gridDim.x * 4L) {
+    const long t = idx ? (long)idx[r] : r;
+    if (t < 0) continue;
+    const bf16_t* s = src + r * lds;
+    float* d = dst + t * ldd;
+    for (int e = lane * 8; e < H; e += 512) {
+      const bf16x8 v = __builtin_nontemporal_load((const bf16x8*)(s + e));
+      const f32x4 lo = {bf2f((bf16_t)v[0]), bf2f((bf16_t)v[1]), bf2f((bf16_t)v[2]), bf2f((bf16_t)v[3])};
+      const f32x4 hi = {bf2f((bf16_t)v[4]), bf2f((bf16_t)v[5]), bf2f((bf16_t)v[6]), bf2f((bf16_t)v[7])};
+      __builtin_nontemporal_store(lo, (f32x4*)(d + e));
+      __builtin_nontemporal_store(hi, (f32x4*)(d + e + 4));
+    }
+  }
+}
+
 // deterministic sum of n floats -> out[0] (single block; n is small: per-row losses / partials)
 __global__ __launch_bounds__(1024) void sum_f32_kernel(const float* __restrict__ x, float* __restrict__ out, long n, float scale) {
   __shared__ float red[16];
@@ -497,6 +518,13 @@ int vp_cast_bf16_to_f32(long n, const void* x, float* y, int accumulate, hipStre
   VP_REQUIRE(n > 0, VP_ERR_BAD_ARG, "vp_cast_bf16_to_f32: bad n");
   hipLaunchKernelGGL(cast_bf16_to_f32_kernel, GRID_FOR(n), dim3(256), 0, s, (const bf16_t*)x, y, n, accumulate);
   return vp_check_launch("vp_cast_bf16_to_f32");
+}
+
+int vp_scatter_rows_bf16_to_f32(long n, int H, const void* src, long lds, const int* idx, float* dst, long ldd, hipStream_t s) {
+  VP_REQUIRE(n > 0 && H > 0 && H % 8 == 0 && lds % 8 == 0 && ldd % 4 == 0 && src && dst, VP_ERR_BAD_ARG, "vp_scatter_rows_bf16_to_f32: bad args");
+  hipLaunchKernelGGL(scatter_rows_bf16_to_f32_kernel, dim3((unsigned)min(8192L, (n + 3) / 4)), dim3(256), 0, s, (const bf16_t*)src, lds, idx, dst,
+                     ldd, n, H);
+  return vp_check_launch("vp_scatter_rows_bf16_to_f32");
 }
 
 int vp_sum_f32(long n, const float* x, float* out, float scale, hipStream_t s) {

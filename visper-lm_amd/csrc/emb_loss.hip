@@ -19,7 +19,6 @@
 #include "common.h"
 #include <type_traits>
 #include <stdlib.h>
-#include <mutex>
 
 namespace {
 
@@ -28,10 +27,9 @@ namespace {
 #endif
 constexpr int G1 = EL_G1;              // blocks per first-level reduction group (and the most groups the second level sums per chunk)
 constexpr int MAX_GROUPS = 1024;       // njc * ngrp
-constexpr int N_SLOTS = 32;            // independent counter sets, one per DISTINCT stream (el_slot_for: a registry, not a hash, so two streams
-                                       // can never share tickets); calls on one stream are ordered by the stream itself
 constexpr int MAX_TASKS = 8;           // distillation heads batched into one launch (vp_emb_loss_fwd_multi: blockIdx.z = task)
-__device__ unsigned g_counters[N_SLOTS][MAX_TASKS][1 + MAX_GROUPS];   // zero at module load; every launch leaves its slot zeroed again
+// Ticket counters of the "last block done" tree: MAX_TASKS x (1 + MAX_GROUPS) unsigned in a CALLER-owned block (`counters`,
+// vp_emb_loss_counter_bytes()), zeroed once by the caller; every launch leaves it zeroed again.  The library owns no device memory.
 
 struct ElArgs {
   const bf16_t* pred;
@@ -44,7 +42,8 @@ struct ElArgs {
   float* part2;      // [njc][ngrp][NS]
   float* fin;        // PT[B][Bw] | TT[Bw] | PP[B] | SL[B]
   long D;
-  int B, Bw, rank, nblk, njc, ngrp, slot, task;
+  int B, Bw, rank, nblk, njc, ngrp, task;
+  unsigned* cnt;     // this task's ticket counters: [1 + MAX_GROUPS], zero on entry, zero on exit
   float w_con;
   long long* dbg;    // dev aid: 8 wall-clock stamps (100 MHz) of the finishing block, or null
 };
@@ -417,7 +416,7 @@ __device__ __forceinline__ void emb_loss_fwd_body(const ElMulti mt) {
   // write-through `sc0 sc1` stores, every wave drains its own stores with an EXPLICIT s_waitcnt vmcnt(0) (inline asm: not left to what the
   // compiler happens to emit for __syncthreads), the workgroup barrier collects the waves, and only then one lane takes the agent-scope
   // ticket; the reducer reads the partials with `sc0 sc1` loads that bypass its L1 and the (non-coherent) L2 lines.
-  unsigned* cnt = g_counters[a.slot][a.task];
+  unsigned* cnt = a.cnt;
   const int grp = bx / G1, gsz = min(G1, a.nblk - grp * G1);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -589,55 +588,6 @@ struct ElPlan {
   bool pack;
 };
 
-// One ticket-counter set per distinct stream (a registry, not a hash: two live streams never share a set).  N_SLOTS sets exist; when a 33rd
-// stream shows up the least recently used set is re-assigned to it (the registry used to fill up for good — short-lived streams,
-// graph-capture streams and torch's stream pools reach 32 — and every later call failed).  A set is only handed on after the last launch
-// that used it has finished: each launch records a fence event behind itself (el_slot_done) and eviction waits for it on the host (the rare
-// path; ~never blocks, that launch is >= 31 other streams' launches old).  A destroyed stream whose handle value is reused simply finds its
-// old set again — harmless for the same reason (every launch leaves its counters zeroed).
-struct ElSlot { hipStream_t stream; hipEvent_t fence; unsigned long tick; bool used; int busy; bool pinned; };
-static std::mutex g_slot_mu;
-static ElSlot g_slots[N_SLOTS];
-static unsigned long g_slot_tick = 0;
-// A set is HELD (busy > 0) from el_slot_for until the fence behind its launch is recorded (el_slot_done), so a second thread can never evict it
-// in that window and wait on a stale / never-recorded event; a set whose last launch was captured into a graph is pinned for good
-// (no host-visible fence exists for replays).  -2: every set is held or pinned.
-int el_slot_for(hipStream_t s) {
-  std::lock_guard<std::mutex> lk(g_slot_mu);
-  int free_id = -1, lru = -1;
-  for (int i = 0; i < N_SLOTS; ++i) {
-    if (g_slots[i].used && g_slots[i].stream == s) { g_slots[i].tick = ++g_slot_tick; ++g_slots[i].busy; return i; }
-    if (!g_slots[i].used && free_id < 0) free_id = i;
-    if (g_slots[i].used && g_slots[i].busy == 0 && !g_slots[i].pinned && (lru < 0 || g_slots[i].tick < g_slots[lru].tick)) lru = i;
-  }
-  int id = free_id;
-  if (id < 0) {                                                    // evict: wait until the set's last launch is done, then hand it on
-    if (lru < 0) return -2;
-    id = lru;
-    if (g_slots[id].fence && hipEventSynchronize(g_slots[id].fence) != hipSuccess) (void)hipGetLastError();
-  } else if (hipEventCreateWithFlags(&g_slots[id].fence, hipEventDisableTiming) != hipSuccess) {
-    g_slots[id].fence = nullptr;
-    (void)hipGetLastError();
-    return -1;
-  }
-  g_slots[id].stream = s; g_slots[id].used = true; g_slots[id].tick = ++g_slot_tick; g_slots[id].busy = 1; g_slots[id].pinned = false;
-  return id;
-}
-void el_slot_done(int id, hipStream_t s, bool launched) {           // fence behind the launch that just used set `id`, then release the hold
-  std::lock_guard<std::mutex> lk(g_slot_mu);
-  if (launched) {
-    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(s, &cap) != hipSuccess) { (void)hipGetLastError(); cap = hipStreamCaptureStatusNone; }
-    if (cap != hipStreamCaptureStatusNone) g_slots[id].pinned = true;      // inside a graph capture: replays own this set from now on
-    else if (g_slots[id].fence && hipEventRecord(g_slots[id].fence, s) != hipSuccess) (void)hipGetLastError();
-  }
-  if (g_slots[id].busy > 0) --g_slots[id].busy;
-}
-struct ElSlotHold {                                                 // releases the hold on every exit path of the launcher
-  int id; hipStream_t s; bool launched;
-  ~ElSlotHold() { if (id >= 0) el_slot_done(id, s, launched); }
-};
-
 ElPlan el_plan(int B, int Bw, long D) {
   ElPlan p;
   p.npb = B <= 16 ? 1 : (B <= 32 ? 2 : 4);
@@ -671,7 +621,9 @@ void el_launch(int ng, dim3 grid, hipStream_t s, const ElMulti& a) {
 
 }  // namespace
 
+#ifdef VP_DEBUG
 long long* g_dbg = nullptr;
+#endif
 
 extern "C" {
 
@@ -679,6 +631,9 @@ extern "C" {
 #ifdef VP_DEBUG
 int vp_debug_emb_loss_stamps(long long* dev_buf) { g_dbg = dev_buf; return VP_OK; }
 #endif
+
+// bytes of the caller-owned ticket-counter block of vp_emb_loss_fwd / _fwd_multi (zeroed once; left zeroed by every launch)
+long vp_emb_loss_counter_bytes(void) { return (long)MAX_TASKS * (1 + MAX_GROUPS) * sizeof(unsigned); }
 
 // fp32 workspace of vp_emb_loss_fwd, in floats: per-block partials + group partials + final statistics (contents need not be
 // initialised; nothing is kept between calls).
@@ -693,16 +648,12 @@ long vp_emb_loss_workspace(int B, int Bw, long D) {
 // (base_ola_vlm.py:445-534); batching them turns 2 x ntask tiny launches per step into 2, and a single launch streams all heads' bytes.
 int vp_emb_loss_fwd_multi(int ntask, int B, int Bw, const long* D, int rank, const void* const* pred, const void* const* tgt_all,
                           const float* const* mask, const float* const* logit_scale, const float* w_contrastive, float* const* out3,
-                          float* const* coef, float* const* workspace, hipStream_t s) {
-  VP_REQUIRE(ntask >= 1 && ntask <= MAX_TASKS && D && pred && tgt_all && mask && logit_scale && w_contrastive && out3 && coef && workspace,
-             VP_ERR_BAD_ARG, "vp_emb_loss_fwd_multi: 1 <= ntask <= %d and non-null arrays", MAX_TASKS);
+                          float* const* coef, float* const* workspace, unsigned* counters, hipStream_t s) {
+  VP_REQUIRE(ntask >= 1 && ntask <= MAX_TASKS && D && pred && tgt_all && mask && logit_scale && w_contrastive && out3 && coef && workspace && counters,
+             VP_ERR_BAD_ARG, "vp_emb_loss_fwd_multi: 1 <= ntask <= %d and non-null arrays / counters", MAX_TASKS);
   VP_REQUIRE(B > 0 && B <= 64 && Bw >= B && Bw <= 1024, VP_ERR_UNSUPPORTED_SHAPE,
              "vp_emb_loss_fwd: need 0<B<=64, B<=Bw<=1024 (got B=%d Bw=%d)", B, Bw);
   VP_REQUIRE(rank >= 0 && (long)(rank + 1) * B <= Bw, VP_ERR_BAD_ARG, "vp_emb_loss_fwd: rank/B/Bw mismatch");
-  const int slot = el_slot_for(s);
-  VP_REQUIRE(slot >= 0, VP_ERR_HIP, slot == -2 ? "vp_emb_loss_fwd: all %d ticket-counter sets are in use by concurrent launches / captured graphs"
-                                               : "vp_emb_loss_fwd: could not create the fence event of a ticket-counter set (of %d)", N_SLOTS);
-  ElSlotHold hold{slot, s, false};
   ElMulti m;
   ElPlan p0 = el_plan(B, Bw, D[0] > 0 ? D[0] : 8);
   int gx = 0;
@@ -719,9 +670,13 @@ int vp_emb_loss_fwd_multi(int ntask, int B, int Bw, const long* D, int rank, con
     a.part2 = a.part + (long)p.njc * p.nblk * p.ns;
     a.fin = a.part2 + (long)p.njc * p.ngrp * p.ns;
     a.D = D[t]; a.B = B; a.Bw = Bw; a.rank = rank; a.nblk = p.nblk; a.njc = p.njc; a.ngrp = p.ngrp;
-    a.slot = slot; a.task = t;
+    a.task = t; a.cnt = counters + (long)t * (1 + MAX_GROUPS);
     a.w_con = w_contrastive[t];
+#ifdef VP_DEBUG
     a.dbg = t == 0 ? g_dbg : nullptr;
+#else
+    a.dbg = nullptr;
+#endif
     gx = p.nblk > gx ? p.nblk : gx;
     p0 = p;
   }
@@ -730,16 +685,16 @@ int vp_emb_loss_fwd_multi(int ntask, int B, int Bw, const long* D, int rank, con
   else if (p0.npb == 1) el_launch<1>(p0.ng, grid, s, m);
   else if (p0.npb == 2) el_launch<2>(p0.ng, grid, s, m);
   else el_launch<4>(p0.ng, grid, s, m);
-  hold.launched = true;
   return vp_check_launch("vp_emb_loss_fwd");
 }
 
 int vp_emb_loss_fwd(int B, int Bw, long D, int rank, const void* pred, const void* tgt_all, const float* mask,
-                    const float* logit_scale, float w_contrastive, float* out3, float* coef, float* workspace, hipStream_t s) {
+                    const float* logit_scale, float w_contrastive, float* out3, float* coef, float* workspace, unsigned* counters,
+                    hipStream_t s) {
   VP_REQUIRE(B > 0 && B <= 64 && Bw >= B && Bw <= 1024, VP_ERR_UNSUPPORTED_SHAPE,
              "vp_emb_loss_fwd: need 0<B<=64, B<=Bw<=1024 (got B=%d Bw=%d)", B, Bw);
   VP_REQUIRE(pred && tgt_all && mask && out3 && coef && workspace, VP_ERR_BAD_ARG, "vp_emb_loss_fwd: null pointer");
-  return vp_emb_loss_fwd_multi(1, B, Bw, &D, rank, &pred, &tgt_all, &mask, &logit_scale, &w_contrastive, &out3, &coef, &workspace, s);
+  return vp_emb_loss_fwd_multi(1, B, Bw, &D, rank, &pred, &tgt_all, &mask, &logit_scale, &w_contrastive, &out3, &coef, &workspace, counters, s);
 }
 
 int vp_emb_loss_bwd_multi(int ntask, int B, int Bw, const long* D, int rank, const void* const* pred, const void* const* tgt_all,

@@ -14,8 +14,6 @@
 // ends up with 4 consecutive output columns of one token row.  Block ids are remapped XCD-aware so tiles sharing an operand
 // panel sit in one XCD's L2.
 #include "common.h"
-#include <mutex>
-#include <unordered_map>
 #include <cstdlib>
 #include <utility>
 #include <type_traits>
@@ -1118,7 +1116,7 @@ __global__ __launch_bounds__(512) void gemm_nt_256p8(GemmArgs p) {
     // per-XCD counter, so tile v still runs on XCD v & 7 and the super-block walk keeps its L2 residency.  The claim for the NEXT tile is made
     // here, at the start of the current one; every wave reads it a K loop (many barriers) later.
     if (dyn && tid == 0) {
-      const int kq = atomicAdd(p.sched + (blockIdx.x & 7), 1);
+      const int kq = 32 + atomicAdd(p.sched + (blockIdx.x & 7), 1);      // (counters rest at 0: the first 32 tiles of an XCD are the blocks' static ones)
       s_next = (kq >> 5) * 256 + (kq & 31) * 8 + (int)(blockIdx.x & 7);
     }
     for (int t = 0; t < nt; ++t) {
@@ -1235,7 +1233,7 @@ __global__ __launch_bounds__(512) void gemm_nt_256p8(GemmArgs p) {
     __threadfence();
     if (atomicAdd(p.sched + 8, 1) == (int)gridDim.x - 1) {
 #pragma unroll
-      for (int x = 0; x < 8; ++x) p.sched[x] = 32;
+      for (int x = 0; x < 8; ++x) p.sched[x] = 0;
       p.sched[8] = 0;
       __threadfence();
     }
@@ -1389,7 +1387,7 @@ __global__ __launch_bounds__(512) void gemm_tn_256p8(GemmArgs p) {
     const TileCoord tcur = tc;
     int vnext = v + gridDim.x;
     if (dyn && tid == 0) {                               // dynamic per-XCD tile claim for the NEXT tile (see gemm_nt_256p8)
-      const int kq = atomicAdd(p.sched + (blockIdx.x & 7), 1);
+      const int kq = 32 + atomicAdd(p.sched + (blockIdx.x & 7), 1);      // (counters rest at 0: the first 32 tiles of an XCD are the blocks' static ones)
       s_next = (kq >> 5) * 256 + (kq & 31) * 8 + (int)(blockIdx.x & 7);
     }
     for (int t = 0; t < nt; ++t) {
@@ -1485,7 +1483,7 @@ __global__ __launch_bounds__(512) void gemm_tn_256p8(GemmArgs p) {
     __threadfence();
     if (atomicAdd(p.sched + 8, 1) == (int)gridDim.x - 1) {
 #pragma unroll
-      for (int x = 0; x < 8; ++x) p.sched[x] = 32;
+      for (int x = 0; x < 8; ++x) p.sched[x] = 0;
       p.sched[8] = 0;
       __threadfence();
     }
@@ -1884,31 +1882,15 @@ __global__ __launch_bounds__(256) void transpose_bf16_kernel(const bf16_t* in, b
   }
 }
 
-// Dynamic tile scheduling of the persistent 8-phase kernel: off by default (single GPU: nothing else runs beside the GEMMs), switched on by
-// vp_gemm_set_dynamic(1) / VP_GEMM_DYN=1 when collectives run concurrently.  One 9-int counter block per stream, created on first use (the
-// only device memory the library owns); the kernel re-arms it itself, so launches on one stream need no host work in between.
+// Dynamic tile scheduling of the persistent 8-phase kernels: a launch claims its tiles from per-XCD counters when the caller hands it a
+// counter block (`sched_ws`: 16 ints of caller-owned device memory, zeroed once; the kernel leaves it zeroed, so back-to-back launches on one
+// stream share one block), else the static round-robin walk.  The library owns no device memory and keeps no pointer (SURVEY 8b "Ownership").
 __global__ void occupy_kernel(long cycles) {
   extern __shared__ unsigned char occ_lds[];
   occ_lds[threadIdx.x] = 1;
   const long t0 = clock64();
   while (clock64() - t0 < cycles) __builtin_amdgcn_s_sleep(8);
   if (occ_lds[threadIdx.x] == 77) occ_lds[0] = 2;
-}
-static int g_dyn_mode = -1;
-static int* vp_sched_for(hipStream_t s) {
-  if (g_dyn_mode < 0) { const char* v = getenv("VP_GEMM_DYN"); g_dyn_mode = v ? atoi(v) : 0; }
-  if (!g_dyn_mode) return nullptr;
-  static std::mutex mu;
-  static std::unordered_map<hipStream_t, int*> tab;
-  std::lock_guard<std::mutex> lk(mu);
-  auto it = tab.find(s);
-  if (it != tab.end()) return it->second;
-  int* d = nullptr;
-  if (hipMalloc(&d, 9 * sizeof(int)) != hipSuccess) return nullptr;
-  const int init[9] = {32, 32, 32, 32, 32, 32, 32, 32, 0};
-  if (hipMemcpy(d, init, sizeof(init), hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(d); return nullptr; }
-  tab[s] = d;
-  return d;
 }
 
 static bool vp_c_nt_enabled() {                        // VP_GEMM_C_NT=0 switches the non-temporal C stores off (A/B)
@@ -1927,13 +1909,7 @@ static bool vp_ph4_enabled() {
 
 extern "C" {
 
-// 1: the persistent GEMM claims its tiles dynamically (per-XCD counters) so that CUs held by a concurrent kernel (RCCL) only cost their own
-// share; 0: static assignment (default).  Returns the previous setting.
-int vp_gemm_set_dynamic(int on) {
-  const int prev = g_dyn_mode > 0 ? 1 : 0;
-  g_dyn_mode = on ? 1 : 0;
-  return prev;
-}
+long vp_gemm_sched_workspace_bytes(void) { return 64; }
 
 #ifdef VP_DEBUG
 // dev aid (tools/gemm_interference.py): `blocks` workgroups that each pin 64 KB of LDS (so no 8-phase GEMM block fits beside them) and spin
@@ -1947,11 +1923,15 @@ int vp_debug_occupy(int blocks, long cycles, hipStream_t stream) {
 }
 #endif
 
-static int g_gemm_dbg = -1;                           // VP_GEMM_DBG, or vp_debug_gemm_flags()
+#ifdef VP_DEBUG
+static int g_gemm_dbg = -1;                           // VP_GEMM_DBG, or vp_debug_gemm_flags(): measurement flags exist in -DVP_DEBUG builds only
 static int vp_gemm_dbg() {
   if (g_gemm_dbg < 0) { const char* e = getenv("VP_GEMM_DBG"); g_gemm_dbg = e ? atoi(e) : 0; }
   return g_gemm_dbg;
 }
+#else
+static constexpr int vp_gemm_dbg() { return 0; }      // the sealed library reads no debug switch (a stray VP_GEMM_DBG cannot reach a kernel)
+#endif
 #ifdef VP_DEBUG
 // measurement aid (bench.py: shader clock under load): 0x10000 = the persistent kernel's first tile writes wall-clock / shader-cycle stamps
 int vp_debug_gemm_flags(int flags) { g_gemm_dbg = flags; return 0; }
@@ -1962,7 +1942,7 @@ int vp_debug_stamps(long* host) {
 #endif
 
 int vp_gemm_bf16(int M, int N, int K, const void* A, long lda, const void* B, long ldb, void* C, long ldc,
-                 const void* bias, const void* residual, long ldr, int epilogue, int out_f32, int force_generic,
+                 const void* bias, const void* residual, long ldr, int epilogue, int out_f32, int force_generic, int* sched_ws,
                  hipStream_t stream) {
   VP_REQUIRE(M > 0 && N > 0 && K > 0, VP_ERR_BAD_ARG, "vp_gemm_bf16: non-positive dims %d %d %d", M, N, K);
   VP_REQUIRE(A && B && C, VP_ERR_BAD_ARG, "vp_gemm_bf16: null operand");
@@ -1988,7 +1968,7 @@ int vp_gemm_bf16(int M, int N, int K, const void* A, long lda, const void* B, lo
     // (tools/gemm_interference.py: up to 1.45x for the launches that overlap a collective); in the PT step that is the handful of GEMMs under the
     // 0.2 GB gradient all-reduce, against 6-10 % on every launch with the 8-phase kernel and its per-XCD tile claims — so the multi-GPU step uses
     // it too (VP_GEMM_W4=0 / VP_GEMM_W4=2 "only when no collective can run beside it" select the 8-phase kernel).
-    if (w4_ok && (force_generic == 8 || (force_generic == 0 && (w4_env == 1 || (w4_env == 2 && g_dyn_mode != 1))))) {
+    if (w4_ok && (force_generic == 8 || (force_generic == 0 && (w4_env == 1 || (w4_env == 2 && !sched_ws))))) {
       p.c_nt = (!out_f32 && N <= 8192 && vp_c_nt_enabled()) ? 1 : 0;
       static bool attr_w4 = false;
       if (!attr_w4) {
@@ -2034,7 +2014,7 @@ int vp_gemm_bf16(int M, int N, int K, const void* A, long lda, const void* B, lo
     // persistent (one block per CU streaming its output tiles) when the K-tile count is even (buffer parity is then the same
     // for every output tile); otherwise one block per output tile
     const unsigned g8 = (unsigned)(((K / 64) % 2 == 0 && big_tiles > 256 && !(p.dbg & 0x20000)) ? 256 : big_tiles);
-    if (g8 == 256) p.sched = vp_sched_for(stream);
+    if (g8 == 256) p.sched = sched_ws;
     p.c_nt = (!out_f32 && N <= 8192 && (long)M * ldc * 2 < 0x7fffffffL && vp_c_nt_enabled()) ? 1 : 0;
     if (out_f32) hipLaunchKernelGGL(gemm_nt_256p8<true>, dim3(g8), dim3(512), 131072, stream, p);
     else if (vp_ph4_enabled() && force_generic == 0) {
@@ -2129,7 +2109,7 @@ int vp_gemm_bf16_rope(int M, int N, int K, const void* A, long lda, const void* 
 //   mode 2 (backward): d_act[M,N] = A B^T stays on chip; aux = gate_up[M,2N]; C[M,2N] = d_gate_up  (C2 unused)
 // Only the 8-phase kernel implements these epilogues: M, N multiples of 256, K a multiple of 64, 16-byte aligned rows.
 int vp_gemm_bf16_swiglu(int mode, int M, int N, int K, const void* A, long lda, const void* B, long ldb, void* C, long ldc,
-                        void* C2, long ldc2, const void* aux, long ldaux, hipStream_t stream) {
+                        void* C2, long ldc2, const void* aux, long ldaux, int* sched_ws, hipStream_t stream) {
   VP_REQUIRE(mode == 1 || mode == 2, VP_ERR_BAD_ARG, "vp_gemm_bf16_swiglu: mode %d", mode);
   VP_REQUIRE(M > 0 && N > 0 && K > 0 && A && B && C, VP_ERR_BAD_ARG, "vp_gemm_bf16_swiglu: bad operands");
   VP_REQUIRE(M % 256 == 0 && N % 256 == 0 && K % 64 == 0, VP_ERR_UNSUPPORTED_SHAPE,
@@ -2154,7 +2134,7 @@ int vp_gemm_bf16_swiglu(int mode, int M, int N, int K, const void* A, long lda, 
   {
     static int w4_env = -1;
     if (w4_env < 0) { const char* e = getenv("VP_GEMM_W4"); w4_env = e ? atoi(e) : 1; }
-    if ((w4_env == 1 || (w4_env == 2 && g_dyn_mode != 1)) && K % 128 == 0 && big_tiles >= 192 && ldc < (1L << 21) && ldc2 < (1L << 21) && ldaux < (1L << 21)) {   // same routing as vp_gemm_bf16
+    if ((w4_env == 1 || (w4_env == 2 && !sched_ws)) && K % 128 == 0 && big_tiles >= 192 && ldc < (1L << 21) && ldc2 < (1L << 21) && ldaux < (1L << 21)) {   // same routing as vp_gemm_bf16
       static bool attr_w4 = false;
       if (!attr_w4) {
         (void)hipFuncSetAttribute((const void*)gemm_nt_256w4<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
@@ -2178,7 +2158,7 @@ int vp_gemm_bf16_swiglu(int mode, int M, int N, int K, const void* A, long lda, 
     attr_p8 = true;
   }
   const unsigned g8 = (unsigned)(((K / 64) % 2 == 0 && big_tiles > 256) ? 256 : big_tiles);
-  if (g8 == 256) p.sched = vp_sched_for(stream);
+  if (g8 == 256) p.sched = sched_ws;
   if (vp_ph4_enabled()) {
     static bool attr_p4 = false;
     if (!attr_p4) {
@@ -2195,7 +2175,7 @@ int vp_gemm_bf16_swiglu(int mode, int M, int N, int K, const void* A, long lda, 
 // only: M, N multiples of 256, K a multiple of 64, 16-byte aligned rows; anything else is VP_ERR_UNSUPPORTED_SHAPE (the caller then
 // transposes and uses vp_gemm_bf16).  accumulate != 0 (fp32 output only) adds into C.
 int vp_gemm_tn_bf16(int M, int N, int K, const void* A, long lda, const void* B, long ldb, void* C, long ldc, int out_f32,
-                    int accumulate, hipStream_t stream) {
+                    int accumulate, int* sched_ws, hipStream_t stream) {
   VP_REQUIRE(M > 0 && N > 0 && K > 0 && A && B && C, VP_ERR_BAD_ARG, "vp_gemm_tn_bf16: bad operands");
   VP_REQUIRE(M % 256 == 0 && N % 256 == 0 && K % 64 == 0, VP_ERR_UNSUPPORTED_SHAPE,
              "vp_gemm_tn_bf16: needs M, N multiples of 256 and K a multiple of 64 (got %d %d %d)", M, N, K);
@@ -2213,7 +2193,7 @@ int vp_gemm_tn_bf16(int M, int N, int K, const void* A, long lda, const void* B,
   }
   const long big_tiles = (long)(M / 256) * (N / 256);
   const unsigned g8 = (unsigned)(((K / 64) % 2 == 0 && big_tiles > 256) ? 256 : big_tiles);
-  if (g8 == 256) p.sched = vp_sched_for(stream);
+  if (g8 == 256) p.sched = sched_ws;
   if (out_f32) hipLaunchKernelGGL(gemm_tn_256p8<true>, dim3(g8), dim3(512), 131072, stream, p);
   else hipLaunchKernelGGL(gemm_tn_256p8<false>, dim3(g8), dim3(512), 131072, stream, p);
   return vp_check_launch("vp_gemm_tn_bf16");

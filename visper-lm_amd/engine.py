@@ -174,6 +174,7 @@ class Engine:
         self._red = None
         self.comm = None       # parallel.NativeComm when the C ABI's own communicator carries the collectives (set_distributed)
         self.keep_logits = False
+        self.lm_head_all_rows = False # True: no labelled-row compaction — every row through lm_head + CE + the d_hidden GEMM, literally as ola_llama.py:121-136 (A/B + test aid)
         self.keep_states = False      # True: train_step also returns every decoder-layer state (HF `hidden_states`: embeddings, layer outputs, final norm)
 
     def _load_frozen_decoder(self, W, d):
@@ -416,7 +417,7 @@ class Engine:
         # with collectives running beside the GEMMs the persistent kernel claims its tiles dynamically (a CU held by an RCCL kernel then
         # costs its own share instead of stalling the whole static grid); single GPU keeps the static walk
         if self.dev.type == "cuda" and os.environ.get("VP_GEMM_DYN") is None:
-            ops._lib.raw("vp_gemm_set_dynamic", 1 if world > 1 else 0)
+            ops.set_dynamic(world > 1)
 
     def _reducer(self):
         from .parallel import GradReducer
@@ -721,12 +722,21 @@ class Engine:
         # loss, zero d_logits, never scattered back) so that every chunk of the two vocabulary-wide GEMMs takes the aligned 4-wave kernel
         ce_labels = hp["ce_labels"]
         n_ce = int(tabs["ce_rows"].size)
+        tabs = dict(tabs, ce_dst=tabs["ce_rows"], un_kind=np.zeros(tabs["un_rows"].size, np.int32), un_dst=tabs["un_rows"])
         if n_ce >= 512 and n_ce % 256:
             pad = 256 - n_ce % 256
             tabs = dict(tabs, ce_rows=np.concatenate([tabs["ce_rows"], np.zeros(pad, np.int32)]),
-                        ce_kind=np.concatenate([tabs["ce_kind"], np.full(pad, -1, np.int32)]))
+                        ce_kind=np.concatenate([tabs["ce_kind"], np.full(pad, -1, np.int32)]),
+                        ce_dst=np.concatenate([tabs["ce_dst"], np.full(pad, -1, np.int32)]))
             ce_labels = np.concatenate([ce_labels, np.full(pad, IGNORE_INDEX, ce_labels.dtype)])
             n_ce += pad
+        n_un = int(tabs["un_rows"].size)                              # same padding for the label-less rows' forward-only lm_head pass (keep_logits)
+        if n_un >= 512 and n_un % 256:
+            pad = 256 - n_un % 256
+            tabs = dict(tabs, un_rows=np.concatenate([tabs["un_rows"], np.zeros(pad, np.int32)]),
+                        un_kind=np.concatenate([tabs["un_kind"], np.full(pad, -1, np.int32)]),
+                        un_dst=np.concatenate([tabs["un_dst"], np.full(pad, -1, np.int32)]))
+            n_un += pad
         offs, tot = {}, 0
         for name, a in tabs.items():
             offs[name] = (tot, a.size)
@@ -738,13 +748,14 @@ class Engine:
             hv[o:o + n] = a.reshape(-1)
         devbuf = host.to(self.dev, non_blocking=True)
         M = plan["B"] * plan["S"]
-        plan["n_ce"] = n_ce
+        plan["n_ce"], plan["n_un"] = n_ce, n_un
         shift_h = torch.from_numpy(np.concatenate([hp["shift_labels"], ce_labels])).pin_memory()
         plan["_host_bufs"] = (host, shift_h)                          # keep the pinned sources alive until the async copies ran
         shift_d = shift_h.to(self.dev, non_blocking=True)
         plan["shift_labels"], plan["ce_labels"] = shift_d[:M], shift_d[M:]
         view = lambda name: devbuf[offs[name][0]:offs[name][0] + offs[name][1]]
-        for name in ("kind", "row", "lens", "img_dst", "tok_src", "embed_idx", "ce_rows", "ce_inv", "ce_kind", "ce_inv_kind"):
+        for name in ("kind", "row", "lens", "img_dst", "tok_src", "embed_idx", "ce_rows", "ce_inv", "ce_kind", "ce_inv_kind", "ce_dst", "un_rows",
+                     "un_kind", "un_dst"):
             plan[name] = view(name)
         plan["present"] = (view("present_kind"), view("present")) if "present" in offs else None
         heads = hp["heads"]
@@ -1039,16 +1050,19 @@ class Engine:
         return best[1]
 
     def _ntp(self, hidden, plan, compute_grads, out):
-        """a7: lm_head + NTP loss (ola_llama.py:121-136), row-chunked; dlogits -> d_hidden in the same sweep.  Unless the caller wants the
-        logits, only the rows that carry a label go through the two vocabulary-wide GEMMs and the cross-entropy (the others have zero loss
-        and zero d_logits): their hidden rows are compacted by one row gather, and d_hidden is scattered back with zeros elsewhere.
-        Returns (text_loss, d_hidden or None)."""
+        """a7: lm_head + NTP loss (ola_llama.py:121-136), row-chunked; dlogits -> d_hidden in the same sweep.  Only the rows that carry a
+        label go through the two vocabulary-wide GEMMs and the cross-entropy (the others have zero loss and zero d_logits): their hidden rows
+        are compacted by one row gather, and d_hidden is scattered back with zeros elsewhere.  When the caller wants the reference's `logits`
+        (keep_logits; ola_llama.py:121-122: `lm_head(hidden_states).float()` of EVERY row) each chunk's bf16 logits are widened straight into
+        their rows of ONE fp32 [B, S, V] tensor before the cross-entropy overwrites them, and the label-less rows take a forward-only lm_head
+        pass (no CE, no d_hidden GEMM) into the same tensor.  Returns (text_loss, d_hidden or None)."""
         fz, ps, dev = self.fz, self.ps, self.dev
         H = self.cfg.hidden_size
         M = plan["B"] * plan["S"]
         n_valid = plan["n_valid"]
         gscale = 1.0 / n_valid if n_valid > 0 else float("nan")
-        compact = (not self.keep_logits) and 0 < n_valid < M
+        direct = self.keep_logits and plan["present"] is None     # (ragged LEFT padding re-lays the rows for presentation: old cat + gather path)
+        compact = 0 < n_valid < M and (direct or not self.keep_logits) and not self.lm_head_all_rows
         if compact:
             Mc = plan["n_ce"]                                    # n_valid rounded up to whole 256-row tiles (pad rows: zeros, label -100)
             h_ce = torch.empty(Mc, H, device=dev, dtype=BF16)
@@ -1058,13 +1072,16 @@ class Engine:
             h_ce, lab_ce, Mc = hidden, plan["shift_labels"], M
         d_hce = torch.empty(Mc, H, device=dev, dtype=BF16) if compute_grads else None
         row_loss = torch.empty(Mc, device=dev, dtype=F32)
-        logits_keep = [] if self.keep_logits else None
+        logits_keep = [] if (self.keep_logits and not direct) else None
+        logits_f32 = torch.empty(M, fz["lm_head"].shape[0], device=dev, dtype=F32) if direct else None
         R = self._lm_chunk(Mc, H)
         for r0 in range(0, Mc, R):
             r1 = min(Mc, r0 + R)
             lg = ops.gemm(h_ce[r0:r1], fz["lm_head"])
             if logits_keep is not None:
                 logits_keep.append(lg.clone())
+            if direct:
+                ops.scatter_rows_to_f32(lg, plan["ce_dst"][r0:r1], logits_f32) if compact else ops.scatter_rows_to_f32(lg, None, logits_f32[r0:r1])
             ops.ce_fwd_bwd(lg, lab_ce[r0:r1], gscale, write_grad=compute_grads, out=row_loss[r0:r1])
             if compute_grads:
                 ops.gemm(lg, fz["lm_head_T"], out=d_hce[r0:r1])
@@ -1076,8 +1093,17 @@ class Engine:
             ops.gather_rows([d_hce], plan["ce_inv_kind"], plan["ce_inv"], H, d_hidden)        # rows without a label: zeros
         text_loss = ops.sum_f32(row_loss, gscale)
         out["text_loss"] = text_loss
-        if logits_keep is not None:
-            out["logits"] = self.present(torch.cat(logits_keep, 0), plan)
+        if direct and compact and plan["n_un"] > 0:           # label-less rows: lm_head forward only
+            Mu = plan["n_un"]
+            h_un = torch.empty(Mu, H, device=dev, dtype=BF16)
+            ops.gather_rows([hidden], plan["un_kind"], plan["un_rows"], H, h_un)
+            for r0 in range(0, Mu, self.lm_chunk_rows):
+                r1 = min(Mu, r0 + self.lm_chunk_rows)
+                ops.scatter_rows_to_f32(ops.gemm(h_un[r0:r1], fz["lm_head"]), plan["un_dst"][r0:r1], logits_f32)
+        if direct:
+            out["logits"] = logits_f32.view(plan["B"], plan["S"], -1)
+        elif logits_keep is not None:
+            out["logits"] = self.present(torch.cat(logits_keep, 0), plan).float()
         return text_loss, d_hidden
 
     def _heads(self, states, plan, batch, compute_grads, out):

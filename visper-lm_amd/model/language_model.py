@@ -86,10 +86,9 @@ def _run_engine(module, eng, batch, labels, output_hidden_states, kwargs, force_
     finally:
         eng.keep_logits, eng.keep_states = False, False
     out = module._last
-    logits = out.get("logits")
-    if logits is not None and ref_out:
-        logits = logits.float()                                      # ola_llama.py:122
-    hidden_states = out.get("hidden_states") or (out["inputs_embeds"], out["hidden"])
+    logits = out.pop("logits", None)                                 # fp32 [B, S, V] (ola_llama.py:122), written once by Engine._ntp
+    # popped: `module._last` must not keep the 8.4 GB of logits / the L + 1 layer states alive until the next call
+    hidden_states = out.pop("hidden_states", None) or (out["inputs_embeds"], out["hidden"])
     return loss, out, logits, hidden_states
 
 
@@ -107,12 +106,27 @@ class _VisperStep(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gout):
+        """d loss / d parameter = the engine's flat fp32 gradient buffer x the incoming scalar.  ONE scale over the flat buffer and ONE cast to
+        the bf16 the Parameters are stored in (two launches; round 5 issued a multiply + a cast per parameter, ~260 launches); each
+        Parameter's gradient is a view of the result."""
         eng = ctx.owner._get_engine()
         eng.finish_grads()
+        ps = eng.ps
+        g32 = torch.mul(ps.grad, gout.to(torch.float32))
+        g16 = None
         grads = []
         for n, p in zip(ctx.names, ctx.owner._trainable_params):
-            g = eng.ps.g(n).reshape(p.shape) * gout
-            grads.append(g.to(p.dtype) if p.requires_grad else None)
+            if not p.requires_grad:
+                grads.append(None)
+                continue
+            off, cnt, _ = ps.index[n]
+            if p.dtype == torch.float32:
+                grads.append(g32[off:off + cnt].view(p.shape))
+            else:
+                if g16 is None:
+                    from .. import ops
+                    g16 = ops.cast_to_bf16(g32) if p.dtype == torch.bfloat16 else g32.to(p.dtype)
+                grads.append(g16[off:off + cnt].view(p.shape))
         return (None, None, *grads)
 
 
@@ -404,7 +418,7 @@ class _OlaCausalLMBase(OlaLlavaMetaForCausalLM, BaseOLA_VLM, EngineModule):
                 labels=None, use_cache=None, output_attentions=None, output_hidden_states=None, images=None,
                 image_sizes=None, return_dict=None, pil_images=None, gen_mask=None, seg_mask=None, depth_mask=None, **kwargs):
         """ola_llama.py:190-244 signature, ola_llama.py:170-188 outputs.  Extra kwargs: gen_target / depth_target / seg_target (precomputed
-        frozen-teacher features).  With `config.reference_outputs` (default True) the call returns what the reference returns: fp32
+        frozen-teacher features), images_resident (device images already written: the frozen tower may run on the side stream).  With `config.reference_outputs` (default True) the call returns what the reference returns: fp32
         `logits` [B, S, V] always (ola_llama.py:121-122) and all L + 1 `hidden_states` (`output_hidden_states=True` is forced at :113);
         `return_dict=False` gives the reference's tuple.  `config.reference_outputs = False` is the lean mode for training loops that only read
         `loss`: lm_head + CE run on labelled rows only, `logits` is None unless `output_logits=True` / `labels is None`, and `hidden_states`
@@ -422,7 +436,10 @@ class _OlaCausalLMBase(OlaLlavaMetaForCausalLM, BaseOLA_VLM, EngineModule):
                 images = images.to(dev, non_blocking=True)
             batch = dict(input_ids=input_ids, attention_mask=attention_mask, labels=labels, images=images, images_resident=True)
         else:
-            batch = dict(input_ids=input_ids, attention_mask=attention_mask, labels=labels, images=images.to(dev))
+            # images_resident=True (extension kwarg): the caller states the device images were written before anything still pending on the
+            # current stream (a dataloader copying on its own stream; bench.py's resident pool) -> the frozen tower runs on the side stream
+            batch = dict(input_ids=input_ids, attention_mask=attention_mask, labels=labels, images=images.to(dev),
+                         images_resident=bool(kwargs.get("images_resident", False)) and images.device == dev)
         for task, tg in self._collect_targets(pil_images, kwargs, B, dev).items():
             batch[f"{task}_target"] = tg
             m = {"gen": gen_mask, "seg": seg_mask, "depth": depth_mask}[task]
@@ -433,7 +450,9 @@ class _OlaCausalLMBase(OlaLlavaMetaForCausalLM, BaseOLA_VLM, EngineModule):
                                          image_embs=embs.get("gen", []), seg_embs=embs.get("seg", []),
                                          depth_embs=out.get("depth_feats") or embs.get("depth", []),
                                          depth_preds=out.get("depth_preds", []))     # filled when config.depth_decoder
-        if return_dict is not None and not return_dict:             # ola_llama.py:170-172: (loss,) + (logits,) + outputs[1:]
+        if return_dict is None:                                      # ola_llama.py:102
+            return_dict = bool(getattr(self.config, "use_return_dict", True))
+        if not return_dict:                                          # ola_llama.py:170-172: (loss,) + (logits,) + outputs[1:]
             return tuple(v for v in (loss, logits, hidden_states) if v is not None)
         return res
 

@@ -20,6 +20,42 @@ def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+# Dynamic tile claims of the persistent 8-phase GEMM kernels (include/visper_hip.h `sched_ws`): the counter blocks are CALLER-owned — one zeroed
+# block per (device, stream), allocated here through torch the first time a GEMM is launched on that stream while `set_dynamic(True)`.
+_DYNAMIC = [os.environ.get("VP_GEMM_DYN") == "1"]
+_SCHED_WS = {}
+
+
+def set_dynamic(on):
+    """Per-XCD dynamic tile claims for the GEMMs launched from here on (Engine.set_distributed: on for world > 1, where RCCL kernels run beside
+    the GEMMs).  Returns the previous setting."""
+    prev = _DYNAMIC[0]
+    _DYNAMIC[0] = bool(on)
+    return prev
+
+
+def _loss_counters():
+    """The distillation loss's ticket-counter block for the current stream (include/visper_hip.h `counters`): caller-owned, zeroed once, left
+    zeroed by every launch."""
+    st = torch.cuda.current_stream()
+    key = ("el", st.device.index, st.cuda_stream)
+    ws = _SCHED_WS.get(key)
+    if ws is None:
+        ws = _SCHED_WS[key] = torch.zeros(_lib.raw("vp_emb_loss_counter_bytes") // 4, device=st.device, dtype=torch.int32)
+    return C.c_void_p(ws.data_ptr())
+
+
+def _sched():
+    if not _DYNAMIC[0]:
+        return None
+    st = torch.cuda.current_stream()
+    key = (st.device.index, st.cuda_stream)
+    ws = _SCHED_WS.get(key)
+    if ws is None:
+        ws = _SCHED_WS[key] = torch.zeros(_lib.raw("vp_gemm_sched_workspace_bytes") // 4, device=st.device, dtype=torch.int32)
+    return C.c_void_p(ws.data_ptr())
+
+
 def _p(t):
     if t is None:
         return None
@@ -59,7 +95,7 @@ def gemm(a, w, bias=None, residual=None, epi=EPI_NONE, out=None, out_f32=False, 
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
     _lib.call("vp_gemm_bf16", M, N, K, _p(a), lda, _p(w), ldb, _p(out), ldc, _p(bias), _p(residual), ldr, epi,
-              1 if out.dtype == torch.float32 else 0, int(force_generic), _stream())
+              1 if out.dtype == torch.float32 else 0, int(force_generic), _sched(), _stream())
     if GEMM_PROF is not None:
         e1.record()
         GEMM_PROF.append((e0, e1, 2.0 * M * N * K, (M, N, K), "nt_lean" if (bias is None and epi == 0) else "nt_epi"))
@@ -150,7 +186,7 @@ def gemm_swiglu_fwd(a, w_gu, row_scale=None):
     if GEMM_PROF is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    _lib.call("vp_gemm_bf16_swiglu", 1, M, N, K, _p(a), lda, _p(w_gu), ldb, _p(gu), N, _p(act), N // 2, _p(row_scale), 0, _stream())
+    _lib.call("vp_gemm_bf16_swiglu", 1, M, N, K, _p(a), lda, _p(w_gu), ldb, _p(gu), N, _p(act), N // 2, _p(row_scale), 0, _sched(), _stream())
     if GEMM_PROF is not None:
         e1.record()
         GEMM_PROF.append((e0, e1, 2.0 * M * N * K, (M, N, K), "nt_lean" if row_scale is None else "nt_fold"))
@@ -167,7 +203,7 @@ def gemm_swiglu_bwd(dy, w_down_T, gate_up):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
     _lib.call("vp_gemm_bf16_swiglu", 2, M, N, K, _p(dy), lda, _p(w_down_T), ldb, _p(dgu), 2 * N, None, 0, _p(gate_up), 2 * N,
-              _stream())
+              _sched(), _stream())
     if GEMM_PROF is not None:
         e1.record()
         GEMM_PROF.append((e0, e1, 2.0 * M * N * K, (M, N, K), "nt_lean"))
@@ -191,7 +227,7 @@ def gemm_tn(a, b, out=None, out_f32=True, accumulate=False):
     if GEMM_PROF is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    _lib.call("vp_gemm_tn_bf16", M, N, K, _p(a), lda, _p(b), ldb, _p(out), out.stride(0), int(out_f32), int(accumulate), _stream())
+    _lib.call("vp_gemm_tn_bf16", M, N, K, _p(a), lda, _p(b), ldb, _p(out), out.stride(0), int(out_f32), int(accumulate), _sched(), _stream())
     if GEMM_PROF is not None:
         e1.record()
         GEMM_PROF.append((e0, e1, 2.0 * M * N * K, (M, N, K), "tn"))
@@ -448,6 +484,15 @@ def cast_to_f32(x, out=None, accumulate=False):
     return out
 
 
+def scatter_rows_to_f32(src, idx, dst):
+    """dst[idx[r]] = float(src[r]) (idx None: row r; idx < 0 skips): bf16 rows widened into rows of an fp32 2-D tensor."""
+    n, H, lds = _rows2d(src)
+    _, H2, ldd = _rows2d(dst)
+    assert H == H2 and src.dtype == BF16 and dst.dtype == torch.float32 and (idx is None or idx.dtype == torch.int32)
+    _lib.call("vp_scatter_rows_bf16_to_f32", n, H, _p(src), lds, _p(idx), _p(dst), ldd, _stream())
+    return dst
+
+
 def sumsq(x):
     """sum(x^2) of an fp32 tensor -> fp32 [1] (deterministic two-stage reduction)."""
     n = x.numel()
@@ -550,7 +595,7 @@ def emb_loss_fwd(pred, tgt_all, mask, logit_scale, w_con, rank=0):
     coef = torch.empty(2 * B + B * Bw + 1, device=pred.device, dtype=torch.float32)
     out3 = torch.empty(3, device=pred.device, dtype=torch.float32)
     _lib.call("vp_emb_loss_fwd", B, Bw, D, rank, _p(pred), _p(tgt_all), _p(mask), _p(logit_scale), w_con, _p(out3), _p(coef),
-              _p(part), _stream())
+              _p(part), _loss_counters(), _stream())
     return out3, coef
 
 
@@ -577,7 +622,7 @@ def emb_loss_fwd_multi(preds, tgts, masks, scales, w_cons, rank=0):
     arr = lambda xs: (C.c_void_p * n)(*[None if x is None else x.data_ptr() for x in xs])
     wc = (C.c_float * n)(*[float(w) for w in w_cons])
     _lib.call("vp_emb_loss_fwd_multi", n, B, Bw, Ds, rank, arr(preds), arr(tgts), arr(masks), arr(scales), wc, arr([o[0] for o in outs]),
-              arr([o[1] for o in outs]), arr(parts), _stream())
+              arr([o[1] for o in outs]), arr(parts), _loss_counters(), _stream())
     return outs
 
 

@@ -115,6 +115,7 @@ def host_plan(cfg, tasks, ids, am=None, lab=None):
             tok_src   [n_tok_rows, n_img]   task-token row j of image i -> its row of [B*S]
             embed_idx [B*S]  token id of text rows (-1 elsewhere): embed_tokens scatter-add when the LLM trains
             present(_kind) [B*S]  only for ragged left padding: presented row -> physical row
+            ce_rows / ce_inv / un_rows  rows with / without a next-token label (lm_head + CE on the former, lm_head forward alone on the latter)
             rows:<task>, inv:<layer>  head gathers (head_tables / inverse_tables)."""
     side = getattr(cfg, "tokenizer_padding_side", "right")
     if side not in ("right", "left"):
@@ -190,6 +191,9 @@ def host_plan(cfg, tasks, ids, am=None, lab=None):
     plan["ce_labels"] = plan["shift_labels"][ce_rows]
     tables["ce_rows"], tables["ce_inv"] = ce_rows, ce_inv
     tables["ce_kind"], tables["ce_inv_kind"] = np.zeros(ce_rows.size, np.int32), np.where(ce_inv >= 0, 0, -1).astype(np.int32)
+    # ... and the rows that carry none: when the caller wants the reference's `logits` of every row (ola_llama.py:121-122) they only need
+    # the lm_head forward (no cross-entropy, no d_hidden GEMM)
+    tables["un_rows"] = np.flatnonzero(plan["shift_labels"] == IGNORE_INDEX).astype(np.int32)
     if side == "left" and not full:
         src = col - (S - lens)[:, None]                          # presented column c shows physical column c - (S - len)
         ok = src >= 0
