@@ -120,12 +120,14 @@ def run_extras(args, headline_ms, step_tf_hint=None):
     """Secondary legs of the default line, each a FRESH process of this script started after the headline's timed region (this process has
     freed the GPU by then): W = 2 warm-up + K = --extras-steps timed steps between the same barrier + synchronize fences, every other probe
     off.  engine_direct = Engine.train_step / optimizer_step without the model class (rounds 1-5's headline); reference_outputs = the model
-    class with its contract default config.reference_outputs=True (fp32 logits of all B x S rows + all L + 1 layer states, ola_llama.py:113-122);
+    class with its contract default config.reference_outputs=True (all L + 1 layer states returned, fp32 logits of all B x S rows handed out
+    lazily: ola_llama.py:113-122) driven as a trainer drives it (reads .loss); ..._logits_read = the same with out.logits read every step;
     configs[4] / configs[3] = the other two single-GPU configurations of BASELINE.json through the model class."""
     import subprocess
     base = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", str(args.extras_steps), "--warmup", "2", "--no-probes",
             "--no-cpu-baseline", "--no-extras", "--lr", str(args.lr)] + (["--no-depth-decoder"] if args.no_depth_decoder else [])
     legs = [("engine_direct", ["--api", "engine"]), ("reference_outputs", ["--api", "model", "--reference-outputs"]),
+            ("reference_outputs_logits_read", ["--api", "model", "--reference-outputs", "--read-logits"]),
             ("configs[4]_phi3", ["--api", "model", "--workload", "phi3"]), ("configs[3]_convnext", ["--api", "model", "--workload", "convnext"])]
     only = os.environ.get("VP_BENCH_EXTRAS")
     out = {"what": run_extras.__doc__.split("\n")[0].strip() + " ... (bench.py run_extras)", "steps": args.extras_steps, "warmup": 2}
@@ -149,7 +151,7 @@ def run_extras(args, headline_ms, step_tf_hint=None):
                         "gemm_family_frac": rf.get("family", {}).get("frac"), "loss": cf.get("loss"), "api": cf.get("api"), "seq_len": cf.get("seq_len"),
                         "per_gpu_batch": cf.get("per_gpu_batch"), "peak_mem_gb": cf.get("peak_mem_gb"), "lm_head_rows": cf.get("lm_head_rows"),
                         "outputs": cf.get("outputs", "")[:60], "workload": cf.get("workload"), "process_wall_s": round(time.time() - t0, 1)}
-            if tag in ("engine_direct", "reference_outputs"):
+            if tag in ("engine_direct", "reference_outputs", "reference_outputs_logits_read"):
                 out[tag]["delta_ms_vs_headline"] = round(r["ms_per_step"] - headline_ms, 2)
         except Exception as e:                              # noqa: BLE001  (a secondary leg must never cost the headline line)
             out[tag] = {"error": f"{type(e).__name__}: {e}"[:400]}
@@ -467,6 +469,10 @@ def main():
                     help="skip the secondary legs of the default line (engine-direct, reference outputs, configs[4] phi3, configs[3] convnext: each a "
                          "fresh process of this script after the timed region, a few steps between the same fences)")
     ap.add_argument("--extras-steps", type=int, default=3)
+    ap.add_argument("--read-logits", action="store_true",
+                    help="with --reference-outputs: also READ out.logits every step (the training forward hands them out lazily: a trainer that only "
+                         "reads .loss never pays for the fp32 [B, S, V] tensor; this flag times the step of a caller that reads it every step and "
+                         "therefore asks for it with output_logits=True: label-less rows take a forward-only lm_head pass inside the step)")
     ap.add_argument("--same-batch", action="store_true", help="A/B aid: replay one batch (splice-plan cache hit) instead of a fresh one per step")
     ap.add_argument("--force-dist", action="store_true", help="initialise the RCCL process group even with one rank (test hook)")
     args = ap.parse_args()
@@ -592,7 +598,11 @@ def main():
         else:
             # what the reference's trainer does per micro-batch (HF Trainer.training_step under ola_vlm_train.py:1297-1327): forward through
             # the model class, backward through autograd, optimizer, zero_grad
-            res = model(**b)
+            res = model(**b, output_logits=True) if args.read_logits else model(**b)     # (output_logits=True: computed inside the step, not lazily)
+            if args.read_logits:
+                _lg = res.logits                                   # materialise the reference's fp32 [B, S, V] logits (lazy otherwise)
+                assert _lg.dtype == torch.float32 and _lg.shape[-1] == cfg.vocab_size
+                del _lg
             res.loss.backward()
             model.optimizer_step(lr=args.lr, lr_mult=lr_mult)
             model.zero_grad(set_to_none=True)
@@ -743,8 +753,9 @@ def main():
                           "api": ("model: out = %s(**batch); out.loss.backward(); model.optimizer_step(lr); model.zero_grad() "
                                   "(the drop-in boundary: ola_vlm_train.py:1297-1327 -> ola_llama.py:190-244)" % type(model).__name__) if model is not None
                                  else "engine: Engine.train_step(batch) + Engine.optimizer_step(lr) called directly",
-                          "outputs": ("reference (fp32 logits of all B x S rows + all L + 1 layer states returned every step: the model class's contract "
-                                      "default config.reference_outputs=True)" if args.reference_outputs
+                          "outputs": ("reference (all L + 1 layer states returned every step, fp32 logits of all B x S rows %s: the model class's contract "
+                                      "default config.reference_outputs=True)" % ("READ every step" if args.read_logits else "handed out lazily, not read")
+                                      if args.reference_outputs
                                       else "lean: loss + per-layer losses + embeddings (config.reference_outputs=False: no logits tensor, lm_head + CE on "
                                            "labelled rows only; the contract-default mode is timed under extras.reference_outputs)"),
                           "valid": args.layers is None},

@@ -102,6 +102,20 @@ def tiny_nt0_case():
     return cfg, W, batch, g
 
 
+def tiny_noid_case():
+    """(cfg, W, batch, golden) for tests/golden/tiny_llama_noid.npz: the PT step with image_depth["use_intermediate_depth"] = False (no
+    linear_1..3 in the depth head, loss on visual_feats, DPT on [feats[0]] * 4: base_ola_vlm.py:132,462-466, da_v2_head.py:437-455)."""
+    g = load_golden("tiny_llama_noid.npz")
+    base, _, _, _ = tiny_llama_case()
+    t = json.loads(str(g["cfg"]))
+    cfg = O.make_config(**{**vars(base), "image_depth": t["image_depth"]})
+    W = {k: WT.param(k, s) for k, s in json.loads(str(g["manifest"])).items()}
+    B, T, col = json.loads(str(g["batch"]))
+    batch = make_batch(B, T, col)
+    assert np.array_equal(batch["input_ids"].numpy(), g["input_ids"])
+    return cfg, W, batch, g
+
+
 def dinov2_weights(manifest):
     """Closed-form weights of the DINOv2 teacher fixture (same overrides as gen_golden.run_dinov2_teacher)."""
     W = {}

@@ -442,6 +442,58 @@ def run_tiny_nt0():
     print("tiny_llama_nt0: loss", res["loss"], "logits", res["logits_shape"], "layer losses\n", res["layer_losses"], res["layer_shapes"])
 
 
+def run_tiny_noid():
+    """image_depth["use_intermediate_depth"] = False (VERDICT r5 missing-2; base_ola_vlm.py:132,462-466, da_v2_head.py:437-455): the depth head
+    has no linear_1..3, `features` = [(visual_feats, None)], the distillation loss compares visual_feats itself with the target and the frozen DPT
+    decoder runs on [depth_feats[0]] * 4.  The reference's own OlaLlavaLlamaForCausalLM -> tiny_llama_noid.npz (loss, layer-loss triples,
+    depth_embs length, depth_preds samples, gradient norms / samples of every trainable parameter)."""
+    B, T, col = 2, 59, 38
+    ids, labels, images, tg, td, ts = make_batch(B, T, col)
+    tiny = dict(TINY_LLAMA, image_depth=dict(TINY_LLAMA["image_depth"], use_intermediate_depth=False))
+    model, cfg = build_llama(tiny)
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    assert not any(".linear_" in k for k in shapes), "the reference builds linear_1..3 only with use_intermediate_depth"
+    model.load_state_dict({k: WT.param(k, s) for k, s in shapes.items()}, strict=True)
+    model.requires_grad_(False)
+    for n, p in model.named_parameters():
+        if ("mm_projector" in n or "_heads." in n or "special_" in n or "logit_scale" in n):
+            p.requires_grad_(True)
+    model._get_gen_feats = lambda pil, dev: tg
+    model._get_seg_targets = lambda pil, h: ts
+    model._get_dav2_feats = lambda pil, dev: ([(td, None)], torch.zeros(B, 336, 336))
+    captured = []
+    orig = model._emb_loss
+
+    def spy(preds, mask, tgt, scale):
+        r = orig(preds, mask, tgt, scale)
+        captured.append((tuple(preds.shape), [float(x) for x in r]))
+        return r
+    model._emb_loss = spy
+    mk = lambda: torch.ones(B).as_subclass(KeepMask)
+    out = model(input_ids=ids, attention_mask=torch.ones_like(ids, dtype=torch.bool), labels=labels, images=images,
+                pil_images=[None] * B, gen_mask=mk(), seg_mask=mk(), depth_mask=mk())
+    out.loss.backward()
+    res = {"loss": np.float64(out.loss.item()), "layer_losses": np.array([c[1] for c in captured], dtype=np.float64),
+           "layer_shapes": json.dumps([c[0] for c in captured]), "logits_shape": np.array(out.logits.shape),
+           "manifest": json.dumps({k: list(s) for k, s in shapes.items()}),
+           "trainable": json.dumps(sorted(n for n, p in model.named_parameters() if p.requires_grad)),
+           "input_ids": ids.numpy(), "batch": json.dumps([B, T, col]), "cfg": json.dumps(tiny),
+           "depth_embs_len": np.array(len(out.depth_embs[0])), "depth_preds_shape": np.array(out.depth_preds[0].shape),
+           "depth_pred_sub": out.depth_preds[0][:, ::5, ::5].detach().float().numpy().copy(),
+           "depth_emb_sub": sub(out.depth_embs[0][0][0], 2048)}
+    none = []
+    for n, p in model.named_parameters():
+        if p.requires_grad:
+            if p.grad is None:
+                none.append(n)
+            else:
+                res[f"gradnorm::{n}"] = np.float64(p.grad.double().norm().item())
+                res[f"gradsub::{n}"] = sub(p.grad, 128)
+    res["grad_none"] = json.dumps(sorted(none))
+    np.savez_compressed(os.path.join(OUT, "tiny_llama_noid.npz"), **res)
+    print("tiny_llama_noid: loss", res["loss"], "depth_embs_len", res["depth_embs_len"], "layer losses\n", res["layer_losses"], res["layer_shapes"])
+
+
 def run_data_path():
     """f-4: tokenizer_image_token / expand2square outputs of the reference's own functions (ola_vlm/mm_utils.py) on a toy
     whitespace tokenizer and synthetic PIL images."""
@@ -728,7 +780,7 @@ if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
     setup_reference()
-    which = sys.argv[1:] or ["units", "llama", "phi3", "ift", "ift_tok", "nt0", "data", "dino", "clipemb", "swin", "convnext", "ragged"]
+    which = sys.argv[1:] or ["units", "llama", "phi3", "ift", "ift_tok", "nt0", "noid", "data", "dino", "clipemb", "swin", "convnext", "ragged"]
     if "units" in which:
         run_units()
     if "llama" in which:
@@ -741,6 +793,8 @@ if __name__ == "__main__":
         run_tiny_ift("emb")
     if "nt0" in which:
         run_tiny_nt0()
+    if "noid" in which:
+        run_tiny_noid()
     if "data" in which:
         run_data_path()
     if "dino" in which:

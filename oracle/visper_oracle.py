@@ -206,7 +206,8 @@ def task_token_rows(W, cfg) -> List[torch.Tensor]:
 
 
 def prepare_inputs_labels_for_multimodal(input_ids, attention_mask, labels, image_features, W, cfg):
-    """ola_arch.py:256-444 restated for the tensor-`images` path (one feature block per sample).
+    """ola_arch.py:256-444 restated; `image_features` is indexed per <image> token / text-only sample: a [n, 576, H] tensor (stacked 4-D
+    `images`) or the list of flattened [n_j * 576, H] groups of the list / 5-D "flat" merge (:262-275)).
 
     Returns (position_ids, attention_mask, inputs_embeds, labels) after splice / truncate / pad."""
     embed = W["model.embed_tokens.weight"]
@@ -487,6 +488,8 @@ def head_forward(state, task, i, W, cfg):
         b, n, c = v.shape
         g = int(math.sqrt(n))
         return v.permute(0, 2, 1).reshape(b, c, g, g), None          # oneformer_head.py:250-258
+    if not hcfg.get("use_intermediate_depth", True):                  # da_v2_head.py:448-455: features = [(visual_feats, None)]
+        return v, [v]                                                 # loss on visual_feats itself (all_depth_feats[0][0], base_ola_vlm.py:369)
     feats = [_mlp_relu(v, W, f"{name}.{i}.linear_{j}.") for j in (1, 2, 3)] + [v]   # da_v2_head.py:444-457
     return feats[0], feats                                            # loss uses lin1(v): base_ola_vlm.py:369
 
@@ -760,7 +763,13 @@ def emb_loss(preds, mask, targets, logit_scale, w_contrastive, rank=0, gathered_
 def forward(W, batch, cfg, rank=0, gathered=None, need_logits=True):
     """batch: input_ids, attention_mask, labels, images, {gen,depth,seg}_target, {gen,depth,seg}_mask.
     Returns dict(loss, text_loss, logits, per-task loss triples, embeddings, layer_states...)."""
-    feats = encode_images(batch["images"], W, cfg)
+    images = batch["images"]
+    if isinstance(images, (list, tuple)) or images.dim() == 5:        # ola_arch.py:262-275, mm_patch_merge_type "flat"
+        ims = [x.unsqueeze(0) if x.dim() == 3 else x for x in images] if isinstance(images, (list, tuple)) else list(images)
+        enc = encode_images(torch.cat(ims, 0), W, cfg)
+        feats = [f.flatten(0, 1) for f in torch.split(enc, [x.shape[0] for x in ims], dim=0)]
+    else:
+        feats = encode_images(images, W, cfg)
     pid, am, emb, labels = prepare_inputs_labels_for_multimodal(
         batch["input_ids"], batch.get("attention_mask"), batch.get("labels"), feats, W, cfg)
     # the training caller passes no position_ids, so the reference drops the ones it built (`if _position_ids is None: position_ids = None`,
@@ -789,7 +798,10 @@ def forward(W, batch, cfg, rank=0, gathered=None, need_logits=True):
             embs.append(extra if extra is not None else pred)
             if task == "depth" and "da_v2_head.depth_head.projects.0.weight" in W:
                 with torch.no_grad():                          # base_ola_vlm.py:462-470
-                    out.setdefault("depth_preds", []).append(dpt_depth_pred([f.detach() for f in extra], W))
+                    fe = [f.detach() for f in extra]
+                    if len(fe) == 1:                           # use_intermediate_depth False: da_v2_head([depth_feats[0]] * 4), base_ola_vlm.py:465
+                        fe = fe * 4
+                    out.setdefault("depth_preds", []).append(dpt_depth_pred(fe, W))
             tgt = batch.get(f"{task}_target")
             if tgt is None:
                 continue

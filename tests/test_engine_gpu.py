@@ -813,6 +813,89 @@ def test_pt_step_without_task_tokens_matches_oracle_and_reference_golden():
         check(f"nt0/grad/{k}/norm_dev", n, 3e-2)
 
 
+def test_pt_step_without_intermediate_depth_matches_oracle_and_reference_golden():
+    """image_depth["use_intermediate_depth"] = False (VERDICT r5 missing-2; base_ola_vlm.py:132,462-466, da_v2_head.py:437-455): the depth head has
+    no linear_1..3 parameters, its loss compares visual_feats itself, depth_embs entries hold one map and the DPT decoder runs on [feats[0]] * 4.
+    Engine vs tests/golden/tiny_llama_noid.npz (the reference itself, fp32) and vs the fp32 oracle on the same bf16-rounded weights."""
+    from oracle import cases, visper_oracle as O
+    from visper_lm_amd.config import VisperConfig
+    from visper_lm_amd.engine import Engine
+    ocfg, W, batch, g = cases.tiny_noid_case()
+    eng = Engine(VisperConfig(**vars(ocfg), depth_decoder=True))
+    eng.load_weights(W)
+    out = eng.train_step(_to_gpu_batch(batch))
+    tr = json.loads(str(g["trainable"]))
+    assert sorted(eng.ps.index) == tr and not any(".linear_" in k for k in eng.ps.index)
+    check("noid/loss_rel_vs_reference_golden", rel(out["loss"], g["loss"]), 1e-3)
+    order = [("depth", 2), ("seg", 1), ("seg", 2), ("gen", 3)]
+    for i, key in enumerate(order):
+        check(f"noid/layer_loss_vs_golden/{key[0]}@{key[1]}", _trip_err(out["layer_losses"][key].float().cpu().numpy(), g["layer_losses"][i]), 1.2e-2)
+    assert len(out["depth_feats"][0]) == 1 == int(g["depth_embs_len"]) and tuple(out["depth_feats"][0][0].shape) == (2, 576, 1024)
+    dp = out["depth_preds"][0].float().cpu()
+    assert tuple(dp.shape) == tuple(int(v) for v in g["depth_preds_shape"])
+    check("noid/depth_pred_mean_abs_vs_reference_golden", np.abs(dp[:, ::5, ::5].numpy() - g["depth_pred_sub"]).mean(), 2e-2)
+    Wq = {k: v.to(BF).float() for k, v in W.items()}
+    for k in tr:
+        Wq[k] = Wq[k].clone().requires_grad_(True)
+    bq = {k: (v.to(BF).float() if (torch.is_tensor(v) and v.is_floating_point() and not k.endswith("_mask")) else v) for k, v in batch.items()}
+    ref = O.forward(Wq, bq, ocfg)
+    ref["loss"].backward()
+    check("noid/loss_rel_vs_oracle", rel(out["loss"], ref["loss"]), 1e-3)
+    for k in tr:
+        got, want = eng.ps.g(k).detach().float().cpu().reshape(-1), Wq[k].grad
+        if want is None:
+            assert float(got.abs().max()) == 0.0, k
+            continue
+        if got.numel() == 1:
+            check(f"noid/grad/{k}_abs", abs(float(got) - float(want)), 0.05 * abs(float(want)) + 1e-3)
+            continue
+        c, n = grad_err(got, want.reshape(-1))
+        check(f"noid/grad/{k}/one_minus_cos", c, 1.5e-2)
+        check(f"noid/grad/{k}/norm_dev", n, 3e-2)
+
+
+def test_list_and_5d_images_flat_merge(tiny):
+    """VERDICT r5 missing-3: `images` as a list or a 5-D tensor (ola_arch.py:262-275, mm_patch_merge_type "flat").  A list of [3, H, W] tensors is
+    the stacked 4-D batch (bit-identical step).  A 5-D [B, 2, 3, H, W] batch: both images of a sample are encoded, their features flattened to
+    2 x 576 rows behind ONE <image> token, then the task tokens: loss, layer losses and every gradient against the fp32 oracle's own flat merge.
+    Anything but the flat merge is refused with the reference lines."""
+    from oracle import visper_oracle as O
+    eng, batch, ocfg, tr = tiny["eng"], tiny["batch"], tiny["ocfg"], tiny["tr"]
+    gb = _to_gpu_batch(batch)
+    lst = dict(gb, images=[im for im in gb["images"]])
+    out = eng.train_step(lst)
+    assert torch.equal(out["loss"], tiny["out"]["loss"]) and torch.equal(out["logits"], tiny["out"]["logits"])
+    for k in eng.ps.index:
+        assert torch.equal(eng.ps.g(k).detach().float().cpu(), tiny["grads"][k]), k
+    im5 = torch.stack([batch["images"], batch["images"].flip(0) * 0.5], 1)                     # [B, 2, 3, H, W]
+    out5 = eng.train_step(dict(gb, images=im5.cuda()))
+    assert out5["plan"]["S"] == tiny["out"]["plan"]["S"] + 576 and out5["plan"]["n_feat"] == 4 * 576
+    Wq = {k: (v.detach().clone().requires_grad_(True) if k in tr else v.detach()) for k, v in tiny["Wq"].items()}
+    bq = {k: (v.to(BF).float() if (torch.is_tensor(v) and v.is_floating_point() and not k.endswith("_mask")) else v) for k, v in batch.items()}
+    bq["images"] = im5.to(BF).float()
+    ref = O.forward(Wq, bq, ocfg)
+    ref["loss"].backward()
+    check("flat5d/loss_rel_vs_oracle", rel(out5["loss"], ref["loss"]), 1e-3)
+    check("flat5d/text_loss_rel_vs_oracle", rel(out5["text_loss"], ref["text_loss"]), 1e-3)
+    check("flat5d/inputs_embeds_maxrel", max_rel(out5["inputs_embeds"].cpu(), ref["inputs_embeds"].detach()), 1.5e-2)
+    for key, trip in ref["layer_losses"].items():
+        check(f"flat5d/layer_loss/{key[0]}@{key[1]}_vs_oracle", _trip_err(out5["layer_losses"][key].float().cpu().numpy(), np.array([float(x) for x in trip])), 1.2e-2)
+    for k in tr:
+        got, want = eng.ps.g(k).detach().float().cpu().reshape(-1), Wq[k].grad
+        if want is None or got.numel() == 1:
+            continue
+        c, n = grad_err(got, want.reshape(-1))
+        check(f"flat5d/grad/{k}/one_minus_cos", c, 1.5e-2)
+    eng.cfg.mm_patch_merge_type = "spatial_unpad"
+    try:
+        with pytest.raises(NotImplementedError, match="ola_arch.py"):
+            eng.train_step(lst)
+    finally:
+        del eng.cfg.mm_patch_merge_type
+    with pytest.raises(IndexError):
+        eng.train_step(dict(gb, images=[gb["images"][0]]))                                     # fewer entries than <image> tokens
+
+
 def test_emb_loss_batch_repeat_branch_in_the_step():
     """_emb_loss's repeat branch (base_ola_vlm.py:292-299): ONE gen / depth target row for the batch of two predictions -> targets and
     masks tiled.  The rank-4 seg target cannot take that branch (the reference's 3-argument repeat raises): ValueError here."""

@@ -113,9 +113,19 @@ def _compare(tag, got, ref, bounds, baseline=None):
         for j, nm in enumerate(("emb", "sl1", "con")):
             if abs(float(trip[j])) > 1e-9:
                 check(f"{tag}/layer_loss/{key[0]}@{key[1]}/{nm}_rel", rel(mine[j], trip[j]), bd("layer_loss"))
+    state = {}
     for nm in ("inputs_embeds", "hidden", "logits"):
-        check(f"{tag}/{nm}_frob", _frob(got[nm], ref[nm]), bd(nm + "_frob"))
-        check(f"{tag}/{nm}_maxrel", max_rel(got[nm], ref[nm]), bd(nm + "_max"))
+        state[nm + "_frob"], state[nm + "_max"] = _frob(got[nm], ref[nm]), max_rel(got[nm], ref[nm])
+        # element-wise state bounds may be ADAPTIVE (round 6): bounds["state_vs_baseline"] = (factor, cap) -> min(cap, factor x the deviation of
+        # the reference-style bf16 CPU path from the same truth), never looser than the cap
+        fb, mb = bd(nm + "_frob"), bd(nm + "_max")
+        if baseline is not None and "state_vs_baseline" in bounds and "__state__" in baseline:
+            fac, cap = bounds["state_vs_baseline"]
+            fb = min(fb, cap, fac * baseline["__state__"][nm + "_frob"])
+            mb = min(mb, cap, fac * baseline["__state__"][nm + "_max"])
+        check(f"{tag}/{nm}_frob", state[nm + "_frob"], fb)
+        check(f"{tag}/{nm}_maxrel", state[nm + "_max"], mb)
+    errs["__state__"] = state
     worst_c = worst_n = 0.0
     for k, want in ref["grads"].items():
         mine = got["grads"][k]
@@ -134,7 +144,7 @@ def _compare(tag, got, ref, bounds, baseline=None):
         errs[k] = (c, n)
         worst_c, worst_n = max(worst_c, c), max(worst_n, n)
         bc, bn = bd("grad_cos"), bd("grad_norm")
-        if baseline is not None and k in baseline and "grad_vs_baseline" in bounds:
+        if baseline is not None and k in baseline and k != "__state__" and "grad_vs_baseline" in bounds:
             bc = max(bc, bounds["grad_vs_baseline"] * baseline[k][0])
             bn = max(bn, bounds["grad_vs_baseline"] * baseline[k][1])
         check(f"{tag}/grad/{k}/one_minus_cos", c, bc)
@@ -248,7 +258,10 @@ def test_config0_full_depth_vs_fp32_truth_and_reference_style_bf16_cpu_path():
     print(f"[parity] config0: bf16 CPU oracle fwd+bwd {refb['seconds']:.1f} s")
     # measured (r02): HIP vs truth: loss 6.5e-5, seg loss 8e-6, hidden / logits 6.6e-2 (32 bf16 layers; the bf16 CPU path: 6.8e-2),
     # gradients 1 - cos <= 2.7e-3 (bf16 CPU path: 3.0e-3).  HIP vs the bf16 CPU path: loss 1.9e-4, seg contrastive term 1.9e-3.
-    deep = dict(TIGHT, inputs_embeds_frob=4e-2, inputs_embeds_max=4e-2, hidden_frob=0.2, logits_frob=0.2, hidden_max=0.3, logits_max=0.3,
+    # round 6: the element-wise bounds of the 32-layer states were 0.2 / 0.3 for a measured 6.6e-2 / 7.9e-2.  Against fp32
+    # truth they are now min(0.12, 1.5 x the bf16 CPU path's own deviation from that truth) (measured r05: 6.8e-2 / 8.2e-2 -> bounds 0.10 / 0.12);
+    # HIP against the bf16 CPU path itself (two independent bf16 roundings of the same 32 layers; measured 7.7e-2 / 9.8e-2): 0.12 / 0.15
+    deep = dict(TIGHT, inputs_embeds_frob=4e-2, inputs_embeds_max=4e-2, hidden_frob=0.12, logits_frob=0.12, hidden_max=0.15, logits_max=0.15,
                 layer_loss=1e-2, grad_cos=1e-2, grad_norm=3e-2, grad_scalar_rel=0.3, grad_scalar_abs=3e-6)
     _compare("config0_vs_bf16_cpu_path", got, refb, deep)
     if _mem_available_gb() < 70:
@@ -256,7 +269,7 @@ def test_config0_full_depth_vs_fp32_truth_and_reference_style_bf16_cpu_path():
     ref32 = _oracle_step(cfg, Wc, batch, tr, torch.float32, got["rows"])
     print(f"[parity] config0: fp32 CPU oracle fwd+bwd {ref32['seconds']:.1f} s")
     base = _compare("config0_INFO_bf16_cpu_path_vs_fp32_truth", refb, ref32, {})
-    _compare("config0_vs_fp32_truth", got, ref32, deep, baseline=base)
+    _compare("config0_vs_fp32_truth", got, ref32, dict(deep, state_vs_baseline=(1.5, 0.12)), baseline=base)
 
 
 def test_fullwidth_phi3_long_context_vs_fp32_oracle():

@@ -88,8 +88,17 @@ def test_forward_returns_what_the_reference_returns(setup):
         got = out.hidden_states[li].float().cpu()[:, ::13, ::3].numpy()
         check(f"model_api/hidden_states[{li}]_sub_maxrel_vs_reference_golden", float(np.abs(got - ref).max() / np.abs(ref).max()), 3e-2)
     out2 = model(labels=batch["labels"], **kw, **tg)                   # with labels: the same fields + loss
+    # round 6: a training call hands the logits out LAZILY (frozen lm_head): nothing is computed until the field is read; out[0] / "loss" / keys()
+    # do not touch it; the tensor read is bit-identical to the label-less call's (and stays materialised afterwards)
+    from visper_lm_amd.model.language_model import _Lazy
+    assert isinstance(object.__getattribute__(out2, "logits"), _Lazy)
+    assert out2[0] is out2.loss and "logits" in out2 and "logits" in out2.keys() and out2["loss"] is out2.loss
+    assert isinstance(object.__getattribute__(out2, "logits"), _Lazy)
     assert tuple(out2.logits.shape) == tuple(out.logits.shape) and len(out2.hidden_states) == L + 1
-    assert torch.equal(out2.logits, out.logits)
+    assert torch.is_tensor(object.__getattribute__(out2, "logits")) and out2.logits.dtype == torch.float32
+    assert torch.equal(out2.logits, out.logits) and torch.equal(out2[1], out.logits)
+    eager = model(labels=batch["labels"], output_logits=True, **kw, **tg)           # computed inside the step instead: same bits
+    assert torch.is_tensor(object.__getattribute__(eager, "logits")) and torch.equal(eager.logits, out.logits)
     check("model_api/loss_rel_vs_reference_golden(reference_outputs)", abs(float(out2.loss) - float(g["keep_loss"])) / float(g["keep_loss"]), 1e-3)
     tup = model(labels=batch["labels"], return_dict=False, **kw, **tg)
     assert isinstance(tup, tuple) and len(tup) == 3 and tup[0].shape == () and torch.equal(tup[1], out.logits) and len(tup[2]) == L + 1

@@ -228,6 +228,32 @@ def test_pt_step_without_task_tokens_matches_reference():
         assert abs(float(W[k].grad.double().norm()) - ref_norm) <= 2e-4 * ref_norm + 1e-9, k
 
 
+def test_pt_step_without_intermediate_depth_matches_reference():
+    """VERDICT r5 missing-2: image_depth["use_intermediate_depth"] = False (base_ola_vlm.py:132,462-466; da_v2_head.py:437-455): no linear_1..3
+    parameters, the loss compares visual_feats itself, depth_embs entries have ONE feature map and the DPT decoder runs on [feats[0]] * 4."""
+    cfg, W, batch, g = cases.tiny_noid_case()
+    tr = json.loads(str(g["trainable"]))
+    assert not any(".linear_" in k for k in W) and cfg.image_depth["use_intermediate_depth"] is False
+    W = {k: (v.clone().requires_grad_(True) if k in tr else v) for k, v in W.items()}
+    out = O.forward(W, batch, cfg)
+    out["loss"].backward()
+    _close(out["loss"].item(), g["loss"], 1e-5, 1e-6)
+    assert json.loads(str(g["layer_shapes"]))[0] == [2, 576, 1024] and int(g["depth_embs_len"]) == 1 == len(out["depth_embs"][0])
+    mine = [out["layer_losses"][("depth", 2)], out["layer_losses"][("seg", 1)], out["layer_losses"][("seg", 2)], out["layer_losses"][("gen", 3)]]
+    for i, trip in enumerate(mine):
+        _close([float(x.detach()) for x in trip], g["layer_losses"][i], 2e-5, 1e-6)
+    _close(cases.sub(out["depth_embs"][0][0], 2048), g["depth_emb_sub"], 1e-3, 2e-5)
+    dp = out["depth_preds"][0]
+    assert tuple(dp.shape) == tuple(g["depth_preds_shape"])
+    assert float(np.abs(dp[:, ::5, ::5].detach().float().numpy() - g["depth_pred_sub"]).max()) < 2e-4
+    none_ref = set(json.loads(str(g["grad_none"])))
+    for k in tr:
+        if k in none_ref:
+            continue
+        ref_norm = float(g[f"gradnorm::{k}"])
+        assert abs(float(W[k].grad.double().norm()) - ref_norm) <= 2e-4 * ref_norm + 1e-9, k
+
+
 @pytest.mark.parametrize("name,dims", [("rs_plain", (32, 12, 48, 40, 1)), ("rs_plain_deep", (64, 5, 48, 24, 2))])
 def test_plain_resampler(name, dims):
     g = cases.load_golden("units.npz")

@@ -82,6 +82,29 @@ def test_plan_reproduces_oracle_splice(side, kw):
     assert np.array_equal(t["ce_inv_kind"], np.where(t["ce_inv"] >= 0, 0, -1)) and not t["ce_kind"].any()
 
 
+@pytest.mark.parametrize("side", ["right", "left"])
+def test_plan_with_image_groups_reproduces_oracle_flat_merge(side):
+    """list / 5-D `images` (ola_arch.py:262-275, mm_patch_merge_type "flat"): entry j holds n_j images whose features are flattened to n_j * 576
+    rows that replace ONE <image> token (followed by the task tokens).  Entries of 2, 1 (text-only sample: consumed, unused), 1 and 3 images."""
+    cfg, ocfg, ids, am, labels, W, _ = _case(side=side, ragged=True, no_image=True, two_images=True)
+    gs = [2, 1, 1, 3]
+    g = torch.Generator().manual_seed(11)
+    groups = [torch.randn(n * 576, H, generator=g) for n in gs]
+    plan = splice.host_plan(cfg, [], ids.numpy(), am.numpy(), labels.numpy(), group_sizes=gs)
+    pid, oam, emb, olab = O.prepare_inputs_labels_for_multimodal(ids, am, labels, groups, W, ocfg)
+    assert plan["S"] == emb.shape[1] == (57 - 2) + (1 + 3) * 576 + 2 * 24 and plan["n_feat"] == 7 * 576 and plan["n_img"] == 4
+    assert np.array_equal(plan["labels"], olab.numpy()) and np.array_equal(plan["attention_mask"], oam.numpy())
+    assert np.array_equal(plan["position_ids"], pid.numpy())
+    assert torch.equal(_apply(plan, W, torch.cat(groups, 0), ocfg), emb)
+    t = plan["tables"]
+    for r, dst in enumerate(t["img_dst"]):                        # backward table = inverse of the gather, unused group (text-only sample) -> -1
+        if dst >= 0:
+            assert t["kind"][dst] == 1 and t["row"][dst] == r
+    assert (t["img_dst"] >= 0).sum() == (t["kind"] == 1).sum() == 6 * 576 and (t["img_dst"][2 * 576:3 * 576] == -1).all()
+    with pytest.raises(IndexError):
+        splice.host_plan(cfg, [], ids.numpy(), am.numpy(), labels.numpy(), group_sizes=[2, 1, 1])       # fewer entries than the batch consumes
+
+
 def test_backward_tables_are_the_inverse_of_the_gather():
     cfg, ocfg, ids, am, labels, W, feats = _case(ragged=True, two_images=True)
     plan = splice.host_plan(cfg, [], ids.numpy(), am.numpy(), labels.numpy())

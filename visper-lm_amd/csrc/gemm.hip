@@ -1532,7 +1532,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   // The wave claims its SIMD's WHOLE register file (256 VGPRs + 256 AGPRs): with fewer (the general variant used 208 + 256) a low-register wave of a
   // kernel running on ANOTHER stream can be placed on the same SIMD, and round 4's side-stream schedule then produced sporadic NaNs in this
   // kernel's output (tools/ift_dbg.py: first seen in a ViT fc2 launch beside the decoder forward's small kernels; never alone).
+#ifndef VP_W4_NO_CLOBBER
   asm volatile("" ::: "v255");
+#endif
   bf16_t* smem = (bf16_t*)smem_raw;                    // [buf 0: A 256x64 | B 256x64][buf 1][C staging 4 x 8 KB]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);

@@ -701,7 +701,30 @@ class Engine:
         ops._lib.call("vp_colsum_finish", 1, n, ops._p(src_f32), ops._p(gview), scale, 1, ops._stream())
 
     # ------------------------------------------------------------------------------------------ splice plan (host)
-    def build_plan(self, input_ids, attention_mask, labels):
+    def image_groups(self, images):
+        """`images` as the reference's prepare_inputs_labels_for_multimodal accepts it (ola_arch.py:262-275) -> (one [N, 3, H, W] tensor for the
+        tower, group_sizes or None).  4-D tensor: one image per <image> token (None).  list of [3, H, W] / [n_j, 3, H, W] tensors or a 5-D
+        [B, n, 3, H, W] tensor: entry j's n_j images are encoded together and their features FLATTENED to n_j * 576 rows that replace ONE
+        <image> token (mm_patch_merge_type "flat", the default and the PT / IFT scripts' setting).  The "spatial" / "anyres" merges
+        (ola_arch.py:276-308: image_newline, unpad) are not built and refused."""
+        if torch.is_tensor(images) and images.dim() == 4:
+            return images, None
+        merge = getattr(self.cfg, "mm_patch_merge_type", "flat")
+        if merge != "flat":
+            raise NotImplementedError(f"mm_patch_merge_type={merge!r}: only the 'flat' merge of list / 5-D `images` is built "
+                                      f"(ola_arch.py:272-275); 'spatial*' / anyres (ola_arch.py:276-308) is out of scope")
+        if isinstance(images, (list, tuple)):
+            ims = [x.unsqueeze(0) if x.dim() == 3 else x for x in images]                   # ola_arch.py:264-265
+            if not ims or any(x.dim() != 4 for x in ims):
+                raise ValueError("a list `images` must hold [3, H, W] or [n, 3, H, W] tensors (ola_arch.py:263-266)")
+            if any(x.shape[1:] != ims[0].shape[1:] for x in ims):
+                raise ValueError("the entries of a list `images` must share (3, H, W): torch.cat in ola_arch.py:266 raises otherwise")
+            return torch.cat(ims, 0), [int(x.shape[0]) for x in ims]
+        if torch.is_tensor(images) and images.dim() == 5:
+            return images.reshape(-1, *images.shape[2:]), [int(images.shape[1])] * int(images.shape[0])
+        raise ValueError(f"`images` must be a 4-D / 5-D tensor or a list of tensors (ola_arch.py:262), got {type(images).__name__}")
+
+    def build_plan(self, input_ids, attention_mask, labels, group_sizes=None):
         """splice.host_plan (the index bookkeeping of prepare_inputs_labels_for_multimodal, ola_arch.py:256-444) + ONE pinned
         int32 buffer -> one async H2D copy of every table.  A fresh batch every step costs ~1 ms of host time, which runs under the
         previous step's GPU work; identical batches hit a small cache."""
@@ -710,11 +733,12 @@ class Engine:
         ids = np.ascontiguousarray(input_ids.detach().cpu().numpy().astype(np.int64, copy=False))
         am = None if attention_mask is None else attention_mask.detach().cpu().numpy().astype(bool, copy=False)
         lab = None if labels is None else labels.detach().cpu().numpy().astype(np.int64, copy=False)
-        key = (ids.tobytes(), None if am is None else am.tobytes(), None if lab is None else lab.tobytes(), cfg.tokenizer_padding_side)
+        key = (ids.tobytes(), None if am is None else am.tobytes(), None if lab is None else lab.tobytes(), cfg.tokenizer_padding_side,
+               None if group_sizes is None else tuple(group_sizes))
         if key in self._plan_cache:
             return self._plan_cache[key]
-        hp = splice.host_plan(cfg, self.tasks, ids, am, lab)
-        plan = {k: hp[k] for k in ("B", "S", "n_img", "n_valid", "lens_host", "n_tok_rows", "full", "side", "tok_cnt")}
+        hp = splice.host_plan(cfg, self.tasks, ids, am, lab, group_sizes)
+        plan = {k: hp[k] for k in ("B", "S", "n_img", "n_feat", "n_valid", "lens_host", "n_tok_rows", "full", "side", "tok_cnt")}
         for k in ("labels", "attention_mask", "position_ids"):
             plan[k] = torch.from_numpy(hp[k])
         tabs = hp["tables"]                                           # name -> int32 array
@@ -835,7 +859,8 @@ class Engine:
 
     def splice_forward(self, input_ids, attention_mask, labels, images):
         """prepare_inputs_labels_for_multimodal's tensor outputs (ola_arch.py:256-444): (inputs_embeds [B,S,H], plan)."""
-        plan = self.build_plan(input_ids, attention_mask, labels)
+        images, gs = self.image_groups(images)
+        plan = self.build_plan(input_ids, attention_mask, labels, gs)
         x, *_ = self._embed(images.to(self.dev), plan)
         return self.present(x, plan), plan
 
@@ -845,7 +870,9 @@ class Engine:
         scalars (fp32 tensors); gradients of the trainable set are in self.ps.grad (zeroed first).
         Stages (each its own method): _embed (a1..a5) -> _decoder_fwd (a6) -> _ntp (a7) -> _heads (a8..a14) -> _decoder_bwd -> _splice_bwd."""
         ps = self.ps
-        plan = self.build_plan(batch["input_ids"], batch.get("attention_mask"), batch.get("labels"))
+        images, gs = self.image_groups(batch["images"])
+        gs = batch.get("image_group_sizes", gs)                   # (a caller that already flattened a list / 5-D `images`: the model mirrors)
+        plan = self.build_plan(batch["input_ids"], batch.get("attention_mask"), batch.get("labels"), gs)
         if compute_grads:
             if self.train_llm:
                 # every decoder / lm_head / norm gradient is overwritten by its wgrad GEMM below: clear only what accumulates
@@ -857,7 +884,7 @@ class Engine:
         out = {"plan": plan}
 
         # ---- vision tower + projector + splice (a1..a5)
-        x, feats, z1, a1, img = self._embed(batch["images"], plan, images_resident=bool(batch.get("images_resident", False)))
+        x, feats, z1, a1, img = self._embed(images, plan, images_resident=bool(batch.get("images_resident", False)))
         out["image_features"] = img
         out["inputs_embeds"] = self.present(x, plan)
 
@@ -1061,8 +1088,12 @@ class Engine:
         M = plan["B"] * plan["S"]
         n_valid = plan["n_valid"]
         gscale = 1.0 / n_valid if n_valid > 0 else float("nan")
-        direct = self.keep_logits and plan["present"] is None     # (ragged LEFT padding re-lays the rows for presentation: old cat + gather path)
-        compact = 0 < n_valid < M and (direct or not self.keep_logits) and not self.lm_head_all_rows
+        keep_logits = self.keep_logits
+        if keep_logits == "lazy":                                 # the caller may never read them: hand out the recipe (same bits: logits_of)
+            out["logits_fn"] = lambda h=hidden, pl=plan: self.logits_of(h, pl)
+            keep_logits = False
+        direct = keep_logits and plan["present"] is None          # (ragged LEFT padding re-lays the rows for presentation: old cat + gather path)
+        compact = 0 < n_valid < M and (direct or not keep_logits) and not self.lm_head_all_rows
         if compact:
             Mc = plan["n_ce"]                                    # n_valid rounded up to whole 256-row tiles (pad rows: zeros, label -100)
             h_ce = torch.empty(Mc, H, device=dev, dtype=BF16)
@@ -1072,7 +1103,7 @@ class Engine:
             h_ce, lab_ce, Mc = hidden, plan["shift_labels"], M
         d_hce = torch.empty(Mc, H, device=dev, dtype=BF16) if compute_grads else None
         row_loss = torch.empty(Mc, device=dev, dtype=F32)
-        logits_keep = [] if (self.keep_logits and not direct) else None
+        logits_keep = [] if (keep_logits and not direct) else None
         logits_f32 = torch.empty(M, fz["lm_head"].shape[0], device=dev, dtype=F32) if direct else None
         R = self._lm_chunk(Mc, H)
         for r0 in range(0, Mc, R):
@@ -1105,6 +1136,21 @@ class Engine:
         elif logits_keep is not None:
             out["logits"] = self.present(torch.cat(logits_keep, 0), plan).float()
         return text_loss, d_hidden
+
+    def logits_of(self, hidden, plan):
+        """fp32 `logits` [B, S, V] of every row from the final (post-norm) hidden state [B*S, H] exactly as the step itself would return them
+        (ola_llama.py:121-122: bf16 lm_head, then `.float()`); bit-identical to the keep_logits=True output (each row's dot products do not
+        depend on which rows share its GEMM: `test_labelled_row_compaction_is_exact`)."""
+        fz = self.fz
+        M, V = hidden.shape[0], fz["lm_head"].shape[0]
+        if plan["present"] is not None:
+            lg = [ops.gemm(hidden[r0:min(M, r0 + self.lm_chunk_rows)], fz["lm_head"]) for r0 in range(0, M, self.lm_chunk_rows)]
+            return self.present(torch.cat(lg, 0), plan).float()
+        lf = torch.empty(M, V, device=self.dev, dtype=F32)
+        for r0 in range(0, M, self.lm_chunk_rows):
+            r1 = min(M, r0 + self.lm_chunk_rows)
+            ops.scatter_rows_to_f32(ops.gemm(hidden[r0:r1], fz["lm_head"]), None, lf[r0:r1])
+        return lf.view(plan["B"], plan["S"], V)
 
     def _heads(self, states, plan, batch, compute_grads, out):
         """a8..a14: every distillation head on its layer state — all forwards, ONE loss launch each way for all of them
@@ -1256,7 +1302,7 @@ class Engine:
         """Backward of the splice and the projector: image rows -> mm_projector (a3), task-token rows -> special-token parameters (a4)."""
         cfg, ps, dev = self.cfg, self.ps, self.dev
         H = cfg.hidden_size
-        d_img = torch.empty(max(plan["n_img"], 1) * N_IMG_TOK, H, device=dev, dtype=BF16)
+        d_img = torch.empty(plan["n_feat"], H, device=dev, dtype=BF16)
         ops.gather_sum_rows(dx, plan["img_dst"], 1, 1.0, d_img)
         if plan["n_tok_rows"] > 0:
             d_tok = torch.empty(plan["n_tok_rows"], H, device=dev, dtype=F32)
@@ -1401,22 +1447,27 @@ class Engine:
         Do = vout.shape[-1]
         emb = vout.view(B, nq, Do)
         pred = vout
-        if task == "depth":                                        # loss on linear_1(visual_feats): base_ola_vlm.py:369
+        uid = task == "depth" and bool(hc.get("use_intermediate_depth", True))      # base_ola_vlm.py:132; False: no linear_1..3, loss on visual_feats
+        if uid:                                                    # loss on linear_1(visual_feats): base_ola_vlm.py:369
             l1 = f"{hname}.{i}.linear_1."
             zd = ops.gemm(vout, ps.w(l1 + "0.weight"), bias=ps.w(l1 + "0.bias"))
             ad = ops.act_fwd(zd, ops.EPI_RELU)
             pred = ops.gemm(ad, ps.w(l1 + "2.weight"), bias=ps.w(l1 + "2.bias"))
         res = dict(emb=emb if task != "depth" else pred.view(B, nq, -1), loss3=None, dx=None)
         if task == "depth" and getattr(cfg, "depth_decoder", False):
-            # depth_embs entry = [lin1(v), lin2(v), lin3(v), v] (da_v2_head.py:444-457); depth_pred = DPT(feats) (base_ola_vlm.py:462-470)
-            fe = [pred]
-            for j in (2, 3):
-                lj = f"{hname}.{i}.linear_{j}."
-                zz = ops.gemm(vout, ps.w(lj + "0.weight"), bias=ps.w(lj + "0.bias"), epi=ops.EPI_RELU)
-                fe.append(ops.gemm(zz, ps.w(lj + "2.weight"), bias=ps.w(lj + "2.bias")))
-            fe.append(vout)
+            # depth_embs entry = [lin1(v), lin2(v), lin3(v), v] (da_v2_head.py:444-457); depth_pred = DPT(feats) (base_ola_vlm.py:462-470);
+            # without use_intermediate_depth: entry = [v], depth_pred = DPT([v] * 4) (da_v2_head.py:448-455, base_ola_vlm.py:464-465)
+            if uid:
+                fe = [pred]
+                for j in (2, 3):
+                    lj = f"{hname}.{i}.linear_{j}."
+                    zz = ops.gemm(vout, ps.w(lj + "0.weight"), bias=ps.w(lj + "0.bias"), epi=ops.EPI_RELU)
+                    fe.append(ops.gemm(zz, ps.w(lj + "2.weight"), bias=ps.w(lj + "2.bias")))
+                fe.append(vout)
+            else:
+                fe = [vout]
             res["depth_feats"] = [t.view(B, nq, -1) for t in fe]
-            res["depth_pred"] = self.dpt_forward(res["depth_feats"])
+            res["depth_pred"] = self.dpt_forward(res["depth_feats"] if uid else res["depth_feats"] * 4)
         tg = targets.get(task)
         sname_ = sname
         scale = ps.p(sname_) if (cfg.use_contrastive and sname_ in ps) else None
@@ -1424,7 +1475,7 @@ class Engine:
         if tg is not None and compute_grads:
             ctx["saved"] = dict(plan=plan, tb=tb, n=n, nq=nq, heads=heads, dh=dh, inner=inner, pf=pf, T=T, nl=nl, mode=mode, xt=xt, own=own,
                                 Dm=Dm, xin2=xin2, Px=Px, blocks=blocks, lat2=lat2, po=po, mo=mo, ro=ro, vout=vout, hname=hname, sname=sname,
-                                ad=ad if task == "depth" else None, zd=zd if task == "depth" else None)
+                                ad=ad if uid else None, zd=zd if uid else None, uid=uid)
         return ctx
 
     def _head_bwd(self, ctx):
@@ -1441,7 +1492,7 @@ class Engine:
         dpred = ctx["dpred"].view(B * nq, -1)
         if scale is not None:
             self._acc(ps.g(sname), coef[-1:], w_t)
-        if task == "depth":
+        if sv["uid"]:
             d_ad = self._lin_bwd(ad, dpred, l1 + "2.weight", l1 + "2.bias")
             d_zd = ops.act_bwd(d_ad, zd, ops.EPI_RELU)
             dvout = self._lin_bwd(vout, d_zd, l1 + "0.weight", l1 + "0.bias")

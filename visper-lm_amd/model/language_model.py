@@ -21,21 +21,45 @@ from .builders import ParamTree, CLIPVisionTower, CLIPConvNextVisionTower
 from .ola_arch import OlaLlavaMetaModel, OlaLlavaMetaForCausalLM
 
 
+class _Lazy:
+    """A field value that is computed on first read (see _ModelOutput)."""
+
+    def __init__(self, fn):
+        self.fn = fn
+
+
 class _ModelOutput:
     """The slice of transformers.utils.ModelOutput that trainers rely on: `out["loss"]`, `out[0]`, `"loss" in out`, `.to_tuple()`
-    (HF Trainer.compute_loss reads `outputs["loss"] if isinstance(outputs, dict) else outputs[0]`)."""
+    (HF Trainer.compute_loss reads `outputs["loss"] if isinstance(outputs, dict) else outputs[0]`).
+    A field may hold a `_Lazy`: it is materialised the first time it is READ (attribute, key, index, to_tuple) and is a plain tensor from
+    then on.  The training forward uses it for `logits`: the reference returns fp32 logits of all B x S rows from every call
+    (ola_llama.py:121-122), 8.4 GB and a 5.6 TFLOP lm_head pass over the label-less rows per step at configs[1], which a trainer that reads
+    `.loss` never touches — the tensor it WOULD read is bit-identical either way (frozen lm_head, final hidden state captured by the closure)."""
+
+    def __getattribute__(self, name):
+        v = object.__getattribute__(self, name)
+        if isinstance(v, _Lazy):
+            v = v.fn()
+            object.__setattr__(self, name, v)
+        return v
+
+    def _present(self):
+        return [f.name for f in dataclasses.fields(self) if object.__getattribute__(self, f.name) is not None]
 
     def to_tuple(self):
-        return tuple(getattr(self, f.name) for f in dataclasses.fields(self) if getattr(self, f.name) is not None)
+        return tuple(getattr(self, n) for n in self._present())
 
     def __getitem__(self, k):
-        return getattr(self, k) if isinstance(k, str) else self.to_tuple()[k]
+        if isinstance(k, str):
+            return getattr(self, k)
+        names = self._present()[k]                     # an index / slice picks its fields first: out[0] (the loss) materialises nothing else
+        return getattr(self, names) if isinstance(names, str) else tuple(getattr(self, n) for n in names)
 
     def __contains__(self, k):
-        return isinstance(k, str) and getattr(self, k, None) is not None
+        return isinstance(k, str) and k in self._present()
 
     def keys(self):
-        return [f.name for f in dataclasses.fields(self) if getattr(self, f.name) is not None]
+        return self._present()
 
 
 @dataclass
@@ -73,9 +97,13 @@ class OlaLlavaPhi3Model(OlaLlavaMetaModel, ParamTree):
 
 def _run_engine(module, eng, batch, labels, output_hidden_states, kwargs, force_states=True):
     """One engine step behind the reference's `forward` contract (shared by the PT and IFT mirrors): returns (loss, engine outputs,
-    logits, hidden_states).  Reference: logits fp32 [B, S, V] always, every decoder-layer state (ola_llama.py:113-122, 181)."""
+    logits, hidden_states).  Reference: logits fp32 [B, S, V] always, every decoder-layer state (ola_llama.py:113-122, 181).
+    Training calls (labels given) of a model whose lm_head is frozen get the logits as a `_Lazy` (computed from the captured final hidden state
+    when first read: same bits); label-less calls, `output_logits=True` and the IFT classes (lm_head trains: a later read would see updated
+    weights) compute them inside the step."""
     ref_out = bool(getattr(module.config, "reference_outputs", True))
-    eng.keep_logits = labels is None or ref_out or bool(kwargs.get("output_logits", False))
+    eager = labels is None or bool(kwargs.get("output_logits", False)) or (ref_out and bool(getattr(eng, "train_llm", False)))
+    eng.keep_logits = True if eager else ("lazy" if ref_out else False)
     eng.keep_states = (ref_out and force_states) or bool(output_hidden_states)
     try:
         if labels is not None:
@@ -87,6 +115,9 @@ def _run_engine(module, eng, batch, labels, output_hidden_states, kwargs, force_
         eng.keep_logits, eng.keep_states = False, False
     out = module._last
     logits = out.pop("logits", None)                                 # fp32 [B, S, V] (ola_llama.py:122), written once by Engine._ntp
+    fn = out.pop("logits_fn", None)
+    if logits is None and fn is not None:
+        logits = _Lazy(fn)
     # popped: `module._last` must not keep the 8.4 GB of logits / the L + 1 layer states alive until the next call
     hidden_states = out.pop("hidden_states", None) or (out["inputs_embeds"], out["hidden"])
     return loss, out, logits, hidden_states
@@ -429,6 +460,7 @@ class _OlaCausalLMBase(OlaLlavaMetaForCausalLM, BaseOLA_VLM, EngineModule):
         eng = self._get_engine()
         dev = eng.dev
         B = input_ids.shape[0]
+        images, gsz = eng.image_groups(images)                       # list / 5-D `images` (ola_arch.py:262-275, "flat" merge) -> one 4-D tensor + group sizes
         if images.device != dev and labels is not None:
             # host images (a collator that leaves them on the CPU): copy AND encode them on the engine's side stream — neither depends on the
             # work still queued on the current stream, so the frozen tower of this batch runs beside the previous step's backward (engine._embed)
@@ -440,6 +472,8 @@ class _OlaCausalLMBase(OlaLlavaMetaForCausalLM, BaseOLA_VLM, EngineModule):
             # current stream (a dataloader copying on its own stream; bench.py's resident pool) -> the frozen tower runs on the side stream
             batch = dict(input_ids=input_ids, attention_mask=attention_mask, labels=labels, images=images.to(dev),
                          images_resident=bool(kwargs.get("images_resident", False)) and images.device == dev)
+        if gsz is not None:
+            batch["image_group_sizes"] = gsz
         for task, tg in self._collect_targets(pil_images, kwargs, B, dev).items():
             batch[f"{task}_target"] = tg
             m = {"gen": gen_mask, "seg": seg_mask, "depth": depth_mask}[task]
@@ -453,7 +487,7 @@ class _OlaCausalLMBase(OlaLlavaMetaForCausalLM, BaseOLA_VLM, EngineModule):
         if return_dict is None:                                      # ola_llama.py:102
             return_dict = bool(getattr(self.config, "use_return_dict", True))
         if not return_dict:                                          # ola_llama.py:170-172: (loss,) + (logits,) + outputs[1:]
-            return tuple(v for v in (loss, logits, hidden_states) if v is not None)
+            return tuple(v for v in (loss, res.logits, hidden_states) if v is not None)
         return res
 
     _forward = forward

@@ -136,14 +136,18 @@ class _LlavaCausalLMBase(LlavaMetaForCausalLM, EngineModule):
                 raise ValueError("input_ids carry an <image> token but no `images` tensor was given")
             side = self.config.cnx_image if self.config.is_convnext else self.config.vit_image
             images = torch.zeros(input_ids.shape[0], 3, side, side, device=eng.dev, dtype=torch.bfloat16)
+        images, gsz = eng.image_groups(images)                       # list / 5-D `images` (llava_arch.py: same branch as ola_arch.py:262-275)
         batch = dict(input_ids=input_ids, attention_mask=attention_mask, labels=labels, images=images.to(eng.dev),
                      images_resident=bool(kwargs.get("images_resident", False)) and images.device == eng.dev)
+        if gsz is not None:
+            batch["image_group_sizes"] = gsz
         loss, out, logits, hidden_states = _run_engine(self, eng, batch, labels, output_hidden_states, kwargs, force_states=False)   # HF LlamaForCausalLM: states on request
         if return_dict is None:                                      # HF LlamaForCausalLM.forward: `return_dict if not None else config.use_return_dict`
             return_dict = bool(getattr(self.config, "use_return_dict", True))
         if not return_dict:                                          # llava_llama.py -> HF LlamaForCausalLM: (loss,) + (logits,) + outputs[1:]; states on request only
             want_hs = bool(output_hidden_states) or bool(getattr(self.config, "output_hidden_states", False))
-            return tuple(v for v in (loss, logits, hidden_states if want_hs else None) if v is not None)
+            res = CausalLMOutputWithPast(loss=loss, logits=logits)
+            return tuple(v for v in (loss, res.logits, hidden_states if want_hs else None) if v is not None)
         return CausalLMOutputWithPast(loss=loss, logits=logits, hidden_states=hidden_states)
 
 

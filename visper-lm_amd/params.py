@@ -53,7 +53,8 @@ def param_shapes(cfg, vit_nested=True, with_vit=True) -> "OrderedDict[str, tuple
         for i in range(len(layer_indices(hc["depth_layer_indices"]))):
             # TaskTokenDepthHead: dim = llm hidden (da_v2_head.py:427-436); the num_task_tokens == 0 DepthHead: dim = output_dim (:386-395)
             _resampler(f"image_depth_heads.{i}.projector.", H if nt > 0 else hc["output_dim"], H, hc["output_dim"], hc, sh, nt == 0)
-            for j in (1, 2, 3):
+            # linear_1..3 exist only with use_intermediate_depth (da_v2_head.py:437-442; the flag's default: base_ola_vlm.py:132)
+            for j in ((1, 2, 3) if hc.get("use_intermediate_depth", True) else ()):
                 p = f"image_depth_heads.{i}.linear_{j}."
                 sh[p + "0.weight"] = (hc["output_dim"], hc["output_dim"]); sh[p + "0.bias"] = (hc["output_dim"],)
                 sh[p + "2.weight"] = (hc["output_dim"], hc["output_dim"]); sh[p + "2.bias"] = (hc["output_dim"],)

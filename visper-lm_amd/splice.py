@@ -106,8 +106,11 @@ def inverse_tables(tasks, heads, M):
     return out
 
 
-def host_plan(cfg, tasks, ids, am=None, lab=None):
-    """ids [B,T] int64 (IMAGE_TOKEN_INDEX marks an image), am [B,T] bool or None, lab [B,T] int64 or None ->
+def host_plan(cfg, tasks, ids, am=None, lab=None, group_sizes=None):
+    """ids [B,T] int64 (IMAGE_TOKEN_INDEX marks an image), am [B,T] bool or None, lab [B,T] int64 or None,
+    group_sizes: None (every <image> token / text-only sample consumes ONE image's 576 feature rows: a stacked 4-D `images`) or the number of
+    images n_j in each entry of a list / 5-D `images` (ola_arch.py:262-275, mm_patch_merge_type "flat": entry j's features are flattened to
+    n_j * 576 rows and ONE <image> token is replaced by all of them, followed by the task tokens) ->
     dict(B, S, lens_host, labels, attention_mask, position_ids, shift_labels, tables{name: int32 array}, heads, ...).
 
     tables: kind/row  [B*S]  gather source (0 = embed_tokens, 1 = image features, 2 = task-token rows, -1 = zeros) and row in it
@@ -126,11 +129,18 @@ def host_plan(cfg, tasks, ids, am=None, lab=None):
     if lab is None:
         lab = np.full((B, T), IGNORE_INDEX, np.int64)
     n_tok_rows = sum(r for _, r, _ in task_token_rows(cfg))    # rows the task tokens take behind every image (pooled or raw layout)
-    blk = N_IMG_TOK + n_tok_rows
-    blk_kind = np.concatenate([np.full(N_IMG_TOK, 1, np.int32), np.full(n_tok_rows, 2, np.int32)])
-    blk_lab = np.full(blk, IGNORE_INDEX, np.int64)
-    img_rows = np.arange(N_IMG_TOK, dtype=np.int32)
     tok_rows = np.arange(n_tok_rows, dtype=np.int32)
+    gs = None if group_sizes is None else [int(n) for n in group_sizes]
+    goff = None if gs is None else np.concatenate(([0], np.cumsum(gs))).astype(np.int64) * N_IMG_TOK      # first feature row of every entry
+
+    def group(j):
+        """(feature rows of entry j, its first row)"""
+        if gs is None:
+            return N_IMG_TOK, j * N_IMG_TOK
+        if j >= len(gs):
+            raise IndexError(f"`images` has {len(gs)} entries but the batch consumes more (one per <image> token and per text-only sample: "
+                             f"ola_arch.py:347-354,372-374)")
+        return gs[j] * N_IMG_TOK, int(goff[j])
     mx = cfg.tokenizer_model_max_length
     seqs = []
     img_idx = 0
@@ -139,6 +149,7 @@ def host_plan(cfg, tasks, ids, am=None, lab=None):
         pos = np.flatnonzero(idb == IMAGE_TOKEN_INDEX)
         if pos.size == 0:
             k, r, lo, im = np.zeros(idb.size, np.int32), idb.astype(np.int32), lb, np.full(idb.size, -1, np.int32)
+            group(img_idx)                                      # (a list / 5-D `images` must have the entry: the reference indexes it)
             img_idx += 1                                        # the reference consumes one (empty) feature slot: ola_arch.py:347-354
         else:
             ks, rs, ls, ims = [], [], [], []
@@ -148,7 +159,10 @@ def host_plan(cfg, tasks, ids, am=None, lab=None):
                 ks.append(np.zeros(hi_ - lo_, np.int32)); rs.append(idb[lo_:hi_].astype(np.int32)); ls.append(lb[lo_:hi_])
                 ims.append(np.full(hi_ - lo_, -1, np.int32))
                 if i < pos.size:
-                    ks.append(blk_kind); rs.append(img_rows + img_idx * N_IMG_TOK); rs.append(tok_rows); ls.append(blk_lab)
+                    g_rows, g0 = group(img_idx)
+                    blk = g_rows + n_tok_rows
+                    ks.append(np.concatenate([np.full(g_rows, 1, np.int32), np.full(n_tok_rows, 2, np.int32)]))
+                    rs.append(np.arange(g0, g0 + g_rows, dtype=np.int32)); rs.append(tok_rows); ls.append(np.full(blk, IGNORE_INDEX, np.int64))
                     ims.append(np.full(blk, img_idx, np.int32))
                     img_idx += 1
             k, r, lo, im = np.concatenate(ks), np.concatenate(rs), np.concatenate(ls), np.concatenate(ims)
@@ -171,7 +185,8 @@ def host_plan(cfg, tasks, ids, am=None, lab=None):
     full = bool((lens == S).all())
     fk, fr, fi = kind.reshape(-1), row.reshape(-1), imgi.reshape(-1)
     posn = np.arange(M, dtype=np.int32)
-    img_dst = np.full(max(n_img, 1) * N_IMG_TOK, -1, np.int32)
+    n_feat = max(n_img, 1) * N_IMG_TOK if gs is None else max(int(goff[-1]), N_IMG_TOK)      # rows of the tower's output
+    img_dst = np.full(n_feat, -1, np.int32)
     m1 = fk == 1
     img_dst[fr[m1]] = posn[m1]
     tok_src = np.full((max(n_tok_rows, 1), max(n_img, 1)), -1, np.int32)
@@ -180,7 +195,7 @@ def host_plan(cfg, tasks, ids, am=None, lab=None):
     embed_idx = np.where(fk == 0, fr, -1).astype(np.int32)
     col = np.arange(S, dtype=np.int32)[None, :]
     real = col < lens[:, None]                                   # physical (left-aligned) validity
-    plan = dict(B=B, S=S, n_img=n_img, n_valid=int((shift != IGNORE_INDEX).sum()), lens_host=lens, n_tok_rows=n_tok_rows,
+    plan = dict(B=B, S=S, n_img=n_img, n_feat=n_feat, n_valid=int((shift != IGNORE_INDEX).sum()), lens_host=lens, n_tok_rows=n_tok_rows,
                 full=full, side=side, tok_cnt=max(n_img, 1), shift_labels=shift.reshape(-1))
     tables = dict(kind=fk, row=fr, lens=lens, img_dst=img_dst, tok_src=tok_src.reshape(-1), embed_idx=embed_idx)
     # rows that carry a next-token label: the lm_head GEMMs and the cross-entropy only run on those (image / task-token / prompt /
