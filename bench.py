@@ -473,6 +473,9 @@ def main():
                     help="with --reference-outputs: also READ out.logits every step (the training forward hands them out lazily: a trainer that only "
                          "reads .loss never pays for the fp32 [B, S, V] tensor; this flag times the step of a caller that reads it every step and "
                          "therefore asks for it with output_logits=True: label-less rows take a forward-only lm_head pass inside the step)")
+    ap.add_argument("--trace-markers", action="store_true",
+                    help="profiling runs: one marker launch (gather_rows_kernel on a grid of 1237 workgroups) behind the fence that opens the timed "
+                         "region and one behind the fence that closes it, so tools/kernel_stats_steps.py can cut the kernel trace to the timed steps")
     ap.add_argument("--same-batch", action="store_true", help="A/B aid: replay one batch (splice-plan cache hit) instead of a fresh one per step")
     ap.add_argument("--force-dist", action="store_true", help="initialise the RCCL process group even with one rank (test hook)")
     args = ap.parse_args()
@@ -617,6 +620,12 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    def marker():
+        n = 1237 * 4
+        src = torch.zeros(8, 8, device=dev, dtype=torch.bfloat16)
+        ops.gather_rows([src], torch.zeros(n, device=dev, dtype=torch.int32), torch.zeros(n, device=dev, dtype=torch.int32), 8,
+                        torch.empty(n, 8, device=dev, dtype=torch.bfloat16))
+
     def timed_leg(n_warm_, n_steps, profile=False):
         """W untimed steps, then exactly K timed steps between barrier + device-synchronize fences; returns (seconds of THIS rank, last out,
         per-GEMM HIP-event records)."""
@@ -626,11 +635,16 @@ def main():
         fence()
         if profile:
             ops.GEMM_PROF = []
+        if args.trace_markers and profile:
+            marker()
         t0_ = time.perf_counter()
         for _ in range(n_steps):
             out_ = step()
         fence()
         el = time.perf_counter() - t0_
+        if args.trace_markers and profile:
+            marker()
+            torch.cuda.synchronize()
         prof_ = None
         if profile:
             prof_, ops.GEMM_PROF = ops.GEMM_PROF, None

@@ -67,3 +67,21 @@ def test_asm_owned_registers_are_never_touched_by_the_compiler():
         n, problems = au.audit(au.isa(debug=dbg))
         assert n >= 12, (dbg, n)
         assert not problems, (dbg, problems[:10])
+
+
+def test_w4_epilogue_accumulator_reads_never_overwrite_pending_store_data():
+    """Round 6, the root cause of round 4's "NaNs beside other kernels": an `asm volatile("v_accvgpr_read_b32 ...")` of the one-wave-per-SIMD GEMM's
+    epilogue (opaque to the compiler's hazard recogniser) was allocated the VGPR holding dword 0 of the buffer_store issued just before; when the CU's
+    memory pipeline is shared with another kernel's waves the store fetches its data late and writes the next block's raw accumulator
+    (tools/nan_pattern_r06.py, profiles/r06_nan_root_cause.txt).  gemm.hip's W4_KEEP2 keeps the previous block's store-data registers live across the
+    next block's accumulator reads; tools/w4_store_data_audit.py checks the built ISA of every instantiation: no asm accumulator read writes a data
+    register of the last two 16-byte stores (0 with the fix, 647-1247 per instantiation without; needs hipcc: ~1 min)."""
+    import shutil
+    import w4_store_data_audit as au
+    if not (shutil.which("hipcc") or os.path.exists(au.HIPCC)):
+        pytest.skip("needs hipcc")
+    res = au.audit(au.isa())
+    assert len(res) >= 4, list(res)
+    assert sum(r[0] for r in res.values()) >= 3000 and sum(r[1] for r in res.values()) >= 400          # the audit saw the epilogues
+    for name, (_, _, probs) in res.items():
+        assert not probs, (name, probs[:5])

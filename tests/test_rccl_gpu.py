@@ -294,3 +294,52 @@ print("COMM_BESIDE_GEMM_OK")
     env = dict(os.environ, VP_ROOT=root, HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([sys.executable, "-c", script], env=env, capture_output=True, text=True, timeout=600)
     assert "COMM_BESIDE_GEMM_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_w4_gemms_beside_1000_rccl_collectives_world1():
+    """the one-wave-per-SIMD GEMM (all three epilogue instantiations: lean, general with bias / activation / residual and an M
+    tail, RMSNorm-fold with sums of squares) beside RCCL kernels on the communicator's side stream for >= 1000 GEMM launches: self all-reduces of a
+    16 MB bucket at world 1, issued back to back so that a collective kernel is resident for the whole run (the next co-resident party after the
+    side stream's small kernels, and on CUs the GEMM's register-file claim does not cover).  Every output must equal the bits of the solo launch."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = r"""
+import os, sys, torch
+sys.path.insert(0, os.environ["VP_ROOT"])
+torch.cuda.set_device(0)
+from visper_lm_amd import ops
+from visper_lm_amd.parallel import NativeComm
+M, N, K = 8192, 4096, 1024
+g = torch.Generator(device="cuda").manual_seed(7)
+a = torch.randn(M, K, device="cuda", generator=g).to(torch.bfloat16)
+w = (torch.randn(N, K, device="cuda", generator=g) * 0.1).to(torch.bfloat16)
+bias = torch.randn(N, device="cuda", generator=g).to(torch.bfloat16)
+res = torch.randn(M, N, device="cuda", generator=g).to(torch.bfloat16)
+Mt = M - 100
+def launch():
+    return (ops.gemm(a, w), ops.gemm(a, w, bias=bias, residual=res, epi=ops.EPI_QUICK_GELU, force_generic=14),
+            ops.gemm(a[:Mt], w, bias=bias, force_generic=14), *ops.gemm_sumsq(a, w, res))
+solo = launch()
+torch.cuda.synchronize()
+c = NativeComm(rank=0, world=1)
+buf = torch.randn(8 * 1024 * 1024, device="cuda", generator=g).to(torch.bfloat16)         # 16 MB bucket
+keep = buf.clone()
+n = 0
+for it in range(260):                                  # 260 x 4 = 1040 GEMM launches
+    c.allreduce_async(buf); c.allreduce_async(buf)     # two collectives in flight beside this round's four GEMMs
+    got = launch()
+    n += 4
+    if it % 10 == 9:
+        c.wait()
+    for i, (g_, s_) in enumerate(zip(got, solo)):
+        assert torch.equal(g_, s_), f"round {it}, output {i}: differs from the solo launch"
+c.wait()
+torch.cuda.synchronize()
+assert torch.equal(buf, keep) and n >= 1000
+c.close()
+print("W4_BESIDE_RCCL_OK", n)
+"""
+    env = dict(os.environ, VP_ROOT=root, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-c", script], env=env, capture_output=True, text=True, timeout=900)
+    assert "W4_BESIDE_RCCL_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]

@@ -460,6 +460,23 @@ __device__ __forceinline__ void epilogue_swz(const GemmArgs& p, bf16_t* wave_lds
 //   lanes fr < 8:  z1 = own x,             z2 = y of lane fr + 8        lanes fr >= 8:  z1 = y of lane fr - 8,   z2 = own x
 // One v_cndmask_b32_dpp (row_ror:8 on the y operand) per dword and store: 8 VALU per pair of stores.  (DPP reads of a VGPR written by the
 // VALU instruction in front need two wait states: the s_nop.)
+// Store-data keep-alive (round 6; the root cause of round 4's "NaNs beside other kernels", tools/nan_pattern_r06.py, EXPERIMENTS round 6).  The epilogues
+// read the accumulators with `asm volatile("v_accvgpr_read_b32 ...")`, opaque to the compiler's hazard recogniser.  The register allocator hands the FIRST
+// such read of the next 16-row block the VGPR that held dword 0 of the buffer_store_dwordx4 issued just before, and on gfx950 nothing holds a
+// v_accvgpr_read back while a store still fetches its data from that VGPR: when the CU's memory pipeline is busy with ANOTHER kernel's waves (a
+// co-resident wave of the other stream) the store picks its data up late and writes the next block's raw fp32 accumulator for lanes 12..15 of every
+// 16-lane row (bit-exactly what the wrong elements were).  Alone on its CU the data is gone before the read issues, which is why the kernel was only ever
+// wrong beside other kernels, and why claiming the whole register file (no foreign wave on the CU) hid it.  Fix: the previous block's store-data registers
+// stay LIVE (an empty asm use) until this block's accumulator reads have issued, so the allocator cannot give them to those reads; their next writers are
+// ordinary VALU instructions (cvt_pk / DPP), which the hardware does order behind the store's data fetch.
+#ifndef VP_W4_STORE_KEEP
+#define VP_W4_STORE_KEEP 1
+#endif
+#if VP_W4_STORE_KEEP
+#define W4_KEEP2(A, B) asm volatile("" ::"v"(A), "v"(B))
+#else
+#define W4_KEEP2(A, B) do { } while (0)
+#endif
 __device__ __forceinline__ void w4_rows8_swap(u32x4& z1, u32x4& z2, const u32x4& x, const u32x4& y) {
   uint32_t a0, a1, a2, a3, b0, b1, b2, b3;
   const unsigned long long lo8 = 0x00ff00ff00ff00ffull, hi8 = 0xff00ff00ff00ff00ull;
@@ -540,6 +557,7 @@ __device__ __forceinline__ void epilogue_w4(const GemmArgs& p, f32x4 (&acc)[2][8
       // in its h = 0 registers and d + 64 in its h = 1 registers, so the rotation pairs never leave the lane.  Both halves of a 16-row block are
       // finished together (the loop over h is innermost here), rounding points as rope_kernel: bf(bf(x1 c) - bf(x2 s)), bf(bf(x2 c) + bf(x1 s)).
       const bool do_rope = ncol0 < p.rope_cols;
+      u32x4 pz1 = u32x4{0u, 0u, 0u, 0u}, pz2 = pz1, pz3 = pz1, pz4 = pz1;      // the previous row block's store data (W4_KEEP2)
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         const int row = mrow0 + 16 * i + fr;
@@ -578,6 +596,7 @@ __device__ __forceinline__ void epilogue_w4(const GemmArgs& p, f32x4 (&acc)[2][8
             v[1][s2][e] = pack_bf16x2(a1[2 * e], a1[2 * e + 1]);
           }
         }
+        W4_KEEP2(pz1, pz2); W4_KEEP2(pz3, pz4);          // (every accumulator read of this row block has issued)
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
           u32x4 z1, z2;
@@ -585,6 +604,7 @@ __device__ __forceinline__ void epilogue_w4(const GemmArgs& p, f32x4 (&acc)[2][8
           const int so = __builtin_amdgcn_readfirstlane(i * cstep + h * 128);
           __builtin_amdgcn_raw_buffer_store_b128(z1, crs, coff1, so, 0);
           __builtin_amdgcn_raw_buffer_store_b128(z2, crs, coff2, so, 0);
+          if (h == 0) { pz1 = z1; pz2 = z2; } else { pz3 = z1; pz4 = z2; }
         }
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -621,6 +641,7 @@ __device__ __forceinline__ void epilogue_w4(const GemmArgs& p, f32x4 (&acc)[2][8
 #pragma unroll
           for (int s2 = 0; s2 < 2; ++s2) rv[i][s2] = __builtin_amdgcn_raw_buffer_load_b128(rrs, roff + i * rstep, s2 * 64, 0);
       }
+      u32x4 pz1 = u32x4{0u, 0u, 0u, 0u}, pz2 = pz1;       // the previous block's store data (W4_KEEP2)
 #pragma unroll
       for (int h = 0; h < 2; ++h)
 #pragma unroll
@@ -654,11 +675,13 @@ __device__ __forceinline__ void epilogue_w4(const GemmArgs& p, f32x4 (&acc)[2][8
             }
             xy[s2] = v;
           }
+          W4_KEEP2(pz1, pz2);
           u32x4 z1, z2;
           w4_rows8_swap(z1, z2, xy[0], xy[1]);
           const int so = __builtin_amdgcn_readfirstlane(i * cstep + h * 128);
           __builtin_amdgcn_raw_buffer_store_b128(z1, crs, coff1, so, 0);
           __builtin_amdgcn_raw_buffer_store_b128(z2, crs, coff2, so, 0);
+          pz1 = z1; pz2 = z2;
           __builtin_amdgcn_sched_barrier(0);
         }
     };
@@ -681,6 +704,7 @@ __device__ __forceinline__ void epilogue_w4(const GemmArgs& p, f32x4 (&acc)[2][8
     const int aoff = (fr * p.ldaux + g * 16) * 2, astep = p.ldaux * 32, dstep = p.ldc * 32;
     const int doff1 = ((fr & 7) * p.ldc + g * 16 + ((fr & 8) ? 8 : 0)) * 2, doff2 = ((8 + (fr & 7)) * p.ldc + g * 16 + ((fr & 8) ? 0 : 8)) * 2;
     u32x4 gv[8][2], uv[8][2];
+    u32x4 pz1 = u32x4{0u, 0u, 0u, 0u}, pz2 = pz1;         // the previous sub-block's store data (W4_KEEP2)
 #pragma unroll
     for (int i = 0; i < 8; ++i)
 #pragma unroll
@@ -695,6 +719,7 @@ __device__ __forceinline__ void epilogue_w4(const GemmArgs& p, f32x4 (&acc)[2][8
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
           const bf16x8 dv = __builtin_bit_cast(bf16x8, pk(h, i, s2));
+          W4_KEEP2(pz1, pz2);
           const bf16x8 gq = __builtin_bit_cast(bf16x8, gv[i][s2]), uq = __builtin_bit_cast(bf16x8, uv[i][s2]);
           bf16x8 og, ou;
 #pragma unroll
@@ -710,6 +735,7 @@ __device__ __forceinline__ void epilogue_w4(const GemmArgs& p, f32x4 (&acc)[2][8
           const int so = __builtin_amdgcn_readfirstlane(i * dstep + h * 256 + s2 * 128);
           __builtin_amdgcn_raw_buffer_store_b128(z1, drs, doff1, so, 0);
           __builtin_amdgcn_raw_buffer_store_b128(z2, drs, doff2, so, 0);
+          pz1 = z1; pz2 = z2;
           if (h == 0) {
             gv[i][s2] = __builtin_amdgcn_raw_buffer_load_b128(ars, aoff + i * astep, 256 + s2 * 128, 0);
             uv[i][s2] = __builtin_amdgcn_raw_buffer_load_b128(ars, aoff + i * astep, 256 + s2 * 128 + 16, 0);
@@ -752,17 +778,20 @@ __device__ __forceinline__ void epilogue_w4(const GemmArgs& p, f32x4 (&acc)[2][8
     const int coff1 = ((fr & 7) * p.ldc + g * 8 + (hi8 ? 32 : 0)) * 2, coff2 = ((8 + (fr & 7)) * p.ldc + g * 8 + (hi8 ? 0 : 32)) * 2;
     const int aoff1 = ((fr & 7) * p.ldc2 + pq * 8 + (hi8 ? 32 : 0)) * 2, aoff2 = ((8 + (fr & 7)) * p.ldc2 + pq * 8 + (hi8 ? 0 : 32)) * 2;
     const int astep = p.ldc2 * 32;
+    u32x4 pz1 = u32x4{0u, 0u, 0u, 0u}, pz2 = pz1, pz3 = pz1, pz4 = pz1, pz5 = pz1, pz6 = pz1;      // the data of the last six stores (W4_KEEP2)
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       u32x4 oh[2];
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         u32x4 x = pks(h, i, 0), y = pks(h, i, 1);
+        W4_KEEP2(pz1, pz2); W4_KEEP2(pz3, pz4); W4_KEEP2(pz5, pz6);
         u32x4 z1, z2;
         w4_rows8_swap(z1, z2, x, y);
         const int so = __builtin_amdgcn_readfirstlane(i * cstep + h * 128);
         __builtin_amdgcn_raw_buffer_store_b128(z1, crs, coff1, so, 0);
         __builtin_amdgcn_raw_buffer_store_b128(z2, crs, coff2, so, 0);
+        if (h == 0) { pz1 = z1; pz2 = z2; } else { pz5 = z1; pz6 = z2; }
 #pragma unroll
         for (int d = 0; d < 4; ++d) {
           const auto r = __builtin_amdgcn_permlane16_swap(x[d], y[d], false, false);
@@ -779,6 +808,7 @@ __device__ __forceinline__ void epilogue_w4(const GemmArgs& p, f32x4 (&acc)[2][8
       const int sa = __builtin_amdgcn_readfirstlane(i * astep);
       __builtin_amdgcn_raw_buffer_store_b128(a1, ars, aoff1, sa, 0);
       __builtin_amdgcn_raw_buffer_store_b128(a2, ars, aoff2, sa, 0);
+      pz3 = a1; pz4 = a2;
       __builtin_amdgcn_sched_barrier(0);
     }
     };
@@ -810,6 +840,8 @@ __device__ __forceinline__ void epilogue_w4(const GemmArgs& p, f32x4 (&acc)[2][8
       ssoff = (fr * npr + g) * 4;
     }
     u32x4 rv[8][2];
+    u32x4 pz1 = u32x4{0u, 0u, 0u, 0u}, pz2 = pz1;         // the previous block's store data (W4_KEEP2)
+    float psq = 0.f;                                      // ... and its sum-of-squares partial (a one-dword store of its own)
     const __amdgpu_buffer_rsrc_t rrs = tile_rs(RES ? (const void*)p.res : p.C, RES ? p.ldr : p.ldc, ncol0);
     const int roff = (fr * p.ldr + g * 8) * 2, rstep = p.ldr * 32;
     if (RES) {
@@ -839,6 +871,8 @@ __device__ __forceinline__ void epilogue_w4(const GemmArgs& p, f32x4 (&acc)[2][8
           }
           xy[s2] = v;
         }
+        W4_KEEP2(pz1, pz2);
+        if (SSQ) W4_KEEP2(psq, psq);
         u32x4 z1, z2;
         w4_rows8_swap(z1, z2, xy[0], xy[1]);
         const int so = __builtin_amdgcn_readfirstlane(i * cstep + h * 128);      // row block + half in the scalar offset: no address VALU per store
@@ -850,6 +884,7 @@ __device__ __forceinline__ void epilogue_w4(const GemmArgs& p, f32x4 (&acc)[2][8
           __builtin_amdgcn_raw_buffer_store_b128(z2, crs, coff2, so, 0);
         }
         if (SSQ) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, sq), srs, ssoff, __builtin_amdgcn_readfirstlane((i * 16 * npr + h * 4) * 4), 0);
+        pz1 = z1; pz2 = z2; psq = sq;
         __builtin_amdgcn_sched_barrier(0);
       }
   };
@@ -1529,12 +1564,19 @@ __global__ __launch_bounds__(512) void gemm_tn_256p8(GemmArgs p) {
 template <bool OUT_F32, int VAR = 0>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void gemm_nt_256w4(GemmArgs p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  // The wave claims its SIMD's WHOLE register file (256 VGPRs + 256 AGPRs): with fewer (the general variant used 208 + 256) a low-register wave of a
-  // kernel running on ANOTHER stream can be placed on the same SIMD, and round 4's side-stream schedule then produced sporadic NaNs in this
-  // kernel's output (tools/ift_dbg.py: first seen in a ViT fc2 launch beside the decoder forward's small kernels; never alone).
-#ifndef VP_W4_NO_CLOBBER
-  asm volatile("" ::: "v255");
+  // The wave claims its SIMD's WHOLE register file (an asm clobber of v255: 256 VGPRs + 256 AGPRs), so no wave of another kernel can be placed on this
+  // CU while the block runs.  Round 4 added it because with fewer registers (the general variant: 208 + 256) the output sporadically carried garbage /
+  // NaNs beside the other stream's kernels; round 6 found WHY (W4_KEEP2 above: an asm v_accvgpr_read overwriting the data register of a buffer_store
+  // that fetches its data late when the CU's memory pipeline is shared with foreign waves) and fixed the mechanism in the epilogues: without the claim
+  // and with the fix the repro configurations are clean (0 of 1572 side-stream launches differ, IFT bench finite 4 of 4; with neither: 3 of 400, NaN
+  // every run), and the step time is the same either way (PT 402.4 / 402.4 / 402.9 ms without vs 402.4 / 402.8 / 403.1 with the claim, IFT 687.8 / 686.6
+  // vs 687.9 / 687.0: profiles/r06_nan_root_cause.txt).  The claim STAYS as the second line of defence: the keep-alive moves the overwrite one 16-row
+  // block (hundreds of cycles) away from the store, it is not an interlock, while a CU without foreign waves fetches store data at once.
+  // VP_W4_CLOBBER_MASK (bit VAR set = that instantiation claims) exists for the experiments (tools/nan_bisect_r06.sh, tools/nan_validate_r06.sh).
+#ifndef VP_W4_CLOBBER_MASK
+#define VP_W4_CLOBBER_MASK 7
 #endif
+  if constexpr ((VP_W4_CLOBBER_MASK >> VAR) & 1) asm volatile("" ::: "v255");
   bf16_t* smem = (bf16_t*)smem_raw;                    // [buf 0: A 256x64 | B 256x64][buf 1][C staging 4 x 8 KB]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);

@@ -817,6 +817,10 @@ class Engine:
         H = cfg.hidden_size
         if images_resident and os.environ.get("VP_TOWER_STREAM", "1") != "0":
             main, side = torch.cuda.current_stream(), self._side_stream()
+            after = os.environ.get("VP_TOWER_AFTER")                # dev aid (tools/nan_bisect_r06.sh): the tower may only start once the PREVIOUS
+            ev_prev = getattr(self, "_phase_ev", {}).get(after)     # step's decoder forward ("fwd") / backward ("bwd") is done on the main stream
+            if ev_prev is not None:
+                side.wait_event(ev_prev)
             with torch.cuda.stream(side):
                 feats = self.vit_forward(images)
                 ev = torch.cuda.Event()
@@ -889,6 +893,8 @@ class Engine:
         out["inputs_embeds"] = self.present(x, plan)
 
         dec = self._decoder_fwd(x, plan, compute_grads)
+        if os.environ.get("VP_TOWER_AFTER"):
+            self.__dict__.setdefault("_phase_ev", {})["fwd"] = torch.cuda.current_stream().record_event()
         out["hidden"] = self.present(dec["hidden"], plan)
         out["layer_states"] = {l: self.present(t, plan) for l, t in dec["states"].items()}      # the tapped states the heads read (views when right-padded)
         if dec["hidden_states"] is not None:             # (embeddings, layer 1 .. L-1 outputs, norm(layer L output)): ola_llama.py:113,181
@@ -948,6 +954,8 @@ class Engine:
             total()
             return out
         dx = self._decoder_bwd(d_hidden, dec, d_state, plan)
+        if os.environ.get("VP_TOWER_AFTER"):
+            self.__dict__.setdefault("_phase_ev", {})["bwd"] = torch.cuda.current_stream().record_event()
         self._join_heads()
         total()
         out["d_inputs_embeds"] = self.present(dx, plan)
