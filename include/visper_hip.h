@@ -102,6 +102,11 @@ int vp_gemm_tn_bf16(int M, int N, int K, const void* A, long lda, const void* B,
 /* (measurement / development entry points — vp_debug_* — are NOT part of this ABI: include/visper_hip_debug.h, built with -DVP_DEBUG) */
 
 int vp_transpose_bf16(int rows, int cols, const void* in, long ld_in, void* out, long ld_out, vp_stream_t stream);
+/* `batch` independent [rows, cols] -> [cols, rows] transposes in ONE launch (matrix b at in + b * batch_stride_in / out + b * batch_stride_out,
+ * strides in elements, multiples of 8): the (B, C, 24, 24) segmentation targets re-laid to the prediction's (B, 576, C) order once per step
+ * (base_ola_vlm.py:289-320 compares preds [B, C, 24, 24] with targets of the same layout; the loss kernel streams both linearly). */
+int vp_transpose_batched_bf16(int batch, int rows, int cols, const void* in, long batch_stride_in, long ld_in, void* out, long batch_stride_out,
+                              long ld_out, vp_stream_t stream);
 
 /* ---- norms.  HF LlamaRMSNorm (modeling_llama.py:53-68); nn.LayerNorm in CLIP and the resampler
  * (resampler.py:12,37-38,189).  rstd/mean: fp32 [M] saved for backward. */

@@ -129,6 +129,14 @@ def test_gemm_strided_views(ops):
     assert float(outbuf[:, :N].abs().max()) == 0 and float(outbuf[:, 2 * N:].abs().max()) == 0
 
 
+def test_transpose_batched(ops):
+    x = rnd(5, 136, 200, seed=77)                                      # edge tiles in both directions
+    got = ops.transpose_batched(dev(x))
+    assert torch.equal(got.cpu(), x.transpose(1, 2).contiguous())
+    y = rnd(8, 1536, 576, seed=78)                                     # the seg targets' shape
+    assert torch.equal(ops.transpose_batched(dev(y)).cpu(), y.transpose(1, 2).contiguous())
+
+
 def test_transpose(ops):
     x = rnd(130, 75, seed=9)
     out = ops.transpose(dev(x))

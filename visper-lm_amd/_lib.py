@@ -30,6 +30,7 @@ _SIGS = {
     "vp_rstd_from_sumsq": [i, i, p, i, f, p, p],
     "vp_gemm_tn_bf16": [i, i, i, p, l, p, l, p, l, i, i, p, p],
     "vp_transpose_bf16": [i, i, p, l, p, l, p],
+    "vp_transpose_batched_bf16": [i, i, i, p, l, l, p, l, l, p],
     "vp_rmsnorm_fwd": [i, i, p, l, p, f, p, l, p, p],
     "vp_rmsnorm_bwd": [i, i, p, p, p, p, p, p, l, p],
     "vp_layernorm_fwd": [i, i, p, l, p, p, f, p, l, p, p, p],

@@ -1890,8 +1890,10 @@ __global__ __launch_bounds__(256) void gemm_nt_generic(GemmArgs p) {
 // 16-byte vectors on both sides (row pitch 66 elements keeps the column gathers conflict-free); edge / unaligned tiles go element-wise.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void transpose_bf16_kernel(const bf16_t* in, bf16_t* out, int rows, int cols, long ldi,
-                                                             long ldo) {
+                                                             long ldo, long bsi = 0, long bso = 0) {
   __shared__ bf16_t t[64][66];
+  in += (long)blockIdx.z * bsi;                        // batched form (vp_transpose_batched_bf16): matrix blockIdx.z of the batch
+  out += (long)blockIdx.z * bso;
   const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
   const bool vec = r0 + 64 <= rows && c0 + 64 <= cols && (ldi & 7) == 0 && (ldo & 7) == 0 &&
                    ((((uintptr_t)in) | ((uintptr_t)out)) & 15) == 0;
@@ -2248,8 +2250,18 @@ int vp_transpose_bf16(int rows, int cols, const void* in, long ld_in, void* out,
   VP_REQUIRE(rows > 0 && cols > 0 && in && out, VP_ERR_BAD_ARG, "vp_transpose_bf16: bad args");
   dim3 grid((cols + 63) / 64, (rows + 63) / 64);
   hipLaunchKernelGGL(transpose_bf16_kernel, grid, dim3(256), 0, stream, (const bf16_t*)in, (bf16_t*)out, rows, cols,
-                     ld_in, ld_out);
+                     ld_in, ld_out, 0L, 0L);
   return vp_check_launch("vp_transpose_bf16");
+}
+
+int vp_transpose_batched_bf16(int batch, int rows, int cols, const void* in, long batch_stride_in, long ld_in, void* out, long batch_stride_out,
+                              long ld_out, hipStream_t stream) {
+  VP_REQUIRE(batch > 0 && batch <= 65535 && rows > 0 && cols > 0 && in && out, VP_ERR_BAD_ARG, "vp_transpose_batched_bf16: bad args");
+  VP_REQUIRE(batch_stride_in % 8 == 0 && batch_stride_out % 8 == 0, VP_ERR_BAD_ARG, "vp_transpose_batched_bf16: batch strides must be multiples of 8 elements");
+  dim3 grid((cols + 63) / 64, (rows + 63) / 64, batch);
+  hipLaunchKernelGGL(transpose_bf16_kernel, grid, dim3(256), 0, stream, (const bf16_t*)in, (bf16_t*)out, rows, cols, ld_in, ld_out,
+                     batch_stride_in, batch_stride_out);
+  return vp_check_launch("vp_transpose_batched_bf16");
 }
 
 }  // extern "C"

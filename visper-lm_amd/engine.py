@@ -658,12 +658,17 @@ class Engine:
         Mp = (M + 63) // 64 * 64
         # zero-padded transposed operands live in a small pool keyed by (role, rows, M): the pad columns are zeroed once, the transposes only
         # ever rewrite columns < M, and every use is ordered on the one stream (was: two fill kernels per call, ~230 launches per step)
-        pool = self.__dict__.setdefault("_wgrad_pool", {})
+        # one pool per STREAM (the heads' weight gradients run on the side stream, the projector's on the main stream: a shared buffer would be
+        # rewritten by one stream while a GEMM of the other still reads it); when a pool overflows (ragged batches: M changes every step) the
+        # stream is drained before its buffers are dropped, so no queued kernel can still read a freed block
+        st = torch.cuda.current_stream()
+        pool = self.__dict__.setdefault("_wgrad_pool", {}).setdefault(st.cuda_stream, {})
 
         def padded(role, rows):
             key = (role, rows, M)
             if key not in pool:
                 if len(pool) >= 64:
+                    st.synchronize()
                     pool.clear()
                 pool[key] = torch.zeros(rows, Mp, device=self.dev, dtype=BF16)
             return pool[key]
@@ -1346,10 +1351,14 @@ class Engine:
             Bn = tg.shape[0]
             if task == "seg" and tg.dim() == 4:
                 Cc = tg.shape[1]
-                flat = torch.empty(Bn, tg.shape[2] * tg.shape[3], Cc, device=self.dev, dtype=BF16)
-                t3 = tg.reshape(Bn, Cc, -1).contiguous()
-                for b in range(Bn):
-                    ops.transpose(t3[b], out=flat[b])
+                t3 = tg.reshape(Bn, Cc, -1)
+                if (Cc * t3.shape[2]) % 8 == 0 and t3.is_contiguous():
+                    flat = ops.transpose_batched(t3)                  # ONE launch (round 5: one transpose per sample)
+                else:
+                    flat = torch.empty(Bn, t3.shape[2], Cc, device=self.dev, dtype=BF16)
+                    t3 = t3.contiguous()
+                    for b in range(Bn):
+                        ops.transpose(t3[b], out=flat[b])
                 flat = flat.view(Bn, -1)
             else:
                 flat = tg.reshape(Bn, -1).contiguous()

@@ -243,6 +243,16 @@ def transpose(x, out=None):
     return out
 
 
+def transpose_batched(x, out=None):
+    """[B, R, C] -> [B, C, R] (bf16, contiguous), one launch."""
+    B, R, Cc = x.shape
+    assert x.is_contiguous() and x.dtype == BF16
+    if out is None:
+        out = torch.empty(B, Cc, R, device=x.device, dtype=BF16)
+    _lib.call("vp_transpose_batched_bf16", B, R, Cc, _p(x), R * Cc, Cc, _p(out), R * Cc, R, _stream())
+    return out
+
+
 def rmsnorm_fwd(x, w, eps, save_rstd=True):
     M, H, ldx = _rows2d(x)
     y = torch.empty(x.shape, device=x.device, dtype=BF16)
